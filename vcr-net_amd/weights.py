@@ -1,0 +1,136 @@
+"""Parameter inventory and deterministic weight generator for the VCR-Net hot path.
+
+The key names and shapes are the reference's ``state_dict`` contract
+(model/lpdnet_model.py:85-94, model/transformer.py:196,231-233,137-138,
+model/vcrnet_model.py:93-102,353-354,428-429).  The trained VCR-Net checkpoints
+are not available, so everything except the LPD-pretrained
+``emb_nn.*`` tensors comes from :func:`generate_weights`: a documented, seeded
+recipe that both this package and the golden-vector script load into the
+reference so the two sides share weights without shipping a 22 MB blob.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LPD_FIXTURE = os.path.join(os.path.dirname(_HERE), "tests", "golden", "lpd_pretrained.npz")
+
+
+def param_shapes(emb_nn: str = "lpdnet", pointer: str = "transformer", vcp_nn: str = "topK",
+                 emb_dims: int = 512, ff_dims: int = 1024, n_blocks: int = 1) -> "OrderedDict[str, tuple]":
+    """Ordered {state_dict key: shape}.  The order is part of the generator recipe."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    E = emb_dims
+    if emb_nn == "lpdnet":
+        s["emb_nn.convDG1.0.weight"] = (128, 128, 1, 1); s["emb_nn.convDG1.0.bias"] = (128,)
+        s["emb_nn.convDG2.0.weight"] = (128, 128, 1, 1); s["emb_nn.convDG2.0.bias"] = (128,)
+        s["emb_nn.convSN1.0.weight"] = (256, 256, 1, 1); s["emb_nn.convSN1.0.bias"] = (256,)
+        s["emb_nn.conv1_lpd.weight"] = (64, 3, 1); s["emb_nn.conv1_lpd.bias"] = (64,)
+        s["emb_nn.conv2_lpd.weight"] = (64, 64, 1); s["emb_nn.conv2_lpd.bias"] = (64,)
+        s["emb_nn.conv3_lpd.weight"] = (E, 512, 1); s["emb_nn.conv3_lpd.bias"] = (E,)
+    elif emb_nn == "dgcnn":
+        chans = [(6, 64), (64, 64), (64, 128), (128, 256), (512, E)]
+        for i, (ci, co) in enumerate(chans, 1):
+            s[f"emb_nn.conv{i}.weight"] = (co, ci, 1, 1)
+        for i, (_, co) in enumerate(chans, 1):
+            s[f"emb_nn.bn{i}.weight"] = (co,); s[f"emb_nn.bn{i}.bias"] = (co,)
+            s[f"emb_nn.bn{i}.running_mean"] = (co,); s[f"emb_nn.bn{i}.running_var"] = (co,)
+    else:
+        raise Exception("Not implemented")
+    if pointer == "transformer":
+        def mha(pre):
+            for i in range(4):
+                s[f"{pre}linears.{i}.weight"] = (E, E); s[f"{pre}linears.{i}.bias"] = (E,)
+
+        def ffn(pre):
+            s[pre + "w_1.weight"] = (ff_dims, E); s[pre + "w_1.bias"] = (ff_dims,)
+            s[pre + "w_2.weight"] = (E, ff_dims); s[pre + "w_2.bias"] = (E,)
+
+        def norm(pre):
+            s[pre + "a_2"] = (E,); s[pre + "b_2"] = (E,)
+
+        for i in range(n_blocks):
+            lp = f"pointer.model.encoder.layers.{i}."
+            mha(lp + "self_attn."); ffn(lp + "feed_forward.")
+            norm(lp + "sublayer.0.norm."); norm(lp + "sublayer.1.norm.")
+        norm("pointer.model.encoder.norm.")
+        for i in range(n_blocks):
+            lp = f"pointer.model.decoder.layers.{i}."
+            mha(lp + "self_attn."); mha(lp + "src_attn."); ffn(lp + "feed_forward.")
+            for j in range(3):
+                norm(lp + f"sublayer.{j}.norm.")
+        norm("pointer.model.decoder.norm.")
+    if vcp_nn == "att":
+        for i in range(2):
+            s[f"head.linears_emb.{i}.weight"] = (E, E); s[f"head.linears_emb.{i}.bias"] = (E,)
+        for i in range(2):
+            s[f"head.linears_3d.{i}.weight"] = (3, 3); s[f"head.linears_3d.{i}.bias"] = (3,)
+    s["svd.reflect"] = (3, 3)
+    return s
+
+
+def load_lpd_fixture(path: Optional[str] = None) -> Dict[str, torch.Tensor]:
+    """The 12 LPD-pretrained ``emb_nn.*`` tensors (pretrained/lpd-pretrained.t7 re-saved as .npz)."""
+    z = np.load(path or LPD_FIXTURE)
+    return {k: torch.from_numpy(z[k].copy()) for k in z.files}
+
+
+def generate_weights(seed: int = 1234, lpd: Optional[Dict[str, torch.Tensor]] = None,
+                     **shape_kwargs) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic fp32 parameters.
+
+    Recipe (walk :func:`param_shapes` in order with ONE CPU ``torch.Generator(seed)``):
+      * ``*.weight`` with >= 2 dims: U(-1/sqrt(fan_in), 1/sqrt(fan_in))   (nn.Linear/Conv default scale)
+      * ``*.bias``                : U(-1/sqrt(fan_in of its layer), +)     (fan_in of the preceding weight)
+      * ``a_2``                   : 1 + 0.1 * U(-1, 1);   ``b_2``: 0.1 * U(-1, 1)
+      * ``bn.weight``             : 1 + 0.2 * U(-1,1); ``bn.bias``/``running_mean``: 0.1 * U(-1,1);
+        ``running_var``           : 1 + 0.5 * U(0,1)
+      * ``svd.reflect``           : diag(1, 1, -1)                         (vcrnet_model.py:353-354)
+    Keys present in ``lpd`` (the pretrained feature extractor) override the generated values
+    AFTER generation, so the random stream does not depend on whether the fixture is used.
+    """
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    u = lambda shape: torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    last_fan_in = 1
+    for key, shape in param_shapes(**shape_kwargs).items():
+        leaf = key.rsplit(".", 1)[-1]
+        if key == "svd.reflect":
+            t = torch.eye(3); t[2, 2] = -1
+        elif leaf == "a_2":
+            t = 1 + 0.1 * u(shape)
+        elif leaf == "b_2":
+            t = 0.1 * u(shape)
+        elif ".bn" in key:
+            if leaf == "weight":
+                t = 1 + 0.2 * u(shape)
+            elif leaf == "running_var":
+                t = 1 + 0.5 * (u(shape) * 0.5 + 0.5)
+            else:
+                t = 0.1 * u(shape)
+        elif leaf == "weight":
+            last_fan_in = int(np.prod(shape[1:]))
+            t = u(shape) / float(np.sqrt(last_fan_in))
+        elif leaf == "bias":
+            t = u(shape) / float(np.sqrt(last_fan_in))
+        else:
+            raise KeyError(key)
+        out[key] = t.contiguous()
+    if lpd is not None:
+        for k, v in lpd.items():
+            if k in out:
+                assert tuple(out[k].shape) == tuple(v.shape), k
+                out[k] = v.to(torch.float32).contiguous()
+    return out
+
+
+def strip_module_prefix(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Accept DataParallel-saved checkpoints (``module.`` prefix; SURVEY section 5 gotcha,
+    util/initPara.py:25-35,260)."""
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
