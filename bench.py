@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Headline benchmark: point-cloud pairs/sec of the VCR-Net registration hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL.)
+
+One "step" = one pass of the whole hot path (VCRNet.forward: LPDNet kNN-graph embedding ->
+Transformer virtual-correspondence block -> soft correspondences -> SVD rigid solve) over one batch
+of 16 synthetic pairs of N=1024 points PER GPU (BASELINE.json configs[1]; weak scaling), inputs already
+resident in HBM, plus -- for N > 1 -- the RCCL all-gather of the per-rank (R, t).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="pairs per GPU")
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="print the per-launch table to stderr")
+    return ap.parse_args()
+
+
+def model_args():
+    return SimpleNamespace(emb_dims=512, cycle=False, emb_nn="lpdnet", pointer="transformer", vcp_nn="topK",
+                           partial=False, overlap2=0.75, t3d=False, tfea=False, n_blocks=1, dropout=0.0,
+                           ff_dims=1024, n_heads=4)
+
+
+def cpu_baseline(w, B, N, k):
+    """The CPU oracle (a port of the reference's PyTorch CPU path) timed on this box's host cores on a
+    bounded sample of the same workload."""
+    import oracle
+    from vcrnet_amd import synth
+    nthreads = torch.get_num_threads()
+    sample_B = min(B, 8)
+    src, tgt, _, _, _ = synth.make_batch(0, sample_B, N)
+    s, t = torch.from_numpy(src), torch.from_numpy(tgt)
+    cfg = oracle.OracleConfig(k=k)
+    t0 = time.perf_counter()
+    oracle.vcrnet_forward(w, s, t, cfg)           # warm-up
+    warm = time.perf_counter() - t0
+    reps = 3 if warm < 8 else 1
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        oracle.vcrnet_forward(w, s, t, cfg)
+        ts.append(time.perf_counter() - t0)
+    best = float(np.median(ts))
+    return {"value": sample_B / best, "unit": "pairs/s", "cores": nthreads, "kind": "port",
+            "sample": f"oracle.vcrnet_forward, B={sample_B}, N={N}, k={k}, fp32, median of {reps} after 1 warm-up, "
+                      f"torch.set_num_threads={nthreads}"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native, shard, synth, weights, workmodel
+    from vcrnet_amd.module import VCRNet
+
+    w = weights.generate_weights(1234, lpd=weights.load_lpd_fixture())
+    net = VCRNet(model_args())
+    net.load_state_dict(w)
+    net.emb_nn.k = a.k
+    net = net.to(dev).eval()
+
+    B, N = a.batch, a.points
+    # each rank owns B consecutive items of the global batch (weak scaling); inputs live in HBM
+    src, tgt, _, _, _ = synth.make_batch(rank * B, B, N)
+    src, tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+
+    def step(trace=None):
+        with torch.no_grad():
+            out = net._forward_fused(src, tgt, trace=trace)
+        pose = torch.cat((out[2].view(B, 9), out[3]), 1)
+        if world > 1:
+            pose = shard.all_gather_poses(pose, world)
+        return pose
+
+    for _ in range(a.warmup):
+        step()
+    traces = [native.LaunchTrace() for _ in range(a.steps)]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(traces[i].trace)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-launch durations from the HIP events recorded inside the timed region
+    fam_ms, fam_flops, fam_bytes, rows = {}, {}, {}, {}
+    for tr in traces:
+        for name, ms in tr.launches():
+            fam = name.split(":")[0]
+            fl, by = workmodel.launch_work(name, B, N, a.k)
+            fam_ms[fam] = fam_ms.get(fam, 0.0) + ms
+            fam_flops[fam] = fam_flops.get(fam, 0.0) + fl
+            fam_bytes[fam] = fam_bytes.get(fam, 0.0) + by
+            r = rows.setdefault(name, [0.0, fl, by, 0])
+            r[0] += ms; r[3] += 1
+        tr.close()
+    if rank == 0:
+        dom = max(fam_ms, key=fam_ms.get)
+        bound = workmodel.FAMILY_BOUND[dom]
+        if bound == "mfma":
+            ach = fam_flops[dom] / (fam_ms[dom] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": workmodel.PEAK_MFMA_F32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / workmodel.PEAK_MFMA_F32_TFLOPS, "traffic": None}
+        else:
+            ach = fam_bytes[dom] / (fam_ms[dom] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": workmodel.PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": ach / workmodel.PEAK_HBM_GBS, "traffic": None}
+        total_ms = sum(fam_ms.values())
+        roof["launches_per_step"] = sum(r[3] for n, r in rows.items() if n.startswith(dom + ":")) // a.steps
+        roof["avg_launch_ms"] = fam_ms[dom] / max(1, roof["launches_per_step"] * a.steps)
+        stages = {f: {"ms_per_step": fam_ms[f] / a.steps, "share": fam_ms[f] / total_ms,
+                      "tflops": fam_flops[f] / (fam_ms[f] * 1e-3) / 1e12, "gbs": fam_bytes[f] / (fam_ms[f] * 1e-3) / 1e9}
+                  for f in sorted(fam_ms, key=fam_ms.get, reverse=True)}
+        if a.stages:
+            for n, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
+                ms = r[0] / r[3]
+                print(f"{n:28s} {ms:8.3f} ms  {r[1] / ms / 1e9:8.2f} TF/s  {r[2] / ms / 1e6:9.1f} GB/s", file=sys.stderr)
+        pairs = B * world * a.steps
+        line = {
+            "metric": "point-cloud pairs/sec (N=1024, batch 16 per GPU)", "value": pairs / elapsed, "unit": "pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: ModelNet40-like whole-to-whole registration, N=%d, batch=%d "
+                                   "pairs per GPU, LPDNet(k=%d)+Transformer+VcpTopK+SVD, iter=1, fp32; synthetic "
+                                   "object clouds with the reference's transform recipe; LPD-pretrained emb_nn + "
+                                   "seeded Transformer weights" % (N, B, a.k),
+                       "num_points": N, "batch_per_gpu": B, "global_batch": B * world, "k": a.k,
+                       "parallelism": f"dp{world} (pairs sharded per rank, RCCL all-gather of R,t)"},
+            "roofline": roof,
+            "stages": stages,
+            "flops_per_pair_reference": workmodel.reference_flops_per_pair(N, a.k)["total"],
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w, B, N, a.k)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,216 @@
+/*
+ * vcr_hip.h -- C-ABI of libvcr_hip.so: the MI355X (gfx950) implementation of the VCR-Net
+ * per-batch registration hot path.
+ *
+ * The reference (qiaozhijian/VCR-Net) is pure Python/PyTorch and has no FFI layer; its
+ * boundary for this path is the nn.Module protocol of VCRNet (model/vcrnet_model.py:463-518).
+ * This header is therefore the NEW native boundary underneath that protocol:
+ * one entry point per kernel family plus whole-forward drivers.  Each declaration cites the
+ * reference code whose arithmetic it replaces.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns every buffer (inputs, outputs, workspace); the library never allocates,
+ *     frees or retains pointers, never synchronises, never exits;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*);
+ *   - return 0 on success, <0 for an argument error (VCR_E*), >0 = a hipError_t from the launch;
+ *   - re-entrant: no global mutable state (safe under nn.DataParallel's thread-per-device).
+ *   - activations are fp32, point-major ("channels-last"): a [B,N,C] tensor is row-major with one
+ *     row per point and an explicit row pitch `ld*` in floats.  Indices are int32.
+ */
+#ifndef VCR_HIP_H
+#define VCR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VCR_OK 0
+#define VCR_EINVAL (-1)      /* bad shape / null pointer / unsupported size          */
+#define VCR_EWORKSPACE (-2)  /* workspace too small (see *_workspace_bytes)           */
+#define VCR_EUNSUPPORTED (-3)/* valid request this build does not implement            */
+
+typedef void* vcr_stream_t;  /* hipStream_t */
+
+const char* vcr_strerror(int code);
+int vcr_abi_version(void);   /* bumped on any signature change */
+
+/* ---- K-a: conv1_lpd + conv2_lpd (model/lpdnet_model.py:111-112), ReLU == LeakyReLU(0.0) ----
+ * x_cf  [B,3,N] channels-first input (the module's forward() argument layout)
+ * xyz4  [B,N,4]  = (x, y, z, x^2+y^2+z^2)          feat64 [B,N,64]     sq64 [B,N] = sum_c feat64^2 */
+typedef struct {
+  const float* x_cf; int B, N;
+  const float* w1; const float* b1;   /* [64,3], [64]  */
+  const float* w2; const float* b2;   /* [64,64], [64] */
+  float* xyz4; float* feat64; float* sq64;
+} vcr_pointwise_args;
+int vcr_pointwise_f32(const vcr_pointwise_args*, vcr_stream_t);
+
+/* ---- kernel 1: fused pairwise-distance + top-k (util/util.py:143-160) ----
+ * D_ij = (-sq_j + 2 x_i.x_j) - sq_i ; idx = indices of the k largest D per row after dropping
+ * rank 0 ("topk(k+1)[:, :, 1:]"), ties -> lower index first.  C == 64 (feature space, fp32 MFMA)
+ * or C == 4 (xyz4 rows; Cartesian, VALU).  k <= 40, N <= 65535. */
+typedef struct {
+  const float* x; int ldx;            /* [B,N,C] rows                                  */
+  const float* sq;                    /* [B,N] squared norms (C==64); ignored for C==4 */
+  int B, N, C, k;
+  int32_t* idx;                       /* [B,N,k], neighbour index within the cloud     */
+} vcr_knn_args;
+int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
+
+/* ---- pointwise linear / 1x1 conv: Y = act(X W^T + bias) (+ residual) ----
+ * replaces nn.Conv1d/Conv2d(kernel 1) and nn.Linear on the path (lpdnet_model.py:123-135 after the
+ * SURVEY-F7 split, transformer.py:210-212,224,237-238).  fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * K % 32 == 0. */
+typedef struct {
+  const float* x; int ldx;            /* [M,K] */
+  const float* w;                     /* [N,K] row-major (PyTorch weight layout) */
+  const float* bias;                  /* [N] or NULL */
+  const float* residual; int ldr;     /* [M,N] or NULL, added AFTER the activation */
+  float* y; int ldy;                  /* [M,N] */
+  int M, N, K;
+  int relu;
+} vcr_linear_args;
+int vcr_linear_f32(const vcr_linear_args*, vcr_stream_t);
+
+/* ---- LayerNorm of model/transformer.py:141-144: a*(x-mean)/(std_unbiased+eps)+b over C ----
+ * optional: y += residual; side4[row] = (xyz4[row].xyz, sum_c y^2) for the correspondence head. */
+typedef struct {
+  const float* x; int ldx; const float* a; const float* b; float eps;
+  const float* residual; int ldr;     /* or NULL */
+  float* y; int ldy; int M, C;        /* C == 512 */
+  const float* xyz4; float* side4;    /* both NULL, or both [M,4] */
+} vcr_layernorm_args;
+int vcr_layernorm_f32(const vcr_layernorm_args*, vcr_stream_t);
+
+/* y = scale*x (y may be NULL or == x) and side4[row] = (xyz4[row].xyz, |scale*x|^2): the head's side
+ * record when the embedding does not pass a LayerNorm (pointer None / Identity, vcrnet_model.py:477-482). */
+typedef struct {
+  const float* x; int ldx; int M, C; float scale; float* y; int ldy;
+  const float* xyz4; float* side4;
+} vcr_rowside_args;
+int vcr_rowside_f32(const vcr_rowside_args*, vcr_stream_t);
+
+/* ---- kernel 2a: EdgeConv convDG1 -> max -> convDG2 -> max (lpdnet_model.py:122-126, util.py:176-199)
+ * pq [M,2*Cmid]: P = X Wn^T (cols 0..Cmid-1), Q = X Wc^T + b (cols Cmid..), from vcr_linear_f32.
+ * h_ij = relu(P[nbr_ij] + Q[i]);  x1[i] = max_j h_ij;  x2[i] = relu(max_j (W2 h_ij) + b2).
+ * Cmid == Cout == 128.  idx [M,k] cloud-local; n_per_cloud = N. */
+typedef struct {
+  const float* pq; int ldpq; const int32_t* idx; int k; int M; int n_per_cloud;
+  const float* w2; const float* b2;   /* [128,128], [128] */
+  float* x1; int ldx1; float* x2; int ldx2;
+} vcr_edgeconv_args;
+int vcr_edgeconv_f32(const vcr_edgeconv_args*, vcr_stream_t);
+
+/* ---- kernel 2b: gather + max EdgeConv for a single 1x1 conv (convSN1, lpdnet_model.py:129-132)
+ * y[i] = relu(max_j P[nbr_ij] + Q[i]),  C % 4 == 0, C <= 256. */
+typedef struct {
+  const float* pq; int ldpq; int C; const int32_t* idx; int k; int M; int n_per_cloud;
+  float* y; int ldy;
+} vcr_gathermax_args;
+int vcr_gathermax_f32(const vcr_gathermax_args*, vcr_stream_t);
+
+/* ---- kernel 3: scaled-dot-product attention, flash-style (transformer.py:29-34,55) ----
+ * q,k,v: [nbatch*n, h*128] rows with pitches; head hh uses columns hh*128..+127.
+ * out = softmax(q k^T * scale) v, never materialising the n x n scores.
+ * kv_batch_shift: keys/values of batch b come from batch (b + shift) % nbatch (decoder cross-attn
+ * over the 2B-batched encoder memory).  key_keep: NULL, or uint8 [nbatch, nk] -- keys with 0 are
+ * masked out (transformer.py:46-53; exp underflows to exactly 0 for masked_fill(-1e9)).
+ * rowstat: NULL or [nbatch,h,nq,2] (max, sum) of the scaled scores -- for the partial path. */
+typedef struct {
+  const float* q; int ldq; const float* k; int ldk; const float* v; int ldv;
+  float* out; int ldo;
+  int nbatch, heads, nq, nk; float scale; int kv_batch_shift;
+  const uint8_t* key_keep; float* rowstat;
+} vcr_sdpa_args;
+int vcr_sdpa_f32(const vcr_sdpa_args*, vcr_stream_t);
+
+/* ---- virtual-correspondence head, whole mode (vcrnet_model.py:334-347, :402-421, dcp_model.py:138-142)
+ * corr[i] = sum_j softmax_j(score_ij) * kside4[j].xyz
+ * mode 0: score = (-|q_i|^2 + 2 q_i.k_j) - |k_j|^2 (VcpTopK/VcpAtt); mode 1: q_i.k_j * scale (VcpByDis/DCP).
+ * qside4/kside4 [nbatch*n,4] = (x,y,z,|emb|^2).  E % 64 == 0.  corr4 [nbatch*nq,4] (w = 0). */
+typedef struct {
+  const float* q; int ldq; const float* k; int ldk; const float* qside4; const float* kside4;
+  float* corr4; int nbatch, nq, nk, E; int mode; float scale;
+} vcr_softcorr_args;
+int vcr_softcorr_f32(const vcr_softcorr_args*, vcr_stream_t);
+
+/* ---- kernel 4: weighted-covariance + 3x3 SVD rigid solve (vcrnet_model.py:356-399) ----
+ * src/corr: [B,K,ld] rows (first 3 floats used).  R [B,9] row-major acting on column vectors,
+ * t [B,3]; R_ba = R^T, t_ba = -R^T t (vcrnet_model.py:515-516) written when non-NULL. */
+typedef struct {
+  const float* src; int lds; const float* corr; int ldc; int B, K;
+  float* R; float* t; float* R_ba; float* t_ba; float* H; /* H [B,9] optional diagnostic */
+} vcr_rigid_svd_args;
+int vcr_rigid_svd_f32(const vcr_rigid_svd_args*, vcr_stream_t);
+
+/* ---- whole forward: VCRNet.forward (vcrnet_model.py:495-518), LPDNet + Transformer + VcpTopK(whole)/
+ * VcpByDis + SVD, both clouds batched as 2B.  Weight pointers are the packed device tensors the host
+ * module prepares once; all [N,K] row-major. */
+typedef struct {
+  const float *ln_a, *ln_b;
+} vcr_norm_w;
+typedef struct {
+  const float *wqkv, *bqkv;           /* [3E,E],[3E]  linears.0,1,2 stacked (self-attention) */
+  const float *wq, *bq, *wkv, *bkv;   /* cross-attention split: [E,E],[E],[2E,E],[2E]        */
+  const float *wo, *bo;               /* linears.3 */
+} vcr_mha_w;
+typedef struct {
+  const float *w1, *b1, *w2, *b2;     /* [F,E],[F],[E,F],[E] */
+} vcr_ffn_w;
+typedef struct {
+  /* LPDNet */
+  const float *c1_w, *c1_b, *c2_w, *c2_b;          /* conv1_lpd, conv2_lpd                         */
+  const float *dg1_wpq, *dg1_bpq;                  /* [256,64]: rows 0..127 = W[:, :64] (neighbour), 128.. = W[:, 64:] (centre); bias [256] = (0, b) */
+  const float *dg2_w, *dg2_b;                      /* [128,128]                                     */
+  const float *sn1_wpq, *sn1_bpq;                  /* [512,128], [512]                              */
+  const float *c3_w, *c3_b;                        /* [E,512]                                       */
+  /* Transformer (n_blocks == 1) */
+  vcr_norm_w enc_ln0, enc_ln1, enc_norm, dec_ln0, dec_ln1, dec_ln2, dec_norm;
+  vcr_mha_w enc_self, dec_self, dec_cross;
+  vcr_ffn_w enc_ffn, dec_ffn;
+  int E, F, heads, k;                              /* 512, 1024, 4, 20 */
+  int has_pointer;                                 /* 1 transformer, 0 none, 2 identity (emb*2)     */
+  int head_mode;                                   /* 0 neg-distance (topK whole / att), 1 dot/sqrt(E) */
+} vcr_vcrnet_weights;
+
+typedef struct {
+  const float* src_cf; const float* tgt_cf;        /* [B,3,N] channels-first, as VCRNet.forward gets them */
+  int B, N;
+  float* corr4;                                    /* [B,N,4] src_corr (x,y,z,0) */
+  float* src4;                                     /* [B,N,4] src as rows (x,y,z,|p|^2) */
+  float* R_ab; float* t_ab; float* R_ba; float* t_ba;  /* [B,9],[B,3],[B,9],[B,3] */
+  float* emb_out;                                  /* optional [2B*N,E] final embeddings (src then tgt), may be NULL */
+} vcr_vcrnet_io;
+
+size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights*, int B, int N);
+int vcr_vcrnet_forward_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io*, void* workspace,
+                           size_t workspace_bytes, vcr_stream_t);
+
+/* Optional per-launch timing of the whole forward.  `events` holds `capacity` hipEvent_t handles
+ * created by the caller; event i is recorded on `stream` immediately before launch i and one more
+ * after the last launch, so launch i took elapsed(events[i], events[i+1]).  names[i] is a static
+ * string "family:site" (families: pointwise, knn, linear, edgeconv, gathermax, layernorm, sdpa,
+ * softcorr, rigid_svd, select).  count = number of launches recorded. */
+#define VCR_TRACE_MAX 128
+typedef struct {
+  void** events; int capacity; int count;
+  const char* names[VCR_TRACE_MAX];
+} vcr_trace;
+int vcr_vcrnet_forward_traced_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io*, void* workspace,
+                                  size_t workspace_bytes, vcr_stream_t, vcr_trace*);
+
+/* hipEvent helpers (create / destroy / record / elapsed) bound to the same HIP runtime as the
+ * kernels, for hosts without HIP bindings.  Elapsed needs both events completed (synchronise first). */
+int vcr_event_create(void** ev);
+int vcr_event_destroy(void* ev);
+int vcr_event_record(void* ev, vcr_stream_t stream);
+int vcr_event_elapsed_ms(void* start, void* stop, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VCR_HIP_H */

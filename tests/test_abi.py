@@ -1,0 +1,84 @@
+"""CPU-side checks of the drop-in boundary: libvcr_hip.so loads and exports every entry point
+include/vcr_hip.h declares; argument validation returns error codes without touching a GPU;
+the ctypes structs match the C layout the header implies."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vcr_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import build, native
+    build.build()
+    return native.lib()
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r"\b(vcr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/vcr_hip.h but not exported"
+
+
+def test_version_and_strerror(lib):
+    assert lib.vcr_abi_version() == 1
+    assert lib.vcr_strerror(0) == b"ok"
+    assert b"invalid" in lib.vcr_strerror(-1)
+    assert b"workspace" in lib.vcr_strerror(-2)
+
+
+def test_argument_errors_do_not_need_a_gpu(lib):
+    from vcrnet_amd import native
+    a = native.LinearArgs()          # all NULL
+    assert lib.vcr_linear_f32(ctypes.byref(a), None) == -1
+    k = native.KnnArgs()
+    assert lib.vcr_knn_f32(ctypes.byref(k), None) == -1
+    assert lib.vcr_linear_f32(None, None) == -1
+    w = native.VcrnetWeights()
+    w.E, w.F, w.heads, w.k = 512, 1024, 4, 20
+    n1 = lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 1, 1024)
+    n16 = lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 16, 1024)
+    assert 0 < n1 < n16 < (4 << 30)
+    assert lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 0, 1024) == 0
+
+
+def test_module_contract_on_cpu():
+    """Constructor / state-dict contract of the reference module without a GPU."""
+    from types import SimpleNamespace
+    import torch
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import weights
+    from vcrnet_amd.module import VCRNet
+    args = SimpleNamespace(emb_dims=512, cycle=False, emb_nn="lpdnet", pointer="transformer", vcp_nn="topK",
+                           partial=False, overlap2=0.75, t3d=False, tfea=False, n_blocks=1, dropout=0.0,
+                           ff_dims=1024, n_heads=4)
+    net = VCRNet(args)
+    keys = set(net.state_dict().keys())
+    assert keys == set(weights.param_shapes().keys())
+    assert len(keys) == 59 and sum(p.numel() for p in net.parameters()) == 5625161
+    w = weights.generate_weights(1234, lpd=weights.load_lpd_fixture())
+    net.load_state_dict({"module." + k: v for k, v in w.items()}, strict=True)   # DataParallel-saved checkpoint
+    assert torch.equal(net.emb_nn.conv3_lpd.weight, w["emb_nn.conv3_lpd.weight"])
+    # attributes util/initPara.py:38-65 touches
+    assert hasattr(net.emb_nn, "convDG1") and net.emb_nn.negative_slope == 0.0
+    assert any(isinstance(m, torch.nn.Conv2d) for m in net.emb_nn.modules())
+    assert not hasattr(net.head, "linears_emb")
+    assert net._get_name() == "VCRNet"
+    with pytest.raises(Exception):
+        VCRNet(SimpleNamespace(**{**vars(args), "emb_nn": "nope"}))
+    with pytest.raises(Exception):
+        VCRNet(SimpleNamespace(**{**vars(args), "vcp_nn": "nope"}))
+    net.eval()
+    with torch.no_grad(), pytest.raises(RuntimeError):   # no CPU fallback by design
+        net(torch.zeros(1, 3, 64), torch.zeros(1, 3, 64))

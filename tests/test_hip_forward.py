@@ -1,0 +1,131 @@
+"""End-to-end GPU parity of the drop-in VCRNet module (HIP path through the C-ABI) against
+(a) golden vectors recorded from the reference and (b) the CPU oracle on fresh seeded inputs.
+Tolerance = BASELINE.json north_star: 1e-4 on R, 1e-5 on t."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import cfg_weights, golden
+
+pytestmark = pytest.mark.gpu
+
+R_TOL, T_TOL = 1e-4, 1e-5
+
+
+def assert_mostly_close(got, ref, atol, frac=0.995, hard=2e-2):
+    """Activations / soft correspondences: a single fp32 near-tie in a neighbour set (which the
+    reference itself resolves differently between fp32 and fp64, or 1 vs 8 threads -- SURVEY F5)
+    moves a handful of points, and the 512-d negative-distance soft-max amplifies 1e-6 embedding
+    noise to ~1e-4 in src_corr.  Require `frac` of the entries within `atol` and all within `hard`;
+    the binding tolerance is the one on (R, t)."""
+    d = np.abs(np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64))
+    assert d.max() <= hard, d.max()
+    assert (d <= atol).mean() >= frac, ((d <= atol).mean(), d.max())
+
+
+def make_args(**kw):
+    a = dict(emb_dims=512, cycle=False, emb_nn="lpdnet", pointer="transformer", vcp_nn="topK", partial=False,
+             overlap2=0.75, t3d=False, tfea=False, n_blocks=1, dropout=0.0, ff_dims=1024, n_heads=4)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def build_net(**kw):
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd.module import VCRNet
+    net = VCRNet(make_args(**kw))
+    wkw = {k: kw[k] for k in ("emb_nn", "vcp_nn", "pointer") if k in kw}
+    w = cfg_weights(**wkw)
+    missing = net.load_state_dict(w, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return net.cuda().eval(), w
+
+
+@pytest.mark.parametrize("name", ["whole_n256_b2", "whole_n1024_b2", "whole_k40_n512_b1"])
+def test_whole_vs_reference_golden(name):
+    g = golden(name)
+    net, _ = build_net()
+    net.emb_nn.k = int(g["k"])
+    src, tgt = torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda()
+    with torch.no_grad():
+        srcK, corrK, R, t, R_ba, t_ba, emb = net._forward_fused(src, tgt, want_emb=True)
+        out = net(src, tgt)
+    assert out[0] is src
+    cs = int(g["cstride"])
+    B, N = src.shape[0], src.shape[2]
+    e = emb.cpu().view(2, B, N, 512)
+    assert_mostly_close(e[0].transpose(1, 2)[:, ::cs].numpy(), g["it0_femb_src"], atol=5e-4)
+    assert_mostly_close(e[1].transpose(1, 2)[:, ::cs].numpy(), g["it0_femb_tgt"], atol=5e-4)
+    assert_mostly_close(corrK.cpu().numpy(), g["it0_corrK"], atol=5e-4)
+    np.testing.assert_allclose(R.cpu().numpy(), g["it0_R"], atol=R_TOL)
+    np.testing.assert_allclose(t.cpu().numpy(), g["it0_t"], atol=T_TOL)
+    np.testing.assert_allclose(R_ba.cpu().numpy(), g["it0_R_ba"], atol=R_TOL)
+    np.testing.assert_allclose(t_ba.cpu().numpy(), g["it0_t_ba"], atol=T_TOL)
+    np.testing.assert_allclose(out[2].cpu().numpy(), R.cpu().numpy(), atol=0)
+
+
+@pytest.mark.parametrize("B,N,kind", [(4, 1024, "object"), (3, 320, "object"), (2, 2048, "uniform")])
+def test_whole_vs_oracle(B, N, kind):
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    net, w = build_net()
+    src, tgt, _, _, _ = synth.make_batch(200, B, N, kind=kind)
+    src_t, tgt_t = torch.from_numpy(src), torch.from_numpy(tgt)
+    ref = oracle.vcrnet_forward(w, src_t, tgt_t, oracle.OracleConfig())
+    with torch.no_grad():
+        out = net(src_t.cuda(), tgt_t.cuda())
+    assert_mostly_close(out[1].cpu().numpy(), ref[1].numpy(), atol=5e-4)
+    np.testing.assert_allclose(out[2].cpu().numpy(), ref[2].numpy(), atol=R_TOL)
+    np.testing.assert_allclose(out[3].cpu().numpy(), ref[3].numpy(), atol=T_TOL)
+
+
+@pytest.mark.parametrize("name,kw", [("dist_n256_b2", dict(vcp_nn="dist")), ("identity_n256_b2", dict(pointer="identity"))])
+def test_fused_variants_vs_golden(name, kw):
+    g = golden(name)
+    net, _ = build_net(**kw)
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda())
+    assert_mostly_close(out[1].cpu().numpy(), g["it0_corrK"], atol=5e-4)
+    np.testing.assert_allclose(out[2].cpu().numpy(), g["it0_R"], atol=R_TOL)
+    np.testing.assert_allclose(out[3].cpu().numpy(), g["it0_t"], atol=T_TOL)
+
+
+def test_permutation_invariance_and_inverse_pose():
+    """SURVEY section 4 properties: (R,t) invariant to the point order of tgt; R_ba = R^T, t_ba = -R^T t."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    net, _ = build_net()
+    src, tgt, _, _, _ = synth.make_batch(300, 2, 512)
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    perm = torch.randperm(512, generator=torch.Generator().manual_seed(0)).cuda()
+    with torch.no_grad():
+        a = net(s, t)
+        b = net(s, t[:, :, perm])
+    np.testing.assert_allclose(a[2].cpu().numpy(), b[2].cpu().numpy(), atol=R_TOL)
+    np.testing.assert_allclose(a[3].cpu().numpy(), b[3].cpu().numpy(), atol=T_TOL)
+    R, tt = a[2].cpu(), a[3].cpu()
+    np.testing.assert_allclose(a[4].cpu().numpy(), R.transpose(1, 2).numpy(), atol=1e-6)
+    np.testing.assert_allclose(a[5].cpu().numpy(), -torch.matmul(R.transpose(1, 2), tt.unsqueeze(2)).squeeze(2).numpy(), atol=1e-6)
+    assert torch.allclose(torch.det(R), torch.ones(2), atol=1e-5)
+
+
+def test_cpu_input_fails_loudly():
+    net, _ = build_net()
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 64), torch.zeros(1, 3, 64))
+
+
+def test_iter_wrapper_whole():
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    from vcrnet_amd.module import vcrnetIter
+    net, w = build_net()
+    src, tgt, _, _, _ = synth.make_batch(400, 2, 256)
+    ref = oracle.vcrnet_iter(w, torch.from_numpy(src), torch.from_numpy(tgt), oracle.OracleConfig(), iters=2)
+    with torch.no_grad():
+        out = vcrnetIter(net, torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), iter=2)
+    np.testing.assert_allclose(out[2].cpu().numpy(), ref[2].numpy(), atol=R_TOL)
+    np.testing.assert_allclose(out[3].cpu().numpy(), ref[3].numpy(), atol=2 * T_TOL)

@@ -1,0 +1,238 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle on the same seeded inputs (-m gpu).
+Integer outputs (neighbour sets) must match exactly up to fp32 near-ties adjudicated in fp64;
+floating-point outputs within the tolerance written next to each assert."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from helpers import cfg_weights, golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native
+    native.lib()
+    return native
+
+
+@pytest.fixture(scope="module")
+def W():
+    return cfg_weights()
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def knn_sets_ok(x_cf, idx_gpu, k, tol_rel=2e-6):
+    """x_cf [B,C,N] cpu; idx_gpu [B,N,k].  Exact set match vs the oracle, except rows where fp32
+    near-ties at the k-th place make the choice ambiguous (checked against fp64 distances)."""
+    ref = oracle.knn_indices(x_cf, k).numpy()
+    got = idx_gpu.cpu().numpy().astype(np.int64)
+    a, b = np.sort(got, -1), np.sort(ref, -1)
+    bad = np.argwhere((a != b).any(-1))
+    d64 = oracle.neg_sqdist_knn(x_cf.double()).numpy()
+    scale = np.abs(d64).max()
+    for bi, i in bad:
+        row = d64[bi, i]
+        order = np.sort(row)[::-1]
+        kth = order[k]                       # value of the last kept rank (rank 0 dropped -> ranks 1..k)
+        top = order[0]
+        for j in set(got[bi, i]) ^ set(ref[bi, i]):
+            # every disputed index must sit within rounding of the k-th value, or of rank 0 (the dropped one)
+            assert abs(row[j] - kth) <= tol_rel * scale or abs(row[j] - top) <= tol_rel * scale, (bi, i, j)
+    assert all(len(set(r)) == k for r in got.reshape(-1, k)), "duplicate neighbour"
+    return len(bad)
+
+
+def test_pointwise(nat, W):
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(3, 3, 200, generator=g) * 2 - 1
+    xyz4, f64, sq = nat.pointwise(dev(x), dev(W["emb_nn.conv1_lpd.weight"].view(64, 3)), dev(W["emb_nn.conv1_lpd.bias"]),
+                                  dev(W["emb_nn.conv2_lpd.weight"].view(64, 64)), dev(W["emb_nn.conv2_lpd.bias"]))
+    h = F.relu(F.conv1d(x, W["emb_nn.conv1_lpd.weight"], W["emb_nn.conv1_lpd.bias"]))
+    h = F.relu(F.conv1d(h, W["emb_nn.conv2_lpd.weight"], W["emb_nn.conv2_lpd.bias"]))
+    torch.testing.assert_close(f64.cpu(), h.transpose(1, 2), atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(sq.cpu(), (h ** 2).sum(1), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(xyz4.cpu()[..., :3], x.transpose(1, 2), atol=0, rtol=0)
+    torch.testing.assert_close(xyz4.cpu()[..., 3], (x ** 2).sum(1), atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("N,k", [(256, 20), (1024, 20), (192, 20), (100, 20), (512, 40), (64, 5)])
+def test_knn_feature_space(nat, W, N, k):
+    g = golden("whole_n1024_b2")
+    rs = np.random.RandomState(N + k)
+    x3 = torch.from_numpy(g["src"][:, :, rs.permutation(1024)[:N]])
+    h = F.relu(F.conv1d(x3, W["emb_nn.conv1_lpd.weight"], W["emb_nn.conv1_lpd.bias"]))
+    h = F.relu(F.conv1d(h, W["emb_nn.conv2_lpd.weight"], W["emb_nn.conv2_lpd.bias"]))
+    feat = dev(h.transpose(1, 2))
+    sq = dev((h ** 2).sum(1))
+    idx = nat.knn(feat, sq, k)
+    nbad = knn_sets_ok(h, idx, k)
+    assert nbad <= max(2, h.shape[0] * N // 100)
+
+
+@pytest.mark.parametrize("N,k", [(256, 20), (1024, 20), (768, 20), (100, 20), (512, 40), (2048, 20)])
+def test_knn_cartesian(nat, N, k):
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    src = torch.from_numpy(synth.make_batch(3, 2, N)[0])
+    xyz4 = torch.cat((src.transpose(1, 2), (src ** 2).sum(1).unsqueeze(-1)), -1)
+    idx = nat.knn(dev(xyz4), None, k)
+    nbad = knn_sets_ok(src, idx, k)
+    assert nbad <= max(2, 2 * N // 100)
+
+
+def test_knn_duplicates_drop_rank0(nat):
+    """Duplicate points: 'drop rank 0' keeps the OTHER copy as a neighbour (util.py:159 semantics)."""
+    rs = np.random.RandomState(5)
+    p = rs.uniform(-1, 1, (1, 3, 64)).astype(np.float32)
+    p[0, :, 1] = p[0, :, 0]
+    src = torch.from_numpy(p)
+    xyz4 = torch.cat((src.transpose(1, 2), (src ** 2).sum(1).unsqueeze(-1)), -1)
+    idx = nat.knn(dev(xyz4), None, 4).cpu().numpy()
+    assert (1 in idx[0, 0]) != (0 in idx[0, 0])   # exactly one of the twin copies survives for point 0
+    assert (1 in idx[0, 1]) != (0 in idx[0, 1])
+
+
+@pytest.mark.parametrize("M,N,K,relu,res", [(300, 200, 64, True, False), (1024, 512, 512, False, True),
+                                            (257, 1536, 128, False, False), (128, 64, 1024, True, True)])
+def test_linear(nat, M, N, K, relu, res):
+    g = torch.Generator().manual_seed(M + N + K)
+    xw = torch.randn(M, K + 32, generator=g)
+    x = xw[:, :K]                                            # strided rows (ldx > K)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    xd = dev(xw)[:, :K]
+    y = nat.linear(xd, dev(w), dev(b), relu=relu, residual=dev(r) if res else None)
+    ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    if res:
+        ref = ref + r.double()
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err <= 4e-6 * math.sqrt(K) + 1e-6, err            # fp32 fma-chain error ~ eps * sqrt(K) * |a.b|
+
+
+def test_layernorm(nat):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1000, 512, generator=g) * 3 + 0.5
+    a, b = torch.rand(512, generator=g) + 0.5, torch.randn(512, generator=g)
+    r = torch.randn(1000, 512, generator=g)
+    xyz4 = torch.randn(1000, 4, generator=g)
+    y = nat.layernorm(dev(x), dev(a), dev(b))
+    ref = oracle.layer_norm(x, a, b)
+    torch.testing.assert_close(y.cpu(), ref, atol=5e-6, rtol=1e-5)
+    y2, side = nat.layernorm(dev(x), dev(a), dev(b), residual=dev(r), xyz4=dev(xyz4))
+    torch.testing.assert_close(y2.cpu(), ref + r, atol=5e-6, rtol=1e-5)
+    torch.testing.assert_close(side.cpu()[:, :3], xyz4[:, :3], atol=0, rtol=0)
+    torch.testing.assert_close(side.cpu()[:, 3], ((ref + r) ** 2).sum(-1), atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("N,k", [(256, 20), (512, 40), (96, 7)])
+def test_edgeconv_and_gathermax(nat, W, N, k):
+    g = torch.Generator().manual_seed(N)
+    B = 2
+    x = torch.randn(B, 64, N, generator=g).abs()
+    idx = oracle.knn_indices(x, k)
+    act = lambda t: F.leaky_relu(t, 0.0)
+    gf = oracle.graph_feature(x, idx)
+    h1 = act(F.conv2d(gf, W["emb_nn.convDG1.0.weight"], W["emb_nn.convDG1.0.bias"]))
+    x1 = h1.max(-1)[0]
+    x2 = act(F.conv2d(h1, W["emb_nn.convDG2.0.weight"], W["emb_nn.convDG2.0.bias"])).max(-1)[0]
+    w1 = W["emb_nn.convDG1.0.weight"].view(128, 128)
+    wpq = torch.cat((w1[:, :64], w1[:, 64:]), 0)
+    bpq = torch.cat((torch.zeros(128), W["emb_nn.convDG1.0.bias"]))
+    rows = dev(x.transpose(1, 2).reshape(B * N, 64))
+    pq = nat.linear(rows, dev(wpq), dev(bpq))
+    gx1, gx2 = nat.edgeconv(pq, dev(idx.int().reshape(B * N, k)), N, dev(W["emb_nn.convDG2.0.weight"].view(128, 128)),
+                            dev(W["emb_nn.convDG2.0.bias"]))
+    torch.testing.assert_close(gx1.cpu().view(B, N, 128), x1.transpose(1, 2), atol=3e-6, rtol=1e-5)
+    torch.testing.assert_close(gx2.cpu().view(B, N, 128), x2.transpose(1, 2), atol=3e-6, rtol=1e-5)
+    # SN1-style single conv: gather + max
+    gf3 = oracle.graph_feature(x2, idx)
+    x3 = act(F.conv2d(gf3, W["emb_nn.convSN1.0.weight"], W["emb_nn.convSN1.0.bias"])).max(-1)[0]
+    w3 = W["emb_nn.convSN1.0.weight"].view(256, 256)
+    pq3 = nat.linear(dev(x2.transpose(1, 2).reshape(B * N, 128)), dev(torch.cat((w3[:, :128], w3[:, 128:]), 0)),
+                     dev(torch.cat((torch.zeros(256), W["emb_nn.convSN1.0.bias"]))))
+    gx3 = nat.gathermax(pq3, 256, dev(idx.int().reshape(B * N, k)), N)
+    torch.testing.assert_close(gx3.cpu().view(B, N, 256), x3.transpose(1, 2), atol=3e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("N,shift", [(256, 0), (192, 0), (1024, 2), (100, 1)])
+def test_sdpa(nat, N, shift):
+    g = torch.Generator().manual_seed(N)
+    nb, h = 4, 4
+    q, k, v = (torch.randn(nb, N, h * 128, generator=g) for _ in range(3))
+    kk, vv = torch.roll(k, -shift, 0), torch.roll(v, -shift, 0)          # batch b uses kv of (b + shift) % nb
+    split = lambda t: t.view(nb, N, h, 128).transpose(1, 2)
+    ref = oracle.attention(split(q) * 2, split(kk) * 2, split(vv)).transpose(1, 2).reshape(nb * N, h * 128)
+    qkv = dev(torch.cat((q * 2, k * 2, v), -1).view(nb * N, 3 * h * 128))   # fused-QKV row layout, pitch 1536
+    out = nat.sdpa(qkv[:, :512], qkv[:, 512:1024], qkv[:, 1024:], nb, h, N, N, 1 / math.sqrt(128), kv_batch_shift=shift)
+    torch.testing.assert_close(out.cpu(), ref, atol=5e-6, rtol=1e-5)
+
+
+def test_sdpa_masked_and_rowstat(nat):
+    g = torch.Generator().manual_seed(9)
+    nb, h, N = 2, 4, 160
+    q, k, v = (torch.randn(nb, N, h * 128, generator=g) for _ in range(3))
+    keep = torch.rand(nb, N, generator=g) < 0.7
+    split = lambda t: t.view(nb, N, h, 128).transpose(1, 2)
+    s = torch.matmul(split(q), split(k).transpose(-2, -1)) / math.sqrt(128)
+    p = torch.softmax(s.masked_fill(~keep.view(nb, 1, 1, N), -1e9), -1)
+    ref = torch.matmul(p, split(v)).transpose(1, 2).reshape(nb * N, h * 128)
+    out, rs = nat.sdpa(dev(q.view(nb * N, -1)), dev(k.view(nb * N, -1)), dev(v.view(nb * N, -1)), nb, h, N, N,
+                       1 / math.sqrt(128), key_keep=dev(keep.to(torch.uint8)), want_rowstat=True)
+    torch.testing.assert_close(out.cpu(), ref, atol=5e-6, rtol=1e-5)
+    sm = s.masked_fill(~keep.view(nb, 1, 1, N), float("-inf"))
+    torch.testing.assert_close(rs.cpu()[..., 0], sm.max(-1)[0], atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(rs.cpu()[..., 1], torch.exp(sm - sm.max(-1, keepdim=True)[0]).sum(-1), atol=1e-4, rtol=1e-5)
+    # statistics-only launch (no V, no output)
+    _, rs2 = nat.sdpa(dev(q.view(nb * N, -1)), dev(k.view(nb * N, -1)), None, nb, h, N, N, 1 / math.sqrt(128),
+                      want_rowstat=True, pv=False)
+    s0 = s
+    torch.testing.assert_close(rs2.cpu()[..., 0], s0.max(-1)[0], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("N,mode", [(256, 0), (200, 0), (1024, 0), (256, 1)])
+def test_softcorr(nat, N, mode):
+    g = torch.Generator().manual_seed(N + mode)
+    B, E = 2, 512
+    se = torch.randn(B, E, N, generator=g) * 0.3
+    te = se[:, :, torch.randperm(N, generator=g)] + 0.05 * torch.randn(B, E, N, generator=g)
+    src, tgt = torch.rand(B, 3, N, generator=g), torch.rand(B, 3, N, generator=g)
+    ref = (oracle.head_topk_whole(se, te, src, tgt) if mode == 0 else oracle.head_by_dis(se, te, src, tgt))[1]
+    side = lambda e, p: dev(torch.cat((p.transpose(1, 2), (e ** 2).sum(1).unsqueeze(-1)), -1).reshape(B * N, 4))
+    corr4 = nat.softcorr(dev(se.transpose(1, 2).reshape(B * N, E)), dev(te.transpose(1, 2).reshape(B * N, E)),
+                         side(se, src), side(te, tgt), B, N, N, mode=mode, scale=1 / math.sqrt(E))
+    torch.testing.assert_close(corr4.cpu().view(B, N, 4)[..., :3], ref.transpose(1, 2), atol=3e-6, rtol=1e-5)
+
+
+def test_rigid_svd(nat):
+    rs = np.random.RandomState(0)
+    B, K = 6, 300
+    src = torch.from_numpy(rs.uniform(-1, 1, (B, 3, K)).astype(np.float32))
+    corr = torch.from_numpy(rs.uniform(-1, 1, (B, 3, K)).astype(np.float32)) * 0.3
+    ang = rs.uniform(0, 1, B)
+    for i in range(B):   # mostly rigid pairs with noise; sample 4 is a mirrored cloud (reflection branch)
+        c, s = np.cos(ang[i]), np.sin(ang[i])
+        Rz = torch.tensor([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=torch.float32)
+        corr[i] = 0.05 * corr[i] + Rz @ src[i] + torch.tensor([0.1, 0.2, -0.3]).view(3, 1)
+    corr[4] = torch.diag(torch.tensor([1.0, 1.0, -1.0])) @ src[4]
+    cfg = oracle.OracleConfig(record={})
+    Rr, tr = oracle.rigid_svd(src, corr, cfg)
+    R, t, Rb, tb, H = nat.rigid_svd(dev(src.transpose(1, 2)), dev(corr.transpose(1, 2)), want_h=True)
+    torch.testing.assert_close(H.cpu(), cfg.record["H"], atol=2e-4, rtol=1e-5)
+    torch.testing.assert_close(R.cpu(), Rr, atol=1e-5, rtol=0)          # BASELINE tolerance is 1e-4
+    torch.testing.assert_close(t.cpu(), tr, atol=1e-5, rtol=0)
+    assert torch.allclose(torch.det(R.cpu()), torch.ones(B), atol=1e-5)
+    torch.testing.assert_close(Rb.cpu(), Rr.transpose(1, 2), atol=1e-5, rtol=0)
+    torch.testing.assert_close(tb.cpu(), -torch.matmul(Rr.transpose(1, 2), tr.unsqueeze(2)).squeeze(2), atol=1e-5, rtol=0)

@@ -1,0 +1,103 @@
+"""Kernel-by-kernel forward for the module variants the single fused C entry point does not cover
+(DGCNN embedding, partial-overlap mode, VcpAtt head, cycle consistency) and for stage-level parity
+debugging.  Every arithmetic step is a libvcr_hip.so kernel; torch only allocates and slices."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import native
+
+
+def _sd(net) -> Dict[str, torch.Tensor]:
+    return {k: v.detach().float().contiguous() for k, v in net.state_dict().items()}
+
+
+def lpdnet_embed(net, x_cf: torch.Tensor, rec: Optional[dict] = None):
+    """LPDNet.forward (model/lpdnet_model.py:103-137) on [Bc,3,N] -> rows [Bc*N, E], xyz4 [Bc*N,4]."""
+    P = net._packed
+    Bc, _, N = x_cf.shape
+    k = int(net.emb_nn.k)
+    xyz4, f64, sq = native.pointwise(x_cf, P["c1_w"], P["c1_b"], P["c2_w"], P["c2_b"])
+    idx1 = native.knn(f64, sq, k)
+    M = Bc * N
+    pq1 = native.linear(f64.view(M, 64), P["dg1_wpq"], P["dg1_bpq"])
+    cat = torch.empty(M, 512, dtype=torch.float32, device=x_cf.device)
+    x1, x2 = native.edgeconv(pq1, idx1.view(M, k), N, P["dg2_w"], P["dg2_b"])
+    idx3 = native.knn(xyz4, None, k)
+    pq3 = native.linear(x2, P["sn1_wpq"], P["sn1_bpq"])
+    x3 = native.gathermax(pq3, 256, idx3.view(M, k), N)
+    cat[:, :128], cat[:, 128:256], cat[:, 256:] = x1, x2, x3
+    emb = native.linear(cat, P["c3_w"], P["c3_b"], relu=True)
+    if rec is not None:
+        rec.update(x64=f64, idx_feat=idx1, idx_xyz=idx3, x1=x1, x2=x2, x3=x3, emb0=emb, xyz4=xyz4)
+    return emb, xyz4.view(M, 4)
+
+
+def transformer(net, emb: torch.Tensor, B: int, N: int, rec: Optional[dict] = None,
+                key_keep_fn=None) -> torch.Tensor:
+    """Both directions of model/transformer.py:264-272 on the 2B-batched rows [2B*N, E] (src then tgt).
+    Returns the decoder output rows (pointer embeddings) in the same order."""
+    P = net._packed
+    E, H = net.emb_dims, net._n_heads
+    sc = 1.0 / math.sqrt(E // H)
+    nb = 2 * B
+    ln = lambda x, f: native.layernorm(x, P[f + ".a"], P[f + ".b"])
+    y = ln(emb, "enc_ln0")
+    qkv = native.linear(y, P["enc_self.wqkv"], P["enc_self.bqkv"])
+    att = native.sdpa(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], nb, H, N, N, sc)
+    e1 = native.linear(att, P["enc_self.wo"], P["enc_self.bo"], residual=emb)
+    hid = native.linear(ln(e1, "enc_ln1"), P["enc_ffn.w_1.weight"], P["enc_ffn.w_1.bias"], relu=True)
+    e2 = native.linear(hid, P["enc_ffn.w_2.weight"], P["enc_ffn.w_2.bias"], residual=e1)
+    mem = ln(e2, "enc_norm")
+    y = ln(emb, "dec_ln0")
+    qkv = native.linear(y, P["dec_self.wqkv"], P["dec_self.bqkv"])
+    att = native.sdpa(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], nb, H, N, N, sc)
+    d1 = native.linear(att, P["dec_self.wo"], P["dec_self.bo"], residual=emb)
+    qc = native.linear(ln(d1, "dec_ln1"), P["dec_cross.wq"], P["dec_cross.bq"])
+    kvc = native.linear(mem, P["dec_cross.wkv"], P["dec_cross.bkv"])
+    keep = key_keep_fn(qc, kvc) if key_keep_fn is not None else None
+    att = native.sdpa(qc, kvc[:, :E], kvc[:, E:], nb, H, N, N, sc, kv_batch_shift=B, key_keep=keep)
+    d2 = native.linear(att, P["dec_cross.wo"], P["dec_cross.bo"], residual=d1)
+    hid = native.linear(ln(d2, "dec_ln2"), P["dec_ffn.w_1.weight"], P["dec_ffn.w_1.bias"], relu=True)
+    d3 = native.linear(hid, P["dec_ffn.w_2.weight"], P["dec_ffn.w_2.bias"], residual=d2)
+    if rec is not None:
+        rec.update(mem=mem, e1=e1, e2=e2, d1=d1, d2=d2, d3=d3)
+    return d3
+
+
+def forward_composed(net, src: torch.Tensor, tgt: torch.Tensor, rec: Optional[dict] = None):
+    """VCRNet.forward (model/vcrnet_model.py:495-518), one kernel per step."""
+    P = net._packed
+    B, _, N = src.shape
+    x = torch.cat((src, tgt), 0).contiguous().float()
+    if net._emb_kind != "lpdnet":
+        raise native.VcrHipError("emb_nn=dgcnn on the HIP path: not built yet")
+    emb, xyz4 = lpdnet_embed(net, x, rec)
+    M1 = B * N
+    if P and "dec_norm.a" in P:
+        d3 = transformer(net, emb, B, N, rec)
+        embf, side4 = native.layernorm(d3, P["dec_norm.a"], P["dec_norm.b"], residual=emb, xyz4=xyz4)
+    else:
+        from .module import _Identity
+        embf, side4 = native.rowside(emb, xyz4, 2.0 if isinstance(net.pointer, _Identity) else 1.0)
+    if rec is not None:
+        rec.update(embf=embf, side4=side4)
+    if net._partial or net._vcp == "att":
+        raise native.VcrHipError("partial / att head on the HIP path: not built yet")
+    mode = 1 if net._vcp == "dist" else 0
+    scale = 1.0 / math.sqrt(net.emb_dims)
+
+    def head_and_solve(a0, b0):
+        corr4 = native.softcorr(embf[a0:a0 + M1], embf[b0:b0 + M1], side4[a0:a0 + M1], side4[b0:b0 + M1], B, N, N,
+                                mode=mode, scale=scale)
+        R, t, Rb, tb = native.rigid_svd(xyz4[a0:a0 + M1].view(B, N, 4), corr4.view(B, N, 4))
+        return corr4, R, t, Rb, tb
+
+    corr4, R_ab, t_ab, R_ba, t_ba = head_and_solve(0, M1)
+    if net.cycle:                                                          # vcrnet_model.py:511-513
+        _, R_ba, t_ba, _, _ = head_and_solve(M1, 0)
+    src_corr = corr4.view(B, N, 4)[:, :, :3].transpose(1, 2).contiguous()
+    return src, src_corr, R_ab, t_ab, R_ba, t_ba

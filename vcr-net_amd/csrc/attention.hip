@@ -1,0 +1,295 @@
+// Kernel 3: flash-style attention on fp32 MFMA (model/transformer.py:29-34,55) and the
+// virtual-correspondence head built on the same scheme (model/vcrnet_model.py:334-347,402-421).
+// The n x n score matrix is never written to memory.
+//
+// Orientation ("swapped QK^T"): scores are computed TRANSPOSED, S^T = K Q^T, with KEYS as MFMA rows
+// and QUERIES as MFMA columns.  With v_mfma_f32_32x32x2_f32 a lane then owns one query column
+// (lanes l and l+32 split the 32 keys of a tile), so the soft-max max / sum / rescale are lane-local
+// plus one exchange with lane^32, and the accumulator P^T[key][query] is ALREADY the B operand of the
+// second product  O^T[d][query] += sum_key V^T[d][key] P^T[key][query]:  register r of lane (half, q)
+// holds key (r&3)+8(r>>2)+4*half, the A operand for that k-step is V[that key][d] -- no LDS round trip
+// and no cross-lane movement between the two MFMA chains.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int KP = 132;                                  // K/V tile row pitch (floats)
+
+struct Stage { float k[32][KP]; float v[32][KP]; };
+
+// ------------------------------------------------------------------------------------------------
+// sdpa: d_k = d_v = 128 per head.  Block = 4 waves = 128 queries of one (batch, head); K/V tiles of
+// 32 keys are staged global -> registers -> LDS (double buffered, loads issued before the MFMA block
+// and written after it) and shared by the 4 waves; Q (32 x 128 per wave) lives in 64 VGPRs.
+template <bool HAS_MASK, bool DO_PV>
+__global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Stage* st = reinterpret_cast<Stage*>(smem);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int kvb = (b + p.kv_batch_shift) % p.nbatch;
+  const int q = blockIdx.x * 128 + w * 32 + l31;
+  const int qc = min(q, p.nq - 1);
+
+  f32x4 qf[16];
+  {
+    const float* qp = p.q + ((size_t)b * p.nq + qc) * p.ldq + head * 128 + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) qf[g] = ld4(qp + 8 * g);
+  }
+  const float* kbase = p.k + (size_t)kvb * p.nk * p.ldk + head * 128;
+  const float* vbase = p.v + (size_t)kvb * p.nk * p.ldv + head * 128;
+  const int srow = t >> 5, sc4 = (t & 31) * 4;           // staging: rows srow + 8i, one 16-B chunk
+  const int ntiles = (p.nk + 31) / 32;
+
+  f32x4 rk[4], rv[4];
+  auto stage_load = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = min(tile * 32 + srow + 8 * i, p.nk - 1);
+      rk[i] = ld4(kbase + (size_t)key * p.ldk + sc4);
+      if (DO_PV) rv[i] = ld4(vbase + (size_t)key * p.ldv + sc4);
+    }
+  };
+  auto stage_write = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      st4(&st[buf].k[srow + 8 * i][sc4], rk[i]);
+      if (DO_PV) st4(&st[buf].v[srow + 8 * i][sc4], rv[i]);
+    }
+  };
+
+  f32x16 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o[d] = f32x16{0};
+  float m = VCR_NEG_INF, l = 0.f;
+
+  stage_load(0);
+  stage_write(0);
+  __syncthreads();
+  int cur = 0;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    if (tile + 1 < ntiles) stage_load(tile + 1);
+    f32x16 s = {0};
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const f32x4 kf = ld4(&st[cur].k[l31][8 * g + 4 * half]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s = mfma32(kf[e], qf[g][e], s);
+    }
+    float mt = VCR_NEG_INF;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = tile * 32 + acc_row(r, half);
+      bool ok = key < p.nk;
+      if (HAS_MASK) ok = ok && p.key_keep[(size_t)kvb * p.nk + min(key, p.nk - 1)] != 0;
+      s[r] = ok ? s[r] * p.scale : VCR_NEG_INF;
+      mt = fmaxf(mt, s[r]);
+    }
+    mt = fmaxf(mt, xhalf(mt));
+    const float m_new = fmaxf(m, mt);
+    const float mref = (m_new == VCR_NEG_INF) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f((m - mref) * LOG2E);
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f((s[r] - mref) * LOG2E);
+      ls += s[r];
+    }
+    l = l * alpha + ls;
+    m = m_new;
+    if (DO_PV) {
+      if (__any(alpha != 1.f)) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = o[d] * alpha;
+      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float vf = st[cur].v[acc_row(r, half)][32 * d + l31];
+          o[d] = mfma32(vf, s[r], o[d]);
+        }
+      }
+    }
+    if (tile + 1 < ntiles) stage_write(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  const float lt = l + xhalf(l);
+  if (p.rowstat && half == 0 && q < p.nq) {
+    float* rs = p.rowstat + (((size_t)b * p.heads + head) * p.nq + q) * 2;
+    rs[0] = m; rs[1] = lt;
+  }
+  if (DO_PV) {
+    // O^T (d rows in registers, query on the lane) -> [query][d] rows through this wave's LDS slice,
+    // then 512-B contiguous row stores.  The stage buffers are free (all waves passed the last barrier).
+    const float inv = 1.f / lt;
+    float* ot = reinterpret_cast<float*>(smem) + (size_t)w * 32 * KP;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[l31 * KP + 32 * d + acc_row(r, half)] = o[d][r] * inv;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = 2 * i + half;
+      const int qq = blockIdx.x * 128 + w * 32 + row;
+      if (qq < p.nq) {
+        const f32x4 v = ld4(&ot[row * KP + l31 * 4]);
+        st4(p.out + ((size_t)b * p.nq + qq) * p.ldo + head * 128 + l31 * 4, v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// softcorr: corr_i = sum_j softmax_j(score_ij) * xyz_j over E-wide embeddings (E = 512).
+// Block = 32 queries of one sample; their embeddings sit in LDS (66 KB) and are the B operand for all
+// four waves; wave w walks key tiles w, w+4, ... with the key embeddings streamed global -> registers
+// (double-buffered 64-wide chunks) as the A operand.  d_v = 3, so the second product is plain FMAs on
+// the lane-local probabilities, and the four waves' (m, l, o) partials are merged through LDS.
+// mode 0: score = (-|q|^2 + 2 q.k) - |k|^2 with the reference's association (vcrnet_model.py:337-342):
+//         -|q|^2/2 enters the MFMA chain as an extra k-step, so (2 dot - |q|^2) is rounded once.
+// mode 1: score = q.k * scale (vcrnet_model.py:413-414, dcp_model.py:139-140).
+__global__ __launch_bounds__(256, 2) void softcorr_kernel(vcr_softcorr_args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int QP = p.E + 4;
+  float* Qs = reinterpret_cast<float*>(smem);            // [32][QP]
+  float* mg = Qs + 32 * QP;                              // [4 waves][32 queries][5]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.y, q0 = blockIdx.x * 32;
+  const int chunks = p.E / 64;
+
+  {
+    const int per_row = p.E / 4;
+    for (int i = t; i < 32 * per_row; i += 256) {
+      const int row = i / per_row, c4 = (i % per_row) * 4;
+      const int qr = min(q0 + row, p.nq - 1);
+      st4(&Qs[row * QP + c4], ld4(p.q + ((size_t)b * p.nq + qr) * p.ldq + c4));
+    }
+  }
+  const float sq_q = p.qside4[((size_t)b * p.nq + min(q0 + l31, p.nq - 1)) * 4 + 3];
+  __syncthreads();
+
+  const int ntiles = (p.nk + 31) / 32;
+  const int my_tiles = (ntiles - w + 3) / 4;             // tiles w, w+4, ...
+  const int nflat = my_tiles * chunks;
+  const float* kb = p.k + (size_t)b * p.nk * p.ldk;
+
+  f32x4 bufA[8], bufB[8];
+  auto load_chunk = [&](int flat, f32x4* dst) {
+    const int tile = w + 4 * (flat / chunks), c = flat % chunks;
+    const int key = min(tile * 32 + l31, p.nk - 1);
+    const float* kp = kb + (size_t)key * p.ldk + 64 * c + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) dst[g] = ld4(kp + 8 * g);
+  };
+
+  float m = VCR_NEG_INF, l = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
+  f32x16 s = {0};
+  auto compute = [&](int flat, const f32x4* kf) {
+    const int tile = w + 4 * (flat / chunks), c = flat % chunks;
+    if (c == 0) s = f32x16{0};
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const f32x4 qv = ld4(&Qs[l31 * QP + 64 * c + 8 * g + 4 * half]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s = mfma32(kf[g][e], qv[e], s);
+    }
+    if (c != chunks - 1) return;
+    if (p.mode == 0) s = mfma32(half == 0 ? 1.f : 0.f, half == 0 ? -0.5f * sq_q : 0.f, s);
+    f32x4 side[16];
+    float mt = VCR_NEG_INF;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = tile * 32 + acc_row(r, half);
+      side[r] = ld4(p.kside4 + ((size_t)b * p.nk + min(key, p.nk - 1)) * 4);
+      const float sc = (p.mode == 0) ? (2.f * s[r] - side[r][3]) : s[r] * p.scale;
+      s[r] = key < p.nk ? sc : VCR_NEG_INF;
+      mt = fmaxf(mt, s[r]);
+    }
+    mt = fmaxf(mt, xhalf(mt));
+    const float m_new = fmaxf(m, mt);
+    const float alpha = __builtin_amdgcn_exp2f((m - m_new) * LOG2E);
+    float ls = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pr = __builtin_amdgcn_exp2f((s[r] - m_new) * LOG2E);
+      ls += pr;
+      ax = fmaf(pr, side[r][0], ax); ay = fmaf(pr, side[r][1], ay); az = fmaf(pr, side[r][2], az);
+    }
+    l = l * alpha + ls; ox = ox * alpha + ax; oy = oy * alpha + ay; oz = oz * alpha + az;
+    m = m_new;
+  };
+
+  if (nflat > 0) load_chunk(0, bufA);
+  for (int f = 0; f < nflat; f += 2) {                   // nflat is even (chunks = E/64 is even for E % 128 == 0)
+    if (f + 1 < nflat) load_chunk(f + 1, bufB);
+    compute(f, bufA);
+    if (f + 2 < nflat) load_chunk(f + 2, bufA);
+    if (f + 1 < nflat) compute(f + 1, bufB);
+  }
+  // halves hold disjoint keys of the same query at the same running max
+  l += xhalf(l); ox += xhalf(ox); oy += xhalf(oy); oz += xhalf(oz);
+  if (half == 0) {
+    float* g = mg + (w * 32 + l31) * 5;
+    g[0] = m; g[1] = l; g[2] = ox; g[3] = oy; g[4] = oz;
+  }
+  __syncthreads();
+  if (t < 32 && q0 + t < p.nq) {
+    float M = VCR_NEG_INF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) M = fmaxf(M, mg[(i * 32 + t) * 5]);
+    float L = 0.f, X = 0.f, Y = 0.f, Z = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* g = mg + (i * 32 + t) * 5;
+      const float a = __builtin_amdgcn_exp2f((g[0] - M) * LOG2E);   // exp2(-inf) = 0 for a wave with no tiles
+      L = fmaf(g[1], a, L); X = fmaf(g[2], a, X); Y = fmaf(g[3], a, Y); Z = fmaf(g[4], a, Z);
+    }
+    st4(p.corr4 + ((size_t)b * p.nq + q0 + t) * 4, f32x4{X / L, Y / L, Z / L, 0.f});
+  }
+}
+
+}  // namespace
+
+extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
+  if (!a || !a->q || !a->k) return VCR_EINVAL;
+  const bool pv = a->out != nullptr;
+  if (pv && !a->v) return VCR_EINVAL;
+  if (!pv && !a->rowstat) return VCR_EINVAL;
+  if (a->nbatch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return VCR_EINVAL;
+  if ((a->ldq & 3) || (a->ldk & 3) || (pv && ((a->ldv & 3) || (a->ldo & 3)))) return VCR_EINVAL;
+  if (a->ldq < a->heads * 128 || a->ldk < a->heads * 128) return VCR_EINVAL;
+  dim3 grid((a->nq + 127) / 128, a->heads, a->nbatch);
+  const int lds = 2 * sizeof(Stage);
+  hipStream_t s = (hipStream_t)stream;
+#define VCR_SDPA_LAUNCH(M, P)                                                                                         \
+  do {                                                                                                                 \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sdpa_kernel<M, P>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        lds);                                                                                          \
+    hipLaunchKernelGGL((sdpa_kernel<M, P>), grid, dim3(256), lds, s, *a);                                             \
+  } while (0)
+  if (a->key_keep) { if (pv) VCR_SDPA_LAUNCH(true, true); else VCR_SDPA_LAUNCH(true, false); }
+  else             { if (pv) VCR_SDPA_LAUNCH(false, true); else VCR_SDPA_LAUNCH(false, false); }
+#undef VCR_SDPA_LAUNCH
+  return VCR_LAUNCH_RC();
+}
+
+extern "C" int vcr_softcorr_f32(const vcr_softcorr_args* a, vcr_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->qside4 || !a->kside4 || !a->corr4) return VCR_EINVAL;
+  if (a->nbatch <= 0 || a->nq <= 0 || a->nk <= 0 || a->E <= 0 || (a->E % 128) || a->E > 1024) return VCR_EINVAL;
+  if ((a->ldq & 3) || (a->ldk & 3) || a->ldq < a->E || a->ldk < a->E) return VCR_EINVAL;
+  if (a->mode != 0 && a->mode != 1) return VCR_EINVAL;
+  const int lds = (32 * (a->E + 4) + 4 * 32 * 5) * 4;
+  if (lds > 160 * 1024) return VCR_EUNSUPPORTED;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(softcorr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  dim3 grid((a->nq + 31) / 32, a->nbatch);
+  hipLaunchKernelGGL(softcorr_kernel, grid, dim3(256), lds, (hipStream_t)stream, *a);
+  return VCR_LAUNCH_RC();
+}

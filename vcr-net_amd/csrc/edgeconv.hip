@@ -1,0 +1,156 @@
+// Kernel 2: EdgeConv on the kNN graph (model/lpdnet_model.py:122-132, util/util.py:176-199).
+//
+// The reference materialises [B, 2C, N, k] = cat(x_j, x_i) and runs 1x1 convs over it.  Because the
+// conv is 1x1, W [x_j; x_i] + b = Wn x_j + (Wc x_i + b)  (SURVEY F7), so the first conv of each
+// EdgeConv is a per-POINT linear (P = X Wn^T, Q = X Wc^T + b, done by vcr_linear_f32) followed by a
+// neighbour gather; only convDG2, which acts on the post-ReLU per-EDGE features, is a real N*k GEMM.
+//
+// edgeconv_dg_kernel (convDG1 -> max -> convDG2 -> max):
+//   per point i: H[j] = relu(P[nbr_ij] + Q[i])  (k rows of 128, padded to 32-row MFMA tiles by
+//   repeating the last neighbour, which cannot change a max);  x1[i] = max_j H[j];
+//   Y = H W2^T on v_mfma_f32_32x32x2_f32 with EDGES as MFMA rows, so the max over a point's edges is a
+//   max over accumulator registers (+ one cross-half exchange);  x2[i] = relu(max_j Y[j] + b2).
+//   A 4-wave block shares one H tile in LDS (double buffered, the next point's gather is in flight
+//   during the MFMAs); wave w owns output channels 32w..32w+31 and keeps its 32x128 slice of W2 in
+//   64 VGPRs for the whole kernel.
+// gathermax_kernel (convSN1 -> max): y[i] = relu(max_j P[nbr_ij] + Q[i]); one wave per point,
+//   whole 16-B-per-lane row loads, L2-bound.
+#include "common.h"
+
+namespace {
+
+constexpr int HP = 132;  // H row pitch in floats: 528 B -> 16-lane ds_read_b128 groups conflict-free
+
+__global__ __launch_bounds__(256, 2) void edgeconv_dg_kernel(vcr_edgeconv_args p) {
+  __shared__ __attribute__((aligned(16))) float Hs[2][32][HP];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int rs = lane >> 3, cg = lane & 7;              // build mapping: rows rs+8i, channels 32w+4cg..+3
+  const int ch = 32 * w + 4 * cg;
+
+  f32x4 wf[16];                                          // W2[32w + l31][8g + 4 half + s]
+#pragma unroll
+  for (int g = 0; g < 16; ++g) wf[g] = ld4(p.w2 + (size_t)(32 * w + l31) * 128 + 8 * g + 4 * half);
+  const float bias2 = p.b2[32 * w + l31];
+
+  // this block's work items: points blockIdx.x, +gridDim.x, ... ; each point = row_tiles consecutive items
+  const int row_tiles = (p.k + 31) / 32;
+  if ((int)blockIdx.x >= p.M) return;
+  const int my_pts = (p.M - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int n_items = my_pts * row_tiles;
+
+  f32x4 hr[4];                                           // staged rows of the item being built
+  auto gather = [&](int it) {
+    const int pt = (int)blockIdx.x + (it / row_tiles) * (int)gridDim.x, rt = it % row_tiles;
+    const int base = (pt / p.n_per_cloud) * p.n_per_cloud;
+    const f32x4 q = ld4(p.pq + (size_t)pt * p.ldpq + 128 + ch);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = min(rt * 32 + rs + 8 * i, p.k - 1);
+      const int nb = p.idx[(size_t)pt * p.k + r];
+      const f32x4 v = ld4(p.pq + (size_t)(base + nb) * p.ldpq + ch) + q;
+      hr[i] = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+    }
+  };
+  f32x4 x1m = f32x4{0.f, 0.f, 0.f, 0.f};                 // H >= 0, so 0 is the identity of this max
+  auto commit = [&](int it, int buf) {                   // registers -> LDS, and the x1 running max
+    const int pt = (int)blockIdx.x + (it / row_tiles) * (int)gridDim.x, rt = it % row_tiles;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      st4(&Hs[buf][rs + 8 * i][ch], hr[i]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) x1m[c] = fmaxf(x1m[c], hr[i][c]);
+    }
+    if (rt == row_tiles - 1) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = x1m[c];
+        v = fmaxf(v, __shfl_xor(v, 8, 64));
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        v = fmaxf(v, __shfl_xor(v, 32, 64));
+        x1m[c] = v;
+      }
+      if (rs == 0) st4(p.x1 + (size_t)pt * p.ldx1 + ch, x1m);
+      x1m = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  gather(0);
+  commit(0, 0);
+  __syncthreads();
+  int cur = 0;
+  float x2m = VCR_NEG_INF;
+  for (int item = 0; item < n_items; ++item) {
+    const int nxt = item + 1;
+    if (nxt < n_items) gather(nxt);
+    f32x16 acc = {0};
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const f32x4 af = ld4(&Hs[cur][l31][8 * g + 4 * half]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma32(af[s], wf[g][s], acc);
+    }
+    float m = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+    x2m = fmaxf(x2m, m);
+    const int pt = (int)blockIdx.x + (item / row_tiles) * (int)gridDim.x, rt = item % row_tiles;
+    if (rt == row_tiles - 1) {
+      const float v = fmaxf(x2m, xhalf(x2m));
+      if (half == 0) p.x2[(size_t)pt * p.ldx2 + 32 * w + l31] = fmaxf(v + bias2, 0.f);
+      x2m = VCR_NEG_INF;
+    }
+    if (nxt < n_items) commit(nxt, cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void gathermax_kernel(vcr_gathermax_args p) {
+  const int lane = threadIdx.x & 63;
+  const int pt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pt >= p.M) return;
+  const int c = lane * 4;
+  if (c >= p.C) return;
+  const int base = (pt / p.n_per_cloud) * p.n_per_cloud;
+  const int32_t* id = p.idx + (size_t)pt * p.k;
+  f32x4 m = ld4(p.pq + (size_t)(base + id[0]) * p.ldpq + c);
+  int j = 1;
+  for (; j + 3 < p.k; j += 4) {
+    const f32x4 a0 = ld4(p.pq + (size_t)(base + id[j]) * p.ldpq + c);
+    const f32x4 a1 = ld4(p.pq + (size_t)(base + id[j + 1]) * p.ldpq + c);
+    const f32x4 a2 = ld4(p.pq + (size_t)(base + id[j + 2]) * p.ldpq + c);
+    const f32x4 a3 = ld4(p.pq + (size_t)(base + id[j + 3]) * p.ldpq + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = fmaxf(fmaxf(fmaxf(m[i], a0[i]), fmaxf(a1[i], a2[i])), a3[i]);
+  }
+  for (; j < p.k; ++j) {
+    const f32x4 a0 = ld4(p.pq + (size_t)(base + id[j]) * p.ldpq + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], a0[i]);
+  }
+  const f32x4 q = ld4(p.pq + (size_t)pt * p.ldpq + p.C + c);
+  f32x4 y;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) y[i] = fmaxf(m[i] + q[i], 0.f);
+  st4(p.y + (size_t)pt * p.ldy + c, y);
+}
+
+}  // namespace
+
+extern "C" int vcr_edgeconv_f32(const vcr_edgeconv_args* a, vcr_stream_t stream) {
+  if (!a || !a->pq || !a->idx || !a->w2 || !a->b2 || !a->x1 || !a->x2) return VCR_EINVAL;
+  if (a->M <= 0 || a->k <= 0 || a->k > 64 || a->n_per_cloud <= 0 || (a->M % a->n_per_cloud)) return VCR_EINVAL;
+  if (a->ldpq < 256 || (a->ldpq & 3) || (a->ldx1 & 3) || a->ldx1 < 128 || a->ldx2 < 128) return VCR_EINVAL;
+  const int grid = a->M < 2048 ? a->M : 2048;
+  hipLaunchKernelGGL(edgeconv_dg_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+  return VCR_LAUNCH_RC();
+}
+
+extern "C" int vcr_gathermax_f32(const vcr_gathermax_args* a, vcr_stream_t stream) {
+  if (!a || !a->pq || !a->idx || !a->y) return VCR_EINVAL;
+  if (a->M <= 0 || a->k <= 0 || a->C <= 0 || a->C > 256 || (a->C & 3)) return VCR_EINVAL;
+  if (a->n_per_cloud <= 0 || (a->M % a->n_per_cloud) || a->ldpq < 2 * a->C || (a->ldpq & 3) || (a->ldy & 3)) return VCR_EINVAL;
+  hipLaunchKernelGGL(gathermax_kernel, dim3((a->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
+  return VCR_LAUNCH_RC();
+}

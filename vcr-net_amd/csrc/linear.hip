@@ -1,0 +1,124 @@
+// Pointwise linear / 1x1 convolution on fp32 MFMA:  Y = act(X W^T + bias) (+ residual).
+// Replaces nn.Conv1d/Conv2d(k=1)/nn.Linear on the path (model/lpdnet_model.py:123-135 after the F7
+// split, model/transformer.py:210-212,224,237-238).
+//
+// 128x128x32 block tile, 4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x2_f32 tiles.
+// Both operands are K-contiguous ([M,K] and [N,K]), so the LDS image of each is [rows][32+4 pad]
+// and a lane fetches its fragment as ONE ds_read_b128 = 4 consecutive k, fed to 4 successive
+// MFMAs; the k order inside the instruction's (lane-half, step) grid is permuted the same way on A
+// and B (k = 8g + 4*half + s), which a sum over k does not care about.  Pitch 36 floats (144 B)
+// makes the 16-lane b128 groups conflict-free.  Register-staged double buffering: the next
+// K-slab's global loads are issued before the MFMA block and written to the other LDS buffer after it.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, PITCH = BK + 4;
+
+struct Tile { float a[BM][PITCH]; float b[BN][PITCH]; };
+
+__global__ __launch_bounds__(256, 2) void linear_kernel(vcr_linear_args p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Tile* tile = reinterpret_cast<Tile*>(smem);           // [2]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware mapping: consecutive block ids land on different XCDs (round robin), so give every
+  // XCD a contiguous run of tiles; tiles that share an X panel (same tm) then share an L2.
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, i = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // global -> register staging: thread owns 4 rows (r0 + 32 i) x one 16-B column chunk of each operand
+  const int r0 = t >> 3, c4 = (t & 7) * 4;
+  const float* xa[4];
+  const float* wb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xa[i] = p.x + (size_t)min(m0 + r0 + 32 * i, p.M - 1) * p.ldx + c4;
+    wb[i] = p.w + (size_t)min(n0 + r0 + 32 * i, p.N - 1) * p.K + c4;
+  }
+  f32x4 ra[4], rb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ra[i] = ld4(xa[i]); rb[i] = ld4(wb[i]); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { st4(&tile[0].a[r0 + 32 * i][c4], ra[i]); st4(&tile[0].b[r0 + 32 * i][c4], rb[i]); }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
+
+  const int nk = p.K / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ra[i] = ld4(xa[i] + (kt + 1) * BK); rb[i] = ld4(wb[i] + (kt + 1) * BK); }
+    }
+    const Tile& T = tile[cur];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = ld4(&T.a[wm * 64 + i * 32 + l31][8 * g + 4 * half]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = ld4(&T.b[wn * 64 + j * 32 + l31][8 * g + 4 * half]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i][s], fb[j][s], acc[i][j]);
+    }
+    if (kt + 1 < nk) {
+      Tile& Nx = tile[cur ^ 1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { st4(&Nx.a[r0 + 32 * i][c4], ra[i]); st4(&Nx.b[r0 + 32 * i][c4], rb[i]); }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: D[row = (r&3)+8(r>>2)+4 half][col = l31]; a half-wave writes 128 contiguous bytes per row
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + l31;
+    if (col >= p.N) continue;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + acc_row(r, half);
+        if (row < p.M) {
+          float v = acc[i][j][r] + bias;
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (p.residual) v += p.residual[(size_t)row * p.ldr + col];
+          p.y[(size_t)row * p.ldy + col] = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
+  if (!a || !a->x || !a->w || !a->y) return VCR_EINVAL;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0) return VCR_EINVAL;
+  if ((a->ldx & 3) || a->ldx < a->K || a->ldy < a->N || (a->residual && a->ldr < a->N)) return VCR_EINVAL;
+  if (((uintptr_t)a->x | (uintptr_t)a->w) & 15) return VCR_EINVAL;
+  const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
+  static const int lds = 2 * sizeof(Tile);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(linear_kernel, dim3(tiles_m * tiles_n), dim3(256), lds, (hipStream_t)stream, *a, tiles_m, tiles_n);
+  return VCR_LAUNCH_RC();
+}

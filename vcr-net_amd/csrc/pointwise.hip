@@ -1,0 +1,78 @@
+// K-a: conv1_lpd (3->64) + ReLU + conv2_lpd (64->64) + ReLU  (model/lpdnet_model.py:111-112)
+// plus the side products the later kernels need: xyz4 rows and squared feature norms.
+// 0.009 GF per cloud: VALU, one launch, weights staged once per block in LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int PTS = 64;  // points per 256-thread block; 4 threads per point, 16 channels each
+
+__global__ __launch_bounds__(256) void pointwise12_kernel(vcr_pointwise_args a) {
+  __shared__ float w2t[64][64];       // [k][c]
+  __shared__ float h1s[PTS][65];
+  __shared__ float w1s[64][4];        // (w0,w1,w2,b1)
+  __shared__ float b2s[64];
+  const int t = threadIdx.x;
+  for (int i = t; i < 64 * 64; i += 256) w2t[i & 63][i >> 6] = a.w2[i];   // w2[c][k] -> [k][c]
+  if (t < 64) {
+    w1s[t][0] = a.w1[t * 3 + 0]; w1s[t][1] = a.w1[t * 3 + 1]; w1s[t][2] = a.w1[t * 3 + 2];
+    w1s[t][3] = a.b1[t]; b2s[t] = a.b2[t];
+  }
+  const int b = blockIdx.y;
+  const int p = t >> 2, g = t & 3;
+  const int n = blockIdx.x * PTS + p;
+  const bool live = n < a.N;
+  const int nc = live ? n : a.N - 1;
+  const float* xb = a.x_cf + (size_t)b * 3 * a.N;
+  const float x = xb[nc], y = xb[a.N + nc], z = xb[2 * a.N + nc];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = g * 16 + j;
+    float v = fmaf(w1s[c][2], z, fmaf(w1s[c][1], y, w1s[c][0] * x)) + w1s[c][3];
+    h1s[p][c] = fmaxf(v, 0.f);
+  }
+  __syncthreads();
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int k = 0; k < 64; ++k) {
+    const float h = h1s[p][k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 w = ld4(&w2t[k][g * 16 + q * 4]);
+      acc[q * 4 + 0] = fmaf(w[0], h, acc[q * 4 + 0]);
+      acc[q * 4 + 1] = fmaf(w[1], h, acc[q * 4 + 1]);
+      acc[q * 4 + 2] = fmaf(w[2], h, acc[q * 4 + 2]);
+      acc[q * 4 + 3] = fmaf(w[3], h, acc[q * 4 + 3]);
+    }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    acc[j] = fmaxf(acc[j] + b2s[g * 16 + j], 0.f);
+    ss = fmaf(acc[j], acc[j], ss);
+  }
+  ss += __shfl_xor(ss, 1, 64);
+  ss += __shfl_xor(ss, 2, 64);
+  if (live) {
+    const size_t row = (size_t)b * a.N + n;
+    float* o = a.feat64 + row * 64 + g * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st4(o + q * 4, f32x4{acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]});
+    if (g == 0) {
+      a.sq64[row] = ss;
+      st4(a.xyz4 + row * 4, f32x4{x, y, z, fmaf(z, z, fmaf(y, y, x * x))});
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vcr_pointwise_f32(const vcr_pointwise_args* a, vcr_stream_t stream) {
+  if (!a || !a->x_cf || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->xyz4 || !a->feat64 || !a->sq64) return VCR_EINVAL;
+  if (a->B <= 0 || a->N <= 0) return VCR_EINVAL;
+  dim3 grid((a->N + PTS - 1) / PTS, a->B);
+  hipLaunchKernelGGL(pointwise12_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+  return VCR_LAUNCH_RC();
+}

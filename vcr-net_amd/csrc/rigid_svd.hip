@@ -1,0 +1,125 @@
+// Kernel 4: centred 3x3 cross-covariance + SVD rigid solve (model/vcrnet_model.py:356-399).
+// The reference loops over the batch in Python with one LAPACK call and one host sync (det < 0) per
+// sample; here one 256-thread block per sample reduces the covariance (fp64 accumulation of the fp32
+// inputs) and a single lane finishes with a one-sided Jacobi SVD in fp64.
+//   H = sum_k (s_k - s_mean)(c_k - c_mean)^T,  H = U S V^T,  R = V U^T,
+//   det R < 0  ->  flip the column of V that belongs to the SMALLEST singular value (torch.svd sorts
+//   descending, so the reference's V @ diag(1,1,-1) is exactly that; :382-386),  t = -R s_mean + c_mean.
+// R = V U^T does not depend on the SVD's sign/order conventions while the singular values are distinct,
+// so LAPACK-vs-Jacobi differences do not leak into (R, t).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ void svd3_rotation(const double H[9], double R[9]) {
+  double A[3][3], V[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { A[i][j] = H[3 * i + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0;
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
+      double al = 0, be = 0, ga = 0;
+      for (int i = 0; i < 3; ++i) { al += A[i][p] * A[i][p]; be += A[i][q] * A[i][q]; ga += A[i][p] * A[i][q]; }
+      if (fabs(ga) <= 1e-30 + 1e-17 * sqrt(al * be)) continue;
+      off = fmax(off, fabs(ga) / sqrt(al * be + 1e-300));
+      const double zeta = (be - al) / (2.0 * ga);
+      const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+      const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+      for (int i = 0; i < 3; ++i) {
+        const double ap = A[i][p], aq = A[i][q];
+        A[i][p] = c * ap - s * aq; A[i][q] = s * ap + c * aq;
+        const double vp = V[i][p], vq = V[i][q];
+        V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
+      }
+    }
+    if (off < 1e-15) break;
+  }
+  double sig[3];
+  int ord[3] = {0, 1, 2};
+  for (int j = 0; j < 3; ++j) sig[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2 - i; ++j)
+      if (sig[ord[j]] < sig[ord[j + 1]]) { const int tmp = ord[j]; ord[j] = ord[j + 1]; ord[j + 1] = tmp; }
+  double U[3][3], W[3][3];
+  for (int j = 0; j < 3; ++j) {
+    const int c = ord[j];
+    const double inv = sig[c] > 0 ? 1.0 / sig[c] : 0.0;
+    for (int i = 0; i < 3; ++i) { U[i][j] = A[i][c] * inv; W[i][j] = V[i][c]; }
+  }
+  // a vanishing smallest singular value leaves its left vector undefined: complete the frame
+  // (either sign gives the same R after the determinant rule below)
+  if (sig[ord[2]] <= 1e-12 * sig[ord[0]]) {
+    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+  }
+  auto build = [&]() {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) R[3 * i + j] = W[i][0] * U[j][0] + W[i][1] * U[j][1] + W[i][2] * U[j][2];
+  };
+  build();
+  const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) +
+                     R[2] * (R[3] * R[7] - R[4] * R[6]);
+  if (det < 0) {
+    for (int i = 0; i < 3; ++i) W[i][2] = -W[i][2];
+    build();
+  }
+}
+
+__global__ __launch_bounds__(256) void rigid_svd_kernel(vcr_rigid_svd_args p) {
+  __shared__ double red[4];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* S = p.src + (size_t)b * p.K * p.lds;
+  const float* C = p.corr + (size_t)b * p.K * p.ldc;
+  double sm[3] = {0, 0, 0}, cm[3] = {0, 0, 0};
+  for (int i = t; i < p.K; i += 256)
+    for (int c = 0; c < 3; ++c) { sm[c] += S[(size_t)i * p.lds + c]; cm[c] += C[(size_t)i * p.ldc + c]; }
+  for (int c = 0; c < 3; ++c) { sm[c] = block_sum(sm[c], red) / p.K; cm[c] = block_sum(cm[c], red) / p.K; }
+  // the reference centres in fp32 (src - src.mean): round the means to fp32 like it does
+  float smf[3], cmf[3];
+  for (int c = 0; c < 3; ++c) { smf[c] = (float)sm[c]; cmf[c] = (float)cm[c]; }
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = t; i < p.K; i += 256) {
+    float sc[3], cc[3];
+    for (int c = 0; c < 3; ++c) { sc[c] = S[(size_t)i * p.lds + c] - smf[c]; cc[c] = C[(size_t)i * p.ldc + c] - cmf[c]; }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) H[3 * r + c] += (double)sc[r] * (double)cc[c];
+  }
+  for (int e = 0; e < 9; ++e) H[e] = block_sum(H[e], red);
+  if (t == 0) {
+    double R[9];
+    svd3_rotation(H, R);
+    float* Ro = p.R + (size_t)b * 9;
+    float* to = p.t + (size_t)b * 3;
+    float Rf[9], tf[3];
+    for (int e = 0; e < 9; ++e) { Rf[e] = (float)R[e]; Ro[e] = Rf[e]; }
+    for (int r = 0; r < 3; ++r) {
+      tf[r] = (float)(-(R[3 * r] * smf[0] + R[3 * r + 1] * smf[1] + R[3 * r + 2] * smf[2]) + cmf[r]);
+      to[r] = tf[r];
+    }
+    if (p.R_ba) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) p.R_ba[(size_t)b * 9 + 3 * r + c] = Rf[3 * c + r];
+    if (p.t_ba) for (int r = 0; r < 3; ++r)
+      p.t_ba[(size_t)b * 3 + r] = -(Rf[r] * tf[0] + Rf[3 + r] * tf[1] + Rf[6 + r] * tf[2]);
+    if (p.H) for (int e = 0; e < 9; ++e) p.H[(size_t)b * 9 + e] = (float)H[e];
+  }
+}
+
+}  // namespace
+
+extern "C" int vcr_rigid_svd_f32(const vcr_rigid_svd_args* a, vcr_stream_t stream) {
+  if (!a || !a->src || !a->corr || !a->R || !a->t) return VCR_EINVAL;
+  if (a->B <= 0 || a->K < 3 || a->lds < 3 || a->ldc < 3) return VCR_EINVAL;
+  hipLaunchKernelGGL(rigid_svd_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a);
+  return VCR_LAUNCH_RC();
+}

@@ -1,0 +1,304 @@
+"""ctypes binding of include/vcr_hip.h (libvcr_hip.so).
+
+The product path has NO fallback: if the HIP library is missing or a call fails this module
+raises.  ``import torch`` must happen before the library is loaded so that it binds to the HIP
+runtime torch already loaded (torch bundles its own libamdhip64 with the same soname).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvcr_hip.so")
+VCR_TRACE_MAX = 128
+
+f32p = C.c_void_p  # device pointers travel as integers
+
+
+class PointwiseArgs(C.Structure):
+    _fields_ = [("x_cf", f32p), ("B", C.c_int), ("N", C.c_int), ("w1", f32p), ("b1", f32p), ("w2", f32p),
+                ("b2", f32p), ("xyz4", f32p), ("feat64", f32p), ("sq64", f32p)]
+
+
+class KnnArgs(C.Structure):
+    _fields_ = [("x", f32p), ("ldx", C.c_int), ("sq", f32p), ("B", C.c_int), ("N", C.c_int), ("C", C.c_int),
+                ("k", C.c_int), ("idx", f32p)]
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [("x", f32p), ("ldx", C.c_int), ("w", f32p), ("bias", f32p), ("residual", f32p), ("ldr", C.c_int),
+                ("y", f32p), ("ldy", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("relu", C.c_int)]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [("x", f32p), ("ldx", C.c_int), ("a", f32p), ("b", f32p), ("eps", C.c_float), ("residual", f32p),
+                ("ldr", C.c_int), ("y", f32p), ("ldy", C.c_int), ("M", C.c_int), ("C", C.c_int), ("xyz4", f32p),
+                ("side4", f32p)]
+
+
+class RowsideArgs(C.Structure):
+    _fields_ = [("x", f32p), ("ldx", C.c_int), ("M", C.c_int), ("C", C.c_int), ("scale", C.c_float), ("y", f32p),
+                ("ldy", C.c_int), ("xyz4", f32p), ("side4", f32p)]
+
+
+class EdgeconvArgs(C.Structure):
+    _fields_ = [("pq", f32p), ("ldpq", C.c_int), ("idx", f32p), ("k", C.c_int), ("M", C.c_int),
+                ("n_per_cloud", C.c_int), ("w2", f32p), ("b2", f32p), ("x1", f32p), ("ldx1", C.c_int),
+                ("x2", f32p), ("ldx2", C.c_int)]
+
+
+class GathermaxArgs(C.Structure):
+    _fields_ = [("pq", f32p), ("ldpq", C.c_int), ("C", C.c_int), ("idx", f32p), ("k", C.c_int), ("M", C.c_int),
+                ("n_per_cloud", C.c_int), ("y", f32p), ("ldy", C.c_int)]
+
+
+class SdpaArgs(C.Structure):
+    _fields_ = [("q", f32p), ("ldq", C.c_int), ("k", f32p), ("ldk", C.c_int), ("v", f32p), ("ldv", C.c_int),
+                ("out", f32p), ("ldo", C.c_int), ("nbatch", C.c_int), ("heads", C.c_int), ("nq", C.c_int),
+                ("nk", C.c_int), ("scale", C.c_float), ("kv_batch_shift", C.c_int), ("key_keep", f32p),
+                ("rowstat", f32p)]
+
+
+class SoftcorrArgs(C.Structure):
+    _fields_ = [("q", f32p), ("ldq", C.c_int), ("k", f32p), ("ldk", C.c_int), ("qside4", f32p), ("kside4", f32p),
+                ("corr4", f32p), ("nbatch", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("E", C.c_int),
+                ("mode", C.c_int), ("scale", C.c_float)]
+
+
+class RigidSvdArgs(C.Structure):
+    _fields_ = [("src", f32p), ("lds", C.c_int), ("corr", f32p), ("ldc", C.c_int), ("B", C.c_int), ("K", C.c_int),
+                ("R", f32p), ("t", f32p), ("R_ba", f32p), ("t_ba", f32p), ("H", f32p)]
+
+
+class NormW(C.Structure):
+    _fields_ = [("ln_a", f32p), ("ln_b", f32p)]
+
+
+class MhaW(C.Structure):
+    _fields_ = [("wqkv", f32p), ("bqkv", f32p), ("wq", f32p), ("bq", f32p), ("wkv", f32p), ("bkv", f32p),
+                ("wo", f32p), ("bo", f32p)]
+
+
+class FfnW(C.Structure):
+    _fields_ = [("w1", f32p), ("b1", f32p), ("w2", f32p), ("b2", f32p)]
+
+
+class VcrnetWeights(C.Structure):
+    _fields_ = [("c1_w", f32p), ("c1_b", f32p), ("c2_w", f32p), ("c2_b", f32p),
+                ("dg1_wpq", f32p), ("dg1_bpq", f32p), ("dg2_w", f32p), ("dg2_b", f32p),
+                ("sn1_wpq", f32p), ("sn1_bpq", f32p), ("c3_w", f32p), ("c3_b", f32p),
+                ("enc_ln0", NormW), ("enc_ln1", NormW), ("enc_norm", NormW), ("dec_ln0", NormW),
+                ("dec_ln1", NormW), ("dec_ln2", NormW), ("dec_norm", NormW),
+                ("enc_self", MhaW), ("dec_self", MhaW), ("dec_cross", MhaW),
+                ("enc_ffn", FfnW), ("dec_ffn", FfnW),
+                ("E", C.c_int), ("F", C.c_int), ("heads", C.c_int), ("k", C.c_int),
+                ("has_pointer", C.c_int), ("head_mode", C.c_int)]
+
+
+class VcrnetIo(C.Structure):
+    _fields_ = [("src_cf", f32p), ("tgt_cf", f32p), ("B", C.c_int), ("N", C.c_int), ("corr4", f32p), ("src4", f32p),
+                ("R_ab", f32p), ("t_ab", f32p), ("R_ba", f32p), ("t_ba", f32p), ("emb_out", f32p)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("events", C.POINTER(C.c_void_p)), ("capacity", C.c_int), ("count", C.c_int),
+                ("names", C.c_char_p * VCR_TRACE_MAX)]
+
+
+_SIGS = {
+    "vcr_pointwise_f32": PointwiseArgs, "vcr_knn_f32": KnnArgs, "vcr_linear_f32": LinearArgs,
+    "vcr_layernorm_f32": LayerNormArgs, "vcr_rowside_f32": RowsideArgs, "vcr_edgeconv_f32": EdgeconvArgs,
+    "vcr_gathermax_f32": GathermaxArgs, "vcr_sdpa_f32": SdpaArgs, "vcr_softcorr_f32": SoftcorrArgs,
+    "vcr_rigid_svd_f32": RigidSvdArgs,
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class VcrHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libvcr_hip.so (once).  Raises if it has not been built -- there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VcrHipError(f"{LIB_PATH} not built: run `python vcr-net_amd/build.py` "
+                              "(or __graft_entry__.build()); the HIP path has no fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, st in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = [C.POINTER(st), C.c_void_p]
+            fn.restype = C.c_int
+        L.vcr_strerror.argtypes = [C.c_int]; L.vcr_strerror.restype = C.c_char_p
+        L.vcr_abi_version.restype = C.c_int
+        L.vcr_vcrnet_workspace_bytes.argtypes = [C.POINTER(VcrnetWeights), C.c_int, C.c_int]
+        L.vcr_vcrnet_workspace_bytes.restype = C.c_size_t
+        L.vcr_vcrnet_forward_f32.argtypes = [C.POINTER(VcrnetWeights), C.POINTER(VcrnetIo), C.c_void_p, C.c_size_t,
+                                             C.c_void_p]
+        L.vcr_vcrnet_forward_f32.restype = C.c_int
+        L.vcr_vcrnet_forward_traced_f32.argtypes = [C.POINTER(VcrnetWeights), C.POINTER(VcrnetIo), C.c_void_p,
+                                                    C.c_size_t, C.c_void_p, C.POINTER(Trace)]
+        L.vcr_vcrnet_forward_traced_f32.restype = C.c_int
+        L.vcr_event_create.argtypes = [C.POINTER(C.c_void_p)]; L.vcr_event_create.restype = C.c_int
+        L.vcr_event_destroy.argtypes = [C.c_void_p]; L.vcr_event_destroy.restype = C.c_int
+        L.vcr_event_record.argtypes = [C.c_void_p, C.c_void_p]; L.vcr_event_record.restype = C.c_int
+        L.vcr_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        L.vcr_event_elapsed_ms.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+class LaunchTrace:
+    """A pool of HIP events for vcr_vcrnet_forward_traced_f32: one event before every kernel launch
+    and one after the last, recorded on the launch stream (include/vcr_hip.h, vcr_trace)."""
+
+    def __init__(self, capacity: int = VCR_TRACE_MAX):
+        L = lib()
+        self.capacity = capacity
+        self._arr = (C.c_void_p * capacity)()
+        for i in range(capacity):
+            e = C.c_void_p()
+            check(L.vcr_event_create(C.byref(e)), "vcr_event_create")
+            self._arr[i] = e.value
+        self.trace = Trace(C.cast(self._arr, C.POINTER(C.c_void_p)), capacity, 0)
+
+    def launches(self):
+        """[(name, ms)] of the last traced forward -- call after the stream has been synchronised."""
+        L = lib()
+        n = min(self.trace.count, self.capacity - 1, VCR_TRACE_MAX)
+        out = []
+        for i in range(n):
+            ms = C.c_float()
+            check(L.vcr_event_elapsed_ms(self._arr[i], self._arr[i + 1], C.byref(ms)), "vcr_event_elapsed_ms")
+            out.append((self.trace.names[i].decode(), ms.value))
+        return out
+
+    def close(self):
+        L = lib()
+        for i in range(self.capacity):
+            if self._arr[i]:
+                L.vcr_event_destroy(self._arr[i])
+                self._arr[i] = None
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise VcrHipError(f"{what}: rc={rc} ({lib().vcr_strerror(rc).decode()})")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a CUDA(HIP) fp32/int32/uint8 tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VcrHipError("vcr-net_amd kernels take device tensors only (no CPU fallback)")
+    return t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, args: C.Structure) -> None:
+    check(getattr(lib(), name)(C.byref(args), C.c_void_p(stream_ptr())), name)
+
+
+# ---- thin tensor-level wrappers (used by the tests and by the module for the non-fused variants) -------------
+
+def _f32(*shape, device):
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+def pointwise(x_cf, w1, b1, w2, b2):
+    B, _, N = x_cf.shape
+    x_cf = x_cf.contiguous()
+    xyz4, f64, sq = _f32(B, N, 4, device=x_cf.device), _f32(B, N, 64, device=x_cf.device), _f32(B, N, device=x_cf.device)
+    call("vcr_pointwise_f32", PointwiseArgs(ptr(x_cf), B, N, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(xyz4),
+                                            ptr(f64), ptr(sq)))
+    return xyz4, f64, sq
+
+
+def knn(x, sq, k):
+    """x [B,N,C] rows (C = 64 with sq [B,N], or C = 4 xyz4 rows) -> int32 idx [B,N,k]."""
+    B, N, Cc = x.shape
+    idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+    call("vcr_knn_f32", KnnArgs(ptr(x), x.stride(1), ptr(sq), B, N, Cc, k, ptr(idx)))
+    return idx
+
+
+def linear(x, w, bias=None, relu=False, residual=None, out=None):
+    M, K = x.shape
+    N = w.shape[0]
+    y = out if out is not None else _f32(M, N, device=x.device)
+    call("vcr_linear_f32", LinearArgs(ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(residual),
+                                      residual.stride(0) if residual is not None else 0, ptr(y), y.stride(0),
+                                      M, N, K, int(relu)))
+    return y
+
+
+def layernorm(x, a, b, eps=1e-6, residual=None, xyz4=None):
+    M, Cc = x.shape
+    y = _f32(M, Cc, device=x.device)
+    side4 = _f32(M, 4, device=x.device) if xyz4 is not None else None
+    call("vcr_layernorm_f32", LayerNormArgs(ptr(x), x.stride(0), ptr(a), ptr(b), eps, ptr(residual),
+                                            residual.stride(0) if residual is not None else 0, ptr(y), Cc, M, Cc,
+                                            ptr(xyz4), ptr(side4)))
+    return (y, side4) if xyz4 is not None else y
+
+
+def rowside(x, xyz4, scale=1.0):
+    M, Cc = x.shape
+    y, side4 = _f32(M, Cc, device=x.device), _f32(M, 4, device=x.device)
+    call("vcr_rowside_f32", RowsideArgs(ptr(x), x.stride(0), M, Cc, scale, ptr(y), Cc, ptr(xyz4), ptr(side4)))
+    return y, side4
+
+
+def edgeconv(pq, idx, n_per_cloud, w2, b2):
+    M = pq.shape[0]
+    k = idx.shape[-1]
+    x1, x2 = _f32(M, 128, device=pq.device), _f32(M, 128, device=pq.device)
+    call("vcr_edgeconv_f32", EdgeconvArgs(ptr(pq), pq.stride(0), ptr(idx), k, M, n_per_cloud, ptr(w2), ptr(b2),
+                                          ptr(x1), 128, ptr(x2), 128))
+    return x1, x2
+
+
+def gathermax(pq, Cc, idx, n_per_cloud):
+    M = pq.shape[0]
+    k = idx.shape[-1]
+    y = _f32(M, Cc, device=pq.device)
+    call("vcr_gathermax_f32", GathermaxArgs(ptr(pq), pq.stride(0), Cc, ptr(idx), k, M, n_per_cloud, ptr(y), Cc))
+    return y
+
+
+def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None, want_rowstat=False, pv=True):
+    """q [nbatch*nq, >=heads*128] (row views allowed), k/v likewise -> out [nbatch*nq, heads*128]."""
+    out = _f32(nbatch * nq, heads * 128, device=q.device) if pv else None
+    rs = _f32(nbatch, heads, nq, 2, device=q.device) if want_rowstat else None
+    call("vcr_sdpa_f32", SdpaArgs(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v) if pv else None,
+                                  v.stride(0) if pv else 0, ptr(out), heads * 128 if pv else 0, nbatch, heads, nq, nk,
+                                  scale, kv_batch_shift, ptr(key_keep), ptr(rs)))
+    return (out, rs) if want_rowstat else out
+
+
+def softcorr(q, k, qside4, kside4, nbatch, nq, nk, mode=0, scale=1.0):
+    corr4 = _f32(nbatch * nq, 4, device=q.device)
+    call("vcr_softcorr_f32", SoftcorrArgs(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(qside4), ptr(kside4),
+                                          ptr(corr4), nbatch, nq, nk, q.shape[1], mode, scale))
+    return corr4
+
+
+def rigid_svd(src, corr, want_h=False):
+    """src/corr [B,K,>=3] rows -> R [B,3,3], t [B,3], R_ba, t_ba (and H when asked)."""
+    B, K, _ = src.shape
+    dev = src.device
+    R, t, Rb, tb = _f32(B, 3, 3, device=dev), _f32(B, 3, device=dev), _f32(B, 3, 3, device=dev), _f32(B, 3, device=dev)
+    H = _f32(B, 3, 3, device=dev) if want_h else None
+    call("vcr_rigid_svd_f32", RigidSvdArgs(ptr(src), src.stride(1), ptr(corr), corr.stride(1), B, K, ptr(R), ptr(t),
+                                           ptr(Rb), ptr(tb), ptr(H)))
+    return (R, t, Rb, tb, H) if want_h else (R, t, Rb, tb)

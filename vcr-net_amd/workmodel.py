@@ -1,0 +1,61 @@
+"""Algorithmic work per kernel launch of the whole-path forward (SURVEY.md section 8d figures):
+FLOPs and kernel-boundary bytes as functions of (B pairs, N points, k, E, F).  Used by bench.py to
+turn measured launch durations into roofline fractions.  Peaks from MI355X_MICROARCH.md:
+fp32 matrix (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s, HBM3E 8 TB/s."""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+PEAK_MFMA_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+# which roofline bounds each kernel family
+FAMILY_BOUND = {"pointwise": "hbm", "knn": "mfma", "linear": "mfma", "edgeconv": "mfma", "gathermax": "hbm",
+                "layernorm": "hbm", "sdpa": "mfma", "softcorr": "mfma", "rigid_svd": "hbm"}
+
+_LINEAR_SHAPES = {  # site -> (N_out, K) as multiples resolved below
+    "dg1_pq": (256, 64), "sn1_pq": (512, 128), "conv3": ("E", 512),
+    "enc.qkv": ("3E", "E"), "enc.wo": ("E", "E"), "enc.ffn1": ("F", "E"), "enc.ffn2": ("E", "F"),
+    "dec.qkv": ("3E", "E"), "dec.self.wo": ("E", "E"), "dec.cross.q": ("E", "E"), "dec.cross.kv": ("2E", "E"),
+    "dec.cross.wo": ("E", "E"), "dec.ffn1": ("F", "E"), "dec.ffn2": ("E", "F"),
+}
+
+
+def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1024) -> Tuple[float, float]:
+    """(flops, bytes) of one launch called `name` ("family:site") for B pairs of N points."""
+    fam, site = name.split(":", 1)
+    M1, M2 = B * N, 2 * B * N
+    sym = {"E": E, "2E": 2 * E, "3E": 3 * E, "F": F}
+    r = lambda v: sym[v] if isinstance(v, str) else v
+    if fam == "pointwise":
+        return 2.0 * M1 * (3 * 64 + 64 * 64), 4.0 * M1 * (3 + 4 + 64 + 1)
+    if fam == "knn":
+        C = 64 if site == "feat64" else 3
+        return 2.0 * C * N * N * 2 * B, 4.0 * M2 * ((C if C == 64 else 4) + (1 if C == 64 else 0) + k)
+    if fam == "linear":
+        n, kk = (r(v) for v in _LINEAR_SHAPES[site])
+        return 2.0 * M2 * n * kk, 4.0 * (M2 * kk + n * kk + M2 * n)
+    if fam == "edgeconv":      # convDG2 on the per-edge features (the per-point half of convDG1 is linear:dg1_pq)
+        return 2.0 * M2 * k * 128 * 128, 4.0 * M2 * (k * 128 + 128 + k + 256)
+    if fam == "gathermax":
+        return 1.0 * M2 * k * 256, 4.0 * M2 * (k * 256 + 256 + k + 256)
+    if fam == "layernorm":
+        extra = 1 if site.endswith("+res") else 0
+        return 8.0 * M2 * E, 4.0 * M2 * E * (2 + extra)
+    if fam == "sdpa":
+        return 4.0 * 2 * B * N * N * E, 4.0 * M2 * E * 4
+    if fam == "softcorr":
+        return 2.0 * B * N * N * E + 6.0 * B * N * N, 4.0 * (M2 * E + M2 * 4)
+    if fam == "rigid_svd":
+        return 18.0 * M1, 4.0 * M1 * 8
+    raise KeyError(name)
+
+
+def reference_flops_per_pair(N: int, k: int = 20, E: int = 512, F: int = 1024) -> Dict[str, float]:
+    """SURVEY section 8d per-pair FLOP count of the REFERENCE formulation (un-split EdgeConv)."""
+    emb = 2 * N * (3 * 64 + 64 * 64) + 2 * 64 * N * N + 2 * (2 * 128 * 128 * N * k) + 6 * N * N \
+        + 2 * 256 * 256 * N * k + 2 * 512 * 512 * N
+    tr = 2 * (3 * (8 * E * E * N + 4 * E * N * N) + 2 * (4 * E * F * N))
+    head = 2 * E * N * N + 6 * N * N
+    return {"emb": 2.0 * emb, "transformer": float(tr), "head": float(head), "svd": 18.0 * N,
+            "total": 2.0 * emb + tr + head + 18.0 * N}
