@@ -150,6 +150,17 @@ def main():
             ach = fam_bytes[dom] / (fam_ms[dom] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": workmodel.PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": ach / workmodel.PEAK_HBM_GBS, "traffic": None}
+        # HBM traffic per launch of that kernel comes from SEPARATE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+        # of this same command, condensed by profiles/summarize.py; null when no summary is committed.
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+        if pmcs and (B, N, a.k) == (16, 1024, 20):
+            kname = {"linear": "linear_kernel", "sdpa": "sdpa_kernel<false, true>", "edgeconv": "edgeconv_dg_kernel",
+                     "softcorr": "softcorr_kernel"}.get(dom)
+            ent = json.load(open(pmcs[-1])).get(kname, {})
+            if "hbm_bytes_per_launch" in ent:
+                roof["traffic"] = ent["hbm_bytes_per_launch"]
+                roof["traffic_source"] = os.path.relpath(pmcs[-1], ROOT)
         total_ms = sum(fam_ms.values())
         roof["launches_per_step"] = sum(r[3] for n, r in rows.items() if n.startswith(dom + ":")) // a.steps
         roof["avg_launch_ms"] = fam_ms[dom] / max(1, roof["launches_per_step"] * a.steps)

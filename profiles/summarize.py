@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 output (gpurun_out/<dir>/.../*_kernel_stats.csv and *_counter_collection.csv)
+into the small per-round files committed under profiles/.
+
+  python profiles/summarize.py r1 gpurun_out/prof_r1 gpurun_out/pmc_fetch_r1 gpurun_out/pmc_write_r1
+
+PMC units follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced read, so the read side is doubled."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def short(name):
+    for key in ("linear_kernel", "sdpa_kernel", "edgeconv_dg_kernel", "softcorr_kernel", "layernorm512_kernel",
+                "knn3_kernel", "knn64_kernel", "gathermax_kernel", "pointwise12_kernel", "rigid_svd_kernel",
+                "rowside_kernel", "colmass_kernel", "select_kernel"):
+        if key in name:
+            return key + (name[name.index(key) + len(key):].split("(")[0] if "<" in name else "")
+    return name[:48]
+
+
+def main():
+    tag, stats_dir = sys.argv[1], sys.argv[2]
+    pmc_dirs = sys.argv[3:]
+    rows = []
+    for f in glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            rows.append((short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]),
+                         float(r["Percentage"]), float(r["MinNs"]), float(r["MaxNs"])))
+    rows.sort(key=lambda r: -r[2])
+    with open(os.path.join(HERE, f"{tag}_kernel_stats.csv"), "w") as fh:
+        fh.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
+        for r in rows:
+            fh.write(",".join(str(x) for x in r) + "\n")
+    pmc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for d in pmc_dirs:
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                a = pmc[short(r["Kernel_Name"])][r["Counter_Name"]]
+                a[0] += float(r["Counter_Value"]); a[1] += 1
+    out = {}
+    for k, cs in pmc.items():
+        e = {c: {"avg": v[0] / v[1], "dispatches": v[1]} for c, v in cs.items()}
+        fetch = e.get("FETCH_SIZE", {}).get("avg")
+        write = e.get("WRITE_SIZE", {}).get("avg")
+        if fetch is not None and write is not None:
+            e["hbm_bytes_per_launch"] = (2.0 * fetch + write) * 1024.0     # gfx950 FETCH_SIZE correction
+        out[k] = e
+    if out:
+        json.dump(out, open(os.path.join(HERE, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    print("wrote", tag, len(rows), "kernels,", len(out), "pmc entries")
+
+
+if __name__ == "__main__":
+    main()
