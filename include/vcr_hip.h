@@ -138,6 +138,38 @@ typedef struct {
 } vcr_softcorr_args;
 int vcr_softcorr_f32(const vcr_softcorr_args*, vcr_stream_t);
 
+/* ---- general pair-score kernel (partial-overlap path): everything the reference derives from an
+ * n_own x n_str score matrix it materialises (vcrnet_model.py:190-332 selectCom/getCopair, transformer.py:35-53)
+ * op 0 SOFTMAX_PV: corr4[o] = sum_s softmax_s(score) * str_side4[s].xyz            (== vcr_softcorr_f32)
+ * op 1 STATS     : stat2[o] = (max_s score, sum_s exp(score - max)), argmax[o] = first arg-max s (optional)
+ * op 2 MASS      : mass[o] (+)= sum_s exp(score - m_s) / l_s with (m_s, l_s) = str_stat2[s]  -- the column sums
+ *                  of a row soft-max whose rows are the STREAMED index
+ * score 0: (-|own|^2 + 2 own.str) - |str|^2;  2: (-|str|^2 + 2 own.str) - |own|^2;  1: own.str * scale.
+ * The streamed batch of owner batch b is (b + str_batch_shift) % nbatch; str_stat2 is indexed
+ * [streamed batch * str_stat_batch_stride + s*2].  E % 128 == 0, E <= 1024. */
+typedef struct {
+  const float* own; int ld_own; const float* str; int ld_str;
+  const float* own_side4; const float* str_side4;   /* [nbatch*n,4] = (x,y,z,|emb|^2); may be NULL for score 1 */
+  int nbatch, n_own, n_str, E; int score; float scale; int str_batch_shift; int op;
+  float* corr4; float* stat2; int32_t* argmax;
+  const float* str_stat2; long str_stat_batch_stride; float* mass; int accumulate;
+} vcr_pairscore_args;
+int vcr_pairscore_f32(const vcr_pairscore_args*, vcr_stream_t);
+
+/* ---- per-sample top-K of n scores in descending order, ties -> lower index (Tensor.topk at
+ * transformer.py:42, vcrnet_model.py:223,245,312).  order [nbatch,K] int32 and/or mask [nbatch,n] uint8. */
+typedef struct {
+  const float* values; int nbatch, n, K; int32_t* order; uint8_t* mask;
+  int largest;                        /* 1: K largest, descending; 0: K smallest, ascending */
+} vcr_rankselect_args;
+int vcr_rankselect_f32(const vcr_rankselect_args*, vcr_stream_t);
+
+/* ---- out[b][r][0:C] = in[b][idx[b][r]][0:C]  (index gathers of vcrnet_model.py:230-260,305-330) */
+typedef struct {
+  const float* in; int ld_in; int n_in; const int32_t* idx; int nbatch, n_out, C; float* out; int ld_out;
+} vcr_gather_args;
+int vcr_gather_rows_f32(const vcr_gather_args*, vcr_stream_t);
+
 /* ---- kernel 4: weighted-covariance + 3x3 SVD rigid solve (vcrnet_model.py:356-399) ----
  * src/corr: [B,K,ld] rows (first 3 floats used).  R [B,9] row-major acting on column vectors,
  * t [B,3]; R_ba = R^T, t_ba = -R^T t (vcrnet_model.py:515-516) written when non-NULL. */

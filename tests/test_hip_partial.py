@@ -1,0 +1,167 @@
+"""GPU parity of the partial-overlap path (BASELINE config 3: --partial, overlap 0.575) and its kernels.
+The path is discretely chaotic in the reference itself (1 vs 8 CPU threads flip one of 196
+pairs and move R by 3e-3), so parity is asserted per iteration with teacher-forced inputs, as:
+  (1) every discrete selection (key keep-mask, overlap sets, hard pairs) equals the reference's up to a
+      small number of fp32 near-tie flips;
+  (2) everything downstream of the GPU's OWN selections is exact: (R,t) equals the oracle's SVD solve of the
+      GPU-selected pairs within 1e-5;
+  (3) when no selection flipped, (R,t) equals the reference's within the BASELINE tolerance 1e-4 / 1e-5."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import golden
+from test_hip_forward import build_net, R_TOL, T_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native
+    native.lib()
+    return native
+
+
+def test_rankselect_and_gather(nat):
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn(5, 700, generator=g)
+    v[0, 10] = v[0, 3]                                        # exact tie -> lower index first
+    order, mask = nat.rankselect(v.cuda(), 123, want_mask=True)
+    ref = torch.sort(v, dim=1, descending=True, stable=True)[1][:, :123]
+    assert torch.equal(order.cpu().long(), ref)
+    m = torch.zeros(5, 700, dtype=torch.uint8)
+    m.scatter_(1, ref, 1)
+    assert torch.equal(mask.cpu(), m)
+    asc, _ = nat.rankselect(v.cuda(), 50, largest=False)
+    assert torch.equal(asc.cpu().long(), torch.sort(v, dim=1, stable=True)[1][:, :50])
+    x = torch.randn(5 * 700, 64, generator=g)
+    out = nat.gather_rows(x.cuda(), order, 5, 700)
+    ref_rows = x.view(5, 700, 64)[torch.arange(5).view(-1, 1), ref]
+    assert torch.equal(out.cpu().view(5, 123, 64), ref_rows)
+
+
+@pytest.mark.parametrize("N1,N2", [(256, 256), (200, 330)])
+def test_pairscore_stats_and_mass(nat, N1, N2):
+    g = torch.Generator().manual_seed(N1)
+    B, E = 2, 512
+    a = torch.randn(B, E, N1, generator=g) * 0.2
+    b = torch.randn(B, E, N2, generator=g) * 0.2
+    S = oracle.neg_sqdist_head(a, b)                          # [B,N1,N2], row term (a) first
+    rows = lambda e: e.transpose(1, 2).reshape(-1, E).contiguous().cuda()
+    side = lambda e: torch.cat((torch.zeros(e.shape[0], e.shape[2], 3), (e ** 2).sum(1).unsqueeze(-1)), -1).reshape(-1, 4).cuda()
+    # row statistics (owner = a rows): score form 0
+    st, am = nat.pairscore(rows(a), rows(b), B, N1, N2, op=1, score=0, own_side4=side(a), str_side4=side(b), want_argmax=True)
+    st = st.cpu().view(B, N1, 2)
+    torch.testing.assert_close(st[..., 0], S.max(2)[0], atol=1e-4, rtol=1e-6)
+    torch.testing.assert_close(st[..., 1], torch.exp(S - S.max(2, keepdim=True)[0]).sum(2), atol=1e-4, rtol=2e-5)
+    assert (am.cpu().view(B, N1).long() == S.argmax(2)).float().mean() > 0.99
+    # column statistics (owner = b cols, streamed = a): same matrix, score form 2
+    ct, _ = nat.pairscore(rows(b), rows(a), B, N2, N1, op=1, score=2, own_side4=side(b), str_side4=side(a))
+    ct = ct.cpu().view(B, N2, 2)
+    torch.testing.assert_close(ct[..., 0], S.max(1)[0], atol=1e-4, rtol=1e-6)
+    # column sums of the row soft-max / row sums of the column soft-max (vcrnet_model.py:221-222,243-244)
+    colsum = nat.pairscore(rows(b), rows(a), B, N2, N1, op=2, score=2, own_side4=side(b), str_side4=side(a),
+                           str_stat2=st.reshape(-1, 2).cuda())
+    torch.testing.assert_close(colsum.cpu(), torch.softmax(S, 2).sum(1), atol=2e-5, rtol=2e-5)
+    rowsum = nat.pairscore(rows(a), rows(b), B, N1, N2, op=2, score=0, own_side4=side(a), str_side4=side(b),
+                           str_stat2=ct.reshape(-1, 2).cuda())
+    torch.testing.assert_close(rowsum.cpu(), torch.softmax(S, 1).sum(2), atol=2e-5, rtol=2e-5)
+
+
+def test_attention_key_mass(nat):
+    """transformer.py:40: probability mass per key summed over heads and queries, with the batch shift."""
+    g = torch.Generator().manual_seed(4)
+    nb, h, N = 4, 4, 160
+    q, k = (torch.randn(nb, N, h * 128, generator=g) for _ in range(2))
+    sc = 1 / math.sqrt(128)
+    qd, kd = q.view(nb * N, -1).cuda(), k.view(nb * N, -1).cuda()
+    _, rs = nat.sdpa(qd, kd, None, nb, h, N, N, sc, kv_batch_shift=2, want_rowstat=True, pv=False)
+    mass = torch.empty(nb, N, device="cuda")
+    for hh in range(h):
+        nat.pairscore(kd[:, hh * 128:(hh + 1) * 128], qd[:, hh * 128:(hh + 1) * 128], nb, N, N, op=2, score=1, scale=sc,
+                      shift=2, str_stat2=rs.view(-1)[hh * N * 2:], str_stat_stride=h * N * 2, mass=mass, accumulate=hh > 0)
+    split = lambda t_: t_.view(nb, N, h, 128).transpose(1, 2)
+    kk = torch.roll(k, -2, 0)                                 # query batch b sees keys of batch (b+2)%nb
+    p = torch.softmax(torch.matmul(split(q), split(kk).transpose(-2, -1)) * sc, -1)
+    ref_by_qbatch = p.sum(dim=[1, 2])                         # [nb(query batch), N keys]
+    ref = torch.roll(ref_by_qbatch, 2, 0)                     # re-index by KEY batch kb = (b+2)%nb
+    torch.testing.assert_close(mass.cpu(), ref, atol=2e-4, rtol=2e-5)
+
+
+def _sym_diff(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return sum(len(set(x) ^ set(y)) for x, y in zip(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])))
+
+
+@pytest.mark.parametrize("name", ["partial_n192_b2_it2", "partial_n768_b2_it3"])
+def test_partial_vs_reference_golden(name):
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import composed
+    g = golden(name)
+    net, w = build_net(partial=True, overlap2=float(g["overlap2"]))
+    tgt = torch.from_numpy(g["tgt"]).cuda()
+    B = tgt.shape[0]
+    exact_iters = 0
+    for it in range(int(g["iters"])):
+        p = f"it{it}_"
+        cur = torch.from_numpy(g[p + "in"]).cuda()
+        rec = {}
+        net._pack()
+        with torch.no_grad():
+            srcK, corrK, R, t, R_ba, t_ba = composed.forward_composed(net, cur, tgt, rec)
+        N = cur.shape[2]
+        keep = rec["key_keep"].cpu().numpy()                  # [2B, N] by key batch: rows 0..B-1 = src as keys
+        gk_tgt = np.zeros((B, N), np.uint8); np.put_along_axis(gk_tgt, g[p + "keep_dir_src"].astype(np.int64), 1, 1)
+        gk_src = np.zeros((B, N), np.uint8); np.put_along_axis(gk_src, g[p + "keep_dir_tgt"].astype(np.int64), 1, 1)
+        # model(src,tgt): memory = enc(src) -> keys are SRC points (key batch 0..B-1); model(tgt,src): keys = tgt
+        flips = int((keep[:B] != gk_tgt).sum() + (keep[B:] != gk_src).sum()) // 2
+        d_sel = _sym_diff(rec["sel_src"].cpu().numpy(), g[p + "sel_src"]) + _sym_diff(rec["sel_tgt"].cpu().numpy(), g[p + "sel_tgt"])
+        sel_s, sel_t = rec["sel_src"].cpu().long(), rec["sel_tgt"].cpu().long()
+        pairs_gpu = {(b, int(sel_s[b, i]), int(sel_t[b, j])) for b in range(B)
+                     for i, j in zip(rec["pair_src"][b].cpu().tolist(), rec["pair_tgt"][b].cpu().tolist())}
+        gs, gt_ = g[p + "sel_src"].astype(np.int64), g[p + "sel_tgt"].astype(np.int64)
+        pairs_ref = {(b, int(gs[b, i]), int(gt_[b, g[p + "argmax_tgt"][b, i]])) for b in range(B) for i in g[p + "pair_src"][b]}
+        d_pairs = len(pairs_gpu ^ pairs_ref)
+        n_pairs = len(pairs_ref)
+        # (1) discrete decisions: at most ~1 % near-tie flips
+        assert flips <= max(2, 2 * B * N // 100), flips
+        assert d_sel <= max(4, 2 * B * N // 50), d_sel
+        assert d_pairs <= max(4, n_pairs // 10), (d_pairs, n_pairs)
+        # (2) downstream of the GPU's own choices everything is exact
+        cur_c, tgt_c = cur.cpu(), tgt.cpu()
+        for b in range(B):
+            ps = sel_s[b][rec["pair_src"][b].cpu().long()]
+            pt = sel_t[b][rec["pair_tgt"][b].cpu().long()]
+            assert torch.equal(srcK[b].cpu(), cur_c[b][:, ps]) and torch.equal(corrK[b].cpu(), tgt_c[b][:, pt])
+        R_o, t_o = oracle.rigid_svd(srcK.cpu(), corrK.cpu())
+        np.testing.assert_allclose(R.cpu().numpy(), R_o.numpy(), atol=1e-5)
+        np.testing.assert_allclose(t.cpu().numpy(), t_o.numpy(), atol=1e-5)
+        # (3) identical decisions -> BASELINE tolerance against the reference
+        if flips == 0 and d_sel == 0 and d_pairs == 0:
+            exact_iters += 1
+            np.testing.assert_allclose(R.cpu().numpy(), g[p + "R"], atol=R_TOL)
+            np.testing.assert_allclose(t.cpu().numpy(), g[p + "t"], atol=T_TOL)
+        print(f"{name} it{it}: key flips {flips}, overlap-set diff {d_sel}, pair diff {d_pairs}/{n_pairs}, "
+              f"max|dR| {np.abs(R.cpu().numpy() - g[p + 'R']).max():.2e}")
+    assert exact_iters >= 1
+
+
+def test_partial_module_forward_and_iter():
+    """The nn.Module entry point dispatches partial mode to the composed HIP path; vcrnetIter composes poses."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd.module import vcrnetIter
+    g = golden("partial_n192_b2_it2")
+    net, _ = build_net(partial=True, overlap2=float(g["overlap2"]))
+    src, tgt = torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda()
+    with torch.no_grad():
+        out = vcrnetIter(net, src, tgt, iter=2)
+    assert out[0].shape == (2, 3, 48) and out[1].shape == (2, 3, 48)
+    R = out[2].cpu()
+    assert torch.allclose(torch.det(R), torch.ones(2), atol=1e-5)
+    # aggregate check vs the reference's composed pose: loose (chaotic path), sanity only
+    assert np.abs(R.numpy() - g["R_final"]).max() < 5e-2

@@ -58,7 +58,20 @@ def transformer(net, emb: torch.Tensor, B: int, N: int, rec: Optional[dict] = No
     d1 = native.linear(att, P["dec_self.wo"], P["dec_self.bo"], residual=emb)
     qc = native.linear(ln(d1, "dec_ln1"), P["dec_cross.wq"], P["dec_cross.bq"])
     kvc = native.linear(mem, P["dec_cross.wkv"], P["dec_cross.bkv"])
-    keep = key_keep_fn(qc, kvc) if key_keep_fn is not None else None
+    keep = None
+    if net._partial:
+        # transformer.py:35-53: soft-max once, total probability mass each KEY receives over heads and queries,
+        # keep the int(nk*overlap2) heaviest keys, soft-max again over those only.
+        _, rs = native.sdpa(qc, kvc[:, :E], None, nb, H, N, N, sc, kv_batch_shift=B, want_rowstat=True, pv=False)
+        dk = E // H
+        mass = torch.empty(nb, N, dtype=torch.float32, device=emb.device)
+        for h in range(H):   # owner = keys of batch kb, streamed = queries of batch (kb + B) % nb with their (m, l)
+            native.pairscore(kvc[:, h * dk:(h + 1) * dk], qc[:, h * dk:(h + 1) * dk], nb, N, N, op=2, score=1,
+                             scale=sc, shift=B, str_stat2=rs.view(-1)[h * N * 2:], str_stat_stride=H * N * 2,
+                             mass=mass, accumulate=h > 0)
+        _, keep = native.rankselect(mass, int(N * net._overlap2), want_order=False, want_mask=True)
+        if rec is not None:
+            rec.update(key_mass=mass, key_keep=keep)
     att = native.sdpa(qc, kvc[:, :E], kvc[:, E:], nb, H, N, N, sc, kv_batch_shift=B, key_keep=keep)
     d2 = native.linear(att, P["dec_cross.wo"], P["dec_cross.bo"], residual=d1)
     hid = native.linear(ln(d2, "dec_ln2"), P["dec_ffn.w_1.weight"], P["dec_ffn.w_1.bias"], relu=True)
@@ -66,6 +79,43 @@ def transformer(net, emb: torch.Tensor, B: int, N: int, rec: Optional[dict] = No
     if rec is not None:
         rec.update(mem=mem, e1=e1, e2=e2, d1=d1, d2=d2, d3=d3)
     return d3
+
+
+def _partial_head(net, src, embf, side4, B: int, N: int, rec: Optional[dict]):
+    """VcpTopK partial mode: selectCom (model/vcrnet_model.py:190-262) + getCopair (:264-332) + SVD.
+    The N x N score matrix and its two soft-maxes are never written: two STATS passes give the row /
+    column soft-max statistics, two MASS passes the column / row probability sums, rankselect the
+    overlap sets, one more STATS pass (with arg-max) on the reduced sets the hard correspondences."""
+    M1 = B * N
+    o2 = net._overlap2
+    se, te, ss, ts = embf[:M1], embf[M1:], side4[:M1], side4[M1:]
+    src_k = int(N * 0.84 * o2)                                             # :208
+    tgt_k = int(N * 0.84 * o2)                                             # :209
+    # score_ij = (-|s_i|^2 + 2 s_i.t_j) - |t_j|^2 for BOTH soft-maxes (one matrix in the reference, :211-216):
+    # owner = src -> score form 0; owner = tgt -> form 2 (streamed-side norm first), the same association.
+    rstat, _ = native.pairscore(se, te, B, N, N, op=1, score=0, own_side4=ss, str_side4=ts)      # softmax(dim=2)
+    cstat, _ = native.pairscore(te, se, B, N, N, op=1, score=2, own_side4=ts, str_side4=ss)      # softmax(dim=1)
+    colsum = native.pairscore(te, se, B, N, N, op=2, score=2, own_side4=ts, str_side4=ss, str_stat2=rstat)  # :222
+    rowsum = native.pairscore(se, te, B, N, N, op=2, score=0, own_side4=ss, str_side4=ts, str_stat2=cstat)  # :244
+    idx_t, _ = native.rankselect(colsum, tgt_k)                            # :223
+    idx_s, _ = native.rankselect(rowsum, src_k)                            # :245
+    so_e, to_e = native.gather_rows(se, idx_s, B, N), native.gather_rows(te, idx_t, B, N)        # :251-260,:235-238
+    so_s, to_s = native.gather_rows(ss, idx_s, B, N), native.gather_rows(ts, idx_t, B, N)
+    # getCopair on the overlap sets: peak soft-max probability = 1/l and its arg-max target (:295-298)
+    st, amax = native.pairscore(so_e, to_e, B, src_k, tgt_k, op=1, score=0, own_side4=so_s, str_side4=to_s,
+                                want_argmax=True)
+    k2 = int(src_k * 0.52 * o2)                                            # :284
+    lsum = st.view(B, src_k, 2)[:, :, 1].contiguous()
+    pick, _ = native.rankselect(lsum, k2, largest=False)                   # largest peak prob == smallest l (:312)
+    pair_t = torch.gather(amax.view(B, src_k), 1, pick.long()).int()       # index plumbing only
+    srcK4 = native.gather_rows(so_s, pick, B, src_k)                       # :328-330
+    corr4 = native.gather_rows(to_s, pair_t, B, tgt_k)                     # :325 (weights are exactly 1)
+    R, t, Rb, tb = native.rigid_svd(srcK4.view(B, k2, 4), corr4.view(B, k2, 4))
+    if rec is not None:
+        rec.update(sel_src=idx_s, sel_tgt=idx_t, pair_src=pick, pair_tgt=pair_t, colsum=colsum, rowsum=rowsum,
+                   peak_l=lsum, argmax_tgt=amax.view(B, src_k))
+    tr = lambda x: x.view(B, k2, 4)[:, :, :3].transpose(1, 2).contiguous()
+    return tr(srcK4), tr(corr4), R, t, Rb, tb
 
 
 def forward_composed(net, src: torch.Tensor, tgt: torch.Tensor, rec: Optional[dict] = None):
@@ -85,8 +135,14 @@ def forward_composed(net, src: torch.Tensor, tgt: torch.Tensor, rec: Optional[di
         embf, side4 = native.rowside(emb, xyz4, 2.0 if isinstance(net.pointer, _Identity) else 1.0)
     if rec is not None:
         rec.update(embf=embf, side4=side4)
-    if net._partial or net._vcp == "att":
-        raise native.VcrHipError("partial / att head on the HIP path: not built yet")
+    if net._vcp == "att":                                                  # VcpAtt: vcrnet_model.py:444-449
+        sd = _sd(net)
+        q = native.linear(embf[:M1], sd["head.linears_emb.0.weight"], sd["head.linears_emb.0.bias"])
+        kx = native.linear(embf[M1:], sd["head.linears_emb.1.weight"], sd["head.linears_emb.1.bias"])
+        embf = torch.cat((q, kx), 0)
+        _, side4 = native.rowside(embf, xyz4, 1.0)
+    if net._partial and net._vcp == "topK":
+        return _partial_head(net, src, embf, side4, B, N, rec)
     mode = 1 if net._vcp == "dist" else 0
     scale = 1.0 / math.sqrt(net.emb_dims)
 

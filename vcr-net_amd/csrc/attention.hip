@@ -1,5 +1,5 @@
-// Kernel 3: flash-style attention on fp32 MFMA (model/transformer.py:29-34,55) and the
-// virtual-correspondence head built on the same scheme (model/vcrnet_model.py:334-347,402-421).
+// Kernel 3: flash-style attention on fp32 MFMA (model/transformer.py:29-34,55).  The
+// virtual-correspondence head built on the same scheme lives in pairscore.hip.
 // The n x n score matrix is never written to memory.
 //
 // Orientation ("swapped QK^T"): scores are computed TRANSPOSED, S^T = K Q^T, with KEYS as MFMA rows
@@ -146,116 +146,6 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// softcorr: corr_i = sum_j softmax_j(score_ij) * xyz_j over E-wide embeddings (E = 512).
-// Block = 32 queries of one sample; their embeddings sit in LDS (66 KB) and are the B operand for all
-// four waves; wave w walks key tiles w, w+4, ... with the key embeddings streamed global -> registers
-// (double-buffered 64-wide chunks) as the A operand.  d_v = 3, so the second product is plain FMAs on
-// the lane-local probabilities, and the four waves' (m, l, o) partials are merged through LDS.
-// mode 0: score = (-|q|^2 + 2 q.k) - |k|^2 with the reference's association (vcrnet_model.py:337-342):
-//         -|q|^2/2 enters the MFMA chain as an extra k-step, so (2 dot - |q|^2) is rounded once.
-// mode 1: score = q.k * scale (vcrnet_model.py:413-414, dcp_model.py:139-140).
-__global__ __launch_bounds__(256, 2) void softcorr_kernel(vcr_softcorr_args p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int QP = p.E + 4;
-  float* Qs = reinterpret_cast<float*>(smem);            // [32][QP]
-  float* mg = Qs + 32 * QP;                              // [4 waves][32 queries][5]
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.y, q0 = blockIdx.x * 32;
-  const int chunks = p.E / 64;
-
-  {
-    const int per_row = p.E / 4;
-    for (int i = t; i < 32 * per_row; i += 256) {
-      const int row = i / per_row, c4 = (i % per_row) * 4;
-      const int qr = min(q0 + row, p.nq - 1);
-      st4(&Qs[row * QP + c4], ld4(p.q + ((size_t)b * p.nq + qr) * p.ldq + c4));
-    }
-  }
-  const float sq_q = p.qside4[((size_t)b * p.nq + min(q0 + l31, p.nq - 1)) * 4 + 3];
-  __syncthreads();
-
-  const int ntiles = (p.nk + 31) / 32;
-  const int my_tiles = (ntiles - w + 3) / 4;             // tiles w, w+4, ...
-  const int nflat = my_tiles * chunks;
-  const float* kb = p.k + (size_t)b * p.nk * p.ldk;
-
-  f32x4 bufA[8], bufB[8];
-  auto load_chunk = [&](int flat, f32x4* dst) {
-    const int tile = w + 4 * (flat / chunks), c = flat % chunks;
-    const int key = min(tile * 32 + l31, p.nk - 1);
-    const float* kp = kb + (size_t)key * p.ldk + 64 * c + 4 * half;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) dst[g] = ld4(kp + 8 * g);
-  };
-
-  float m = VCR_NEG_INF, l = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
-  f32x16 s = {0};
-  auto compute = [&](int flat, const f32x4* kf) {
-    const int tile = w + 4 * (flat / chunks), c = flat % chunks;
-    if (c == 0) s = f32x16{0};
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const f32x4 qv = ld4(&Qs[l31 * QP + 64 * c + 8 * g + 4 * half]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s = mfma32(kf[g][e], qv[e], s);
-    }
-    if (c != chunks - 1) return;
-    if (p.mode == 0) s = mfma32(half == 0 ? 1.f : 0.f, half == 0 ? -0.5f * sq_q : 0.f, s);
-    f32x4 side[16];
-    float mt = VCR_NEG_INF;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = tile * 32 + acc_row(r, half);
-      side[r] = ld4(p.kside4 + ((size_t)b * p.nk + min(key, p.nk - 1)) * 4);
-      const float sc = (p.mode == 0) ? (2.f * s[r] - side[r][3]) : s[r] * p.scale;
-      s[r] = key < p.nk ? sc : VCR_NEG_INF;
-      mt = fmaxf(mt, s[r]);
-    }
-    mt = fmaxf(mt, xhalf(mt));
-    const float m_new = fmaxf(m, mt);
-    const float alpha = __builtin_amdgcn_exp2f((m - m_new) * LOG2E);
-    float ls = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pr = __builtin_amdgcn_exp2f((s[r] - m_new) * LOG2E);
-      ls += pr;
-      ax = fmaf(pr, side[r][0], ax); ay = fmaf(pr, side[r][1], ay); az = fmaf(pr, side[r][2], az);
-    }
-    l = l * alpha + ls; ox = ox * alpha + ax; oy = oy * alpha + ay; oz = oz * alpha + az;
-    m = m_new;
-  };
-
-  if (nflat > 0) load_chunk(0, bufA);
-  for (int f = 0; f < nflat; f += 2) {                   // nflat is even (chunks = E/64 is even for E % 128 == 0)
-    if (f + 1 < nflat) load_chunk(f + 1, bufB);
-    compute(f, bufA);
-    if (f + 2 < nflat) load_chunk(f + 2, bufA);
-    if (f + 1 < nflat) compute(f + 1, bufB);
-  }
-  // halves hold disjoint keys of the same query at the same running max
-  l += xhalf(l); ox += xhalf(ox); oy += xhalf(oy); oz += xhalf(oz);
-  if (half == 0) {
-    float* g = mg + (w * 32 + l31) * 5;
-    g[0] = m; g[1] = l; g[2] = ox; g[3] = oy; g[4] = oz;
-  }
-  __syncthreads();
-  if (t < 32 && q0 + t < p.nq) {
-    float M = VCR_NEG_INF;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) M = fmaxf(M, mg[(i * 32 + t) * 5]);
-    float L = 0.f, X = 0.f, Y = 0.f, Z = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float* g = mg + (i * 32 + t) * 5;
-      const float a = __builtin_amdgcn_exp2f((g[0] - M) * LOG2E);   // exp2(-inf) = 0 for a wave with no tiles
-      L = fmaf(g[1], a, L); X = fmaf(g[2], a, X); Y = fmaf(g[3], a, Y); Z = fmaf(g[4], a, Z);
-    }
-    st4(p.corr4 + ((size_t)b * p.nq + q0 + t) * 4, f32x4{X / L, Y / L, Z / L, 0.f});
-  }
-}
-
 }  // namespace
 
 extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
@@ -278,18 +168,5 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   if (a->key_keep) { if (pv) VCR_SDPA_LAUNCH(true, true); else VCR_SDPA_LAUNCH(true, false); }
   else             { if (pv) VCR_SDPA_LAUNCH(false, true); else VCR_SDPA_LAUNCH(false, false); }
 #undef VCR_SDPA_LAUNCH
-  return VCR_LAUNCH_RC();
-}
-
-extern "C" int vcr_softcorr_f32(const vcr_softcorr_args* a, vcr_stream_t stream) {
-  if (!a || !a->q || !a->k || !a->qside4 || !a->kside4 || !a->corr4) return VCR_EINVAL;
-  if (a->nbatch <= 0 || a->nq <= 0 || a->nk <= 0 || a->E <= 0 || (a->E % 128) || a->E > 1024) return VCR_EINVAL;
-  if ((a->ldq & 3) || (a->ldk & 3) || a->ldq < a->E || a->ldk < a->E) return VCR_EINVAL;
-  if (a->mode != 0 && a->mode != 1) return VCR_EINVAL;
-  const int lds = (32 * (a->E + 4) + 4 * 32 * 5) * 4;
-  if (lds > 160 * 1024) return VCR_EUNSUPPORTED;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(softcorr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  dim3 grid((a->nq + 31) / 32, a->nbatch);
-  hipLaunchKernelGGL(softcorr_kernel, grid, dim3(256), lds, (hipStream_t)stream, *a);
   return VCR_LAUNCH_RC();
 }

@@ -1,0 +1,231 @@
+// Pair-score kernels over E-wide embeddings (E = 512 for the correspondence head, 128 per attention
+// head): everything the reference computes from an n_own x n_str score matrix that it materialises
+// and we do not (model/vcrnet_model.py:190-347,402-460, model/transformer.py:35-53).
+//
+// Geometry (same swapped-QK^T scheme as attention.hip): a block owns 32 "owner" points of one sample;
+// their embeddings sit in LDS ([32][E+4], conflict-free ds_read_b128) and are the MFMA B operand, so
+// each lane owns ONE owner column.  The "streamed" points are MFMA rows: wave w walks streamed tiles
+// w, w+4, ... with their embeddings going global -> registers in double-buffered 64-wide chunks.
+// The four waves' per-owner partials are merged through LDS.
+//
+//   op 0  SOFTMAX_PV : corr_o = sum_s softmax_s(score) * xyz_s              (getCopairALL / VcpByDis / DCP)
+//   op 1  STATS      : (max_s score, sum_s exp(score - max), argmax_s)       (row / column soft-max statistics)
+//   op 2  MASS       : mass_o = sum_s exp(score - m_s) / l_s                 (column sums of a ROW soft-max whose
+//                      statistics (m_s, l_s) belong to the STREAMED index: selectCom's scoresColSum/RowSum,
+//                      and the key mass of transformer.py:40)
+//   score 0: (-|own|^2 + 2 own.str) - |str|^2   score 2: (-|str|^2 + 2 own.str) - |own|^2   (the reference's
+//            association with the owner / the streamed side as ITS row index; the first norm rides the
+//            MFMA chain as an extra k-step so that (2 dot - norm) is rounded once, like `-xx - inner`)
+//   score 1: own.str * scale
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int OP>
+__global__ __launch_bounds__(256, 2) void pairscore_kernel(vcr_pairscore_args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int QP = p.E + 4;
+  float* Os = reinterpret_cast<float*>(smem);            // [32][QP] owner embeddings
+  float* mg = Os + 32 * QP;                              // [4 waves][32 owners][5]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.y, o0 = blockIdx.x * 32;
+  const int sb = (b + p.str_batch_shift) % p.nbatch;
+  const int chunks = p.E / 64;
+
+  {
+    const int per_row = p.E / 4;
+    for (int i = t; i < 32 * per_row; i += 256) {
+      const int row = i / per_row, c4 = (i % per_row) * 4;
+      const int orow = min(o0 + row, p.n_own - 1);
+      st4(&Os[row * QP + c4], ld4(p.own + ((size_t)b * p.n_own + orow) * p.ld_own + c4));
+    }
+  }
+  const size_t own_row = (size_t)b * p.n_own + min(o0 + l31, p.n_own - 1);
+  const float own_norm = p.score == 1 ? 0.f : p.own_side4[own_row * 4 + 3];
+  __syncthreads();
+
+  const int ntiles = (p.n_str + 31) / 32;
+  const int my_tiles = (ntiles - w + 3) / 4;             // tiles w, w+4, ...
+  const int nflat = my_tiles * chunks;
+  const float* sbase = p.str + (size_t)sb * p.n_str * p.ld_str;
+  const float* sside = p.str_side4 ? p.str_side4 + (size_t)sb * p.n_str * 4 : nullptr;
+  const float* sstat = (OP == 2) ? p.str_stat2 + (size_t)sb * p.str_stat_batch_stride : nullptr;
+
+  f32x4 bufA[8], bufB[8];
+  auto load_chunk = [&](int flat, f32x4* dst) {
+    const int tile = w + 4 * (flat / chunks), c = flat % chunks;
+    const int row = min(tile * 32 + l31, p.n_str - 1);
+    const float* kp = sbase + (size_t)row * p.ld_str + 64 * c + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) dst[g] = ld4(kp + 8 * g);
+  };
+
+  float m = VCR_NEG_INF, l = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;   // OP 0/1 state
+  float best = VCR_NEG_INF; int bidx = 0x7fffffff;                 // OP 1 argmax
+  float mass = 0.f;                                                // OP 2
+  f32x16 s = {0};
+  auto compute = [&](int flat, const f32x4* kf) {
+    const int tile = w + 4 * (flat / chunks), c = flat % chunks;
+    if (c == 0) s = f32x16{0};
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const f32x4 qv = ld4(&Os[l31 * QP + 64 * c + 8 * g + 4 * half]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s = mfma32(kf[g][e], qv[e], s);
+    }
+    if (c != chunks - 1) return;
+    if (p.score == 0) {
+      s = mfma32(half == 0 ? 1.f : 0.f, half == 0 ? -0.5f * own_norm : 0.f, s);
+    } else if (p.score == 2) {
+      const float rn = sside[(size_t)min(tile * 32 + l31, p.n_str - 1) * 4 + 3];
+      s = mfma32(half == 0 ? -0.5f * rn : 0.f, half == 0 ? 1.f : 0.f, s);
+    }
+    f32x4 side[16];
+    float mt = VCR_NEG_INF;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = tile * 32 + acc_row(r, half);
+      const int jc = min(j, p.n_str - 1);
+      if (OP == 0 || p.score == 0) side[r] = ld4(sside + (size_t)jc * 4);
+      float sc;
+      if (p.score == 0) sc = 2.f * s[r] - side[r][3];
+      else if (p.score == 2) sc = 2.f * s[r] - own_norm;
+      else sc = s[r] * p.scale;
+      s[r] = j < p.n_str ? sc : VCR_NEG_INF;
+      mt = fmaxf(mt, s[r]);
+    }
+    if (OP == 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = tile * 32 + acc_row(r, half);
+        const int jc = min(j, p.n_str - 1);
+        const float ms = sstat[(size_t)jc * 2], ls = sstat[(size_t)jc * 2 + 1];
+        mass += __builtin_amdgcn_exp2f((s[r] - ms) * LOG2E) / ls;   // exp2(-inf) = 0 past the tail
+      }
+      return;
+    }
+    if (OP == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = tile * 32 + acc_row(r, half);
+        if (s[r] > best) { best = s[r]; bidx = j; }
+      }
+    }
+    mt = fmaxf(mt, xhalf(mt));
+    const float m_new = fmaxf(m, mt);
+    const float alpha = __builtin_amdgcn_exp2f((m - m_new) * LOG2E);
+    float ls = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pr = __builtin_amdgcn_exp2f((s[r] - m_new) * LOG2E);
+      ls += pr;
+      if (OP == 0) { ax = fmaf(pr, side[r][0], ax); ay = fmaf(pr, side[r][1], ay); az = fmaf(pr, side[r][2], az); }
+    }
+    l = l * alpha + ls;
+    if (OP == 0) { ox = ox * alpha + ax; oy = oy * alpha + ay; oz = oz * alpha + az; }
+    m = m_new;
+  };
+
+  if (nflat > 0) load_chunk(0, bufA);
+  for (int f = 0; f < nflat; f += 2) {                   // nflat is even: chunks = E/64 is even (E % 128 == 0)
+    if (f + 1 < nflat) load_chunk(f + 1, bufB);
+    compute(f, bufA);
+    if (f + 2 < nflat) load_chunk(f + 2, bufA);
+    if (f + 1 < nflat) compute(f + 1, bufB);
+  }
+
+  // the two halves of a wave hold disjoint streamed rows of the same owner (same running max)
+  if (OP == 2) {
+    mass += xhalf(mass);
+    if (half == 0) mg[(w * 32 + l31) * 5] = mass;
+  } else {
+    l += xhalf(l);
+    if (OP == 0) { ox += xhalf(ox); oy += xhalf(oy); oz += xhalf(oz); }
+    if (OP == 1) {
+      const float ob = xhalf(best);
+      const int oi = __shfl_xor(bidx, 32, 64);
+      if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    if (half == 0) {
+      float* g = mg + (w * 32 + l31) * 5;
+      g[0] = m; g[1] = l;
+      if (OP == 0) { g[2] = ox; g[3] = oy; g[4] = oz; }
+      else { g[2] = best; g[3] = __int_as_float(bidx); }
+    }
+  }
+  __syncthreads();
+  if (t < 32 && o0 + t < p.n_own) {
+    const size_t orow = (size_t)b * p.n_own + o0 + t;
+    if (OP == 2) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc += mg[(i * 32 + t) * 5];
+      p.mass[orow] = p.accumulate ? p.mass[orow] + acc : acc;
+      return;
+    }
+    float M = VCR_NEG_INF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) M = fmaxf(M, mg[(i * 32 + t) * 5]);
+    float L = 0.f, X = 0.f, Y = 0.f, Z = 0.f, Bv = VCR_NEG_INF;
+    int Bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* g = mg + (i * 32 + t) * 5;
+      const float a = __builtin_amdgcn_exp2f((g[0] - M) * LOG2E);   // exp2(-inf) = 0 for a wave with no tiles
+      L = fmaf(g[1], a, L);
+      if (OP == 0) { X = fmaf(g[2], a, X); Y = fmaf(g[3], a, Y); Z = fmaf(g[4], a, Z); }
+      else {
+        const int gi = __float_as_int(g[3]);
+        if (g[2] > Bv || (g[2] == Bv && gi < Bi)) { Bv = g[2]; Bi = gi; }
+      }
+    }
+    if (OP == 0) {
+      st4(p.corr4 + orow * 4, f32x4{X / L, Y / L, Z / L, 0.f});
+    } else {
+      p.stat2[orow * 2] = M; p.stat2[orow * 2 + 1] = L;
+      if (p.argmax) p.argmax[orow] = Bi;
+    }
+  }
+}
+
+int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
+  if (!a || !a->own || !a->str) return VCR_EINVAL;
+  if (a->nbatch <= 0 || a->n_own <= 0 || a->n_str <= 0 || a->E <= 0 || (a->E % 128) || a->E > 1024) return VCR_EINVAL;
+  if ((a->ld_own & 3) || (a->ld_str & 3) || a->ld_own < a->E || a->ld_str < a->E) return VCR_EINVAL;
+  if (a->score < 0 || a->score > 2 || a->op < 0 || a->op > 2) return VCR_EINVAL;
+  if (a->score != 1 && (!a->own_side4 || !a->str_side4)) return VCR_EINVAL;
+  if (a->op == 0 && (!a->corr4 || !a->str_side4)) return VCR_EINVAL;
+  if (a->op == 1 && !a->stat2) return VCR_EINVAL;
+  if (a->op == 2 && (!a->mass || !a->str_stat2)) return VCR_EINVAL;
+  const int lds = (32 * (a->E + 4) + 4 * 32 * 5) * 4;
+  if (lds > 160 * 1024) return VCR_EUNSUPPORTED;
+  dim3 grid((a->n_own + 31) / 32, a->nbatch);
+  hipStream_t s = (hipStream_t)stream;
+#define VCR_PS_LAUNCH(OPV)                                                                                              \
+  do {                                                                                                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pairscore_kernel<OPV>),                                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                         \
+    hipLaunchKernelGGL((pairscore_kernel<OPV>), grid, dim3(256), lds, s, *a);                                           \
+  } while (0)
+  if (a->op == 0) VCR_PS_LAUNCH(0); else if (a->op == 1) VCR_PS_LAUNCH(1); else VCR_PS_LAUNCH(2);
+#undef VCR_PS_LAUNCH
+  return VCR_LAUNCH_RC();
+}
+
+}  // namespace
+
+extern "C" int vcr_pairscore_f32(const vcr_pairscore_args* a, vcr_stream_t stream) { return launch(a, stream); }
+
+extern "C" int vcr_softcorr_f32(const vcr_softcorr_args* a, vcr_stream_t stream) {
+  if (!a || !a->qside4 || !a->kside4 || !a->corr4) return VCR_EINVAL;
+  if (a->mode != 0 && a->mode != 1) return VCR_EINVAL;
+  vcr_pairscore_args p{};
+  p.own = a->q; p.ld_own = a->ldq; p.str = a->k; p.ld_str = a->ldk;
+  p.own_side4 = a->qside4; p.str_side4 = a->kside4;
+  p.nbatch = a->nbatch; p.n_own = a->nq; p.n_str = a->nk; p.E = a->E;
+  p.score = a->mode; p.scale = a->scale; p.str_batch_shift = 0; p.op = 0; p.corr4 = a->corr4;
+  return launch(&p, stream);
+}

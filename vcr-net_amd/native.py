@@ -69,6 +69,24 @@ class SoftcorrArgs(C.Structure):
                 ("mode", C.c_int), ("scale", C.c_float)]
 
 
+class PairscoreArgs(C.Structure):
+    _fields_ = [("own", f32p), ("ld_own", C.c_int), ("str", f32p), ("ld_str", C.c_int), ("own_side4", f32p),
+                ("str_side4", f32p), ("nbatch", C.c_int), ("n_own", C.c_int), ("n_str", C.c_int), ("E", C.c_int),
+                ("score", C.c_int), ("scale", C.c_float), ("str_batch_shift", C.c_int), ("op", C.c_int),
+                ("corr4", f32p), ("stat2", f32p), ("argmax", f32p), ("str_stat2", f32p),
+                ("str_stat_batch_stride", C.c_long), ("mass", f32p), ("accumulate", C.c_int)]
+
+
+class RankselectArgs(C.Structure):
+    _fields_ = [("values", f32p), ("nbatch", C.c_int), ("n", C.c_int), ("K", C.c_int), ("order", f32p),
+                ("mask", f32p), ("largest", C.c_int)]
+
+
+class GatherArgs(C.Structure):
+    _fields_ = [("in_", f32p), ("ld_in", C.c_int), ("n_in", C.c_int), ("idx", f32p), ("nbatch", C.c_int),
+                ("n_out", C.c_int), ("C", C.c_int), ("out", f32p), ("ld_out", C.c_int)]
+
+
 class RigidSvdArgs(C.Structure):
     _fields_ = [("src", f32p), ("lds", C.c_int), ("corr", f32p), ("ldc", C.c_int), ("B", C.c_int), ("K", C.c_int),
                 ("R", f32p), ("t", f32p), ("R_ba", f32p), ("t_ba", f32p), ("H", f32p)]
@@ -113,7 +131,8 @@ _SIGS = {
     "vcr_pointwise_f32": PointwiseArgs, "vcr_knn_f32": KnnArgs, "vcr_linear_f32": LinearArgs,
     "vcr_layernorm_f32": LayerNormArgs, "vcr_rowside_f32": RowsideArgs, "vcr_edgeconv_f32": EdgeconvArgs,
     "vcr_gathermax_f32": GathermaxArgs, "vcr_sdpa_f32": SdpaArgs, "vcr_softcorr_f32": SoftcorrArgs,
-    "vcr_rigid_svd_f32": RigidSvdArgs,
+    "vcr_rigid_svd_f32": RigidSvdArgs, "vcr_pairscore_f32": PairscoreArgs, "vcr_rankselect_f32": RankselectArgs,
+    "vcr_gather_rows_f32": GatherArgs,
 }
 
 _lib: Optional[C.CDLL] = None
@@ -302,3 +321,41 @@ def rigid_svd(src, corr, want_h=False):
     call("vcr_rigid_svd_f32", RigidSvdArgs(ptr(src), src.stride(1), ptr(corr), corr.stride(1), B, K, ptr(R), ptr(t),
                                            ptr(Rb), ptr(tb), ptr(H)))
     return (R, t, Rb, tb, H) if want_h else (R, t, Rb, tb)
+
+
+def pairscore(own, strm, nbatch, n_own, n_str, op, score=0, scale=1.0, own_side4=None, str_side4=None,
+              shift=0, str_stat2=None, str_stat_stride=None, mass=None, accumulate=False, want_argmax=False):
+    """vcr_pairscore_f32: op 0 -> corr4; op 1 -> (stat2 [nbatch*n_own,2], argmax or None); op 2 -> mass."""
+    dev = own.device
+    corr4 = _f32(nbatch * n_own, 4, device=dev) if op == 0 else None
+    stat2 = _f32(nbatch * n_own, 2, device=dev) if op == 1 else None
+    amax = torch.empty(nbatch * n_own, dtype=torch.int32, device=dev) if (op == 1 and want_argmax) else None
+    if op == 2 and mass is None:
+        mass = _f32(nbatch, n_own, device=dev)
+    call("vcr_pairscore_f32", PairscoreArgs(
+        ptr(own), own.stride(0), ptr(strm), strm.stride(0), ptr(own_side4), ptr(str_side4), nbatch, n_own, n_str,
+        own.shape[1], score, scale, shift, op, ptr(corr4), ptr(stat2), ptr(amax), ptr(str_stat2),
+        int(str_stat_stride if str_stat_stride is not None else n_str * 2), ptr(mass), int(accumulate)))
+    if op == 0:
+        return corr4
+    if op == 1:
+        return stat2, amax
+    return mass
+
+
+def rankselect(values, K, want_order=True, want_mask=False, largest=True):
+    nb, n = values.shape
+    order = torch.empty(nb, K, dtype=torch.int32, device=values.device) if want_order else None
+    mask = torch.empty(nb, n, dtype=torch.uint8, device=values.device) if want_mask else None
+    call("vcr_rankselect_f32", RankselectArgs(ptr(values.contiguous()), nb, n, K, ptr(order), ptr(mask), int(largest)))
+    return order, mask
+
+
+def gather_rows(x, idx, nbatch, n_in):
+    """x [nbatch*n_in, C] rows, idx [nbatch, n_out] int32 -> [nbatch*n_out, C]."""
+    n_out = idx.shape[1]
+    Cc = x.shape[1]
+    out = _f32(nbatch * n_out, Cc, device=x.device)
+    call("vcr_gather_rows_f32", GatherArgs(ptr(x), x.stride(0), n_in, ptr(idx.contiguous()), nbatch, n_out, Cc,
+                                           ptr(out), Cc))
+    return out
