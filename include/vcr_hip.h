@@ -113,6 +113,17 @@ typedef struct {
 } vcr_gathermax_args;
 int vcr_gathermax_f32(const vcr_gathermax_args*, vcr_stream_t);
 
+/* ---- EdgeConv chains (DGCNN, vcrnet_model.py:104-118): per-edge rows h[(i,j)] = relu(P[nbr_ij] + Q[i])
+ * ([M*k, C], feeding vcr_linear_f32 for conv2..conv4) and the max over each point's k edge rows. */
+typedef struct {
+  const float* pq; int ldpq; int C; const int32_t* idx; int k; int M; int n_per_cloud; float* h; int ldh;
+} vcr_edgerows_args;
+int vcr_edgerows_f32(const vcr_edgerows_args*, vcr_stream_t);
+typedef struct {
+  const float* x; int ldx; int M, k, C; float* y; int ldy;
+} vcr_segmax_args;
+int vcr_segmax_f32(const vcr_segmax_args*, vcr_stream_t);
+
 /* ---- kernel 3: scaled-dot-product attention, flash-style (transformer.py:29-34,55) ----
  * q,k,v: [nbatch*n, h*128] rows with pitches; head hh uses columns hh*128..+127.
  * out = softmax(q k^T * scale) v, never materialising the n x n scores.

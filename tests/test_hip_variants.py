@@ -1,0 +1,78 @@
+"""GPU parity of the non-default module variants against
+vectors recorded from the reference: DGCNN embedding, VcpAtt head, cycle consistency, DCP."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import cfg_weights, golden
+from test_hip_forward import assert_mostly_close, build_net, make_args, R_TOL, T_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def run(name, **kw):
+    g = golden(name)
+    net, _ = build_net(**kw)
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda())
+    return g, out
+
+
+def check(g, out):
+    assert_mostly_close(out[1].cpu().numpy(), g["it0_corrK"], atol=5e-4)
+    np.testing.assert_allclose(out[2].cpu().numpy(), g["it0_R"], atol=R_TOL)
+    np.testing.assert_allclose(out[3].cpu().numpy(), g["it0_t"], atol=T_TOL)
+    np.testing.assert_allclose(out[4].cpu().numpy(), g["it0_R_ba"], atol=R_TOL)
+    np.testing.assert_allclose(out[5].cpu().numpy(), g["it0_t_ba"], atol=T_TOL)
+
+
+def test_dgcnn_embedding():
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import composed
+    g = golden("dgcnn_n256_b2")
+    net, _ = build_net(emb_nn="dgcnn")
+    src, tgt = torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda()
+    rec = {}
+    net._pack()
+    with torch.no_grad():
+        out = composed.forward_composed(net, src, tgt, rec)
+        out2 = net(src, tgt)
+    cs = int(g["cstride"])
+    e0 = rec["emb0"].cpu().view(2, 2, 256, 512)
+    assert_mostly_close(e0[0].transpose(1, 2)[:, ::cs].numpy(), g["it0_emb0_src"], atol=2e-5)
+    assert_mostly_close(e0[1].transpose(1, 2)[:, ::cs].numpy(), g["it0_emb0_tgt"], atol=2e-5)
+    check(g, out)
+    np.testing.assert_allclose(out2[2].cpu().numpy(), out[2].cpu().numpy(), atol=1e-6)
+
+
+def test_vcp_att_head():
+    check(*run("att_n256_b2", vcp_nn="att"))
+
+
+def test_cycle_consistency():
+    check(*run("cycle_n256_b2", cycle=True))
+
+
+def test_dcp_model():
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd.module import DCP
+    g = golden("dcp_n256_b2")
+    args = make_args()
+    args.head, args.use_mFea = "svd", False
+    net = DCP(args)
+    w = cfg_weights()
+    w = {k: v for k, v in w.items() if not k.startswith("svd.")}
+    w["head.reflect"] = torch.diag(torch.tensor([1.0, 1.0, -1.0]))
+    res = net.load_state_dict(w, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    net = net.cuda().eval()
+    with torch.no_grad():
+        R, t, R_ba, t_ba, s, corr = net(torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda())
+    assert_mostly_close(corr.cpu().numpy(), g["corr"], atol=5e-4)
+    np.testing.assert_allclose(R.cpu().numpy(), g["R"], atol=R_TOL)
+    np.testing.assert_allclose(t.cpu().numpy(), g["t"], atol=T_TOL)
+    np.testing.assert_allclose(t_ba.cpu().numpy(), g["t_ba"], atol=T_TOL)
+    with pytest.raises(Exception):
+        DCP(SimpleNamespace(**{**vars(args), "head": "mlp"}))

@@ -36,6 +36,48 @@ def lpdnet_embed(net, x_cf: torch.Tensor, rec: Optional[dict] = None):
     return emb, xyz4.view(M, 4)
 
 
+def _fold_bn(sd, conv: str, bn: str, eps: float = 1e-5):
+    """Eval-mode BatchNorm folded into the preceding bias-free 1x1 conv: bn(conv(x)) = W'x + b'."""
+    s = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + eps)
+    w = sd[conv + ".weight"].reshape(sd[conv + ".weight"].shape[0], -1)
+    return (w * s.view(-1, 1)).contiguous(), (sd[bn + ".bias"] - sd[bn + ".running_mean"] * s).contiguous()
+
+
+def dgcnn_embed(net, x_cf: torch.Tensor, rec: Optional[dict] = None):
+    """DGCNN.forward (model/vcrnet_model.py:104-123, eval-mode BN folded): one Cartesian kNN, conv1 via the F7
+    split (per-point P/Q + neighbour gather), conv2..conv4 as N*k GEMMs over per-edge rows, max over k after
+    each, concat 512, conv5."""
+    sd = _sd(net)
+    Bc, _, N = x_cf.shape
+    k = int(net.emb_nn.k)
+    dev = x_cf.device
+    M = Bc * N
+    z = lambda n, v: torch.zeros(n, dtype=torch.float32, device=dev) if v is None else v
+    # xyz4 rows come from the pointwise kernel's side output (its 64-d features are unused here)
+    xyz4, _, _ = native.pointwise(x_cf, z(64 * 3, None).view(64, 3), z(64, None), z(64 * 64, None).view(64, 64), z(64, None))
+    idx = native.knn(xyz4, None, k)
+    w1, b1 = _fold_bn(sd, "emb_nn.conv1", "emb_nn.bn1")                    # [64,6]: cols 0..2 neighbour, 3..5 centre
+    wpq = torch.zeros(128, 32, dtype=torch.float32, device=dev)            # K padded 3 -> 32 for the MFMA tile
+    wpq[:64, :3], wpq[64:, :3] = w1[:, :3], w1[:, 3:]
+    xin = torch.zeros(M, 32, dtype=torch.float32, device=dev)
+    xin[:, :3] = xyz4.view(M, 4)[:, :3]
+    pq = native.linear(xin, wpq, torch.cat((torch.zeros_like(b1), b1)))
+    cat = torch.empty(M, 512, dtype=torch.float32, device=dev)
+    h = native.edgerows(pq, 64, idx.view(M, k), N)                         # relu(bn1(conv1(.)))  [M*k,64]
+    native.segmax(h, M, k, out=cat[:, 0:64])
+    col = 64
+    for i, co in ((2, 64), (3, 128), (4, 256)):
+        w, b = _fold_bn(sd, f"emb_nn.conv{i}", f"emb_nn.bn{i}")
+        h = native.linear(h, w, b, relu=True)
+        native.segmax(h, M, k, out=cat[:, col:col + co])
+        col += co
+    w5, b5 = _fold_bn(sd, "emb_nn.conv5", "emb_nn.bn5")
+    emb = native.linear(cat, w5, b5, relu=True)
+    if rec is not None:
+        rec.update(idx_xyz=idx, cat=cat, emb0=emb, xyz4=xyz4)
+    return emb, xyz4.view(M, 4)
+
+
 def transformer(net, emb: torch.Tensor, B: int, N: int, rec: Optional[dict] = None,
                 key_keep_fn=None) -> torch.Tensor:
     """Both directions of model/transformer.py:264-272 on the 2B-batched rows [2B*N, E] (src then tgt).
@@ -123,9 +165,9 @@ def forward_composed(net, src: torch.Tensor, tgt: torch.Tensor, rec: Optional[di
     P = net._packed
     B, _, N = src.shape
     x = torch.cat((src, tgt), 0).contiguous().float()
-    if net._emb_kind != "lpdnet":
-        raise native.VcrHipError("emb_nn=dgcnn on the HIP path: not built yet")
-    emb, xyz4 = lpdnet_embed(net, x, rec)
+    if net.cycle and (net._partial or net._vcp == "att"):
+        raise native.VcrHipError("cycle=True is built for the whole-mode topK / dist heads only")
+    emb, xyz4 = (lpdnet_embed if net._emb_kind == "lpdnet" else dgcnn_embed)(net, x, rec)
     M1 = B * N
     if P and "dec_norm.a" in P:
         d3 = transformer(net, emb, B, N, rec)

@@ -136,7 +136,54 @@ __global__ __launch_bounds__(256) void gathermax_kernel(vcr_gathermax_args p) {
   st4(p.y + (size_t)pt * p.ldy + c, y);
 }
 
+// Per-edge feature rows for EdgeConv CHAINS (DGCNN, model/vcrnet_model.py:104-118): conv2..conv4 act on the
+// post-ReLU per-edge tensor, so every layer is a true N*k GEMM (vcr_linear_f32 over [M*k, C] edge rows) and
+// only the first conv enjoys the F7 split.  h[(i,j)] = relu(P[nbr_ij] + Q[i]).
+__global__ __launch_bounds__(256) void edge_rows_kernel(vcr_edgerows_args p) {
+  const int lane = threadIdx.x & 63;
+  const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= (long)p.M * p.k) return;
+  const int pt = (int)(e / p.k);
+  const int base = (pt / p.n_per_cloud) * p.n_per_cloud;
+  const int nb = p.idx[e];
+  for (int c = lane * 4; c < p.C; c += 256) {
+    const f32x4 v = ld4(p.pq + (size_t)(base + nb) * p.ldpq + c) + ld4(p.pq + (size_t)pt * p.ldpq + p.C + c);
+    st4(p.h + (size_t)e * p.ldh + c, f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)});
+  }
+}
+
+// y[i] = max_j x[(i,j)]   (x.max(dim=-1) of vcrnet_model.py:109-118)
+__global__ __launch_bounds__(256) void segmax_kernel(vcr_segmax_args p) {
+  const int lane = threadIdx.x & 63;
+  const int pt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pt >= p.M) return;
+  for (int c = lane * 4; c < p.C; c += 256) {
+    f32x4 m = ld4(p.x + ((size_t)pt * p.k) * p.ldx + c);
+    for (int j = 1; j < p.k; ++j) {
+      const f32x4 v = ld4(p.x + ((size_t)pt * p.k + j) * p.ldx + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], v[i]);
+    }
+    st4(p.y + (size_t)pt * p.ldy + c, m);
+  }
+}
+
 }  // namespace
+
+extern "C" int vcr_edgerows_f32(const vcr_edgerows_args* a, vcr_stream_t stream) {
+  if (!a || !a->pq || !a->idx || !a->h) return VCR_EINVAL;
+  if (a->M <= 0 || a->k <= 0 || a->C <= 0 || (a->C & 3) || (a->ldpq & 3) || (a->ldh & 3) || a->ldpq < 2 * a->C) return VCR_EINVAL;
+  if (a->n_per_cloud <= 0 || (a->M % a->n_per_cloud)) return VCR_EINVAL;
+  const long rows = (long)a->M * a->k;
+  hipLaunchKernelGGL(edge_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  return VCR_LAUNCH_RC();
+}
+
+extern "C" int vcr_segmax_f32(const vcr_segmax_args* a, vcr_stream_t stream) {
+  if (!a || !a->x || !a->y || a->M <= 0 || a->k <= 0 || a->C <= 0 || (a->C & 3) || (a->ldx & 3) || (a->ldy & 3)) return VCR_EINVAL;
+  hipLaunchKernelGGL(segmax_kernel, dim3((a->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
+  return VCR_LAUNCH_RC();
+}
 
 extern "C" int vcr_edgeconv_f32(const vcr_edgeconv_args* a, vcr_stream_t stream) {
   if (!a || !a->pq || !a->idx || !a->w2 || !a->b2 || !a->x1 || !a->x2) return VCR_EINVAL;

@@ -209,27 +209,26 @@ class VCRNet(nn.Module):
         key = self._fingerprint()
         if self._packed is not None and key == self._packed_key:
             return
-        if self._emb_kind != "lpdnet":
-            self._packed, self._packed_key, self._cw = {}, key, None
-            return
         sd = {k: v.detach().float() for k, v in self.state_dict().items()}
         P: Dict[str, torch.Tensor] = {}
         g = lambda k: sd[k].contiguous()
-        P["c1_w"] = g("emb_nn.conv1_lpd.weight").view(64, 3).contiguous(); P["c1_b"] = g("emb_nn.conv1_lpd.bias")
-        P["c2_w"] = g("emb_nn.conv2_lpd.weight").view(64, 64).contiguous(); P["c2_b"] = g("emb_nn.conv2_lpd.bias")
-        w = g("emb_nn.convDG1.0.weight").view(128, 128)                    # cat((neighbour, centre)): util.py:197
-        P["dg1_wpq"] = torch.cat((w[:, :64], w[:, 64:]), 0).contiguous()
-        P["dg1_bpq"] = torch.cat((torch.zeros_like(sd["emb_nn.convDG1.0.bias"]), sd["emb_nn.convDG1.0.bias"]))
-        P["dg2_w"] = g("emb_nn.convDG2.0.weight").view(128, 128).contiguous(); P["dg2_b"] = g("emb_nn.convDG2.0.bias")
-        w = g("emb_nn.convSN1.0.weight").view(256, 256)
-        P["sn1_wpq"] = torch.cat((w[:, :128], w[:, 128:]), 0).contiguous()
-        P["sn1_bpq"] = torch.cat((torch.zeros_like(sd["emb_nn.convSN1.0.bias"]), sd["emb_nn.convSN1.0.bias"]))
-        P["c3_w"] = g("emb_nn.conv3_lpd.weight").view(self.emb_dims, 512).contiguous()
-        P["c3_b"] = g("emb_nn.conv3_lpd.bias")
         cw = native.VcrnetWeights()
-        for k in ("c1_w", "c1_b", "c2_w", "c2_b", "dg1_wpq", "dg1_bpq", "dg2_w", "dg2_b", "sn1_wpq", "sn1_bpq",
-                  "c3_w", "c3_b"):
-            setattr(cw, k, native.ptr(P[k]))
+        if self._emb_kind == "lpdnet":
+            P["c1_w"] = g("emb_nn.conv1_lpd.weight").view(64, 3).contiguous(); P["c1_b"] = g("emb_nn.conv1_lpd.bias")
+            P["c2_w"] = g("emb_nn.conv2_lpd.weight").view(64, 64).contiguous(); P["c2_b"] = g("emb_nn.conv2_lpd.bias")
+            w = g("emb_nn.convDG1.0.weight").view(128, 128)                # cat((neighbour, centre)): util.py:197
+            P["dg1_wpq"] = torch.cat((w[:, :64], w[:, 64:]), 0).contiguous()
+            P["dg1_bpq"] = torch.cat((torch.zeros_like(sd["emb_nn.convDG1.0.bias"]), sd["emb_nn.convDG1.0.bias"]))
+            P["dg2_w"] = g("emb_nn.convDG2.0.weight").view(128, 128).contiguous()
+            P["dg2_b"] = g("emb_nn.convDG2.0.bias")
+            w = g("emb_nn.convSN1.0.weight").view(256, 256)
+            P["sn1_wpq"] = torch.cat((w[:, :128], w[:, 128:]), 0).contiguous()
+            P["sn1_bpq"] = torch.cat((torch.zeros_like(sd["emb_nn.convSN1.0.bias"]), sd["emb_nn.convSN1.0.bias"]))
+            P["c3_w"] = g("emb_nn.conv3_lpd.weight").view(self.emb_dims, 512).contiguous()
+            P["c3_b"] = g("emb_nn.conv3_lpd.bias")
+            for k in ("c1_w", "c1_b", "c2_w", "c2_b", "dg1_wpq", "dg1_bpq", "dg2_w", "dg2_b", "sn1_wpq", "sn1_bpq",
+                      "c3_w", "c3_b"):
+                setattr(cw, k, native.ptr(P[k]))
         if isinstance(self.pointer, _TransformerParams):
             pre = "pointer.model."
 
@@ -274,7 +273,8 @@ class VCRNet(nn.Module):
             cw.has_pointer = 2 if isinstance(self.pointer, _Identity) else 0
         cw.E, cw.F, cw.heads, cw.k = self.emb_dims, self._ff, self._n_heads, int(self.emb_nn.k)
         cw.head_mode = 1 if self._vcp == "dist" else 0
-        self._packed, self._packed_key, self._cw = P, key, cw
+        self._packed, self._packed_key = P, key
+        self._cw = cw if self._emb_kind == "lpdnet" else None              # the fused C driver is LPDNet-only
 
     def _buffers_for(self, B: int, N: int, device) -> Dict[str, torch.Tensor]:
         key = (B, N, device, int(self.emb_nn.k))
@@ -330,6 +330,27 @@ class VCRNet(nn.Module):
         src_corr = corr4[:, :, :3].transpose(1, 2).contiguous()
         out = (src, src_corr, R_ab, t_ab, R_ba, t_ba)
         return out + (emb,) if want_emb else out
+
+
+class DCP(VCRNet):
+    """Drop-in for the reference's DCP with head='svd', use_mFea=False (model/dcp_model.py:177-223): the same
+    embedding + pointer, the scaled-dot-product soft correspondences fused with the SVD solve
+    (dcp_model.py:126-174).  Output order (R_ab, t_ab, R_ba, t_ba, src, src_corr) differs from VCRNet's."""
+
+    def __init__(self, args):
+        if getattr(args, "head", "svd") != "svd" or getattr(args, "use_mFea", False):
+            raise Exception("Not implemented")                             # dcp_model.py:198-203 (mlp head: out of scope)
+        if args.pointer not in ("identity", "transformer"):
+            raise Exception("Not implemented")                             # dcp_model.py:191-196
+        a = dict(vars(args))
+        a.update(vcp_nn="dist", partial=False)
+        super().__init__(type("Args", (), a)())
+        del self.svd
+        self.head = _SVDHead()                                             # key 'head.reflect' (dcp_model.py:121-122)
+
+    def forward(self, *input):
+        src, corr, R_ab, t_ab, R_ba, t_ba = super().forward(*input)
+        return R_ab, t_ab, R_ba, t_ba, src, corr
 
 
 def vcrnetIter(net, src, tgt, iter=1):

@@ -87,6 +87,16 @@ class GatherArgs(C.Structure):
                 ("n_out", C.c_int), ("C", C.c_int), ("out", f32p), ("ld_out", C.c_int)]
 
 
+class EdgerowsArgs(C.Structure):
+    _fields_ = [("pq", f32p), ("ldpq", C.c_int), ("C", C.c_int), ("idx", f32p), ("k", C.c_int), ("M", C.c_int),
+                ("n_per_cloud", C.c_int), ("h", f32p), ("ldh", C.c_int)]
+
+
+class SegmaxArgs(C.Structure):
+    _fields_ = [("x", f32p), ("ldx", C.c_int), ("M", C.c_int), ("k", C.c_int), ("C", C.c_int), ("y", f32p),
+                ("ldy", C.c_int)]
+
+
 class RigidSvdArgs(C.Structure):
     _fields_ = [("src", f32p), ("lds", C.c_int), ("corr", f32p), ("ldc", C.c_int), ("B", C.c_int), ("K", C.c_int),
                 ("R", f32p), ("t", f32p), ("R_ba", f32p), ("t_ba", f32p), ("H", f32p)]
@@ -132,7 +142,7 @@ _SIGS = {
     "vcr_layernorm_f32": LayerNormArgs, "vcr_rowside_f32": RowsideArgs, "vcr_edgeconv_f32": EdgeconvArgs,
     "vcr_gathermax_f32": GathermaxArgs, "vcr_sdpa_f32": SdpaArgs, "vcr_softcorr_f32": SoftcorrArgs,
     "vcr_rigid_svd_f32": RigidSvdArgs, "vcr_pairscore_f32": PairscoreArgs, "vcr_rankselect_f32": RankselectArgs,
-    "vcr_gather_rows_f32": GatherArgs,
+    "vcr_gather_rows_f32": GatherArgs, "vcr_edgerows_f32": EdgerowsArgs, "vcr_segmax_f32": SegmaxArgs,
 }
 
 _lib: Optional[C.CDLL] = None
@@ -341,6 +351,22 @@ def pairscore(own, strm, nbatch, n_own, n_str, op, score=0, scale=1.0, own_side4
     if op == 1:
         return stat2, amax
     return mass
+
+
+def edgerows(pq, Cc, idx, n_per_cloud):
+    """pq [M, 2C] (P | Q), idx [M,k] -> per-edge rows relu(P[nbr] + Q[i]) as [M*k, C]."""
+    M, k = idx.shape
+    h = _f32(M * k, Cc, device=pq.device)
+    call("vcr_edgerows_f32", EdgerowsArgs(ptr(pq), pq.stride(0), Cc, ptr(idx), k, M, n_per_cloud, ptr(h), Cc))
+    return h
+
+
+def segmax(x, M, k, out=None):
+    """x [M*k, C] edge rows -> [M, C] max over each point's k rows (out may be a strided row view)."""
+    Cc = x.shape[1]
+    y = out if out is not None else _f32(M, Cc, device=x.device)
+    call("vcr_segmax_f32", SegmaxArgs(ptr(x), x.stride(0), M, k, Cc, ptr(y), y.stride(0)))
+    return y
 
 
 def rankselect(values, K, want_order=True, want_mask=False, largest=True):
