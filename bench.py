@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print the per-launch table to stderr")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm); gloo only "
+                                                      "for exercising the multi-rank control flow on a 1-GPU box")
     return ap.parse_args()
 
 
@@ -76,12 +78,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    ndev = torch.cuda.device_count()
+    if a.backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but {ndev} GPUs: one process per GPU")
+    local = local % max(1, ndev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import native, shard, synth, weights, workmodel
@@ -116,6 +125,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:   # sanity: the gathered poses must hold every rank's block in rank order
+        g = step()
+        mine = g[rank * B:(rank + 1) * B]
+        own = step()[rank * B:(rank + 1) * B]
+        assert g.shape == (world * B, 12) and torch.allclose(mine, own)
+
     fence()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -123,7 +138,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

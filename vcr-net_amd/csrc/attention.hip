@@ -28,9 +28,20 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
   Stage* st = reinterpret_cast<Stage*>(smem);
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int head = blockIdx.y, b = blockIdx.z;
+  // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD whole
+  // (batch, head) pairs -- all query blocks of a pair then stream the same K/V through ONE L2 instead of
+  // eight (measured before: 1.14 GB fetched per launch = 8 x the K/V bytes).  Speed only, never correctness.
+  const int nqb = (p.nq + 127) / 128, nbh = p.nbatch * p.heads;
+  int qb, bh;
+  if ((nbh & 7) == 0) {
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    qb = i % nqb; bh = (i / nqb) * 8 + xcd;
+  } else {
+    qb = blockIdx.x % nqb; bh = blockIdx.x / nqb;
+  }
+  const int head = bh % p.heads, b = bh / p.heads;
   const int kvb = (b + p.kv_batch_shift) % p.nbatch;
-  const int q = blockIdx.x * 128 + w * 32 + l31;
+  const int q = qb * 128 + w * 32 + l31;
   const int qc = min(q, p.nq - 1);
 
   f32x4 qf[16];
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = 2 * i + half;
-      const int qq = blockIdx.x * 128 + w * 32 + row;
+      const int qq = qb * 128 + w * 32 + row;
       if (qq < p.nq) {
         const f32x4 v = ld4(&ot[row * KP + l31 * 4]);
         st4(p.out + ((size_t)b * p.nq + qq) * p.ldo + head * 128 + l31 * 4, v);
@@ -156,7 +167,7 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   if (a->nbatch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return VCR_EINVAL;
   if ((a->ldq & 3) || (a->ldk & 3) || (pv && ((a->ldv & 3) || (a->ldo & 3)))) return VCR_EINVAL;
   if (a->ldq < a->heads * 128 || a->ldk < a->heads * 128) return VCR_EINVAL;
-  dim3 grid((a->nq + 127) / 128, a->heads, a->nbatch);
+  dim3 grid(((a->nq + 127) / 128) * a->heads * a->nbatch);
   const int lds = 2 * sizeof(Stage);
   hipStream_t s = (hipStream_t)stream;
 #define VCR_SDPA_LAUNCH(M, P)                                                                                         \

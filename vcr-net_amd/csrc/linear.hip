@@ -13,11 +13,19 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, PITCH = BK + 4;
+constexpr int BM = 128, BN = 128;
 
-struct Tile { float a[BM][PITCH]; float b[BN][PITCH]; };
+template <int BK> struct TileT { float a[BM][BK + 4]; float b[BN][BK + 4]; };
 
-__global__ __launch_bounds__(256, 2) void linear_kernel(vcr_linear_args p, int tiles_m, int tiles_n) {
+// BK = 32: 73.7 KB LDS, 2 blocks/CU.  BK = 16: 40 KB LDS, 3 blocks/CU (VGPR-limited): the third block's MFMAs
+// cover the other blocks' prologue / epilogue bubbles.
+template <int BK>
+__global__ __launch_bounds__(256, (BK == 32 ? 2 : 3)) void linear_kernel(vcr_linear_args p, int tiles_m, int tiles_n,
+                                                                        int vec_epilogue) {
+  using Tile = TileT<BK>;
+  constexpr int CPR = BK / 4;                            // 16-B chunks per row
+  constexpr int RPP = 256 / CPR;                         // rows covered per staging pass
+  constexpr int NPASS = BM / RPP;                        // staging passes per operand
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tile* tile = reinterpret_cast<Tile*>(smem);           // [2]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -35,20 +43,20 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(vcr_linear_args p, int t
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // global -> register staging: thread owns 4 rows (r0 + 32 i) x one 16-B column chunk of each operand
-  const int r0 = t >> 3, c4 = (t & 7) * 4;
-  const float* xa[4];
-  const float* wb[4];
+  // global -> register staging: thread owns NPASS rows (r0 + RPP i) x one 16-B column chunk of each operand
+  const int r0 = t / CPR, c4 = (t % CPR) * 4;
+  const float* xa[NPASS];
+  const float* wb[NPASS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    xa[i] = p.x + (size_t)min(m0 + r0 + 32 * i, p.M - 1) * p.ldx + c4;
-    wb[i] = p.w + (size_t)min(n0 + r0 + 32 * i, p.N - 1) * p.K + c4;
+  for (int i = 0; i < NPASS; ++i) {
+    xa[i] = p.x + (size_t)min(m0 + r0 + RPP * i, p.M - 1) * p.ldx + c4;
+    wb[i] = p.w + (size_t)min(n0 + r0 + RPP * i, p.N - 1) * p.K + c4;
   }
-  f32x4 ra[4], rb[4];
+  f32x4 ra[NPASS], rb[NPASS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { ra[i] = ld4(xa[i]); rb[i] = ld4(wb[i]); }
+  for (int i = 0; i < NPASS; ++i) { ra[i] = ld4(xa[i]); rb[i] = ld4(wb[i]); }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { st4(&tile[0].a[r0 + 32 * i][c4], ra[i]); st4(&tile[0].b[r0 + 32 * i][c4], rb[i]); }
+  for (int i = 0; i < NPASS; ++i) { st4(&tile[0].a[r0 + RPP * i][c4], ra[i]); st4(&tile[0].b[r0 + RPP * i][c4], rb[i]); }
   __syncthreads();
 
   f32x16 acc[2][2];
@@ -62,11 +70,11 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(vcr_linear_args p, int t
     const int cur = kt & 1;
     if (kt + 1 < nk) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { ra[i] = ld4(xa[i] + (kt + 1) * BK); rb[i] = ld4(wb[i] + (kt + 1) * BK); }
+      for (int i = 0; i < NPASS; ++i) { ra[i] = ld4(xa[i] + (kt + 1) * BK); rb[i] = ld4(wb[i] + (kt + 1) * BK); }
     }
     const Tile& T = tile[cur];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < BK / 8; ++g) {
       f32x4 fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) fa[i] = ld4(&T.a[wm * 64 + i * 32 + l31][8 * g + 4 * half]);
@@ -82,12 +90,47 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(vcr_linear_args p, int t
     if (kt + 1 < nk) {
       Tile& Nx = tile[cur ^ 1];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { st4(&Nx.a[r0 + 32 * i][c4], ra[i]); st4(&Nx.b[r0 + 32 * i][c4], rb[i]); }
+      for (int i = 0; i < NPASS; ++i) { st4(&Nx.a[r0 + RPP * i][c4], ra[i]); st4(&Nx.b[r0 + RPP * i][c4], rb[i]); }
     }
     __syncthreads();
   }
 
-  // epilogue: D[row = (r&3)+8(r>>2)+4 half][col = l31]; a half-wave writes 128 contiguous bytes per row
+  // epilogue.  Fast path: transpose the wave's 64x64 tile through its slice of the (now free) LDS so that
+  // every lane owns 4 consecutive columns: bias / ReLU / residual / store all move 16 B per lane and a
+  // wave-instruction covers 4 rows x 256 contiguous bytes (the accumulator layout itself only offers
+  // 4-byte accesses at a 32-lane stride per row).
+  if (vec_epilogue) {
+    constexpr int EP = 68;
+    float* ot = reinterpret_cast<float*>(smem) + wave * 32 * EP;     // 8.7 KB per wave, reused for both row halves
+    const int c4e = (lane & 15) * 4, col = n0 + wn * 64 + c4e;
+    const f32x4 bias = (p.bias && col < p.N) ? ld4(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[acc_row(r, half) * EP + j * 32 + l31] = acc[i][j][r];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      if (col < p.N) {
+#pragma unroll 4
+        for (int ps = 0; ps < 8; ++ps) {
+          const int rl = ps * 4 + (lane >> 4);
+          const int row = m0 + wm * 64 + i * 32 + rl;
+          if (row < p.M) {
+            f32x4 v = ld4(&ot[rl * EP + c4e]) + bias;
+            if (p.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+            if (p.residual) v = v + ld4(p.residual + (size_t)row * p.ldr + col);
+            st4(p.y + (size_t)row * p.ldy + col, v);
+          }
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+  // generic path: D[row = (r&3)+8(r>>2)+4 half][col = l31]; a half-wave writes 128 contiguous bytes per row
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wn * 64 + j * 32 + l31;
@@ -109,16 +152,31 @@ __global__ __launch_bounds__(256, 2) void linear_kernel(vcr_linear_args p, int t
   }
 }
 
+int g_variant = 0;   // debug/tuning only (vcr_debug_linear_variant): 0 = BK 32, 1 = BK 16
+
 }  // namespace
+
+extern "C" void vcr_debug_linear_variant(int v) { g_variant = v; }
 
 extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->w || !a->y) return VCR_EINVAL;
-  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % BK) != 0) return VCR_EINVAL;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % 32) != 0) return VCR_EINVAL;
   if ((a->ldx & 3) || a->ldx < a->K || a->ldy < a->N || (a->residual && a->ldr < a->N)) return VCR_EINVAL;
   if (((uintptr_t)a->x | (uintptr_t)a->w) & 15) return VCR_EINVAL;
   const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
-  static const int lds = 2 * sizeof(Tile);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(linear_kernel, dim3(tiles_m * tiles_n), dim3(256), lds, (hipStream_t)stream, *a, tiles_m, tiles_n);
+  const int lds32 = 2 * sizeof(TileT<32>), lds16 = 2 * sizeof(TileT<16>);
+  static_assert(2 * sizeof(TileT<16>) >= 4 * 32 * 68 * 4, "epilogue slice fits the staging buffers");
+  const int vec = (a->N % 4 == 0) && (a->ldy % 4 == 0) && (((uintptr_t)a->y & 15) == 0) &&
+                  (!a->bias || ((uintptr_t)a->bias & 15) == 0) &&
+                  (!a->residual || ((a->ldr % 4 == 0) && ((uintptr_t)a->residual & 15) == 0));
+  if (g_variant == 1) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    hipLaunchKernelGGL(linear_kernel<16>, dim3(tiles_m * tiles_n), dim3(256), lds16, (hipStream_t)stream, *a, tiles_m,
+                       tiles_n, vec);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
+    hipLaunchKernelGGL(linear_kernel<32>, dim3(tiles_m * tiles_n), dim3(256), lds32, (hipStream_t)stream, *a, tiles_m,
+                       tiles_n, vec);
+  }
   return VCR_LAUNCH_RC();
 }

@@ -30,6 +30,12 @@ def all_gather_poses(pose: torch.Tensor, world: int) -> torch.Tensor:
     """[b,12] per rank (equal b on every rank) -> [world*b,12] on every rank, in rank order."""
     if world == 1:
         return pose
+    if pose.is_cuda and dist.get_backend() != "nccl":
+        # CPU-only backends (gloo in tests): stage the few hundred bytes through the host
+        host = pose.detach().cpu().contiguous()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        return torch.cat(parts, 0).to(pose.device)
     out = torch.empty((world * pose.shape[0], pose.shape[1]), dtype=pose.dtype, device=pose.device)
     dist.all_gather_into_tensor(out, pose.contiguous())
     return out
