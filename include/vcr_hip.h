@@ -49,6 +49,9 @@ typedef struct {
 } vcr_pointwise_args;
 int vcr_pointwise_f32(const vcr_pointwise_args*, vcr_stream_t);
 
+/* x_cf [B,3,N] channels-first -> xyz4 [B,N,4] rows (x, y, z, x^2+y^2+z^2): layout change only. */
+int vcr_rows4_f32(const float* x_cf, float* xyz4, int B, int N, vcr_stream_t);
+
 /* ---- kernel 1: fused pairwise-distance + top-k (util/util.py:143-160) ----
  * D_ij = (-sq_j + 2 x_i.x_j) - sq_i ; idx = indices of the k largest D per row after dropping
  * rank 0 ("topk(k+1)[:, :, 1:]"), ties -> lower index first.  C == 64 (feature space, fp32 MFMA)
@@ -189,6 +192,18 @@ typedef struct {
   float* R; float* t; float* R_ba; float* t_ba; float* H; /* H [B,9] optional diagnostic */
 } vcr_rigid_svd_args;
 int vcr_rigid_svd_f32(const vcr_rigid_svd_args*, vcr_stream_t);
+
+/* ---- ICP refinement, the --iter 0 path (ICP.forward, model/icp_model.py:26-48; used by vcrnetIcpNet,
+ * model/vcrnet_model.py:46-62): <= max_iterations rounds of {nearest neighbour, best-fit transform, apply},
+ * stopping when the BATCH-mean error changes by < tolerance -- tested on the device, no host sync.
+ * src4 / dst4: [B,N,4] / [B,M,4] rows (x,y,z,|p|^2).  final4 [B,N,4]: the moved source.  R,t: the transform
+ * src -> final (icp_model.py:42).  iterations: optional device int = rounds executed. */
+typedef struct {
+  const float* src4; const float* dst4; int B, N, M; int max_iterations; float tolerance;
+  float* final4; float* R; float* t; float* R_ba; float* t_ba; int* iterations;
+} vcr_icp_args;
+size_t vcr_icp_workspace_bytes(int B, int N);
+int vcr_icp_f32(const vcr_icp_args*, void* workspace, size_t workspace_bytes, vcr_stream_t);
 
 /* ---- whole forward: VCRNet.forward (vcrnet_model.py:495-518), LPDNet + Transformer + VcpTopK(whole)/
  * VcpByDis + SVD, both clouds batched as 2B.  Weight pointers are the packed device tensors the host

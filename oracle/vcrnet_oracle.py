@@ -35,7 +35,7 @@ __all__ = [
     "feed_forward", "encoder_decoder", "transformer_pointer", "head_topk_whole",
     "head_select_overlap", "head_hard_pairs", "head_topk", "head_by_dis", "head_att",
     "rigid_svd", "vcrnet_forward", "vcrnet_iter", "dcp_forward", "transform_point_cloud",
-    "fold_batchnorm",
+    "fold_batchnorm", "icp_nearest", "icp_forward", "vcrnet_icp",
 ]
 
 
@@ -444,6 +444,48 @@ def vcrnet_iter(w: Weights, src: Tensor, tgt: Tensor, cfg: OracleConfig, iters: 
     R_ba = R_f.transpose(2, 1).contiguous()
     t_ba = -torch.matmul(R_ba, t_f.unsqueeze(2)).squeeze(2)
     return srcK, corrK, R_f, t_f, R_ba, t_ba
+
+
+def icp_nearest(src: Tensor, dst: Tensor) -> Tuple[Tensor, Tensor]:
+    """ICP.nearest_neighbor, model/icp_model.py:51-73: arg-max of the negative squared distance in the
+    head's expanded form; returns (mean of the best values over the WHOLE batch, nearest dst points)."""
+    d = neg_sqdist_head(src, dst)
+    val, idx = d.topk(k=1, dim=-1)
+    cand = torch.gather(dst, 2, idx.squeeze(-1).unsqueeze(1).expand(-1, 3, -1))
+    return val.mean(), cand.contiguous()
+
+
+def icp_forward(src_init: Tensor, dst: Tensor, max_iterations: int = 10, tolerance: float = 0.001,
+                trace: Optional[list] = None):
+    """ICP.forward, model/icp_model.py:26-48.  The stop test (:37) compares BATCH-mean errors."""
+    src = src_init
+    prev = 0
+    for _ in range(max_iterations):
+        err, corr = icp_nearest(src, dst)
+        R, t = rigid_svd(src, corr)                                          # best_fit_transform, :75-108
+        src = transform_point_cloud(src, R, t)
+        if trace is not None:
+            trace.append(float(err))
+        if torch.abs(prev - err) < tolerance:
+            break
+        prev = err
+    R, t = rigid_svd(src_init, src)                                          # :42
+    R_ba = R.transpose(2, 1).contiguous()
+    t_ba = -torch.matmul(R_ba, t.unsqueeze(2)).squeeze(2)
+    return src_init, src, R, t, R_ba, t_ba
+
+
+def vcrnet_icp(w: Weights, src: Tensor, tgt: Tensor, cfg: OracleConfig, max_iterations: int = 50):
+    """vcrnetIcpNet, model/vcrnet_model.py:46-62 (the --iter 0 path): one network pass, ICP on the
+    transformed source, poses composed."""
+    _, _, R, t, _, _ = vcrnet_forward(w, src, tgt, cfg)
+    moved = transform_point_cloud(src, R, t)
+    _, _, Ri, ti, _, _ = icp_forward(moved, tgt, max_iterations=max_iterations)
+    R2 = torch.matmul(Ri, R)                                                 # :55
+    t2 = torch.matmul(Ri, t.unsqueeze(2)).squeeze(2) + ti                    # :56-57
+    R_ba = R2.transpose(2, 1).contiguous()
+    t_ba = -torch.matmul(R_ba, t2.unsqueeze(2)).squeeze(2)
+    return moved, tgt, R2, t2, R_ba, t_ba
 
 
 def dcp_forward(w: Weights, src: Tensor, tgt: Tensor, cfg: OracleConfig):

@@ -203,6 +203,31 @@ def run_dcp(name, B, N, first_item, cstride, emb_nn="lpdnet"):
     print(f"{name}: done")
 
 
+def run_icp(name, B, N, first_item):
+    """--iter 0 path: VCRNet pass, then the reference ICP (model/icp_model.py) on the moved source,
+    composed as vcrnetIcpNet does (model/vcrnet_model.py:46-62; its .cuda() calls are bypassed)."""
+    import model.icp_model as ref_icp
+    args = ref_args()
+    net = ref_vcr.VCRNet(args)
+    load_into(net, weights.generate_weights(1234, lpd=LPD))
+    src, tgt, R_gt, t_gt, eul = synth.make_batch(first_item, B, N)
+    s, t = torch.from_numpy(src), torch.from_numpy(tgt)
+    icp = ref_icp.ICP(max_iterations=50)
+    calls = []
+    orig = icp.nearest_neighbor
+    icp.nearest_neighbor = lambda a, b: (calls.append(1), orig(a, b))[1]
+    with torch.no_grad():
+        _, _, R, tt, _, _ = net(s, t)
+        moved = ref_vcr.transform_point_cloud(s, R, tt)
+        _, final, Ri, ti, Rib, tib = icp(moved, t)
+        R2 = torch.matmul(Ri, R)
+        t2 = torch.matmul(Ri, tt.unsqueeze(2)).squeeze(2) + ti
+    out = dict(src=src, tgt=tgt, moved=moved.numpy(), icp_final=final.numpy(), R_icp=Ri.numpy(), t_icp=ti.numpy(),
+               R=R2.numpy(), t=t2.numpy(), iterations=np.int32(len(calls)), R_net=R.numpy(), t_net=tt.numpy())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"{name}: {len(calls)} ICP iterations")
+
+
 if __name__ == "__main__":
     sd = torch.load(os.path.join(REF, "pretrained", "lpd-pretrained.t7"), map_location="cpu")
     np.savez(os.path.join(HERE, "lpd_pretrained.npz"), **{k: v.numpy() for k, v in sd.items()})
@@ -218,3 +243,4 @@ if __name__ == "__main__":
     run_vcrnet("dist_n256_b2", B=2, N=256, first_item=80, cstride=16, vcp_nn="dist")
     run_vcrnet("identity_n256_b2", B=2, N=256, first_item=90, cstride=16, pointer="identity")
     run_dcp("dcp_n256_b2", B=2, N=256, first_item=100, cstride=16)
+    run_icp("icp_n256_b2", B=2, N=256, first_item=110)

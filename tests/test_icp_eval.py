@@ -1,0 +1,86 @@
+"""ICP refinement path (--iter 0: vcrnetIcpNet + ICP) and the eval-harness arithmetic
+(test_one_epoch / testVCRNet, section 8 f1)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import cfg_weights, golden
+
+
+def test_oracle_icp_vs_reference_golden():
+    g = golden("icp_n256_b2")
+    trace = []
+    out = oracle.icp_forward(torch.from_numpy(g["moved"]), torch.from_numpy(g["tgt"]), max_iterations=50, trace=trace)
+    assert len(trace) == int(g["iterations"])
+    np.testing.assert_allclose(out[1].numpy(), g["icp_final"], atol=1e-5)
+    np.testing.assert_allclose(out[2].numpy(), g["R_icp"], atol=1e-5)
+    np.testing.assert_allclose(out[3].numpy(), g["t_icp"], atol=1e-5)
+    full = oracle.vcrnet_icp(cfg_weights(), torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]), oracle.OracleConfig())
+    np.testing.assert_allclose(full[2].numpy(), g["R"], atol=1e-4)
+    np.testing.assert_allclose(full[3].numpy(), g["t"], atol=1e-5)
+
+
+def test_eval_metrics_known_answers():
+    """Perfect predictions give zero errors; a known Euler offset gives exactly that rot_MAE; the zyx Euler
+    angles of the generator's R_ab reproduce euler_ab (util/data.py:277,293 vs util/util.py:99-104)."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import evalmetrics, synth
+    src, tgt, R, t, eul = synth.make_batch(0, 4, 128)
+    np.testing.assert_allclose(evalmetrics.npmat2euler(R), np.degrees(eul), atol=1e-3)
+    T = lambda a: torch.from_numpy(a)
+    acc = evalmetrics.EvalAccumulator()
+    Rb = T(R).transpose(2, 1).contiguous()
+    tb = -torch.matmul(Rb, T(t).unsqueeze(2)).squeeze(2)
+    corr = torch.matmul(T(R), T(src)) + T(t).unsqueeze(2)
+    acc.add_batch(T(src), T(tgt), T(R), T(t), T(eul), (T(src), corr, T(R), T(t), Rb, tb))
+    m = acc.final()
+    for k in ("loss", "mse", "mae", "rot_mse", "rot_mae", "trans_mse", "trans_mae"):
+        assert abs(m[k]) < 1e-4, (k, m[k])   # degrees; fp32 matrices round-trip through Euler angles
+    # 1 degree about z on every sample, 0.01 translation offset
+    from scipy.spatial.transform import Rotation
+    Rp = np.stack([Rotation.from_euler("zyx", np.degrees(e) + [1.0, 0, 0], degrees=True).as_matrix() for e in eul]).astype(np.float32)
+    acc2 = evalmetrics.EvalAccumulator()
+    acc2.add_batch(T(src), T(tgt), T(R), T(t), T(eul), (T(src), corr, T(Rp), T(t) + 0.01, Rb, tb))
+    m2 = acc2.final()
+    assert abs(m2["rot_mae"] - 1.0 / 3.0) < 1e-3 and abs(m2["rot_mse"] - 1.0 / 3.0) < 1e-3
+    assert abs(m2["trans_mae"] - 0.01) < 1e-6 and abs(m2["trans_rmse"] - 0.01) < 1e-6
+    line = evalmetrics.EvalAccumulator.format_final(m2)
+    assert line.startswith("EPOCH:: -1, Loss: ") and "rot_MSE: " in line and line.count(",") == 12
+
+
+@pytest.mark.gpu
+def test_hip_icp_vs_reference_golden():
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd.module import ICP
+    g = golden("icp_n256_b2")
+    icp = ICP(max_iterations=50)
+    s, fin, R, t, Rb, tb = icp(torch.from_numpy(g["moved"]).cuda(), torch.from_numpy(g["tgt"]).cuda())
+    assert int(icp.last_iterations.item()) == int(g["iterations"])
+    np.testing.assert_allclose(fin.cpu().numpy(), g["icp_final"], atol=1e-5)
+    np.testing.assert_allclose(R.cpu().numpy(), g["R_icp"], atol=1e-5)
+    np.testing.assert_allclose(t.cpu().numpy(), g["t_icp"], atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_vcrnet_icp_and_eval():
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import evalmetrics
+    from vcrnet_amd.module import vcrnetIcpNet
+    from test_hip_forward import build_net
+    g = golden("icp_n256_b2")
+    net, _ = build_net()
+    src, tgt = torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda()
+    with torch.no_grad():
+        out = vcrnetIcpNet(SimpleNamespace(max_iterations=50), net, src, tgt)
+    np.testing.assert_allclose(out[2].cpu().numpy(), g["R"], atol=1e-4)
+    np.testing.assert_allclose(out[3].cpu().numpy(), g["t"], atol=1e-5)
+    # eval accumulation runs on device tensors
+    from vcrnet_amd import synth
+    _, _, R_gt, t_gt, eul = synth.make_batch(110, 2, 256)
+    acc = evalmetrics.EvalAccumulator()
+    acc.add_batch(src, tgt, torch.from_numpy(R_gt).cuda(), torch.from_numpy(t_gt).cuda(), eul, out)
+    m = acc.final()
+    assert np.isfinite(list(m.values())).all()

@@ -52,9 +52,7 @@ def dgcnn_embed(net, x_cf: torch.Tensor, rec: Optional[dict] = None):
     k = int(net.emb_nn.k)
     dev = x_cf.device
     M = Bc * N
-    z = lambda n, v: torch.zeros(n, dtype=torch.float32, device=dev) if v is None else v
-    # xyz4 rows come from the pointwise kernel's side output (its 64-d features are unused here)
-    xyz4, _, _ = native.pointwise(x_cf, z(64 * 3, None).view(64, 3), z(64, None), z(64 * 64, None).view(64, 64), z(64, None))
+    xyz4 = native.to_rows4(x_cf)
     idx = native.knn(xyz4, None, k)
     w1, b1 = _fold_bn(sd, "emb_nn.conv1", "emb_nn.bn1")                    # [64,6]: cols 0..2 neighbour, 3..5 centre
     wpq = torch.zeros(128, 32, dtype=torch.float32, device=dev)            # K padded 3 -> 32 for the MFMA tile

@@ -169,7 +169,7 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
   const int vec = (a->N % 4 == 0) && (a->ldy % 4 == 0) && (((uintptr_t)a->y & 15) == 0) &&
                   (!a->bias || ((uintptr_t)a->bias & 15) == 0) &&
                   (!a->residual || ((a->ldr % 4 == 0) && ((uintptr_t)a->residual & 15) == 0));
-  if (g_variant == 1) {
+  if (g_variant & 1) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     hipLaunchKernelGGL(linear_kernel<16>, dim3(tiles_m * tiles_n), dim3(256), lds16, (hipStream_t)stream, *a, tiles_m,
                        tiles_n, vec);

@@ -67,7 +67,24 @@ __global__ __launch_bounds__(256) void pointwise12_kernel(vcr_pointwise_args a) 
   }
 }
 
+// [B,3,N] channels-first points -> [B,N,4] rows (x, y, z, |p|^2): the layout the kNN / ICP kernels read.
+__global__ __launch_bounds__(256) void rows4_kernel(const float* x_cf, float* xyz4, int B, int N) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * N) return;
+  const int b = (int)(i / N), n = (int)(i % N);
+  const float* xb = x_cf + (size_t)b * 3 * N;
+  const float x = xb[n], y = xb[N + n], z = xb[2 * N + n];
+  st4(xyz4 + i * 4, f32x4{x, y, z, (x * x + y * y) + z * z});
+}
+
 }  // namespace
+
+extern "C" int vcr_rows4_f32(const float* x_cf, float* xyz4, int B, int N, vcr_stream_t stream) {
+  if (!x_cf || !xyz4 || B <= 0 || N <= 0) return VCR_EINVAL;
+  hipLaunchKernelGGL(rows4_kernel, dim3((unsigned)(((long)B * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_cf,
+                     xyz4, B, N);
+  return VCR_LAUNCH_RC();
+}
 
 extern "C" int vcr_pointwise_f32(const vcr_pointwise_args* a, vcr_stream_t stream) {
   if (!a || !a->x_cf || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->xyz4 || !a->feat64 || !a->sq64) return VCR_EINVAL;

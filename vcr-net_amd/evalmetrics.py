@@ -1,0 +1,85 @@
+"""Eval-harness arithmetic of the reference: the per-batch accumulation of
+``test_one_epoch`` (model/vcrnet_model.py:546-649) and the final figures / log line of
+``testVCRNet`` (:768-799).  Host-side bookkeeping over the poses the HIP path produces; with
+process-per-GPU sharding the per-rank sums are combined with one all-reduce (``merge``)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation
+
+
+def npmat2euler(mats: np.ndarray, seq: str = "zyx") -> np.ndarray:
+    """util/util.py:99-104 (``Rotation.from_dcm`` was renamed ``from_matrix`` in SciPy >= 1.4)."""
+    return np.asarray([Rotation.from_matrix(m).as_euler(seq, degrees=True) for m in mats], dtype="float32")
+
+
+def transform_point_cloud(p: torch.Tensor, R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    return torch.matmul(R, p) + t.unsqueeze(2)                              # util/util.py:91-96
+
+
+@dataclass
+class EvalAccumulator:
+    """Running sums of test_one_epoch.  ``loss='pose'`` (util/initPara.py default)."""
+    cycle: bool = False
+    num_examples: int = 0
+    sums: Dict[str, float] = field(default_factory=lambda: dict(loss=0.0, loss_vcr=0.0, cycle=0.0, mse_ab=0.0,
+                                                                 mae_ab=0.0, mse_ba=0.0, mae_ba=0.0))
+    R_gt: List[np.ndarray] = field(default_factory=list)
+    t_gt: List[np.ndarray] = field(default_factory=list)
+    R_pred: List[np.ndarray] = field(default_factory=list)
+    t_pred: List[np.ndarray] = field(default_factory=list)
+    euler_gt: List[np.ndarray] = field(default_factory=list)
+
+    def add_batch(self, src, tgt, R_ab, t_ab, euler_ab, out) -> None:
+        """``out`` = (srcK, src_corrK, R_ab_pred, t_ab_pred, R_ba_pred, t_ba_pred) of vcrnetIter."""
+        srcK, corrK, Rp, tp, Rbp, tbp = out
+        B = src.shape[0]
+        self.num_examples += B
+        eye = torch.eye(3, device=Rp.device).unsqueeze(0).repeat(B, 1, 1)
+        mse = torch.nn.functional.mse_loss
+        loss_pose = mse(torch.matmul(Rp.transpose(2, 1), R_ab), eye) + mse(tp, t_ab)      # :606-607
+        self.sums["loss_vcr"] += loss_pose.item() * B                                       # args.loss == 'pose'
+        if self.cycle:                                                                      # :611-620
+            rot = mse(torch.matmul(Rbp, Rp), eye)
+            tr = torch.mean((torch.matmul(Rbp.transpose(2, 1), tp.view(B, 3, 1)).view(B, 3) + tbp) ** 2, dim=[0, 1])
+            cyc = rot + tr
+            loss_pose = loss_pose + cyc * 0.1
+            self.sums["cycle"] += cyc.item() * 0.1 * B
+        self.sums["loss"] += loss_pose.item() * B
+        tsrcK = transform_point_cloud(srcK, R_ab, t_ab)                                     # :585
+        ttgt = transform_point_cloud(tgt, Rbp, tbp)                                         # :583
+        self.sums["mse_ab"] += torch.mean((tsrcK - corrK) ** 2).item() * B                 # :626-627
+        self.sums["mae_ab"] += torch.mean(torch.abs(tsrcK - corrK)).item() * B
+        self.sums["mse_ba"] += torch.mean((ttgt - src) ** 2).item() * B                    # :629-630
+        self.sums["mae_ba"] += torch.mean(torch.abs(ttgt - src)).item() * B
+        self.R_gt.append(R_ab.detach().cpu().numpy()); self.t_gt.append(t_ab.detach().cpu().numpy())
+        self.R_pred.append(Rp.detach().cpu().numpy()); self.t_pred.append(tp.detach().cpu().numpy())
+        self.euler_gt.append(np.asarray(euler_ab.cpu() if torch.is_tensor(euler_ab) else euler_ab))
+
+    def final(self) -> Dict[str, float]:
+        """testVCRNet, :769-790 (A -> B direction)."""
+        n = max(1, self.num_examples)
+        Rp, tp = np.concatenate(self.R_pred, 0), np.concatenate(self.t_pred, 0)
+        tg, eg = np.concatenate(self.t_gt, 0), np.concatenate(self.euler_gt, 0)
+        e = npmat2euler(Rp)
+        d = e - np.degrees(eg)
+        r_mse = float(np.mean(d ** 2))
+        t_mse = float(np.mean((tg - tp) ** 2))
+        mse_ab = self.sums["mse_ab"] / n
+        return {"loss": self.sums["loss_vcr"] / n, "loss_pose": self.sums["loss"] / n,
+                "cycle_loss": self.sums["cycle"] / n, "mse": mse_ab, "rmse": float(np.sqrt(mse_ab)),
+                "mae": self.sums["mae_ab"] / n, "rot_mse": r_mse, "rot_rmse": float(np.sqrt(r_mse)),
+                "rot_mae": float(np.mean(np.abs(d))), "trans_mse": t_mse, "trans_rmse": float(np.sqrt(t_mse)),
+                "trans_mae": float(np.mean(np.abs(tg - tp)))}
+
+    @staticmethod
+    def format_final(m: Dict[str, float], epoch: int = -1) -> str:
+        """The '==FINAL TEST== / A--------->B' line of :792-799."""
+        return ("EPOCH:: %d, Loss: %f, test_LossPose: %f, Cycle Loss: %f, MSE: %f, RMSE: %f, MAE: %f, rot_MSE: %f, "
+                "rot_RMSE: %f, rot_MAE: %f, trans_MSE: %f, trans_RMSE: %f, trans_MAE: %f"
+                % (epoch, m["loss"], m["loss_pose"], m["cycle_loss"], m["mse"], m["rmse"], m["mae"], m["rot_mse"],
+                   m["rot_rmse"], m["rot_mae"], m["trans_mse"], m["trans_rmse"], m["trans_mae"]))

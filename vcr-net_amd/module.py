@@ -353,6 +353,41 @@ class DCP(VCRNet):
         return R_ab, t_ab, R_ba, t_ba, src, corr
 
 
+class ICP(nn.Module):
+    """Drop-in for the reference's torch ICP (model/icp_model.py:16-108): same constructor and the same
+    6-tuple ``(srcInit, src_final, R_ab, t_ab, R_ba, t_ba)``, but the whole loop -- nearest neighbour,
+    best-fit transform, apply, convergence test -- runs on the device from one C-ABI call, with no
+    host sync per iteration."""
+
+    def __init__(self, max_iterations=10, tolerance=0.001):
+        super().__init__()
+        self.max_iterations, self.tolerance = max_iterations, tolerance
+        r = torch.eye(3)
+        r[2, 2] = -1
+        self.reflect = nn.Parameter(r, requires_grad=False)                # icp_model.py:22-23
+        self.last_iterations = None
+
+    def forward(self, srcInit, dst):
+        if not (srcInit.is_cuda and dst.is_cuda):
+            raise native.VcrHipError("vcrnet_amd.ICP runs on the HIP path only (no CPU fallback)")
+        final, R, t, Rb, tb, iters = native.icp(srcInit, dst, self.max_iterations, self.tolerance)
+        self.last_iterations = iters                                       # device int32[1]; read lazily
+        return srcInit, final, R, t, Rb, tb
+
+
+def vcrnetIcpNet(args, net, src, tgt):
+    """model/vcrnet_model.py:46-62 (--iter 0): one network pass, ICP on the moved source, poses composed."""
+    icp = ICP(max_iterations=args.max_iterations)
+    _, _, R, t, _, _ = net(src, tgt)
+    moved = torch.matmul(R, src) + t.unsqueeze(2)
+    _, _, Ri, ti, _, _ = icp(moved, tgt)
+    R2 = torch.matmul(Ri, R)                                               # :55
+    t2 = torch.matmul(Ri, t.unsqueeze(2)).squeeze(2) + ti                  # :56-57
+    R_ba = R2.transpose(2, 1).contiguous()
+    t_ba = -torch.matmul(R_ba, t2.unsqueeze(2)).squeeze(2)
+    return moved, tgt, R2, t2, R_ba, t_ba
+
+
 def vcrnetIter(net, src, tgt, iter=1):
     """model/vcrnet_model.py:21-43: run ``iter`` passes, composing the poses on the device."""
     cur = src

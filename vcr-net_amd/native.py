@@ -353,6 +353,44 @@ def pairscore(own, strm, nbatch, n_own, n_str, op, score=0, scale=1.0, own_side4
     return mass
 
 
+class IcpArgs(C.Structure):
+    _fields_ = [("src4", f32p), ("dst4", f32p), ("B", C.c_int), ("N", C.c_int), ("M", C.c_int),
+                ("max_iterations", C.c_int), ("tolerance", C.c_float), ("final4", f32p), ("R", f32p), ("t", f32p),
+                ("R_ba", f32p), ("t_ba", f32p), ("iterations", f32p)]
+
+
+def to_rows4(x_cf):
+    """[B,3,N] channels-first points -> [B,N,4] rows (x, y, z, |p|^2) (layout plumbing for the C-ABI)."""
+    L = lib()
+    B, _, N = x_cf.shape
+    x = x_cf.contiguous().float()
+    out = _f32(B, N, 4, device=x.device)
+    L.vcr_rows4_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]; L.vcr_rows4_f32.restype = C.c_int
+    check(L.vcr_rows4_f32(ptr(x), ptr(out), B, N, C.c_void_p(stream_ptr())), "vcr_rows4_f32")
+    return out
+
+
+def icp(src_cf, dst_cf, max_iterations=10, tolerance=0.001):
+    """ICP.forward (model/icp_model.py:26-48) on the device: returns (final [B,3,N], R, t, R_ba, t_ba, iters)."""
+    L = lib()
+    B, _, N = src_cf.shape
+    M = dst_cf.shape[2]
+    dev = src_cf.device
+    src4, dst4 = to_rows4(src_cf.float()), to_rows4(dst_cf.float())
+    final4 = _f32(B, N, 4, device=dev)
+    R, t, Rb, tb = _f32(B, 3, 3, device=dev), _f32(B, 3, device=dev), _f32(B, 3, 3, device=dev), _f32(B, 3, device=dev)
+    iters = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.vcr_icp_workspace_bytes.argtypes = [C.c_int, C.c_int]; L.vcr_icp_workspace_bytes.restype = C.c_size_t
+    L.vcr_icp_f32.argtypes = [C.POINTER(IcpArgs), C.c_void_p, C.c_size_t, C.c_void_p]; L.vcr_icp_f32.restype = C.c_int
+    nbytes = L.vcr_icp_workspace_bytes(B, N)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    a = IcpArgs(ptr(src4), ptr(dst4), B, N, M, max_iterations, tolerance, ptr(final4), ptr(R), ptr(t), ptr(Rb),
+                ptr(tb), ptr(iters))
+    check(L.vcr_icp_f32(C.byref(a), C.c_void_p(ws.data_ptr() + off), nbytes, C.c_void_p(stream_ptr())), "vcr_icp_f32")
+    return final4[:, :, :3].transpose(1, 2).contiguous(), R, t, Rb, tb, iters
+
+
 def edgerows(pq, Cc, idx, n_per_cloud):
     """pq [M, 2C] (P | Q), idx [M,k] -> per-edge rows relu(P[nbr] + Q[i]) as [M*k, C]."""
     M, k = idx.shape
