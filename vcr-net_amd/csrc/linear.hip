@@ -152,7 +152,120 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 3)) void linear_kernel(vcr_lin
   }
 }
 
-int g_variant = 0;   // debug/tuning only (vcr_debug_linear_variant): 0 = BK 32, 1 = BK 16
+// ---- direct-to-LDS variant: global_load_lds_dwordx4 (LDS-DMA) instead of register staging.
+// One wave-instruction lands 1 KiB = 8 rows x 128 B CONTIGUOUSLY (wave-uniform base + lane*16), so the LDS
+// image cannot be padded; bank conflicts are avoided by an XOR swizzle of the 16-B chunk index,
+// pc = lc ^ ((row >> 1) & 7), applied to the per-lane GLOBAL source address when filling (the LDS side stays
+// linear) and to the ds_read_b128 address when reading (both sides or neither).  With 128-B rows two rows
+// share a 256-B bank row, so a 16-lane b128 group (16 distinct rows) hits 16 distinct slots.
+// No VGPRs hold the in-flight slab and there is no ds_write pass.
+struct TileG { float a[BM][32]; float b[BN][32]; };
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  TileG* tile = reinterpret_cast<TileG*>(smem);          // [2]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, i = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // fill mapping: wave w covers rows w*32 + 8i + (lane>>3), physical chunk lane&7
+  const int frow = lane >> 3, fpc = lane & 7;
+  const float* xa[4];
+  const float* wb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + 8 * i + frow;
+    const int lc = fpc ^ ((row >> 1) & 7);
+    xa[i] = p.x + (size_t)min(m0 + row, p.M - 1) * p.ldx + 4 * lc;
+    wb[i] = p.w + (size_t)min(n0 + row, p.N - 1) * p.K + 4 * lc;
+  }
+  auto fill = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(xa[i] + k0, &tile[buf].a[wave * 32 + 8 * i][0]);
+      glds16(wb[i] + k0, &tile[buf].b[wave * 32 + 8 * i][0]);
+    }
+  };
+  fill(0, 0);
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
+  int ra_[2], rb_[2], sa[2], sb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ra_[i] = wm * 64 + i * 32 + l31; sa[i] = (ra_[i] >> 1) & 7;
+    rb_[i] = wn * 64 + i * 32 + l31; sb[i] = (rb_[i] >> 1) & 7;
+  }
+  const int nk = p.K / 32;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) fill(cur ^ 1, (kt + 1) * 32);
+    const TileG& T = tile[cur];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = ld4(&T.a[ra_[i]][4 * ((2 * g + half) ^ sa[i])]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = ld4(&T.b[rb_[j]][4 * ((2 * g + half) ^ sb[j])]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i][s], fb[j][s], acc[i][j]);
+    }
+    __syncthreads();                                     // drains the LDS-DMA (vmcnt(0)) and orders the buffers
+  }
+
+  constexpr int EP = 68;
+  float* ot = reinterpret_cast<float*>(smem) + wave * 32 * EP;
+  const int c4e = (lane & 15) * 4, col = n0 + wn * 64 + c4e;
+  const f32x4 bias = (p.bias && col < p.N) ? ld4(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[acc_row(r, half) * EP + j * 32 + l31] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (col < p.N) {
+#pragma unroll 4
+      for (int ps = 0; ps < 8; ++ps) {
+        const int rl = ps * 4 + (lane >> 4);
+        const int row = m0 + wm * 64 + i * 32 + rl;
+        if (row < p.M) {
+          f32x4 v = ld4(&ot[rl * EP + c4e]) + bias;
+          if (p.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+          if (p.residual) v = v + ld4(p.residual + (size_t)row * p.ldr + col);
+          st4(p.y + (size_t)row * p.ldy + col, v);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+int g_variant = 0;   // debug/tuning only (vcr_debug_linear_variant): bit0 = BK 16, bit2 = LDS-DMA staging
 
 }  // namespace
 
@@ -169,7 +282,11 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
   const int vec = (a->N % 4 == 0) && (a->ldy % 4 == 0) && (((uintptr_t)a->y & 15) == 0) &&
                   (!a->bias || ((uintptr_t)a->bias & 15) == 0) &&
                   (!a->residual || ((a->ldr % 4 == 0) && ((uintptr_t)a->residual & 15) == 0));
-  if (g_variant & 1) {
+  if (!(g_variant & 4) && vec) {   // default: LDS-DMA staging (bit2 of the debug variant selects register staging)
+    const int ldsg = 2 * sizeof(TileG);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsg);
+    hipLaunchKernelGGL(linear_glds_kernel, dim3(tiles_m * tiles_n), dim3(256), ldsg, (hipStream_t)stream, *a, tiles_m, tiles_n);
+  } else if (g_variant & 1) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     hipLaunchKernelGGL(linear_kernel<16>, dim3(tiles_m * tiles_n), dim3(256), lds16, (hipStream_t)stream, *a, tiles_m,
                        tiles_n, vec);
