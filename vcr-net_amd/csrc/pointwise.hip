@@ -29,13 +29,15 @@ __global__ __launch_bounds__(256) void pointwise12_kernel(vcr_pointwise_args a) 
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int c = g * 16 + j;
-    float v = fmaf(w1s[c][2], z, fmaf(w1s[c][1], y, w1s[c][0] * x)) + w1s[c][3];
+    // rounding order of the reference's (multi-threaded oneDNN) 1x1 conv, established bit-for-bit against
+    // F.conv1d: accumulator starts at the bias, one fma per input channel in ascending order
+    const float v = fmaf(w1s[c][2], z, fmaf(w1s[c][1], y, fmaf(w1s[c][0], x, w1s[c][3])));
     h1s[p][c] = fmaxf(v, 0.f);
   }
   __syncthreads();
   float acc[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int j = 0; j < 16; ++j) acc[j] = b2s[g * 16 + j];   // same order for conv2: bias first, k ascending
   for (int k = 0; k < 64; ++k) {
     const float h = h1s[p][k];
 #pragma unroll
@@ -47,14 +49,22 @@ __global__ __launch_bounds__(256) void pointwise12_kernel(vcr_pointwise_args a) 
       acc[q * 4 + 3] = fmaf(w[3], h, acc[q * 4 + 3]);
     }
   }
+  // |feat|^2 with torch.sum(x**2, dim=1)'s exact association (ATen cascade sum, 64 rows -> level step 16):
+  // rounded squares, four sequential 16-channel block sums b0..b3 starting from 0, then ((b0 + b1) + b2) + b3.
+  // Each thread owns exactly one block.  Together with the k-ordered MFMA chain of the kNN kernel this makes
+  // the feature-space distance matrix bit-identical to the reference's, so its top-k sets cannot flip.
   float ss = 0.f;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    acc[j] = fmaxf(acc[j] + b2s[g * 16 + j], 0.f);
-    ss = fmaf(acc[j], acc[j], ss);
+    acc[j] = fmaxf(acc[j], 0.f);
+    ss = ss + acc[j] * acc[j];
   }
-  ss += __shfl_xor(ss, 1, 64);
-  ss += __shfl_xor(ss, 2, 64);
+  {
+    const int base = (threadIdx.x & 63) & ~3;
+    const float b0 = __shfl(ss, base, 64), b1 = __shfl(ss, base + 1, 64);
+    const float b2 = __shfl(ss, base + 2, 64), b3 = __shfl(ss, base + 3, 64);
+    ss = ((b0 + b1) + b2) + b3;
+  }
   if (live) {
     const size_t row = (size_t)b * a.N + n;
     float* o = a.feat64 + row * 64 + g * 16;
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(256) void pointwise12_kernel(vcr_pointwise_args a) 
     for (int q = 0; q < 4; ++q) st4(o + q * 4, f32x4{acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]});
     if (g == 0) {
       a.sq64[row] = ss;
-      st4(a.xyz4 + row * 4, f32x4{x, y, z, fmaf(z, z, fmaf(y, y, x * x))});
+      st4(a.xyz4 + row * 4, f32x4{x, y, z, (x * x + y * y) + z * z});   // torch.sum order for 3 rows: sequential
     }
   }
 }
