@@ -8,17 +8,16 @@
 //   idx  = top-(k+1) of D_i. by (value desc, index asc), rank 0 dropped (util.py:159); the k kept
 //          indices are written as a SET (unordered) -- every consumer is a max over neighbours.
 //
-// Work split: a block owns 64 queries; its waves split the CANDIDATES in two interleaved halves, so twice
-// as many waves are resident (2 per SIMD at N = 1024: one wave's MFMAs run under the other's insertion
-// work).  Two sorted lists A, B of length K merge into the top-K SET with K compare-selects,
-// C[i] = max(A[i], B[K-1-i]), so the cross-wave merge costs almost nothing.
-//
-// C == 64: v_mfma_f32_32x32x2_f32 with candidates as MFMA rows and queries as MFMA columns: lanes l and l+32
-//          hold different candidates of the SAME query column.  Both filter against the query's threshold
-//          and park survivors in the query's list; lane l (< 32) alone keeps the sorted list.  -sq_j/2 rides
-//          along as a 33rd k-step, which reproduces the reference's rounding of (-sq_j + 2 dot) exactly.
-//          Operands go global -> registers (candidate tiles are L2-resident).
+// C == 64: v_mfma_f32_32x32x2_f32 with candidates as MFMA rows and queries as MFMA columns, so every lane
+//          owns ONE query column (lanes l and l+32 share a query and split the candidates, their two sorted
+//          lists are merged at the end).  The k order of the MFMA chain is the natural one (step s multiplies
+//          k = 2s, 2s+1) and -sq_j/2 rides along as a 33rd k-step: together with the pointwise kernel's
+//          reference-ordered features and norms the distance matrix is BIT-IDENTICAL to the reference's
+//          (CPU sgemm = k-ascending fma chain; verified), so the feature-space neighbour sets never flip.
+//          Operands go global -> registers (candidate tiles are L2-resident); LDS holds the survivor lists.
 // C == 4 : Cartesian xyz4 rows, one lane per query, candidates broadcast from LDS 16 at a time, VALU.
+//          A block's two waves split the candidates in interleaved halves; two sorted lists A, B merge into
+//          the top-K SET with K compare-selects, C[i] = max(A[i], B[K-1-i]).
 #include "common.h"
 
 namespace {
@@ -140,9 +139,18 @@ __global__ __launch_bounds__(256, (KS > 21 ? 1 : 2)) void knn64_kernel(vcr_knn_a
   // order: the MFMA result is then bit-for-bit the k-ascending fma chain that the reference's CPU sgemm
   // produces (verified against torch.matmul), and with the exact |x|^2 association of the pointwise kernel
   // the whole distance matrix -- hence every top-k set -- equals the reference's.
-  float qf[32];
+  // Loads stay 16 B wide: both lanes of a row fetch the whole row and each keeps its parity.
+  auto pick = [&](const f32x4* raw, float* dst) {
 #pragma unroll
-  for (int st = 0; st < 32; ++st) qf[st] = xb[(size_t)q * a.ldx + 2 * st + half];
+    for (int st = 0; st < 32; ++st) dst[st] = half ? raw[st >> 1][(st & 1) * 2 + 1] : raw[st >> 1][(st & 1) * 2];
+  };
+  float qf[32];
+  {
+    f32x4 raw[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) raw[m] = ld4(xb + (size_t)q * a.ldx + 4 * m);
+    pick(raw, qf);
+  }
   const float sq_q = sqb[q];
 
   TopList<KS> L;
@@ -154,17 +162,19 @@ __global__ __launch_bounds__(256, (KS > 21 ? 1 : 2)) void knn64_kernel(vcr_knn_a
   float csq;
   {
     const int c = min(col, a.N - 1);
+    f32x4 raw[16];
 #pragma unroll
-    for (int st = 0; st < 32; ++st) cf[st] = xb[(size_t)c * a.ldx + 2 * st + half];
+    for (int m = 0; m < 16; ++m) raw[m] = ld4(xb + (size_t)c * a.ldx + 4 * m);
+    pick(raw, cf);
     csq = sqb[c];
   }
   for (int tile = 0; tile < ntiles; ++tile) {
-    float nf[32];
+    f32x4 nraw[16];
     float nsq = 0.f;
-    if (tile + 1 < ntiles) {                            // prefetch next candidate tile (registers)
+    if (tile + 1 < ntiles) {                            // prefetch next candidate tile (raw rows stay in flight)
       const int c = min((tile + 1) * TILE + col, a.N - 1);
 #pragma unroll
-      for (int st = 0; st < 32; ++st) nf[st] = xb[(size_t)c * a.ldx + 2 * st + half];
+      for (int m = 0; m < 16; ++m) nraw[m] = ld4(xb + (size_t)c * a.ldx + 4 * m);
       nsq = sqb[c];
     }
     f32x16 acc = {0};
@@ -186,8 +196,7 @@ __global__ __launch_bounds__(256, (KS > 21 ? 1 : 2)) void knn64_kernel(vcr_knn_a
       if (d > thr && j < a.N) pend.push(d, j, lane);
     }
     if (tile + 1 < ntiles) {
-#pragma unroll
-      for (int st = 0; st < 32; ++st) cf[st] = nf[st];
+      pick(nraw, cf);
       csq = nsq;
     }
   }
