@@ -182,6 +182,16 @@ def main():
         stages = {f: {"ms_per_step": fam_ms[f] / a.steps, "share": fam_ms[f] / total_ms,
                       "tflops": fam_flops[f] / (fam_ms[f] * 1e-3) / 1e12, "gbs": fam_bytes[f] / (fam_ms[f] * 1e-3) / 1e9}
                   for f in sorted(fam_ms, key=fam_ms.get, reverse=True)}
+        # the kNN + EdgeConv (emb_nn) stage that BASELINE.json's north_star prices against the HBM roofline:
+        # algorithmic bytes 2*N*(7448 + 784*k) per pair, time = its launches inside the timed region
+        emb_sites = ("pointwise:", "knn:", "edgeconv:", "gathermax:", "linear:dg1_pq", "linear:sn1_pq", "linear:conv3")
+        emb_ms = sum(r[0] for n, r in rows.items() if n.startswith(emb_sites)) / a.steps
+        emb_bytes = 2.0 * N * (7448 + 784 * a.k) * B
+        emb_stage = {"ms_per_step": emb_ms, "algorithmic_bytes_per_pair": emb_bytes / B,
+                     "achieved_gbs": emb_bytes / (emb_ms * 1e-3) / 1e9,
+                     "hbm_frac": emb_bytes / (emb_ms * 1e-3) / 1e9 / workmodel.PEAK_HBM_GBS,
+                     "note": "fp32 1x1 convs of this stage are MFMA-bound (SURVEY section 7): 48.8 GF per step alone "
+                             "need 0.31 ms at the fp32 matrix peak, i.e. <= 0.31 of the HBM roofline"}
         if a.stages:
             for n, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
                 ms = r[0] / r[3]
@@ -199,6 +209,7 @@ def main():
                        "parallelism": f"dp{world} (pairs sharded per rank, RCCL all-gather of R,t)"},
             "roofline": roof,
             "stages": stages,
+            "knn_edgeconv_stage": emb_stage,
             "flops_per_pair_reference": workmodel.reference_flops_per_pair(N, a.k)["total"],
         }
         if world == 1 and not a.no_cpu_baseline:
