@@ -104,7 +104,9 @@ def main():
 
     B, N = a.batch, a.points
     # each rank owns B consecutive items of the global batch (weak scaling); inputs live in HBM
-    src, tgt, _, _, _ = synth.make_batch(rank * B, B, N)
+    # object-like clouds have 2048 points (the ModelNet40 convention); larger N (configs 4/5) use uniform clouds
+    src, tgt, _, _, _ = synth.make_batch(rank * B, B, N, kind="object" if N <= 2048 else "uniform")
+    assert src.shape == (B, 3, N), src.shape
     src, tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
 
     def step(trace=None):
@@ -170,8 +172,8 @@ def main():
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
         if pmcs and (B, N, a.k) == (16, 1024, 20):
-            kname = {"linear": "linear_kernel", "sdpa": "sdpa_kernel<false, true>", "edgeconv": "edgeconv_dg_kernel",
-                     "softcorr": "softcorr_kernel"}.get(dom)
+            kname = {"linear": "linear_glds_kernel", "sdpa": "sdpa_kernel<false, true>",
+                     "edgeconv": "edgeconv_dg_packed_kernel<20>", "softcorr": "pairscore_kernel<0>"}.get(dom)
             ent = json.load(open(pmcs[-1])).get(kname, {})
             if "hbm_bytes_per_launch" in ent:
                 roof["traffic"] = ent["hbm_bytes_per_launch"]

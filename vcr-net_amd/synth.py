@@ -79,6 +79,8 @@ def make_pair(item: int, num_points: int = 1024, partial: bool = False, reserve:
               factor: float = 4.0, kind: str = "object") -> Pair:
     """One evaluation item.  Call order of the random stream follows util/data.py:258-301."""
     cloud = base_cloud(item) if kind == "object" else uniform_cloud(item, max(num_points, 2048))
+    if num_points > cloud.shape[0]:
+        raise ValueError(f"object clouds hold {cloud.shape[0]} points; use kind='uniform' for num_points={num_points}")
     rs = np.random.RandomState(item)                                   # :255-256
     ax, ay, az = (rs.uniform() * np.pi / factor for _ in range(3))     # :258-260
     cx, cy, cz, sx, sy, sz = np.cos(ax), np.cos(ay), np.cos(az), np.sin(ax), np.sin(ay), np.sin(az)
