@@ -79,6 +79,14 @@ typedef struct {
 } vcr_linear_args;
 int vcr_linear_f32(const vcr_linear_args*, vcr_stream_t);
 
+/* Same operation on the bf16 matrix pipe with fp32-equivalent products: every fp32 operand is split exactly
+ * into three bf16 pieces and the six leading partial products are accumulated in fp32 (error <= 2^-24
+ * relative per product, i.e. fp32-GEMM accuracy at 2.67x the fp32 matrix rate).  `w_planes` = the weight
+ * [N,K] pre-split by vcr_split_bf16x3_f32 (3 consecutive bf16 planes of N*K elements); args->w is ignored.
+ * Needs N % 4 == 0 and 16-byte aligned x / y / bias / residual. */
+int vcr_split_bf16x3_f32(const float* x, void* planes, size_t n, vcr_stream_t);
+int vcr_linear_bf16x3_f32(const vcr_linear_args*, const void* w_planes, vcr_stream_t);
+
 /* ---- LayerNorm of model/transformer.py:141-144: a*(x-mean)/(std_unbiased+eps)+b over C ----
  * optional: y += residual; side4[row] = (xyz4[row].xyz, sum_c y^2) for the correspondence head. */
 typedef struct {
@@ -233,6 +241,14 @@ typedef struct {
   int E, F, heads, k;                              /* 512, 1024, 4, 20 */
   int has_pointer;                                 /* 1 transformer, 0 none, 2 identity (emb*2)     */
   int head_mode;                                   /* 0 neg-distance (topK whole / att), 1 dot/sqrt(E) */
+  /* linear_mode 0: every 1x1 conv / Linear on v_mfma_f32_32x32x2_f32 (vcr_linear_f32).
+   * linear_mode 1: the same products as exact 3-way bf16 splits on the bf16 matrix pipe (vcr_linear_bf16x3_f32);
+   * then `split` holds the weights pre-split by vcr_split_bf16x3_f32, in the order of the sites below. */
+  int linear_mode;
+  struct {
+    const void *dg1_pq, *sn1_pq, *c3, *enc_qkv, *enc_wo, *enc_ffn1, *enc_ffn2, *dec_qkv, *dec_self_wo, *dec_cross_q,
+               *dec_cross_kv, *dec_cross_wo, *dec_ffn1, *dec_ffn2;
+  } split;
 } vcr_vcrnet_weights;
 
 typedef struct {

@@ -131,3 +131,18 @@ def test_iter_wrapper_whole():
         out = vcrnetIter(net, torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), iter=2)
     np.testing.assert_allclose(out[2].cpu().numpy(), ref[2].numpy(), atol=R_TOL)
     np.testing.assert_allclose(out[3].cpu().numpy(), ref[3].numpy(), atol=2 * T_TOL)
+
+
+@pytest.mark.parametrize("name", ["whole_n256_b2", "whole_n1024_b2"])
+def test_bf16x3_linear_mode_vs_reference_golden(name):
+    """Opt-in linear_mode='bf16x3' (exact 3-way bf16 splits on the bf16 matrix pipe) keeps the BASELINE tolerances."""
+    g = golden(name)
+    net, _ = build_net()
+    net.linear_mode = "bf16x3"
+    src, tgt = torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda()
+    with torch.no_grad():
+        out = net(src, tgt)
+    dR = np.abs(out[2].cpu().numpy() - g["it0_R"]).max()
+    dt = np.abs(out[3].cpu().numpy() - g["it0_t"]).max()
+    print(f"{name} bf16x3: max|dR|={dR:.2e} max|dt|={dt:.2e}")
+    assert dR <= R_TOL and dt <= T_TOL

@@ -261,3 +261,26 @@ def test_feature_space_knn_is_bit_exact_vs_reference(nat, W, name):
         idx3 = nat.knn(xyz4, None, k).cpu().numpy()
         a, b = np.sort(idx3, -1), np.sort(g[f"it0_idx_xyz_{cloud}"].astype(np.int64), -1)
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,K,relu,res", [(300, 200, 64, True, False), (1024, 512, 512, False, True),
+                                            (257, 1536, 128, False, False), (128, 64, 1024, True, True)])
+def test_linear_bf16x3(nat, M, N, K, relu, res):
+    """The bf16-pipe linear splits every operand exactly into three bf16 pieces and keeps the six leading
+    partial products: same fp32-GEMM error bound as the fp32-MFMA kernel."""
+    g = torch.Generator().manual_seed(M + N + K + 7)
+    xw = torch.randn(M, K + 32, generator=g)
+    x = xw[:, :K]
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    planes = nat.split_bf16x3(dev(w))
+    assert torch.equal(planes.view(torch.bfloat16).float().sum(0).cpu().view(N, K), w)      # the split is exact
+    y = nat.linear_bf16x3(dev(xw)[:, :K], planes, N, dev(b), relu=relu, residual=dev(r) if res else None)
+    ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    if res:
+        ref = ref + r.double()
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err <= 4e-6 * math.sqrt(K) + 1e-6, err

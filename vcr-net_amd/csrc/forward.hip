@@ -58,12 +58,12 @@ struct Runner {
   }
   bool ok(int r) { if (rc == 0 && r != 0) rc = r; return rc == 0; }
 
-  bool linear(const char* nm, const float* x, int ldx, const float* w, const float* b, float* y, int ldy,
-              int M, int N, int K, int relu, const float* res = nullptr, int ldr = 0) {
+  bool linear(const char* nm, const float* x, int ldx, const float* w, const void* wsplit, const float* b, float* y,
+              int ldy, int M, int N, int K, int relu, const float* res = nullptr, int ldr = 0) {
     if (rc) return false;
     mark(nm);
     vcr_linear_args a{x, ldx, w, b, res, ldr, y, ldy, M, N, K, relu};
-    return ok(vcr_linear_f32(&a, stream));
+    return ok(wsplit ? vcr_linear_bf16x3_f32(&a, wsplit, stream) : vcr_linear_f32(&a, stream));
   }
   bool norm(const char* nm, const float* x, const vcr_norm_w& n, float* y, int M, int E,
             const float* res = nullptr, const float* xyz4 = nullptr, float* side4 = nullptr) {
@@ -94,6 +94,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   const int M1 = B * N, M2 = 2 * M1;
   if (tr) tr->count = 0;
   Runner R{(hipStream_t)stream, tr};
+#define SP(site) (W->linear_mode == 1 ? W->split.site : nullptr)
 
   // ---- emb_nn = LPDNet on both clouds (lpdnet_model.py:103-137)
   for (int c = 0; c < 2 && R.rc == 0; ++c) {
@@ -107,7 +108,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     vcr_knn_args a{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1};
     R.ok(vcr_knn_f32(&a, R.stream));
   }
-  R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
+  R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
   if (R.rc == 0) {
     R.mark("edgeconv:dg1_dg2");
     vcr_edgeconv_args a{w.pq1, 256, w.idx1, k, M2, N, W->dg2_w, W->dg2_b, w.cat, 512, w.cat + 128, 512};
@@ -118,13 +119,13 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     vcr_knn_args a{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3};
     R.ok(vcr_knn_f32(&a, R.stream));
   }
-  R.linear("linear:sn1_pq", w.cat + 128, 512, W->sn1_wpq, W->sn1_bpq, w.pq3, 512, M2, 512, 128, 0);
+  R.linear("linear:sn1_pq", w.cat + 128, 512, W->sn1_wpq, SP(sn1_pq), W->sn1_bpq, w.pq3, 512, M2, 512, 128, 0);
   if (R.rc == 0) {
     R.mark("gathermax:sn1");
     vcr_gathermax_args a{w.pq3, 512, 256, w.idx3, k, M2, N, w.cat + 256, 512};
     R.ok(vcr_gathermax_f32(&a, R.stream));
   }
-  R.linear("linear:conv3", w.cat, 512, W->c3_w, W->c3_b, w.emb, E, M2, E, 512, 1);
+  R.linear("linear:conv3", w.cat, 512, W->c3_w, SP(c3), W->c3_b, w.emb, E, M2, E, 512, 1);
 
   // ---- pointer (transformer.py:264-272) + residual (vcrnet_model.py:504-505)
   const float* head_emb = w.embf;
@@ -132,26 +133,26 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     const int H = W->heads;
     // encoder layer (pre-norm residual sublayers, transformer.py:156-166) on [src; tgt]
     R.norm("layernorm:enc.sub0", w.emb, W->enc_ln0, w.ln, M2, E);
-    R.linear("linear:enc.qkv", w.ln, E, W->enc_self.wqkv, W->enc_self.bqkv, w.qkv, 3 * E, M2, 3 * E, E, 0);
+    R.linear("linear:enc.qkv", w.ln, E, W->enc_self.wqkv, SP(enc_qkv), W->enc_self.bqkv, w.qkv, 3 * E, M2, 3 * E, E, 0);
     R.sdpa("sdpa:enc.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
-    R.linear("linear:enc.wo", w.att, E, W->enc_self.wo, W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E);
+    R.linear("linear:enc.wo", w.att, E, W->enc_self.wo, SP(enc_wo), W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E);
     R.norm("layernorm:enc.sub1", w.e1, W->enc_ln1, w.ln, M2, E);
-    R.linear("linear:enc.ffn1", w.ln, E, W->enc_ffn.w1, W->enc_ffn.b1, w.hid, F, M2, F, E, 1);
-    R.linear("linear:enc.ffn2", w.hid, F, W->enc_ffn.w2, W->enc_ffn.b2, w.e2, E, M2, E, F, 0, w.e1, E);
+    R.linear("linear:enc.ffn1", w.ln, E, W->enc_ffn.w1, SP(enc_ffn1), W->enc_ffn.b1, w.hid, F, M2, F, E, 1);
+    R.linear("linear:enc.ffn2", w.hid, F, W->enc_ffn.w2, SP(enc_ffn2), W->enc_ffn.b2, w.e2, E, M2, E, F, 0, w.e1, E);
     R.norm("layernorm:enc.norm", w.e2, W->enc_norm, w.mem, M2, E);
     // decoder layer (transformer.py:169-185); batch b attends to memory of batch (b + B) mod 2B
     R.norm("layernorm:dec.sub0", w.emb, W->dec_ln0, w.ln, M2, E);
-    R.linear("linear:dec.qkv", w.ln, E, W->dec_self.wqkv, W->dec_self.bqkv, w.qkv, 3 * E, M2, 3 * E, E, 0);
+    R.linear("linear:dec.qkv", w.ln, E, W->dec_self.wqkv, SP(dec_qkv), W->dec_self.bqkv, w.qkv, 3 * E, M2, 3 * E, E, 0);
     R.sdpa("sdpa:dec.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
-    R.linear("linear:dec.self.wo", w.att, E, W->dec_self.wo, W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E);
+    R.linear("linear:dec.self.wo", w.att, E, W->dec_self.wo, SP(dec_self_wo), W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E);
     R.norm("layernorm:dec.sub1", w.d1, W->dec_ln1, w.ln, M2, E);
-    R.linear("linear:dec.cross.q", w.ln, E, W->dec_cross.wq, W->dec_cross.bq, w.qc, E, M2, E, E, 0);
-    R.linear("linear:dec.cross.kv", w.mem, E, W->dec_cross.wkv, W->dec_cross.bkv, w.kvc, 2 * E, M2, 2 * E, E, 0);
+    R.linear("linear:dec.cross.q", w.ln, E, W->dec_cross.wq, SP(dec_cross_q), W->dec_cross.bq, w.qc, E, M2, E, E, 0);
+    R.linear("linear:dec.cross.kv", w.mem, E, W->dec_cross.wkv, SP(dec_cross_kv), W->dec_cross.bkv, w.kvc, 2 * E, M2, 2 * E, E, 0);
     R.sdpa("sdpa:dec.cross", w.qc, E, w.kvc, 2 * E, w.kvc + E, 2 * E, w.att, E, 2 * B, H, N, N, B);
-    R.linear("linear:dec.cross.wo", w.att, E, W->dec_cross.wo, W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E);
+    R.linear("linear:dec.cross.wo", w.att, E, W->dec_cross.wo, SP(dec_cross_wo), W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E);
     R.norm("layernorm:dec.sub2", w.d2, W->dec_ln2, w.ln, M2, E);
-    R.linear("linear:dec.ffn1", w.ln, E, W->dec_ffn.w1, W->dec_ffn.b1, w.hid, F, M2, F, E, 1);
-    R.linear("linear:dec.ffn2", w.hid, F, W->dec_ffn.w2, W->dec_ffn.b2, w.d3, E, M2, E, F, 0, w.d2, E);
+    R.linear("linear:dec.ffn1", w.ln, E, W->dec_ffn.w1, SP(dec_ffn1), W->dec_ffn.b1, w.hid, F, M2, F, E, 1);
+    R.linear("linear:dec.ffn2", w.hid, F, W->dec_ffn.w2, SP(dec_ffn2), W->dec_ffn.b2, w.d3, E, M2, E, F, 0, w.d2, E);
     // final decoder norm, + embedding residual, + the head's side record in one pass
     R.norm("layernorm:dec.norm+res", w.d3, W->dec_norm, w.embf, M2, E, w.emb, w.xyz4, w.side4);
   } else if (R.rc == 0) {
@@ -176,6 +177,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (R.rc == 0 && io->emb_out)
     (void)hipMemcpyAsync(io->emb_out, w.embf, (size_t)M2 * E * sizeof(float), hipMemcpyDeviceToDevice, R.stream);
   R.finish();
+#undef SP
   return R.rc;
 }
 
@@ -206,7 +208,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 1; }
+extern "C" int vcr_abi_version(void) { return 2; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

@@ -9,6 +9,7 @@ the parameter containers.  There is no CPU / eager fallback: CPU tensors or a mi
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -191,6 +192,9 @@ class VCRNet(nn.Module):
         self._n_heads, self._ff = args.n_heads, args.ff_dims
         if getattr(args, "n_blocks", 1) != 1 and args.pointer == "transformer":
             raise Exception("Not implemented")                             # reference default n_blocks = 1
+        # "fp32": every linear on v_mfma_f32_32x32x2_f32 (default).  "bf16x3": the same products as exact 3-way bf16
+        # splits on the bf16 matrix pipe (fp32-equivalent accuracy, ~1.5x faster linears); fused whole-forward only.
+        self.linear_mode = os.environ.get("VCRNET_LINEAR_MODE", "fp32")
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
         self._cw: Optional[native.VcrnetWeights] = None
@@ -203,7 +207,8 @@ class VCRNet(nn.Module):
     # -- weight packing: once per (device, parameter versions) --------------------------------------------------
     def _fingerprint(self):
         ps = list(self.parameters()) + list(self.buffers())
-        return (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]), self.emb_nn.k)
+        return (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]), self.emb_nn.k,
+                self.linear_mode)
 
     def _pack(self):
         key = self._fingerprint()
@@ -271,6 +276,18 @@ class VCRNet(nn.Module):
             cw.has_pointer = 1
         else:
             cw.has_pointer = 2 if isinstance(self.pointer, _Identity) else 0
+        cw.linear_mode = 1 if self.linear_mode == "bf16x3" else 0
+        if cw.linear_mode == 1 and self._emb_kind == "lpdnet":
+            # weights pre-split into exact bf16 triplets for vcr_linear_bf16x3_f32 (fp32-equivalent products)
+            src = {"dg1_pq": "dg1_wpq", "sn1_pq": "sn1_wpq", "c3": "c3_w", "enc_qkv": "enc_self.wqkv",
+                   "enc_wo": "enc_self.wo", "enc_ffn1": "enc_ffn.w_1.weight", "enc_ffn2": "enc_ffn.w_2.weight",
+                   "dec_qkv": "dec_self.wqkv", "dec_self_wo": "dec_self.wo", "dec_cross_q": "dec_cross.wq",
+                   "dec_cross_kv": "dec_cross.wkv", "dec_cross_wo": "dec_cross.wo", "dec_ffn1": "dec_ffn.w_1.weight",
+                   "dec_ffn2": "dec_ffn.w_2.weight"}
+            for site, key in src.items():
+                if key in P:
+                    P["split." + site] = native.split_bf16x3(P[key])
+                    setattr(cw.split, site, native.ptr(P["split." + site]))
         cw.E, cw.F, cw.heads, cw.k = self.emb_dims, self._ff, self._n_heads, int(self.emb_nn.k)
         cw.head_mode = 1 if self._vcp == "dist" else 0
         self._packed, self._packed_key = P, key

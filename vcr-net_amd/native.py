@@ -115,6 +115,14 @@ class FfnW(C.Structure):
     _fields_ = [("w1", f32p), ("b1", f32p), ("w2", f32p), ("b2", f32p)]
 
 
+SPLIT_SITES = ("dg1_pq", "sn1_pq", "c3", "enc_qkv", "enc_wo", "enc_ffn1", "enc_ffn2", "dec_qkv", "dec_self_wo",
+               "dec_cross_q", "dec_cross_kv", "dec_cross_wo", "dec_ffn1", "dec_ffn2")
+
+
+class SplitW(C.Structure):
+    _fields_ = [(s, f32p) for s in SPLIT_SITES]
+
+
 class VcrnetWeights(C.Structure):
     _fields_ = [("c1_w", f32p), ("c1_b", f32p), ("c2_w", f32p), ("c2_b", f32p),
                 ("dg1_wpq", f32p), ("dg1_bpq", f32p), ("dg2_w", f32p), ("dg2_b", f32p),
@@ -124,7 +132,7 @@ class VcrnetWeights(C.Structure):
                 ("enc_self", MhaW), ("dec_self", MhaW), ("dec_cross", MhaW),
                 ("enc_ffn", FfnW), ("dec_ffn", FfnW),
                 ("E", C.c_int), ("F", C.c_int), ("heads", C.c_int), ("k", C.c_int),
-                ("has_pointer", C.c_int), ("head_mode", C.c_int)]
+                ("has_pointer", C.c_int), ("head_mode", C.c_int), ("linear_mode", C.c_int), ("split", SplitW)]
 
 
 class VcrnetIo(C.Structure):
@@ -268,6 +276,29 @@ def linear(x, w, bias=None, relu=False, residual=None, out=None):
     call("vcr_linear_f32", LinearArgs(ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(residual),
                                       residual.stride(0) if residual is not None else 0, ptr(y), y.stride(0),
                                       M, N, K, int(relu)))
+    return y
+
+
+def split_bf16x3(w):
+    """fp32 tensor -> int16 [3, numel] bf16 planes (hi, mid, lo) with hi + mid + lo == w exactly."""
+    L = lib()
+    w = w.contiguous().float()
+    planes = torch.empty(3, w.numel(), dtype=torch.int16, device=w.device)
+    L.vcr_split_bf16x3_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.vcr_split_bf16x3_f32.restype = C.c_int
+    check(L.vcr_split_bf16x3_f32(ptr(w), ptr(planes), w.numel(), C.c_void_p(stream_ptr())), "vcr_split_bf16x3_f32")
+    return planes
+
+
+def linear_bf16x3(x, w_planes, n_out, bias=None, relu=False, residual=None, out=None):
+    L = lib()
+    M, K = x.shape
+    y = out if out is not None else _f32(M, n_out, device=x.device)
+    a = LinearArgs(ptr(x), x.stride(0), None, ptr(bias), ptr(residual),
+                   residual.stride(0) if residual is not None else 0, ptr(y), y.stride(0), M, n_out, K, int(relu))
+    L.vcr_linear_bf16x3_f32.argtypes = [C.POINTER(LinearArgs), C.c_void_p, C.c_void_p]
+    L.vcr_linear_bf16x3_f32.restype = C.c_int
+    check(L.vcr_linear_bf16x3_f32(C.byref(a), ptr(w_planes), C.c_void_p(stream_ptr())), "vcr_linear_bf16x3_f32")
     return y
 
 

@@ -8,6 +8,7 @@ from typing import Dict, Tuple
 
 PEAK_MFMA_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+PEAK_MFMA_BF16_TFLOPS = 2500.0
 
 # which roofline bounds each kernel family
 FAMILY_BOUND = {"pointwise": "hbm", "knn": "mfma", "linear": "mfma", "edgeconv": "mfma", "gathermax": "hbm",
