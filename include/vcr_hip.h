@@ -76,6 +76,12 @@ typedef struct {
   float* y; int ldy;                  /* [M,N] */
   int M, N, K;
   int relu;
+  /* Optional LayerNorm fusion (transformer.py:141-144; all NULL/0 = plain linear; vcr_linear_f32 only):
+   * stats_out   [M, N/64, 2]: the epilogue also writes (sum y, sum y^2) per row and 64-column segment (N % 64 == 0);
+   * ln_stats_in [M, ln_nseg, 2]: such partial sums over the K columns of x; the A operand then becomes
+   *             ln_a[k] * (x - mean) / (std_unbiased + ln_eps) + ln_b[k], applied on the fly. */
+  const float* ln_stats_in; int ln_nseg; const float* ln_a; const float* ln_b; float ln_eps;
+  float* stats_out;
 } vcr_linear_args;
 int vcr_linear_f32(const vcr_linear_args*, vcr_stream_t);
 

@@ -284,3 +284,27 @@ def test_linear_bf16x3(nat, M, N, K, relu, res):
         ref = ref + r.double()
     err = (y.cpu().double() - ref).abs().max().item()
     assert err <= 4e-6 * math.sqrt(K) + 1e-6, err
+
+
+def test_linear_with_fused_layernorm(nat):
+    """the producer's epilogue emits per-row (sum, sum^2) partials, the consumer applies
+    a*(x-mean)/(std_unbiased+eps)+b to its A fragments on the fly -- equal to LayerNorm followed by Linear."""
+    g = torch.Generator().manual_seed(11)
+    M, K, N = 1000, 512, 1536
+    x0 = torch.randn(M, 128, generator=g)
+    w0 = torch.randn(K, 128, generator=g) / math.sqrt(128)
+    b0 = torch.randn(K, generator=g) * 0.5 + 0.3            # non-zero mean rows: exercises the variance formula
+    r0 = torch.randn(M, K, generator=g) * 2
+    a, b = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    w1 = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b1 = torch.randn(N, generator=g)
+    x, stats = nat.linear(dev(x0), dev(w0), dev(b0), residual=dev(r0), want_stats=True)     # producer
+    xs = x.cpu()
+    torch.testing.assert_close(stats.cpu()[..., 0].sum(1), xs.sum(1), atol=2e-4, rtol=1e-5)
+    torch.testing.assert_close(stats.cpu()[..., 1].sum(1), (xs ** 2).sum(1), atol=2e-3, rtol=1e-5)
+    y = nat.linear(x, dev(w1), dev(b1), relu=True, ln=(stats, dev(a), dev(b), 1e-6))         # consumer
+    ref = torch.relu(oracle.layer_norm(xs.double(), a.double(), b.double()) @ w1.double().t() + b1.double())
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err <= 5e-5, err
+    y_unfused = nat.linear(nat.layernorm(x, dev(a), dev(b)), dev(w1), dev(b1), relu=True)
+    assert (y.cpu() - y_unfused.cpu()).abs().max().item() <= 5e-5

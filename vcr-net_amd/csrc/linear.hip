@@ -166,9 +166,17 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// LN_IN : the A operand is LayerNorm(x) of model/transformer.py:141-144, applied on the fly to the fragments read
+//         from LDS: a_k (x - mean) / (std + eps) + b_k with the row statistics rebuilt from per-64-column partial
+//         sums (sum, sum of squares) that the PRODUCING linear wrote from its epilogue (STATS_OUT) -- the separate
+//         LayerNorm launch and its 2 x M x 512 x 4 B round trip disappear.
+// STATS_OUT: epilogue also writes, per row and per 64-column segment, (sum y, sum y^2) of the final outputs.
+template <bool LN_IN, bool STATS_OUT>
 __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileG* tile = reinterpret_cast<TileG*>(smem);          // [2]
+  float* lnA = reinterpret_cast<float*>(smem + 2 * sizeof(TileG));   // [K] scale, then [K] shift (LN_IN only)
+  float* lnB = lnA + p.K;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -200,6 +208,9 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
     }
   };
   fill(0, 0);
+  if (LN_IN) {
+    for (int i = t; i < p.K; i += 256) { lnA[i] = p.ln_a[i]; lnB[i] = p.ln_b[i]; }
+  }
   __syncthreads();
 
   f32x16 acc[2][2];
@@ -213,6 +224,19 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
     ra_[i] = wm * 64 + i * 32 + l31; sa[i] = (ra_[i] >> 1) & 7;
     rb_[i] = wn * 64 + i * 32 + l31; sb[i] = (rb_[i] >> 1) & 7;
   }
+  float ln_inv[2] = {1.f, 1.f}, ln_shift[2] = {0.f, 0.f};   // x_hat = x * inv + shift
+  if (LN_IN) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float* sp = p.ln_stats_in + (size_t)min(m0 + ra_[i], p.M - 1) * p.ln_nseg * 2;
+      float s1 = 0.f, s2 = 0.f;
+      for (int sg = 0; sg < p.ln_nseg; ++sg) { s1 += sp[2 * sg]; s2 += sp[2 * sg + 1]; }   // fixed order
+      const float mean = s1 / (float)p.K;
+      const float var = fmaxf((s2 - s1 * mean) / (float)(p.K - 1), 0.f);                    // unbiased, like x.std()
+      ln_inv[i] = 1.f / (sqrtf(var) + p.ln_eps);
+      ln_shift[i] = -mean * ln_inv[i];
+    }
+  }
   const int nk = p.K / 32;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -225,6 +249,13 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
       for (int i = 0; i < 2; ++i) fa[i] = ld4(&T.a[ra_[i]][4 * ((2 * g + half) ^ sa[i])]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[j] = ld4(&T.b[rb_[j]][4 * ((2 * g + half) ^ sb[j])]);
+      if (LN_IN) {
+        const f32x4 a4 = ld4(&lnA[kt * 32 + 8 * g + 4 * half]), b4 = ld4(&lnB[kt * 32 + 8 * g + 4 * half]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fa[i][e] = fmaf(fmaf(fa[i][e], ln_inv[i], ln_shift[i]), a4[e], b4[e]);
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -257,6 +288,16 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
           if (p.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
           if (p.residual) v = v + ld4(p.residual + (size_t)row * p.ldr + col);
           st4(p.y + (size_t)row * p.ldy + col, v);
+          if (STATS_OUT) {                               // the 16 lanes of a row group hold this wave's 64 columns
+            float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+            float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            if ((lane & 15) == 0) {
+              float* so = p.stats_out + ((size_t)row * (p.N / 64) + (n0 + wn * 64) / 64) * 2;
+              so[0] = s1; so[1] = s2;
+            }
+          }
         }
       }
     }
@@ -282,10 +323,26 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
   const int vec = (a->N % 4 == 0) && (a->ldy % 4 == 0) && (((uintptr_t)a->y & 15) == 0) &&
                   (!a->bias || ((uintptr_t)a->bias & 15) == 0) &&
                   (!a->residual || ((a->ldr % 4 == 0) && ((uintptr_t)a->residual & 15) == 0));
+  if (a->ln_stats_in || a->stats_out) {                  // fused LayerNorm prologue / statistics epilogue
+    if (!vec || (g_variant & 4)) return VCR_EUNSUPPORTED;
+    if (a->ln_stats_in && (!a->ln_a || !a->ln_b || a->ln_nseg <= 0 || a->K > 2048 || a->K < 2)) return VCR_EINVAL;
+    if (a->stats_out && (a->N % 64)) return VCR_EINVAL;
+  }
   if (!(g_variant & 4) && vec) {   // default: LDS-DMA staging (bit2 of the debug variant selects register staging)
-    const int ldsg = 2 * sizeof(TileG);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsg);
-    hipLaunchKernelGGL(linear_glds_kernel, dim3(tiles_m * tiles_n), dim3(256), ldsg, (hipStream_t)stream, *a, tiles_m, tiles_n);
+    const bool ln_in = a->ln_stats_in != nullptr, st_out = a->stats_out != nullptr;
+    const int ldsg = 2 * sizeof(TileG) + (ln_in ? 2 * a->K * 4 : 0);
+#define VCR_LIN_LAUNCH(LI, SO)                                                                                          \
+  do {                                                                                                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_glds_kernel<LI, SO>),                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsg);                                        \
+    hipLaunchKernelGGL((linear_glds_kernel<LI, SO>), dim3(tiles_m * tiles_n), dim3(256), ldsg, (hipStream_t)stream, *a, \
+                       tiles_m, tiles_n);                                                                                \
+  } while (0)
+    if (ln_in && st_out) VCR_LIN_LAUNCH(true, true);
+    else if (ln_in) VCR_LIN_LAUNCH(true, false);
+    else if (st_out) VCR_LIN_LAUNCH(false, true);
+    else VCR_LIN_LAUNCH(false, false);
+#undef VCR_LIN_LAUNCH
   } else if (g_variant & 1) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     hipLaunchKernelGGL(linear_kernel<16>, dim3(tiles_m * tiles_n), dim3(256), lds16, (hipStream_t)stream, *a, tiles_m,

@@ -202,6 +202,7 @@ extern "C" int vcr_split_bf16x3_f32(const float* x, void* planes, size_t n, vcr_
 
 extern "C" int vcr_linear_bf16x3_f32(const vcr_linear_args* a, const void* w_planes, vcr_stream_t stream) {
   if (!a || !a->x || !w_planes || !a->y) return VCR_EINVAL;
+  if (a->ln_stats_in || a->stats_out) return VCR_EUNSUPPORTED;   // LayerNorm fusion lives in vcr_linear_f32
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % TK) != 0) return VCR_EINVAL;
   if ((a->ldx & 3) || a->ldx < a->K || a->ldy < a->N || (a->residual && a->ldr < a->N)) return VCR_EINVAL;
   if ((a->N % 4) || (a->ldy % 4) || ((uintptr_t)a->y & 15) || ((uintptr_t)a->x & 15) || ((uintptr_t)w_planes & 15))

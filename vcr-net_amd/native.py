@@ -31,7 +31,9 @@ class KnnArgs(C.Structure):
 
 class LinearArgs(C.Structure):
     _fields_ = [("x", f32p), ("ldx", C.c_int), ("w", f32p), ("bias", f32p), ("residual", f32p), ("ldr", C.c_int),
-                ("y", f32p), ("ldy", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("relu", C.c_int)]
+                ("y", f32p), ("ldy", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("relu", C.c_int),
+                ("ln_stats_in", f32p), ("ln_nseg", C.c_int), ("ln_a", f32p), ("ln_b", f32p), ("ln_eps", C.c_float),
+                ("stats_out", f32p)]
 
 
 class LayerNormArgs(C.Structure):
@@ -156,6 +158,9 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
+ABI_VERSION = 3          # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+
+
 class VcrHipError(RuntimeError):
     pass
 
@@ -174,6 +179,9 @@ def lib() -> C.CDLL:
             fn.restype = C.c_int
         L.vcr_strerror.argtypes = [C.c_int]; L.vcr_strerror.restype = C.c_char_p
         L.vcr_abi_version.restype = C.c_int
+        if L.vcr_abi_version() != ABI_VERSION:
+            raise VcrHipError(f"{LIB_PATH} exports ABI {L.vcr_abi_version()}, these bindings are for {ABI_VERSION}: "
+                              "rebuild with `python vcr-net_amd/build.py`")
         L.vcr_vcrnet_workspace_bytes.argtypes = [C.POINTER(VcrnetWeights), C.c_int, C.c_int]
         L.vcr_vcrnet_workspace_bytes.restype = C.c_size_t
         L.vcr_vcrnet_forward_f32.argtypes = [C.POINTER(VcrnetWeights), C.POINTER(VcrnetIo), C.c_void_p, C.c_size_t,
@@ -269,14 +277,20 @@ def knn(x, sq, k):
     return idx
 
 
-def linear(x, w, bias=None, relu=False, residual=None, out=None):
+def linear(x, w, bias=None, relu=False, residual=None, out=None, ln=None, want_stats=False):
+    """y = act(x w^T + bias) (+ residual).  ln = (stats [M,nseg,2], a [K], b [K], eps): LayerNorm fused into the
+    A-operand read.  want_stats: also return the [M, N/64, 2] (sum, sum of squares) partials of y."""
     M, K = x.shape
     N = w.shape[0]
     y = out if out is not None else _f32(M, N, device=x.device)
-    call("vcr_linear_f32", LinearArgs(ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(residual),
-                                      residual.stride(0) if residual is not None else 0, ptr(y), y.stride(0),
-                                      M, N, K, int(relu)))
-    return y
+    stats = _f32(M, N // 64, 2, device=x.device) if want_stats else None
+    a = LinearArgs(ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(residual),
+                   residual.stride(0) if residual is not None else 0, ptr(y), y.stride(0), M, N, K, int(relu))
+    if ln is not None:
+        a.ln_stats_in, a.ln_nseg, a.ln_a, a.ln_b, a.ln_eps = ptr(ln[0]), ln[0].shape[1], ptr(ln[1]), ptr(ln[2]), ln[3]
+    a.stats_out = ptr(stats)
+    call("vcr_linear_f32", a)
+    return (y, stats) if want_stats else y
 
 
 def split_bf16x3(w):
