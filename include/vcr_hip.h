@@ -181,20 +181,39 @@ typedef struct {
   int nbatch, n_own, n_str, E; int score; float scale; int str_batch_shift; int op;
   float* corr4; float* stat2; int32_t* argmax;
   const float* str_stat2; long str_stat_batch_stride; float* mass; int accumulate;
+  float* score_out; int ld_score;     /* op 1 only, optional: also keep the scores, S[(b*n_own + o)*ld_score + s];
+                                         ld_score % 4 == 0 and >= n_str rounded up to 32 (the pad receives -inf) */
 } vcr_pairscore_args;
 int vcr_pairscore_f32(const vcr_pairscore_args*, vcr_stream_t);
+
+/* ---- both probability masses of selectCom (vcrnet_model.py:217-248) from a STORED score matrix
+ * score [nbatch, n_rows, ld] and its row statistics row_stat2 [nbatch,n_rows,2] = (max_j, sum_j exp(. - max)):
+ *   col_stat2[j] = (max_i S_ij, sum_i exp(S_ij - max))        soft-max over dim=1
+ *   col_mass[j]  = sum_i exp(S_ij - m_i) / l_i                scoresColSum (:222)
+ *   row_mass[i]  = sum_j exp(S_ij - cm_j) / cl_j              scoresRowSum (:244)
+ * Two HBM-bound passes over S instead of three more N x N x E score GEMMs. */
+typedef struct {
+  const float* score; int ld; int nbatch, n_rows, n_cols;
+  const float* row_stat2; float* col_stat2; float* col_mass; float* row_mass;
+} vcr_scoremass_args;
+int vcr_scoremass_f32(const vcr_scoremass_args*, vcr_stream_t);
 
 /* ---- per-sample top-K of n scores in descending order, ties -> lower index (Tensor.topk at
  * transformer.py:42, vcrnet_model.py:223,245,312).  order [nbatch,K] int32 and/or mask [nbatch,n] uint8. */
 typedef struct {
   const float* values; int nbatch, n, K; int32_t* order; uint8_t* mask;
   int largest;                        /* 1: K largest, descending; 0: K smallest, ascending */
+  int stride;                         /* element stride between consecutive values (0 or 1: dense); sample b starts
+                                         at values + b*n*stride -- lets column 1 of a [nbatch,n,2] record be ranked */
 } vcr_rankselect_args;
 int vcr_rankselect_f32(const vcr_rankselect_args*, vcr_stream_t);
 
-/* ---- out[b][r][0:C] = in[b][idx[b][r]][0:C]  (index gathers of vcrnet_model.py:230-260,305-330) */
+/* ---- out[b][r][0:C] = in[b][idx[b][r]][0:C]  (index gathers of vcrnet_model.py:230-260,305-330).
+ * via (optional, [nbatch,n_via] int32): the row taken is via[b][idx[b][r]] -- the arg-max target of the r-th
+ * kept source in getCopair (vcrnet_model.py:325). */
 typedef struct {
   const float* in; int ld_in; int n_in; const int32_t* idx; int nbatch, n_out, C; float* out; int ld_out;
+  const int32_t* via; int n_via;
 } vcr_gather_args;
 int vcr_gather_rows_f32(const vcr_gather_args*, vcr_stream_t);
 
@@ -255,18 +274,26 @@ typedef struct {
     const void *dg1_pq, *sn1_pq, *c3, *enc_qkv, *enc_wo, *enc_ffn1, *enc_ffn2, *dec_qkv, *dec_self_wo, *dec_cross_q,
                *dec_cross_kv, *dec_cross_wo, *dec_ffn1, *dec_ffn2;
   } split;
+  /* partial-overlap mode (args.partial, vcrnet_model.py:178-187 + transformer.py:35-53; head_mode must be 0):
+   * the decoder's cross-attention keeps the int(N*overlap2) keys with the largest soft-max mass, the head is
+   * selectCom + getCopair and the outputs hold vcr_vcrnet_pairs() hard pairs per sample instead of N soft ones.
+   * overlap2 is a double because the reference truncates float64 products of it (vcrnet_model.py:208,284). */
+  int partial;
+  double overlap2;
 } vcr_vcrnet_weights;
 
 typedef struct {
   const float* src_cf; const float* tgt_cf;        /* [B,3,N] channels-first, as VCRNet.forward gets them */
   int B, N;
-  float* corr4;                                    /* [B,N,4] src_corr (x,y,z,0) */
-  float* src4;                                     /* [B,N,4] src as rows (x,y,z,|p|^2) */
+  float* corr4;                                    /* [B,K,4] src_corr (x,y,z,0); K = vcr_vcrnet_pairs(): N in whole mode */
+  float* src4;                                     /* [B,K,4] the matched src points as rows (x,y,z,|p|^2) */
   float* R_ab; float* t_ab; float* R_ba; float* t_ba;  /* [B,9],[B,3],[B,9],[B,3] */
   float* emb_out;                                  /* optional [2B*N,E] final embeddings (src then tgt), may be NULL */
 } vcr_vcrnet_io;
 
 size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights*, int B, int N);
+/* Correspondences per sample in corr4/src4: N (whole mode) or int(int(N*0.84*overlap2)*0.52*overlap2) (partial). */
+int vcr_vcrnet_pairs(const vcr_vcrnet_weights*, int N);
 int vcr_vcrnet_forward_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io*, void* workspace,
                            size_t workspace_bytes, vcr_stream_t);
 
@@ -275,13 +302,20 @@ int vcr_vcrnet_forward_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io*, void
  * after the last launch, so launch i took elapsed(events[i], events[i+1]).  names[i] is a static
  * string "family:site" (families: pointwise, knn, linear, edgeconv, gathermax, layernorm, sdpa,
  * softcorr, rigid_svd, select).  count = number of launches recorded. */
-#define VCR_TRACE_MAX 128
+#define VCR_TRACE_MAX 256
 typedef struct {
   void** events; int capacity; int count;
   const char* names[VCR_TRACE_MAX];
 } vcr_trace;
 int vcr_vcrnet_forward_traced_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io*, void* workspace,
                                   size_t workspace_bytes, vcr_stream_t, vcr_trace*);
+
+/* vcrnetIter (vcrnet_model.py:21-43): `iters` forwards, each on the source moved by the previous pose
+ * (transform_point_cloud, util/util.py:91-96), poses composed on the device (R_f <- R_i R_f, t_f <- R_i t_f + t_i);
+ * io->R_ab/t_ab receive the composed pose, R_ba/t_ba its inverse, corr4/src4 the LAST iteration's pairs.
+ * No host synchronisation between iterations.  trace may be NULL; launches of all iterations are appended. */
+int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io*, int iters, void* workspace,
+                        size_t workspace_bytes, vcr_stream_t, vcr_trace* trace);
 
 /* hipEvent helpers (create / destroy / record / elapsed) bound to the same HIP runtime as the
  * kernels, for hosts without HIP bindings.  Elapsed needs both events completed (synchronise first). */

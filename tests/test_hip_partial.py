@@ -165,3 +165,91 @@ def test_partial_module_forward_and_iter():
     assert torch.allclose(torch.det(R), torch.ones(2), atol=1e-5)
     # aggregate check vs the reference's composed pose: loose (chaotic path), sanity only
     assert np.abs(R.numpy() - g["R_final"]).max() < 5e-2
+
+
+@pytest.mark.parametrize("name", ["partial_n192_b2_it2", "partial_n768_b2_it3"])
+def test_partial_fused_driver_matches_kernel_by_kernel(name):
+    """vcr_vcrnet_forward_f32 in partial mode (one C call, LayerNorm fused into the linears) against the
+    kernel-by-kernel composition on the reference's teacher-forced inputs: same hard pairs up to near-tie
+    flips, and the same pose whenever the pairs agree."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import composed
+    g = golden(name)
+    net, _ = build_net(partial=True, overlap2=float(g["overlap2"]))
+    assert net.fused_supported()
+    tgt = torch.from_numpy(g["tgt"]).cuda()
+    agree = 0
+    for it in range(int(g["iters"])):
+        cur = torch.from_numpy(g[f"it{it}_in"]).cuda()
+        with torch.no_grad():
+            f = net(cur, tgt)
+            c = composed.forward_composed(net, cur, tgt)
+        assert f[0].shape == c[0].shape and f[1].shape == c[1].shape
+        K = f[0].shape[2]
+        same = 0
+        for b in range(cur.shape[0]):
+            pf = {tuple(x) for x in torch.cat((f[0][b], f[1][b]), 0).t().cpu().numpy().round(6).tolist()}
+            pc = {tuple(x) for x in torch.cat((c[0][b], c[1][b]), 0).t().cpu().numpy().round(6).tolist()}
+            same += len(pf & pc)
+        assert same >= 0.9 * K * cur.shape[0], (same, K)
+        if same == K * cur.shape[0]:
+            agree += 1
+            np.testing.assert_allclose(f[2].cpu().numpy(), c[2].cpu().numpy(), atol=1e-5)
+            np.testing.assert_allclose(f[3].cpu().numpy(), c[3].cpu().numpy(), atol=1e-5)
+    assert agree >= 1
+
+
+def test_iter_c_loop_matches_python_loop():
+    """vcr_vcrnet_iter_f32 (device-side loop, poses composed by pose_step_kernel) against a host loop over
+    vcr_vcrnet_forward_f32 with torch doing the bookkeeping of vcrnet_model.py:32-41."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    from vcrnet_amd.module import vcrnetIter
+    net, _ = build_net()
+    src, tgt, _, _, _ = synth.make_batch(410, 3, 256)
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    with torch.no_grad():
+        out = vcrnetIter(net, s, t, iter=3)
+        cur, Rf, tf = s, None, None
+        for _ in range(3):
+            o = net(cur, t)
+            cur = torch.matmul(o[2], cur) + o[3].unsqueeze(2)
+            Rf, tf = (o[2], o[3]) if Rf is None else (o[2] @ Rf, (o[2] @ tf.unsqueeze(2)).squeeze(2) + o[3])
+    np.testing.assert_allclose(out[2].cpu().numpy(), Rf.cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(out[3].cpu().numpy(), tf.cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(out[4].cpu().numpy(), Rf.transpose(1, 2).cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(out[5].cpu().numpy(), -(Rf.transpose(1, 2) @ tf.unsqueeze(2)).squeeze(2).cpu().numpy(),
+                               atol=2e-5)
+    np.testing.assert_allclose(out[0].cpu().numpy(), o[0].cpu().numpy(), atol=2e-5)      # last iteration's source
+
+
+def test_scoremass_strided_rank_and_indirect_gather(nat):
+    """Stored-score passes of selectCom, ranking one column of a [.,.,2] record, gather through an index map."""
+    g = torch.Generator().manual_seed(5)
+    B, N1, N2, E = 2, 200, 173, 512
+    a, b = torch.randn(B * N1, E, generator=g) * 0.2, torch.randn(B * N2, E, generator=g) * 0.2
+    side = lambda x: torch.cat((torch.zeros(len(x), 3), (x.double() ** 2).sum(1, keepdim=True).float()), 1)
+    ld = (N2 + 31) // 32 * 32
+    S = torch.full((B, N1, ld), float("nan")).cuda()
+    rstat, _ = nat.pairscore(a.cuda(), b.cuda(), B, N1, N2, op=1, score=0, own_side4=side(a).cuda(),
+                             str_side4=side(b).cuda(), score_out=S)
+    Sd = (-(a.double().view(B, N1, 1, E) - b.double().view(B, 1, N2, E)) ** 2).sum(-1)
+    assert (S[:, :, :N2].cpu().double() - Sd).abs().max() < 2e-4
+    assert torch.isinf(S[:, :, N2:]).all()
+    cs, cm, rm = nat.scoremass(S, N2, rstat)
+    Sg = S[:, :, :N2].cpu().double()
+    np.testing.assert_allclose(cm.cpu().numpy(), torch.softmax(Sg, 2).sum(1).numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(rm.cpu().numpy(), torch.softmax(Sg, 1).sum(2).numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(cs.cpu().numpy()[..., 0], Sg.max(1).values.numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(cs.cpu().numpy()[..., 1], torch.exp(Sg - Sg.max(1, keepdim=True).values).sum(1).numpy(),
+                               rtol=2e-5)
+    # rank column 1 of the (max, sum) record, ascending
+    order, _ = nat.rankselect(rstat.view(B, N1, 2)[:, :, 1], 50, largest=False)
+    ref = torch.sort(rstat.view(B, N1, 2)[:, :, 1].cpu(), dim=1, stable=True).indices[:, :50]
+    assert torch.equal(order.cpu().long(), ref)
+    # out[b][r] = x[b][via[b][idx[b][r]]]
+    x = torch.randn(B * N2, 4, generator=g).cuda()
+    via = torch.randint(0, N2, (B, N1), generator=g).int().cuda()
+    out = nat.gather_rows(x, order, B, N2, via=via).view(B, 50, 4)
+    want = torch.stack([x.view(B, N2, 4)[bb][via[bb].long()[order[bb].long()]] for bb in range(B)])
+    assert torch.equal(out, want)

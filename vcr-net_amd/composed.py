@@ -123,8 +123,8 @@ def transformer(net, emb: torch.Tensor, B: int, N: int, rec: Optional[dict] = No
 
 def _partial_head(net, src, embf, side4, B: int, N: int, rec: Optional[dict]):
     """VcpTopK partial mode: selectCom (model/vcrnet_model.py:190-262) + getCopair (:264-332) + SVD.
-    The N x N score matrix and its two soft-maxes are never written: two STATS passes give the row /
-    column soft-max statistics, two MASS passes the column / row probability sums, rankselect the
+    The score matrix is computed and written ONCE (with its row soft-max statistics); the two soft-maxes are
+    never written: a column pass and a row pass over S give the column / row probability sums, rankselect the
     overlap sets, one more STATS pass (with arg-max) on the reduced sets the hard correspondences."""
     M1 = B * N
     o2 = net._overlap2
@@ -133,10 +133,11 @@ def _partial_head(net, src, embf, side4, B: int, N: int, rec: Optional[dict]):
     tgt_k = int(N * 0.84 * o2)                                             # :209
     # score_ij = (-|s_i|^2 + 2 s_i.t_j) - |t_j|^2 for BOTH soft-maxes (one matrix in the reference, :211-216):
     # owner = src -> score form 0; owner = tgt -> form 2 (streamed-side norm first), the same association.
-    rstat, _ = native.pairscore(se, te, B, N, N, op=1, score=0, own_side4=ss, str_side4=ts)      # softmax(dim=2)
-    cstat, _ = native.pairscore(te, se, B, N, N, op=1, score=2, own_side4=ts, str_side4=ss)      # softmax(dim=1)
-    colsum = native.pairscore(te, se, B, N, N, op=2, score=2, own_side4=ts, str_side4=ss, str_stat2=rstat)  # :222
-    rowsum = native.pairscore(se, te, B, N, N, op=2, score=0, own_side4=ss, str_side4=ts, str_stat2=cstat)  # :244
+    # one score GEMM pass keeps S and the row soft-max statistics; the column statistics and both probability
+    # masses then come from two HBM-bound passes over S
+    S = torch.empty(B, N, (N + 31) // 32 * 32, dtype=torch.float32, device=embf.device)
+    rstat, _ = native.pairscore(se, te, B, N, N, op=1, score=0, own_side4=ss, str_side4=ts, score_out=S)   # softmax(dim=2)
+    _, colsum, rowsum = native.scoremass(S, N, rstat)                      # :222, :244
     idx_t, _ = native.rankselect(colsum, tgt_k)                            # :223
     idx_s, _ = native.rankselect(rowsum, src_k)                            # :245
     so_e, to_e = native.gather_rows(se, idx_s, B, N), native.gather_rows(te, idx_t, B, N)        # :251-260,:235-238

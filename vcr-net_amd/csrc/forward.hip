@@ -25,10 +25,21 @@ struct Ws {
   int32_t *idx1, *idx3;
   float *ln, *qkv, *att, *e1, *e2, *mem, *hid, *d1, *d2, *d3, *qc, *kvc, *embf, *side4;
   float *st_emb, *st_e1, *st_e2, *st_d1, *st_d2;       // [M, E/64, 2] LayerNorm partial sums
+  // partial-overlap mode
+  float *rowstat, *keymass; uint8_t* keep;             // cross-attention: [2B,H,N,2], [2B,N], [2B,N]
+  float *rstat, *cstat, *colsum, *rowsum, *score;      // selectCom: [B,N,2] x2, [B,N] x2, [B,N,roundup32(N)]
+  int32_t *sel_s, *sel_t, *amax, *pick;                // [B,K1] x3, [B,K2]
+  float *so_e, *to_e, *so_s, *to_s, *peak;             // overlap sets: [B,K1,E] x2, [B,K1,4] x2; [B,K1,2]
+  // vcrnetIter
+  float *cur_cf, *Ri, *ti, *Rb, *tb;
   size_t bytes;
 };
 
-Ws carve(void* base, int B, int N, int k, int E, int F) {
+// vcrnet_model.py:208-209 and :284 -- Python truncates float64 products, so do we
+inline int overlap_k1(int N, double o2) { return (int)((double)N * 0.84 * o2); }
+inline int overlap_k2(int N, double o2) { return (int)((double)overlap_k1(N, o2) * 0.52 * o2); }
+
+Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, double o2) {
   Bump bp{reinterpret_cast<unsigned char*>(base), 0, 0};
   const size_t M = (size_t)2 * B * N;
   Ws w;
@@ -45,6 +56,21 @@ Ws carve(void* base, int B, int N, int k, int E, int F) {
   const size_t sn = M * (E / 64) * 2;
   w.st_emb = bp.take<float>(sn); w.st_e1 = bp.take<float>(sn); w.st_e2 = bp.take<float>(sn);
   w.st_d1 = bp.take<float>(sn);  w.st_d2 = bp.take<float>(sn);
+  if (partial) {
+    const size_t K1 = (size_t)overlap_k1(N, o2), K2 = (size_t)overlap_k2(N, o2), B1 = (size_t)B;
+    w.rowstat = bp.take<float>(M * heads * 2); w.keymass = bp.take<float>(M); w.keep = bp.take<uint8_t>(M);
+    w.rstat = bp.take<float>(B1 * N * 2); w.cstat = bp.take<float>(B1 * N * 2);
+    w.colsum = bp.take<float>(B1 * N);    w.rowsum = bp.take<float>(B1 * N);
+    w.score = bp.take<float>(B1 * N * ((N + 31) & ~31));
+    w.sel_s = bp.take<int32_t>(B1 * K1);  w.sel_t = bp.take<int32_t>(B1 * K1);
+    w.amax = bp.take<int32_t>(B1 * K1);   w.pick = bp.take<int32_t>(B1 * (K2 ? K2 : 1));
+    w.so_e = bp.take<float>(B1 * K1 * E); w.to_e = bp.take<float>(B1 * K1 * E);
+    w.so_s = bp.take<float>(B1 * K1 * 4); w.to_s = bp.take<float>(B1 * K1 * 4);
+    w.peak = bp.take<float>(B1 * K1 * 2);
+  }
+  w.cur_cf = bp.take<float>((size_t)B * 3 * N);
+  w.Ri = bp.take<float>((size_t)B * 9); w.ti = bp.take<float>((size_t)B * 3);
+  w.Rb = bp.take<float>((size_t)B * 9); w.tb = bp.take<float>((size_t)B * 3);
   w.bytes = bp.off + 256;
   return w;
 }
@@ -82,26 +108,114 @@ struct Runner {
     return ok(vcr_layernorm_f32(&a, stream));
   }
   bool sdpa(const char* nm, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
-            int ldo, int nb, int heads, int nq, int nk, int shift) {
+            int ldo, int nb, int heads, int nq, int nk, int shift, const uint8_t* keep = nullptr,
+            float* rowstat = nullptr) {
     if (rc) return false;
     mark(nm);
-    vcr_sdpa_args a{q, ldq, k, ldk, v, ldv, out, ldo, nb, heads, nq, nk, 1.0f / sqrtf(128.f), shift, nullptr, nullptr};
+    vcr_sdpa_args a{q, ldq, k, ldk, v, ldv, out, ldo, nb, heads, nq, nk, 1.0f / sqrtf(128.f), shift, keep, rowstat};
     return ok(vcr_sdpa_f32(&a, stream));
+  }
+  bool pairscore(const char* nm, const vcr_pairscore_args& a) {
+    if (rc) return false;
+    mark(nm);
+    return ok(vcr_pairscore_f32(&a, stream));
+  }
+  bool rank(const char* nm, const float* values, int stride, int nb, int n, int K, int32_t* order, uint8_t* mask,
+            int largest) {
+    if (rc) return false;
+    mark(nm);
+    vcr_rankselect_args a{values, nb, n, K, order, mask, largest, stride};
+    return ok(vcr_rankselect_f32(&a, stream));
+  }
+  bool gather(const char* nm, const float* in, int ld, int n_in, const int32_t* idx, int nb, int n_out, int C,
+              float* out, const int32_t* via = nullptr, int n_via = 0) {
+    if (rc) return false;
+    mark(nm);
+    vcr_gather_args a{in, ld, n_in, idx, nb, n_out, C, out, C, via, n_via};
+    return ok(vcr_gather_rows_f32(&a, stream));
+  }
+
+  // Decoder cross-attention.  Partial mode (transformer.py:35-53): soft-max once, total probability mass every
+  // KEY receives over heads and queries, keep the int(nk*overlap2) heaviest keys, soft-max again over those.
+  // The first soft-max is never written: a statistics pass leaves (max, sum) per query row, the mass pass
+  // streams the queries past each key block (owner = keys of batch b, streamed = queries of batch (b+B) % 2B).
+  void cross_attention(const vcr_vcrnet_weights* W, const Ws& w, int B, int N) {
+    const int E = W->E, H = W->heads, nb = 2 * B, dk = E / H;
+    const uint8_t* keep = nullptr;
+    if (W->partial) {
+      sdpa("sdpa:dec.cross.stats", w.qc, E, w.kvc, 2 * E, nullptr, 0, nullptr, 0, nb, H, N, N, B, nullptr, w.rowstat);
+      for (int h = 0; h < H; ++h) {
+        vcr_pairscore_args a{};
+        a.own = w.kvc + h * dk; a.ld_own = 2 * E; a.str = w.qc + h * dk; a.ld_str = E;
+        a.nbatch = nb; a.n_own = N; a.n_str = N; a.E = dk; a.score = 1; a.scale = 1.0f / sqrtf((float)dk);
+        a.str_batch_shift = B; a.op = 2; a.str_stat2 = w.rowstat + (size_t)h * N * 2;
+        a.str_stat_batch_stride = (long)H * N * 2; a.mass = w.keymass; a.accumulate = h > 0;
+        pairscore("pairscore:dec.cross.keymass", a);
+      }
+      rank("select:dec.cross.keys", w.keymass, 1, nb, N, (int)((double)N * W->overlap2), nullptr, w.keep, 1);
+      keep = w.keep;
+    }
+    sdpa("sdpa:dec.cross", w.qc, E, w.kvc, 2 * E, w.kvc + E, 2 * E, w.att, E, nb, H, N, N, B, keep);
+  }
+
+  // VcpTopK partial mode: selectCom (vcrnet_model.py:190-262) + getCopair (:264-332) + SVD.  The N x N score
+  // matrix is written once, its two soft-maxes never: rankselect on the column / row probability sums gives the
+  // overlap sets, one more STATS pass (with arg-max) on the reduced sets the hard correspondences.
+  void partial_head(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, const Ws& w, int B, int N) {
+    const int E = W->E, M1 = B * N;
+    const int K1 = overlap_k1(N, W->overlap2), K2 = overlap_k2(N, W->overlap2);
+    const float *se = w.embf, *te = w.embf + (size_t)M1 * E, *ss = w.side4, *ts = w.side4 + (size_t)M1 * 4;
+    auto stats = [&](const char* nm, const float* own, const float* str, const float* os, const float* sd, int no,
+                     int ns, float* stat2, int32_t* amax, float* score_out, int ld_score) {
+      vcr_pairscore_args a{};
+      a.own = own; a.ld_own = E; a.str = str; a.ld_str = E; a.own_side4 = os; a.str_side4 = sd;
+      a.nbatch = B; a.n_own = no; a.n_str = ns; a.E = E; a.score = 0; a.scale = 1.f; a.op = 1;
+      a.stat2 = stat2; a.argmax = amax; a.score_out = score_out; a.ld_score = ld_score;
+      pairscore(nm, a);
+    };
+    // score_ij = (-|s_i|^2 + 2 s_i.t_j) - |t_j|^2 (:211-216), computed and stored once with the row soft-max
+    // statistics (dim=2); the column statistics (dim=1) and both probability masses come from two HBM-bound
+    // passes over it
+    const int ldS = (N + 31) & ~31;
+    stats("pairscore:head.scores", se, te, ss, ts, N, N, w.rstat, nullptr, w.score, ldS);
+    if (rc == 0) {
+      mark("scoremass:head");
+      vcr_scoremass_args a{w.score, ldS, B, N, N, w.rstat, w.cstat, w.colsum, w.rowsum};             // :222, :244
+      ok(vcr_scoremass_f32(&a, stream));
+    }
+    rank("select:head.tgt", w.colsum, 1, B, N, K1, w.sel_t, nullptr, 1);                             // :223
+    rank("select:head.src", w.rowsum, 1, B, N, K1, w.sel_s, nullptr, 1);                             // :245
+    gather("select:gather.src_emb", se, E, N, w.sel_s, B, K1, E, w.so_e);                            // :251-260
+    gather("select:gather.tgt_emb", te, E, N, w.sel_t, B, K1, E, w.to_e);                            // :235-238
+    gather("select:gather.src_xyz", ss, 4, N, w.sel_s, B, K1, 4, w.so_s);
+    gather("select:gather.tgt_xyz", ts, 4, N, w.sel_t, B, K1, 4, w.to_s);
+    // getCopair on the overlap sets: peak soft-max probability = 1/l and its arg-max target (:295-298)
+    stats("pairscore:head.copair", w.so_e, w.to_e, w.so_s, w.to_s, K1, K1, w.peak, w.amax, nullptr, 0);
+    rank("select:head.pairs", w.peak + 1, 2, B, K1, K2, w.pick, nullptr, 0);   // largest peak prob == smallest l (:312)
+    gather("select:gather.srcK", w.so_s, 4, K1, w.pick, B, K2, 4, io->src4);                         // :328-330
+    gather("select:gather.corrK", w.to_s, 4, K1, w.pick, B, K2, 4, io->corr4, w.amax, K1);           // :325 (weights == 1)
+    if (rc) return;
+    mark("rigid_svd:ab");
+    vcr_rigid_svd_args a{io->src4, 4, io->corr4, 4, B, K2, io->R_ab, io->t_ab, io->R_ba, io->t_ba, nullptr};
+    ok(vcr_rigid_svd_f32(&a, stream));
   }
 };
 
 int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* workspace, size_t ws_bytes,
-                 vcr_stream_t stream, vcr_trace* tr) {
+                 vcr_stream_t stream, vcr_trace* tr, bool last = true) {
   if (!W || !io || !workspace || !io->src_cf || !io->tgt_cf || !io->corr4 || !io->src4 || !io->R_ab || !io->t_ab)
     return VCR_EINVAL;
   const int B = io->B, N = io->N, E = W->E, F = W->F, k = W->k;
   if (B <= 0 || N <= 0 || E != 512 || W->heads * 128 != E || k <= 0 || k > 40 || k + 1 > N) return VCR_EINVAL;
   if (W->has_pointer == 1 && (F % 128)) return VCR_EINVAL;
   if (((uintptr_t)workspace) & 255) return VCR_EINVAL;
-  Ws w = carve(workspace, B, N, k, E, F);
+  if (W->partial) {
+    if (W->head_mode != 0 || W->has_pointer != 1) return VCR_EUNSUPPORTED;
+    if (!(W->overlap2 > 0.0 && W->overlap2 <= 1.0) || overlap_k2(N, W->overlap2) < 3) return VCR_EINVAL;
+  }
+  Ws w = carve(workspace, B, N, k, E, F, W->heads, W->partial, W->overlap2);
   if (ws_bytes < w.bytes) return VCR_EWORKSPACE;
   const int M1 = B * N, M2 = 2 * M1;
-  if (tr) tr->count = 0;
   Runner R{(hipStream_t)stream, tr};
 #define SP(site) (W->linear_mode == 1 ? W->split.site : nullptr)
 
@@ -164,7 +278,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
              w.st_d1, &W->dec_ln1);
     R.linear("linear:dec.cross.kv", w.e2, E, W->dec_cross.wkv, nullptr, W->dec_cross.bkv, w.kvc, 2 * E, M2, 2 * E, E, 0,
              nullptr, 0, w.st_e2, &W->enc_norm);
-    R.sdpa("sdpa:dec.cross", w.qc, E, w.kvc, 2 * E, w.kvc + E, 2 * E, w.att, E, 2 * B, H, N, N, B);
+    R.cross_attention(W, w, B, N);
     R.linear("linear:dec.cross.wo", w.att, E, W->dec_cross.wo, nullptr, W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E,
              nullptr, nullptr, w.st_d2);
     R.linear("linear:dec.ffn1", w.d2, E, W->dec_ffn.w1, nullptr, W->dec_ffn.b1, w.hid, F, M2, F, E, 1, nullptr, 0,
@@ -190,7 +304,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     R.norm("layernorm:dec.sub1", w.d1, W->dec_ln1, w.ln, M2, E);
     R.linear("linear:dec.cross.q", w.ln, E, W->dec_cross.wq, SP(dec_cross_q), W->dec_cross.bq, w.qc, E, M2, E, E, 0);
     R.linear("linear:dec.cross.kv", w.mem, E, W->dec_cross.wkv, SP(dec_cross_kv), W->dec_cross.bkv, w.kvc, 2 * E, M2, 2 * E, E, 0);
-    R.sdpa("sdpa:dec.cross", w.qc, E, w.kvc, 2 * E, w.kvc + E, 2 * E, w.att, E, 2 * B, H, N, N, B);
+    R.cross_attention(W, w, B, N);
     R.linear("linear:dec.cross.wo", w.att, E, W->dec_cross.wo, SP(dec_cross_wo), W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E);
     R.norm("layernorm:dec.sub2", w.d2, W->dec_ln2, w.ln, M2, E);
     R.linear("linear:dec.ffn1", w.ln, E, W->dec_ffn.w1, SP(dec_ffn1), W->dec_ffn.b1, w.hid, F, M2, F, E, 1);
@@ -203,14 +317,16 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     R.ok(vcr_rowside_f32(&a, R.stream));
   }
 
-  // ---- head (whole mode) + SVD
-  if (R.rc == 0) {
+  // ---- head + SVD
+  if (W->partial) {
+    R.partial_head(W, io, w, B, N);
+  } else if (R.rc == 0) {
     R.mark("softcorr:head");
     vcr_softcorr_args a{head_emb, E, head_emb + (size_t)M1 * E, E, w.side4, w.side4 + (size_t)M1 * 4,
                         io->corr4, B, N, N, E, W->head_mode, 1.0f / sqrtf((float)E)};
     R.ok(vcr_softcorr_f32(&a, R.stream));
   }
-  if (R.rc == 0) {
+  if (R.rc == 0 && !W->partial) {
     R.mark("rigid_svd:ab");
     (void)hipMemcpyAsync(io->src4, w.xyz4, (size_t)M1 * 4 * sizeof(float), hipMemcpyDeviceToDevice, R.stream);
     vcr_rigid_svd_args a{w.xyz4, 4, io->corr4, 4, B, N, io->R_ab, io->t_ab, io->R_ba, io->t_ba, nullptr};
@@ -218,16 +334,58 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   }
   if (R.rc == 0 && io->emb_out)
     (void)hipMemcpyAsync(io->emb_out, w.embf, (size_t)M2 * E * sizeof(float), hipMemcpyDeviceToDevice, R.stream);
-  R.finish();
+  if (last) R.finish();
 #undef SP
   return R.rc;
+}
+
+// One step of vcrnetIter's bookkeeping (vcrnet_model.py:32-38) for sample blockIdx.y:
+//   out = R_i in + t_i              transform_point_cloud (util/util.py:91-96), skipped when out == NULL
+//   R_f <- R_i R_f,  t_f <- R_i t_f + t_i,  R_ba = R_f^T,  t_ba = -R_ba t_f      (block x == 0, when compose != 0)
+// Products are k-ascending fma chains like the reference's CPU matmul.
+__global__ __launch_bounds__(256) void pose_step_kernel(const float* __restrict__ Ri, const float* __restrict__ ti,
+                                                        const float* in_cf, float* out_cf, int N, int compose,
+                                                        float* Rf, float* tf, float* Rba, float* tba) {
+  const int b = blockIdx.y;
+  float r[9], t[3];
+  for (int i = 0; i < 9; ++i) r[i] = Ri[b * 9 + i];
+  for (int i = 0; i < 3; ++i) t[i] = ti[b * 3 + i];
+  if (out_cf) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < N) {
+      const float* p = in_cf + (size_t)b * 3 * N + n;
+      const float x = p[0], y = p[N], z = p[2 * (size_t)N];
+      float* o = out_cf + (size_t)b * 3 * N + n;
+      for (int c = 0; c < 3; ++c) o[(size_t)c * N] = fmaf(r[c * 3 + 2], z, fmaf(r[c * 3 + 1], y, r[c * 3] * x)) + t[c];
+    }
+  }
+  if (compose && blockIdx.x == 0 && threadIdx.x == 0) {
+    float f[9], g[3], nf[9], ng[3];
+    for (int i = 0; i < 9; ++i) f[i] = Rf[b * 9 + i];
+    for (int i = 0; i < 3; ++i) g[i] = tf[b * 3 + i];
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) nf[i * 3 + j] = fmaf(r[i * 3 + 2], f[6 + j], fmaf(r[i * 3 + 1], f[3 + j], r[i * 3] * f[j]));
+      ng[i] = fmaf(r[i * 3 + 2], g[2], fmaf(r[i * 3 + 1], g[1], r[i * 3] * g[0])) + t[i];
+    }
+    for (int i = 0; i < 9; ++i) Rf[b * 9 + i] = nf[i];
+    for (int i = 0; i < 3; ++i) tf[b * 3 + i] = ng[i];
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) Rba[b * 9 + i * 3 + j] = nf[j * 3 + i];
+      tba[b * 3 + i] = -fmaf(nf[6 + i], ng[2], fmaf(nf[3 + i], ng[1], nf[i] * ng[0]));
+    }
+  }
 }
 
 }  // namespace
 
 extern "C" size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights* W, int B, int N) {
   if (!W || B <= 0 || N <= 0) return 0;
-  return carve(nullptr, B, N, W->k, W->E, W->F).bytes;
+  return carve(nullptr, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2).bytes;
+}
+
+extern "C" int vcr_vcrnet_pairs(const vcr_vcrnet_weights* W, int N) {
+  if (!W || N <= 0) return 0;
+  return W->partial ? overlap_k2(N, W->overlap2) : N;
 }
 
 extern "C" int vcr_vcrnet_forward_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* ws, size_t bytes,
@@ -237,7 +395,37 @@ extern "C" int vcr_vcrnet_forward_f32(const vcr_vcrnet_weights* W, const vcr_vcr
 
 extern "C" int vcr_vcrnet_forward_traced_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* ws,
                                              size_t bytes, vcr_stream_t stream, vcr_trace* tr) {
+  if (tr) tr->count = 0;
   return forward_impl(W, io, ws, bytes, stream, tr);
+}
+
+extern "C" int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, int iters, void* ws,
+                                   size_t bytes, vcr_stream_t stream, vcr_trace* tr) {
+  if (!W || !io || iters < 1 || !io->R_ba || !io->t_ba) return VCR_EINVAL;
+  if (tr) tr->count = 0;
+  if (iters == 1) return forward_impl(W, io, ws, bytes, stream, tr);
+  const int B = io->B, N = io->N;
+  if (B <= 0 || N <= 0) return VCR_EINVAL;
+  const Ws w = carve(ws, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2);
+  if (bytes < w.bytes) return VCR_EWORKSPACE;
+  for (int it = 0; it < iters; ++it) {
+    vcr_vcrnet_io step = *io;
+    if (it > 0) { step.src_cf = w.cur_cf; step.R_ab = w.Ri; step.t_ab = w.ti; step.R_ba = w.Rb; step.t_ba = w.tb; }
+    if (it + 1 < iters) step.emb_out = nullptr;
+    const bool last = it + 1 == iters;
+    const int rc = forward_impl(W, &step, ws, bytes, stream, tr, false);
+    if (rc) return rc;
+    if (last && it == 0) break;
+    Runner R{(hipStream_t)stream, tr};
+    R.mark("pose:step");
+    hipLaunchKernelGGL(pose_step_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, step.R_ab,
+                       step.t_ab, step.src_cf, last ? nullptr : w.cur_cf, N, it > 0 ? 1 : 0, io->R_ab, io->t_ab,
+                       io->R_ba, io->t_ba);
+    const int lrc = VCR_LAUNCH_RC();
+    if (lrc) return lrc;
+    if (last) R.finish();
+  }
+  return VCR_OK;
 }
 
 extern "C" const char* vcr_strerror(int code) {
@@ -250,7 +438,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 3; }
+extern "C" int vcr_abi_version(void) { return 4; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

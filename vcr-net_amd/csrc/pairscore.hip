@@ -97,6 +97,12 @@ __global__ __launch_bounds__(256, 2) void pairscore_kernel(vcr_pairscore_args p)
       s[r] = j < p.n_str ? sc : VCR_NEG_INF;
       mt = fmaxf(mt, s[r]);
     }
+    if (OP == 1 && p.score_out && o0 + l31 < p.n_own) {
+      // keep the scores for the light column / row passes of vcr_scoremass_f32 (the pad past n_str holds -inf)
+      float* srow = p.score_out + (own_row * (size_t)p.ld_score) + tile * 32 + 4 * half;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) st4(srow + 8 * r4, f32x4{s[4 * r4], s[4 * r4 + 1], s[4 * r4 + 2], s[4 * r4 + 3]});
+    }
     if (OP == 2) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -191,6 +197,55 @@ __global__ __launch_bounds__(256, 2) void pairscore_kernel(vcr_pairscore_args p)
   }
 }
 
+// ---- light passes over a stored score matrix S[b][i][j] (selectCom, vcrnet_model.py:217-248) ----
+// column pass: per column j   cm_j = max_i S_ij,  cl_j = sum_i exp(S_ij - cm_j)      (soft-max over dim=1)
+//                             colmass_j = sum_i exp(S_ij - m_i) / l_i                (column sums of soft-max dim=2)
+// 64 columns per block (lanes), rows split over the 4 waves, merged through LDS in wave order.
+__global__ __launch_bounds__(256) void score_colpass_kernel(vcr_scoremass_args p) {
+  __shared__ float mg[4][64][3];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane, jc = min(j, p.n_cols - 1);
+  const float* S = p.score + (size_t)b * p.n_rows * p.ld + jc;
+  const float* rs = p.row_stat2 + (size_t)b * p.n_rows * 2;
+  const int per = (p.n_rows + 3) / 4, i0 = w * per, i1 = min(p.n_rows, i0 + per);
+  float cm = VCR_NEG_INF, cl = 0.f, mass = 0.f;
+  for (int i = i0; i < i1; ++i) {
+    const float v = S[(size_t)i * p.ld];
+    const float mi = rs[2 * i], li = rs[2 * i + 1];
+    mass += __builtin_amdgcn_exp2f((v - mi) * LOG2E) / li;
+    if (v > cm) { cl *= __builtin_amdgcn_exp2f((cm - v) * LOG2E); cm = v; }
+    cl += __builtin_amdgcn_exp2f((v - cm) * LOG2E);
+  }
+  mg[w][lane][0] = cm; mg[w][lane][1] = cl; mg[w][lane][2] = mass;
+  __syncthreads();
+  if (w == 0 && j < p.n_cols) {
+    float M = VCR_NEG_INF, L = 0.f, A = 0.f;
+    for (int q = 0; q < 4; ++q) M = fmaxf(M, mg[q][lane][0]);
+    for (int q = 0; q < 4; ++q) {
+      L = fmaf(mg[q][lane][1], __builtin_amdgcn_exp2f((mg[q][lane][0] - M) * LOG2E), L);
+      A += mg[q][lane][2];
+    }
+    const size_t o = (size_t)b * p.n_cols + j;
+    p.col_stat2[o * 2] = M; p.col_stat2[o * 2 + 1] = L;
+    p.col_mass[o] = A;
+  }
+}
+
+// row pass: rowmass_i = sum_j exp(S_ij - cm_j) / cl_j  (row sums of the dim=1 soft-max); one wave per row.
+__global__ __launch_bounds__(256) void score_rowpass_kernel(vcr_scoremass_args p) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= p.n_rows) return;
+  const float* S = p.score + ((size_t)b * p.n_rows + i) * p.ld;
+  const float* cs = p.col_stat2 + (size_t)b * p.n_cols * 2;
+  float acc = 0.f;
+  for (int j = lane; j < p.n_cols; j += 64)
+    acc += __builtin_amdgcn_exp2f((S[j] - cs[2 * j]) * LOG2E) / cs[2 * j + 1];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) p.row_mass[(size_t)b * p.n_rows + i] = acc;
+}
+
 int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
   if (!a || !a->own || !a->str) return VCR_EINVAL;
   if (a->nbatch <= 0 || a->n_own <= 0 || a->n_str <= 0 || a->E <= 0 || (a->E % 128) || a->E > 1024) return VCR_EINVAL;
@@ -200,6 +255,7 @@ int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
   if (a->op == 0 && (!a->corr4 || !a->str_side4)) return VCR_EINVAL;
   if (a->op == 1 && !a->stat2) return VCR_EINVAL;
   if (a->op == 2 && (!a->mass || !a->str_stat2)) return VCR_EINVAL;
+  if (a->score_out && (a->op != 1 || (a->ld_score & 3) || a->ld_score < ((a->n_str + 31) & ~31))) return VCR_EINVAL;
   const int lds = (32 * (a->E + 4) + 4 * 32 * 5) * 4;
   if (lds > 160 * 1024) return VCR_EUNSUPPORTED;
   dim3 grid((a->n_own + 31) / 32, a->nbatch);
@@ -218,6 +274,15 @@ int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
 }  // namespace
 
 extern "C" int vcr_pairscore_f32(const vcr_pairscore_args* a, vcr_stream_t stream) { return launch(a, stream); }
+
+extern "C" int vcr_scoremass_f32(const vcr_scoremass_args* a, vcr_stream_t stream) {
+  if (!a || !a->score || !a->row_stat2 || !a->col_stat2 || !a->col_mass || !a->row_mass) return VCR_EINVAL;
+  if (a->nbatch <= 0 || a->n_rows <= 0 || a->n_cols <= 0 || a->ld < a->n_cols) return VCR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(score_colpass_kernel, dim3((a->n_cols + 63) / 64, a->nbatch), dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(score_rowpass_kernel, dim3((a->n_rows + 3) / 4, a->nbatch), dim3(256), 0, s, *a);
+  return VCR_LAUNCH_RC();
+}
 
 extern "C" int vcr_softcorr_f32(const vcr_softcorr_args* a, vcr_stream_t stream) {
   if (!a || !a->qside4 || !a->kside4 || !a->corr4) return VCR_EINVAL;

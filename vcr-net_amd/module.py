@@ -290,6 +290,7 @@ class VCRNet(nn.Module):
                     setattr(cw.split, site, native.ptr(P["split." + site]))
         cw.E, cw.F, cw.heads, cw.k = self.emb_dims, self._ff, self._n_heads, int(self.emb_nn.k)
         cw.head_mode = 1 if self._vcp == "dist" else 0
+        cw.partial, cw.overlap2 = int(self._partial), self._overlap2
         self._packed, self._packed_key = P, key
         self._cw = cw if self._emb_kind == "lpdnet" else None              # the fused C driver is LPDNet-only
 
@@ -303,25 +304,34 @@ class VCRNet(nn.Module):
         return bufs
 
     def fused_supported(self) -> bool:
-        return (self._emb_kind == "lpdnet" and not self._partial and self._vcp in ("topK", "dist")
-                and not self.cycle)
+        """True when one vcr_vcrnet_forward_f32 / vcr_vcrnet_iter_f32 call covers this configuration; the other
+        variants (DGCNN, VcpAtt, cycle, partial with a non-topK head) run kernel by kernel from composed.py."""
+        if self._emb_kind != "lpdnet" or self.cycle or self._vcp not in ("topK", "dist"):
+            return False
+        if self._partial:
+            return self._vcp == "topK" and isinstance(self.pointer, _TransformerParams)
+        return True
 
-    # -- forward ------------------------------------------------------------------------------------------------
-    def forward(self, *input):
-        src, tgt = input[0], input[1]
+    def _check_call(self, src, tgt):
         if not (src.is_cuda and tgt.is_cuda):
             raise native.VcrHipError("vcrnet_amd.VCRNet runs on the MI355X HIP path only; move inputs to cuda "
                                      "(there is no CPU fallback by design)")
         if self.training or torch.is_grad_enabled():
             raise native.VcrHipError("inference only: call .eval() and wrap in torch.no_grad() "
                                      "(model/vcrnet_model.py:546); backward kernels are out of scope")
+
+    # -- forward ------------------------------------------------------------------------------------------------
+    def forward(self, *input):
+        src, tgt = input[0], input[1]
+        self._check_call(src, tgt)
         self._pack()
         if not self.fused_supported():
             from .composed import forward_composed
             return forward_composed(self, src, tgt)
         return self._forward_fused(src, tgt)
 
-    def _forward_fused(self, src, tgt, trace: Optional[native.Trace] = None, want_emb: bool = False):
+    def _forward_fused(self, src, tgt, trace: Optional[native.Trace] = None, want_emb: bool = False, iters: int = 1):
+        """One C-ABI call: VCRNet.forward (iters == 1) or the whole vcrnetIter loop (iters > 1)."""
         self._pack()
         B, _, N = src.shape
         dev = src.device
@@ -330,23 +340,37 @@ class VCRNet(nn.Module):
         ws = bufs["ws"]
         off = (-ws.data_ptr()) % 256
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        corr4, src4 = f(B, N, 4), f(B, N, 4)
+        L = native.lib()
+        K = L.vcr_vcrnet_pairs(C.byref(self._cw), N)                      # N, or the hard pairs of partial mode
+        corr4, src4 = f(B, K, 4), f(B, K, 4)
         R_ab, t_ab, R_ba, t_ba = f(B, 3, 3), f(B, 3), f(B, 3, 3), f(B, 3)
         emb = f(2 * B * N, self.emb_dims) if want_emb else None
         io = native.VcrnetIo(native.ptr(srcc), native.ptr(tgtc), B, N, native.ptr(corr4), native.ptr(src4),
                              native.ptr(R_ab), native.ptr(t_ab), native.ptr(R_ba), native.ptr(t_ba), native.ptr(emb))
-        L = native.lib()
         stream = C.c_void_p(native.stream_ptr())
         wsp = C.c_void_p(ws.data_ptr() + off)
-        if trace is None:
+        if iters != 1:
+            rc = L.vcr_vcrnet_iter_f32(C.byref(self._cw), C.byref(io), iters, wsp, ws.numel() - off, stream,
+                                       C.byref(trace) if trace is not None else None)
+        elif trace is None:
             rc = L.vcr_vcrnet_forward_f32(C.byref(self._cw), C.byref(io), wsp, ws.numel() - off, stream)
         else:
             rc = L.vcr_vcrnet_forward_traced_f32(C.byref(self._cw), C.byref(io), wsp, ws.numel() - off, stream,
                                                  C.byref(trace))
-        native.check(rc, "vcr_vcrnet_forward_f32")
-        src_corr = corr4[:, :, :3].transpose(1, 2).contiguous()
-        out = (src, src_corr, R_ab, t_ab, R_ba, t_ba)
+        native.check(rc, "vcr_vcrnet_iter_f32" if iters != 1 else "vcr_vcrnet_forward_f32")
+        rows = lambda x: x[:, :, :3].transpose(1, 2).contiguous()
+        srcK = rows(src4) if (self._partial or iters != 1) else src      # whole mode returns src itself (:347)
+        out = (srcK, rows(corr4), R_ab, t_ab, R_ba, t_ba)
         return out + (emb,) if want_emb else out
+
+    def forward_iter(self, src, tgt, iters: int):
+        """vcrnetIter (model/vcrnet_model.py:21-43) as ONE device-side loop when the fused driver covers this
+        configuration; None otherwise (the caller then loops over forward())."""
+        self._check_call(src, tgt)
+        self._pack()
+        if not self.fused_supported():
+            return None
+        return self._forward_fused(src, tgt, iters=int(iters))
 
 
 class DCP(VCRNet):
@@ -407,6 +431,11 @@ def vcrnetIcpNet(args, net, src, tgt):
 
 def vcrnetIter(net, src, tgt, iter=1):
     """model/vcrnet_model.py:21-43: run ``iter`` passes, composing the poses on the device."""
+    inner = net.module if isinstance(net, nn.DataParallel) else net
+    if isinstance(inner, VCRNet) and inner is net and iter >= 1:
+        out = net.forward_iter(src, tgt, iter)
+        if out is not None:
+            return out
     cur = src
     R_f = t_f = None
     for _ in range(iter):

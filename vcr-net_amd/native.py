@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvcr_hip.so")
-VCR_TRACE_MAX = 128
+VCR_TRACE_MAX = 256
 
 f32p = C.c_void_p  # device pointers travel as integers
 
@@ -76,17 +76,23 @@ class PairscoreArgs(C.Structure):
                 ("str_side4", f32p), ("nbatch", C.c_int), ("n_own", C.c_int), ("n_str", C.c_int), ("E", C.c_int),
                 ("score", C.c_int), ("scale", C.c_float), ("str_batch_shift", C.c_int), ("op", C.c_int),
                 ("corr4", f32p), ("stat2", f32p), ("argmax", f32p), ("str_stat2", f32p),
-                ("str_stat_batch_stride", C.c_long), ("mass", f32p), ("accumulate", C.c_int)]
+                ("str_stat_batch_stride", C.c_long), ("mass", f32p), ("accumulate", C.c_int),
+                ("score_out", f32p), ("ld_score", C.c_int)]
+
+
+class ScoremassArgs(C.Structure):
+    _fields_ = [("score", f32p), ("ld", C.c_int), ("nbatch", C.c_int), ("n_rows", C.c_int), ("n_cols", C.c_int),
+                ("row_stat2", f32p), ("col_stat2", f32p), ("col_mass", f32p), ("row_mass", f32p)]
 
 
 class RankselectArgs(C.Structure):
     _fields_ = [("values", f32p), ("nbatch", C.c_int), ("n", C.c_int), ("K", C.c_int), ("order", f32p),
-                ("mask", f32p), ("largest", C.c_int)]
+                ("mask", f32p), ("largest", C.c_int), ("stride", C.c_int)]
 
 
 class GatherArgs(C.Structure):
     _fields_ = [("in_", f32p), ("ld_in", C.c_int), ("n_in", C.c_int), ("idx", f32p), ("nbatch", C.c_int),
-                ("n_out", C.c_int), ("C", C.c_int), ("out", f32p), ("ld_out", C.c_int)]
+                ("n_out", C.c_int), ("C", C.c_int), ("out", f32p), ("ld_out", C.c_int), ("via", f32p), ("n_via", C.c_int)]
 
 
 class EdgerowsArgs(C.Structure):
@@ -134,7 +140,8 @@ class VcrnetWeights(C.Structure):
                 ("enc_self", MhaW), ("dec_self", MhaW), ("dec_cross", MhaW),
                 ("enc_ffn", FfnW), ("dec_ffn", FfnW),
                 ("E", C.c_int), ("F", C.c_int), ("heads", C.c_int), ("k", C.c_int),
-                ("has_pointer", C.c_int), ("head_mode", C.c_int), ("linear_mode", C.c_int), ("split", SplitW)]
+                ("has_pointer", C.c_int), ("head_mode", C.c_int), ("linear_mode", C.c_int), ("split", SplitW),
+                ("partial", C.c_int), ("overlap2", C.c_double)]
 
 
 class VcrnetIo(C.Structure):
@@ -152,13 +159,13 @@ _SIGS = {
     "vcr_layernorm_f32": LayerNormArgs, "vcr_rowside_f32": RowsideArgs, "vcr_edgeconv_f32": EdgeconvArgs,
     "vcr_gathermax_f32": GathermaxArgs, "vcr_sdpa_f32": SdpaArgs, "vcr_softcorr_f32": SoftcorrArgs,
     "vcr_rigid_svd_f32": RigidSvdArgs, "vcr_pairscore_f32": PairscoreArgs, "vcr_rankselect_f32": RankselectArgs,
-    "vcr_gather_rows_f32": GatherArgs, "vcr_edgerows_f32": EdgerowsArgs, "vcr_segmax_f32": SegmaxArgs,
+    "vcr_gather_rows_f32": GatherArgs, "vcr_scoremass_f32": ScoremassArgs, "vcr_edgerows_f32": EdgerowsArgs, "vcr_segmax_f32": SegmaxArgs,
 }
 
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 3          # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 4          # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -190,6 +197,10 @@ def lib() -> C.CDLL:
         L.vcr_vcrnet_forward_traced_f32.argtypes = [C.POINTER(VcrnetWeights), C.POINTER(VcrnetIo), C.c_void_p,
                                                     C.c_size_t, C.c_void_p, C.POINTER(Trace)]
         L.vcr_vcrnet_forward_traced_f32.restype = C.c_int
+        L.vcr_vcrnet_pairs.argtypes = [C.POINTER(VcrnetWeights), C.c_int]; L.vcr_vcrnet_pairs.restype = C.c_int
+        L.vcr_vcrnet_iter_f32.argtypes = [C.POINTER(VcrnetWeights), C.POINTER(VcrnetIo), C.c_int, C.c_void_p,
+                                          C.c_size_t, C.c_void_p, C.POINTER(Trace)]
+        L.vcr_vcrnet_iter_f32.restype = C.c_int
         L.vcr_event_create.argtypes = [C.POINTER(C.c_void_p)]; L.vcr_event_create.restype = C.c_int
         L.vcr_event_destroy.argtypes = [C.c_void_p]; L.vcr_event_destroy.restype = C.c_int
         L.vcr_event_record.argtypes = [C.c_void_p, C.c_void_p]; L.vcr_event_record.restype = C.c_int
@@ -379,8 +390,10 @@ def rigid_svd(src, corr, want_h=False):
 
 
 def pairscore(own, strm, nbatch, n_own, n_str, op, score=0, scale=1.0, own_side4=None, str_side4=None,
-              shift=0, str_stat2=None, str_stat_stride=None, mass=None, accumulate=False, want_argmax=False):
-    """vcr_pairscore_f32: op 0 -> corr4; op 1 -> (stat2 [nbatch*n_own,2], argmax or None); op 2 -> mass."""
+              shift=0, str_stat2=None, str_stat_stride=None, mass=None, accumulate=False, want_argmax=False,
+              score_out=None):
+    """vcr_pairscore_f32: op 0 -> corr4; op 1 -> (stat2 [nbatch*n_own,2], argmax or None); op 2 -> mass.
+    score_out (op 1): [nbatch, n_own, ld] buffer that also receives the scores."""
     dev = own.device
     corr4 = _f32(nbatch * n_own, 4, device=dev) if op == 0 else None
     stat2 = _f32(nbatch * n_own, 2, device=dev) if op == 1 else None
@@ -390,12 +403,22 @@ def pairscore(own, strm, nbatch, n_own, n_str, op, score=0, scale=1.0, own_side4
     call("vcr_pairscore_f32", PairscoreArgs(
         ptr(own), own.stride(0), ptr(strm), strm.stride(0), ptr(own_side4), ptr(str_side4), nbatch, n_own, n_str,
         own.shape[1], score, scale, shift, op, ptr(corr4), ptr(stat2), ptr(amax), ptr(str_stat2),
-        int(str_stat_stride if str_stat_stride is not None else n_str * 2), ptr(mass), int(accumulate)))
+        int(str_stat_stride if str_stat_stride is not None else n_str * 2), ptr(mass), int(accumulate),
+        ptr(score_out), score_out.stride(1) if score_out is not None else 0))
     if op == 0:
         return corr4
     if op == 1:
         return stat2, amax
     return mass
+
+
+def scoremass(score, n_cols, row_stat2):
+    """vcr_scoremass_f32 on score [nbatch, n_rows, ld]: (col_stat2 [nbatch,n_cols,2], col_mass, row_mass)."""
+    nb, n_rows, ld = score.shape
+    cs, cm, rm = _f32(nb, n_cols, 2, device=score.device), _f32(nb, n_cols, device=score.device), \
+        _f32(nb, n_rows, device=score.device)
+    call("vcr_scoremass_f32", ScoremassArgs(ptr(score), ld, nb, n_rows, n_cols, ptr(row_stat2), ptr(cs), ptr(cm), ptr(rm)))
+    return cs, cm, rm
 
 
 class IcpArgs(C.Structure):
@@ -453,18 +476,23 @@ def segmax(x, M, k, out=None):
 
 
 def rankselect(values, K, want_order=True, want_mask=False, largest=True):
+    """values [nbatch, n] (any element stride along n, e.g. one column of a [nbatch, n, 2] record)."""
     nb, n = values.shape
     order = torch.empty(nb, K, dtype=torch.int32, device=values.device) if want_order else None
     mask = torch.empty(nb, n, dtype=torch.uint8, device=values.device) if want_mask else None
-    call("vcr_rankselect_f32", RankselectArgs(ptr(values.contiguous()), nb, n, K, ptr(order), ptr(mask), int(largest)))
+    stride = values.stride(1) if n > 1 else 1
+    if values.stride(0) != n * stride:
+        values, stride = values.contiguous(), 1
+    call("vcr_rankselect_f32", RankselectArgs(ptr(values), nb, n, K, ptr(order), ptr(mask), int(largest), stride))
     return order, mask
 
 
-def gather_rows(x, idx, nbatch, n_in):
-    """x [nbatch*n_in, C] rows, idx [nbatch, n_out] int32 -> [nbatch*n_out, C]."""
+def gather_rows(x, idx, nbatch, n_in, via=None):
+    """x [nbatch*n_in, C] rows, idx [nbatch, n_out] int32 -> [nbatch*n_out, C]; with via [nbatch, n_via] int32 the
+    row taken is via[b][idx[b][r]]."""
     n_out = idx.shape[1]
     Cc = x.shape[1]
     out = _f32(nbatch * n_out, Cc, device=x.device)
     call("vcr_gather_rows_f32", GatherArgs(ptr(x), x.stride(0), n_in, ptr(idx.contiguous()), nbatch, n_out, Cc,
-                                           ptr(out), Cc))
+                                           ptr(out), Cc, ptr(via), via.shape[1] if via is not None else 0))
     return out
