@@ -238,6 +238,21 @@ typedef struct {
 size_t vcr_icp_workspace_bytes(int B, int N);
 int vcr_icp_f32(const vcr_icp_args*, void* workspace, size_t workspace_bytes, vcr_stream_t);
 
+/* ---- evaluation-pair construction (ModelNet40.__getitem__, util/data.py:247-314; partial crop :320-329).
+ * The host draws the random numbers (the reference seeds legacy NumPy with the item index, :255-256); the
+ * device applies them to base clouds resident in HBM:
+ *   src_i = cloud[pick[perm_src[i]]];   tgt_i = R_ab cloud[pick[perm_tgt[i]]] + t_ab  (float64, then float32)
+ * keep == N: no crop; keep < N: the `keep` points nearest to the LAST point, in order of distance.
+ * cloud [B,P,3]; R_ab [B,9], t_ab [B,3] doubles; pick / perm_src / perm_tgt [B,N] int32; outputs [B,3,keep]. */
+typedef struct {
+  const float* cloud; int P;
+  const double* R_ab; const double* t_ab;
+  const int32_t* pick; const int32_t* perm_src; const int32_t* perm_tgt;
+  int B, N, keep;
+  float* src_cf; float* tgt_cf;
+} vcr_make_pairs_args;
+int vcr_make_pairs_f32(const vcr_make_pairs_args*, vcr_stream_t);
+
 /* ---- whole forward: VCRNet.forward (vcrnet_model.py:495-518), LPDNet + Transformer + VcpTopK(whole)/
  * VcpByDis + SVD, both clouds batched as 2B.  Weight pointers are the packed device tensors the host
  * module prepares once; all [N,K] row-major. */

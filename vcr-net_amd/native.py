@@ -80,6 +80,12 @@ class PairscoreArgs(C.Structure):
                 ("score_out", f32p), ("ld_score", C.c_int)]
 
 
+class MakePairsArgs(C.Structure):
+    _fields_ = [("cloud", f32p), ("P", C.c_int), ("R_ab", f32p), ("t_ab", f32p), ("pick", f32p), ("perm_src", f32p),
+                ("perm_tgt", f32p), ("B", C.c_int), ("N", C.c_int), ("keep", C.c_int), ("src_cf", f32p),
+                ("tgt_cf", f32p)]
+
+
 class ScoremassArgs(C.Structure):
     _fields_ = [("score", f32p), ("ld", C.c_int), ("nbatch", C.c_int), ("n_rows", C.c_int), ("n_cols", C.c_int),
                 ("row_stat2", f32p), ("col_stat2", f32p), ("col_mass", f32p), ("row_mass", f32p)]
@@ -159,7 +165,8 @@ _SIGS = {
     "vcr_layernorm_f32": LayerNormArgs, "vcr_rowside_f32": RowsideArgs, "vcr_edgeconv_f32": EdgeconvArgs,
     "vcr_gathermax_f32": GathermaxArgs, "vcr_sdpa_f32": SdpaArgs, "vcr_softcorr_f32": SoftcorrArgs,
     "vcr_rigid_svd_f32": RigidSvdArgs, "vcr_pairscore_f32": PairscoreArgs, "vcr_rankselect_f32": RankselectArgs,
-    "vcr_gather_rows_f32": GatherArgs, "vcr_scoremass_f32": ScoremassArgs, "vcr_edgerows_f32": EdgerowsArgs, "vcr_segmax_f32": SegmaxArgs,
+    "vcr_gather_rows_f32": GatherArgs, "vcr_scoremass_f32": ScoremassArgs, "vcr_make_pairs_f32": MakePairsArgs,
+    "vcr_edgerows_f32": EdgerowsArgs, "vcr_segmax_f32": SegmaxArgs,
 }
 
 _lib: Optional[C.CDLL] = None
@@ -419,6 +426,21 @@ def scoremass(score, n_cols, row_stat2):
         _f32(nb, n_rows, device=score.device)
     call("vcr_scoremass_f32", ScoremassArgs(ptr(score), ld, nb, n_rows, n_cols, ptr(row_stat2), ptr(cs), ptr(cm), ptr(rm)))
     return cs, cm, rm
+
+
+def make_pairs(cloud, R_ab, t_ab, pick, perm_src, perm_tgt, keep):
+    """vcr_make_pairs_f32: cloud [B,P,3] f32, R_ab [B,3,3] / t_ab [B,3] f64, index maps [B,N] int32 ->
+    (src [B,3,keep], tgt [B,3,keep])."""
+    B, P, _ = cloud.shape
+    N = pick.shape[1]
+    for x, dt in ((cloud, torch.float32), (R_ab, torch.float64), (t_ab, torch.float64), (pick, torch.int32),
+                  (perm_src, torch.int32), (perm_tgt, torch.int32)):
+        if x.dtype != dt or not x.is_contiguous():
+            raise VcrHipError("make_pairs: wrong dtype or non-contiguous argument")
+    src, tgt = _f32(B, 3, keep, device=cloud.device), _f32(B, 3, keep, device=cloud.device)
+    call("vcr_make_pairs_f32", MakePairsArgs(ptr(cloud), P, ptr(R_ab), ptr(t_ab), ptr(pick), ptr(perm_src),
+                                             ptr(perm_tgt), B, N, keep, ptr(src), ptr(tgt)))
+    return src, tgt
 
 
 class IcpArgs(C.Structure):

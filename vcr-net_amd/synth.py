@@ -75,9 +75,21 @@ class Pair:
     euler_ab: np.ndarray   # [3] (z, y, x) radians
 
 
-def make_pair(item: int, num_points: int = 1024, partial: bool = False, reserve: float = RESERVE_0575,
-              factor: float = 4.0, kind: str = "object") -> Pair:
-    """One evaluation item.  Call order of the random stream follows util/data.py:258-301."""
+@dataclass
+class Draws:
+    """The random numbers of one item, in the reference's call order (util/data.py:255-301)."""
+    cloud: np.ndarray      # [P, 3] float32 base cloud
+    R_ab: np.ndarray       # [3, 3] float64
+    t_ab: np.ndarray       # [3] float64
+    euler_ab: np.ndarray   # [3] (z, y, x) radians
+    pick: np.ndarray       # [N] int32: first N rows of permutation(cloud)      (:289)
+    perm_src: np.ndarray   # [N] int32                                         (:298)
+    perm_tgt: np.ndarray   # [N] int32                                         (:301)
+
+
+def draw_pair(item: int, num_points: int = 1024, factor: float = 4.0, kind: str = "object") -> Draws:
+    """Everything random about one evaluation item.  RandomState.permutation(array) and permutation(len)
+    consume the stream identically, so index permutations stand in for the reference's row shuffles."""
     cloud = base_cloud(item) if kind == "object" else uniform_cloud(item, max(num_points, 2048))
     if num_points > cloud.shape[0]:
         raise ValueError(f"object clouds hold {cloud.shape[0]} points; use kind='uniform' for num_points={num_points}")
@@ -89,16 +101,27 @@ def make_pair(item: int, num_points: int = 1024, partial: bool = False, reserve:
     Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
     R_ab = Rx.dot(Ry).dot(Rz)                                          # :277
     t_ab = np.array([rs.uniform(-0.5, 0.5) for _ in range(3)])         # :284-285
-    p1 = rs.permutation(cloud)[:num_points].T                          # :289
-    p2 = R_ab.dot(p1.astype(np.float64)) + t_ab[:, None]               # :290-291
-    p1 = rs.permutation(p1.T).T                                        # :298
+    pick = rs.permutation(cloud.shape[0])[:num_points]                 # :289
+    perm_src = rs.permutation(num_points)                              # :298
+    perm_tgt = rs.permutation(num_points)                              # :301
+    return Draws(cloud, R_ab, t_ab, np.asarray([az, ay, ax], dtype=np.float32), pick.astype(np.int32),
+                 perm_src.astype(np.int32), perm_tgt.astype(np.int32))
+
+
+def make_pair(item: int, num_points: int = 1024, partial: bool = False, reserve: float = RESERVE_0575,
+              factor: float = 4.0, kind: str = "object") -> Pair:
+    """One evaluation item on the host (util/data.py:258-303)."""
+    d = draw_pair(item, num_points, factor, kind)
+    p1 = d.cloud[d.pick].T                                             # :289
+    p2 = d.R_ab.dot(p1.astype(np.float64)) + d.t_ab[:, None]           # :290-291
+    p1 = p1[:, d.perm_src]                                             # :298
     if partial:
         p1 = _nearest_crop(p1, reserve)                                # :299-300
-    p2 = rs.permutation(p2.T).T                                        # :301
+    p2 = p2[:, d.perm_tgt]                                             # :301
     if partial:
         p2 = _nearest_crop(p2, reserve)                                # :302-303
-    return Pair(p1.astype(np.float32), p2.astype(np.float32), R_ab.astype(np.float32),
-                t_ab.astype(np.float32), np.asarray([az, ay, ax], dtype=np.float32))
+    return Pair(p1.astype(np.float32), p2.astype(np.float32), d.R_ab.astype(np.float32),
+                d.t_ab.astype(np.float32), d.euler_ab)
 
 
 def make_batch(first_item: int, batch: int, num_points: int = 1024, partial: bool = False,
@@ -108,3 +131,23 @@ def make_batch(first_item: int, batch: int, num_points: int = 1024, partial: boo
     return (np.stack([p.src for p in ps]), np.stack([p.tgt for p in ps]),
             np.stack([p.R_ab for p in ps]), np.stack([p.t_ab for p in ps]),
             np.stack([p.euler_ab for p in ps]))
+
+
+def make_batch_device(first_item: int, batch: int, num_points: int = 1024, partial: bool = False,
+                      reserve: float = RESERVE_0575, kind: str = "object", device="cuda"):
+    """The same batch as :func:`make_batch`, with the point arithmetic (gather, rigid transform, partial crop)
+    done by vcr_make_pairs_f32 on base clouds resident in HBM.  Returns device tensors
+    (src [B,3,K], tgt [B,3,K]) and host (R_ab, t_ab, euler_ab)."""
+    import torch
+
+    from . import native
+    ds = [draw_pair(first_item + i, num_points, kind=kind) for i in range(batch)]
+    dev = torch.device(device)
+    up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.stack(a))).to(dev, dt)
+    cloud = up([d.cloud for d in ds], torch.float32)
+    keep = int(num_points * reserve) if partial else num_points        # util/data.py:321
+    src, tgt = native.make_pairs(cloud, up([d.R_ab for d in ds], torch.float64), up([d.t_ab for d in ds], torch.float64),
+                                 up([d.pick for d in ds], torch.int32), up([d.perm_src for d in ds], torch.int32),
+                                 up([d.perm_tgt for d in ds], torch.int32), keep)
+    return (src, tgt, np.stack([d.R_ab for d in ds]).astype(np.float32),
+            np.stack([d.t_ab for d in ds]).astype(np.float32), np.stack([d.euler_ab for d in ds]))
