@@ -109,9 +109,9 @@ def main():
     B, N = a.batch, a.points
     # each rank owns B consecutive items of the global batch (weak scaling); inputs live in HBM
     # object-like clouds have 2048 points (the ModelNet40 convention); larger N (configs 4/5) use uniform clouds
-    src, tgt, _, _, _ = synth.make_batch(rank * B, B, N, kind="object" if N <= 2048 else "uniform")
-    assert src.shape == (B, 3, N), src.shape
-    src, tgt = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+    # built on the device from base clouds + host-drawn permutations / poses (vcr_make_pairs_f32; untimed)
+    src, tgt, _, _, _ = synth.make_batch_device(rank * B, B, N, kind="object" if N <= 2048 else "uniform", device=dev)
+    assert src.shape == (B, 3, N) and src.is_cuda, src.shape
 
     def step(trace=None):
         with torch.no_grad():

@@ -78,12 +78,19 @@ typedef struct {
   int relu;
   /* Optional LayerNorm fusion (transformer.py:141-144; all NULL/0 = plain linear; vcr_linear_f32 only):
    * stats_out   [M, N/64, 2]: the epilogue also writes (sum y, sum y^2) per row and 64-column segment (N % 64 == 0);
-   * ln_stats_in [M, ln_nseg, 2]: such partial sums over the K columns of x; the A operand then becomes
-   *             ln_a[k] * (x - mean) / (std_unbiased + ln_eps) + ln_b[k], applied on the fly. */
-  const float* ln_stats_in; int ln_nseg; const float* ln_a; const float* ln_b; float ln_eps;
+   * ln_stats_in [M, ln_nseg, 2]: such partial sums over the K columns of x.  The operation becomes
+   *             Y = act(LayerNorm(X) W0^T + bias0) for the Linear (W0, bias0) and LayerNorm (a, b) that were folded by
+   *             vcr_fold_layernorm_f32 into w, bias and ln_colsum [N]:
+   *             y = inv_m * (sum_k x[m,k] w[n,k] - mean_m * ln_colsum[n]) + bias[n],  inv = 1 / (std_unbiased + ln_eps). */
+  const float* ln_stats_in; int ln_nseg; const float* ln_colsum; float ln_eps;
   float* stats_out;
 } vcr_linear_args;
 int vcr_linear_f32(const vcr_linear_args*, vcr_stream_t);
+
+/* Fold LayerNorm(a, b) into the Linear (w [N,K], bias [N] or NULL) that consumes it, once per weight:
+ * w_out[n,k] = w[n,k] a[k];  colsum[n] = sum_k w_out[n,k];  bias_out[n] = bias[n] + sum_k w[n,k] b[k]. */
+int vcr_fold_layernorm_f32(const float* w, const float* bias, const float* ln_a, const float* ln_b, int N, int K,
+                           float* w_out, float* colsum, float* bias_out, vcr_stream_t);
 
 /* Same operation on the bf16 matrix pipe with fp32-equivalent products: every fp32 operand is split exactly
  * into three bf16 pieces and the six leading partial products are accumulated in fp32 (error <= 2^-24
@@ -289,6 +296,10 @@ typedef struct {
     const void *dg1_pq, *sn1_pq, *c3, *enc_qkv, *enc_wo, *enc_ffn1, *enc_ffn2, *dec_qkv, *dec_self_wo, *dec_cross_q,
                *dec_cross_kv, *dec_cross_wo, *dec_ffn1, *dec_ffn2;
   } split;
+  /* linear_mode 0 with has_pointer 1: the six Linears that consume a LayerNorm, folded with it by
+   * vcr_fold_layernorm_f32 (w [N,E], colsum [N], bias [N]).  dec_cross_kv is folded with the ENCODER's final norm. */
+  struct vcr_folded { const float *w, *colsum, *bias; } fold_enc_qkv, fold_enc_ffn1, fold_dec_qkv, fold_dec_cross_q,
+      fold_dec_cross_kv, fold_dec_ffn1;
   /* partial-overlap mode (args.partial, vcrnet_model.py:178-187 + transformer.py:35-53; head_mode must be 0):
    * the decoder's cross-attention keeps the int(N*overlap2) keys with the largest soft-max mass, the head is
    * selectCom + getCopair and the outputs hold vcr_vcrnet_pairs() hard pairs per sample instead of N soft ones.

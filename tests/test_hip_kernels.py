@@ -287,8 +287,9 @@ def test_linear_bf16x3(nat, M, N, K, relu, res):
 
 
 def test_linear_with_fused_layernorm(nat):
-    """the producer's epilogue emits per-row (sum, sum^2) partials, the consumer applies
-    a*(x-mean)/(std_unbiased+eps)+b to its A fragments on the fly -- equal to LayerNorm followed by Linear."""
+    """the producer's epilogue emits per-row (sum, sum^2) partials; the consumer runs the GEMM
+    on the weight folded with the LayerNorm affine and applies (mean, 1/(std_unbiased+eps)) in its epilogue --
+    equal to LayerNorm followed by Linear."""
     g = torch.Generator().manual_seed(11)
     M, K, N = 1000, 512, 1536
     x0 = torch.randn(M, 128, generator=g)
@@ -302,7 +303,11 @@ def test_linear_with_fused_layernorm(nat):
     xs = x.cpu()
     torch.testing.assert_close(stats.cpu()[..., 0].sum(1), xs.sum(1), atol=2e-4, rtol=1e-5)
     torch.testing.assert_close(stats.cpu()[..., 1].sum(1), (xs ** 2).sum(1), atol=2e-3, rtol=1e-5)
-    y = nat.linear(x, dev(w1), dev(b1), relu=True, ln=(stats, dev(a), dev(b), 1e-6))         # consumer
+    wf, cs, bf = nat.fold_layernorm(dev(w1), dev(b1), dev(a), dev(b))
+    torch.testing.assert_close(wf.cpu(), w1 * a, atol=0, rtol=0)
+    torch.testing.assert_close(cs.cpu().double(), (w1 * a).double().sum(1), atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(bf.cpu().double(), b1.double() + w1.double() @ b.double(), atol=1e-6, rtol=1e-6)
+    y = nat.linear(x, wf, bf, relu=True, ln=(stats, cs, 1e-6))                               # consumer
     ref = torch.relu(oracle.layer_norm(xs.double(), a.double(), b.double()) @ w1.double().t() + b1.double())
     err = (y.cpu().double() - ref).abs().max().item()
     assert err <= 5e-5, err

@@ -88,15 +88,16 @@ struct Runner {
   }
   bool ok(int r) { if (rc == 0 && r != 0) rc = r; return rc == 0; }
 
-  // ln_stats + ln: LayerNorm fused into the A operand (statistics from the producer's epilogue);
+  // ln_stats + ln_colsum: LayerNorm folded into this linear (w, b are the folded weight / bias; the row statistics
+  // come from the producer's epilogue);
   // stats_out: this launch's epilogue writes the (sum, sum^2) partials of its output rows for a later LayerNorm.
   bool linear(const char* nm, const float* x, int ldx, const float* w, const void* wsplit, const float* b, float* y,
               int ldy, int M, int N, int K, int relu, const float* res = nullptr, int ldr = 0,
-              const float* ln_stats = nullptr, const vcr_norm_w* ln = nullptr, float* stats_out = nullptr) {
+              const float* ln_stats = nullptr, const float* ln_colsum = nullptr, float* stats_out = nullptr) {
     if (rc) return false;
     mark(nm);
     vcr_linear_args a{x, ldx, w, b, res, ldr, y, ldy, M, N, K, relu};
-    if (ln_stats) { a.ln_stats_in = ln_stats; a.ln_nseg = K / 64; a.ln_a = ln->ln_a; a.ln_b = ln->ln_b; a.ln_eps = 1e-6f; }
+    if (ln_stats) { a.ln_stats_in = ln_stats; a.ln_nseg = K / 64; a.ln_colsum = ln_colsum; a.ln_eps = 1e-6f; }
     a.stats_out = stats_out;
     return ok(wsplit ? vcr_linear_bf16x3_f32(&a, wsplit, stream) : vcr_linear_f32(&a, stream));
   }
@@ -208,6 +209,10 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   const int B = io->B, N = io->N, E = W->E, F = W->F, k = W->k;
   if (B <= 0 || N <= 0 || E != 512 || W->heads * 128 != E || k <= 0 || k > 40 || k + 1 > N) return VCR_EINVAL;
   if (W->has_pointer == 1 && (F % 128)) return VCR_EINVAL;
+  if (W->has_pointer == 1 && W->linear_mode == 0 &&
+      !(W->fold_enc_qkv.w && W->fold_enc_ffn1.w && W->fold_dec_qkv.w && W->fold_dec_cross_q.w &&
+        W->fold_dec_cross_kv.w && W->fold_dec_ffn1.w))
+    return VCR_EINVAL;
   if (((uintptr_t)workspace) & 255) return VCR_EINVAL;
   if (W->partial) {
     if (W->head_mode != 0 || W->has_pointer != 1) return VCR_EUNSUPPORTED;
@@ -254,35 +259,36 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   // ---- pointer (transformer.py:264-272) + residual (vcrnet_model.py:504-505)
   const float* head_emb = w.embf;
   if (W->has_pointer == 1 && W->linear_mode == 0) {
-    // fp32 path with LayerNorm fused into the consuming linears: each producer of a
-    // residual stream writes per-row (sum, sum^2) partials from its epilogue, each consumer normalises its A
-    // fragments on the fly -- six LayerNorm launches and their 2 x 67 MB round trips are gone.
+    // fp32 path with LayerNorm folded into the consuming linears: each producer of a
+    // residual stream writes per-row (sum, sum^2) partials from its epilogue, each consumer runs the plain GEMM on
+    // the folded weight and applies (mean, 1/(std+eps)) in its epilogue -- six LayerNorm launches and their
+    // 2 x 67 MB round trips are gone.
     const int H = W->heads;
-    R.linear("linear:enc.qkv", w.emb, E, W->enc_self.wqkv, nullptr, W->enc_self.bqkv, w.qkv, 3 * E, M2, 3 * E, E, 0,
-             nullptr, 0, w.st_emb, &W->enc_ln0);
+    R.linear("linear:enc.qkv", w.emb, E, W->fold_enc_qkv.w, nullptr, W->fold_enc_qkv.bias, w.qkv, 3 * E, M2, 3 * E, E, 0,
+             nullptr, 0, w.st_emb, W->fold_enc_qkv.colsum);
     R.sdpa("sdpa:enc.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
     R.linear("linear:enc.wo", w.att, E, W->enc_self.wo, nullptr, W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E,
              nullptr, nullptr, w.st_e1);
-    R.linear("linear:enc.ffn1", w.e1, E, W->enc_ffn.w1, nullptr, W->enc_ffn.b1, w.hid, F, M2, F, E, 1, nullptr, 0,
-             w.st_e1, &W->enc_ln1);
+    R.linear("linear:enc.ffn1", w.e1, E, W->fold_enc_ffn1.w, nullptr, W->fold_enc_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
+             w.st_e1, W->fold_enc_ffn1.colsum);
     R.linear("linear:enc.ffn2", w.hid, F, W->enc_ffn.w2, nullptr, W->enc_ffn.b2, w.e2, E, M2, E, F, 0, w.e1, E,
              nullptr, nullptr, w.st_e2);
     // decoder; batch b attends to the encoder memory (= enc.norm(e2), applied inside the K/V projection) of
     // batch (b + B) mod 2B
-    R.linear("linear:dec.qkv", w.emb, E, W->dec_self.wqkv, nullptr, W->dec_self.bqkv, w.qkv, 3 * E, M2, 3 * E, E, 0,
-             nullptr, 0, w.st_emb, &W->dec_ln0);
+    R.linear("linear:dec.qkv", w.emb, E, W->fold_dec_qkv.w, nullptr, W->fold_dec_qkv.bias, w.qkv, 3 * E, M2, 3 * E, E, 0,
+             nullptr, 0, w.st_emb, W->fold_dec_qkv.colsum);
     R.sdpa("sdpa:dec.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
     R.linear("linear:dec.self.wo", w.att, E, W->dec_self.wo, nullptr, W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E,
              nullptr, nullptr, w.st_d1);
-    R.linear("linear:dec.cross.q", w.d1, E, W->dec_cross.wq, nullptr, W->dec_cross.bq, w.qc, E, M2, E, E, 0, nullptr, 0,
-             w.st_d1, &W->dec_ln1);
-    R.linear("linear:dec.cross.kv", w.e2, E, W->dec_cross.wkv, nullptr, W->dec_cross.bkv, w.kvc, 2 * E, M2, 2 * E, E, 0,
-             nullptr, 0, w.st_e2, &W->enc_norm);
+    R.linear("linear:dec.cross.q", w.d1, E, W->fold_dec_cross_q.w, nullptr, W->fold_dec_cross_q.bias, w.qc, E, M2, E, E, 0, nullptr, 0,
+             w.st_d1, W->fold_dec_cross_q.colsum);
+    R.linear("linear:dec.cross.kv", w.e2, E, W->fold_dec_cross_kv.w, nullptr, W->fold_dec_cross_kv.bias, w.kvc, 2 * E, M2, 2 * E, E, 0,
+             nullptr, 0, w.st_e2, W->fold_dec_cross_kv.colsum);
     R.cross_attention(W, w, B, N);
     R.linear("linear:dec.cross.wo", w.att, E, W->dec_cross.wo, nullptr, W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E,
              nullptr, nullptr, w.st_d2);
-    R.linear("linear:dec.ffn1", w.d2, E, W->dec_ffn.w1, nullptr, W->dec_ffn.b1, w.hid, F, M2, F, E, 1, nullptr, 0,
-             w.st_d2, &W->dec_ln2);
+    R.linear("linear:dec.ffn1", w.d2, E, W->fold_dec_ffn1.w, nullptr, W->fold_dec_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
+             w.st_d2, W->fold_dec_ffn1.colsum);
     R.linear("linear:dec.ffn2", w.hid, F, W->dec_ffn.w2, nullptr, W->dec_ffn.b2, w.d3, E, M2, E, F, 0, w.d2, E);
     R.norm("layernorm:dec.norm+res", w.d3, W->dec_norm, w.embf, M2, E, w.emb, w.xyz4, w.side4);
   } else if (W->has_pointer == 1) {
@@ -438,7 +444,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 4; }
+extern "C" int vcr_abi_version(void) { return 5; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

@@ -72,7 +72,37 @@ __global__ __launch_bounds__(256) void rowside_kernel(vcr_rowside_args p) {
   }
 }
 
+// Fold a LayerNorm's affine into the Linear that consumes it (once per weight, at pack time):
+//   w_out[n,k] = w[n,k] * a[k];  colsum[n] = sum_k w_out[n,k];  bias_out[n] = bias[n] + sum_k w[n,k] * b[k]
+// One wave per output row; the two sums are accumulated in fp64 and rounded once.
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                             const float* __restrict__ a, const float* __restrict__ b,
+                                                             int N, int K, float* w_out, float* colsum, float* bias_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  double c = 0.0, d = 0.0;
+  for (int k = lane; k < K; k += 64) {
+    const float wv = w[(size_t)n * K + k];
+    const float wf = wv * a[k];
+    w_out[(size_t)n * K + k] = wf;
+    c += (double)wf;
+    d += (double)wv * (double)b[k];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { c += __shfl_xor(c, off, 64); d += __shfl_xor(d, off, 64); }
+  if (lane == 0) { colsum[n] = (float)c; bias_out[n] = (float)((bias ? (double)bias[n] : 0.0) + d); }
+}
+
 }  // namespace
+
+extern "C" int vcr_fold_layernorm_f32(const float* w, const float* bias, const float* ln_a, const float* ln_b, int N,
+                                      int K, float* w_out, float* colsum, float* bias_out, vcr_stream_t stream) {
+  if (!w || !ln_a || !ln_b || !w_out || !colsum || !bias_out || N <= 0 || K <= 0) return VCR_EINVAL;
+  hipLaunchKernelGGL(fold_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, bias, ln_a, ln_b,
+                     N, K, w_out, colsum, bias_out);
+  return VCR_LAUNCH_RC();
+}
 
 extern "C" int vcr_rowside_f32(const vcr_rowside_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->xyz4 || !a->side4 || a->M <= 0 || a->C <= 0 || (a->C & 3) || (a->ldx & 3)) return VCR_EINVAL;

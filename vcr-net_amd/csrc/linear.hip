@@ -161,22 +161,34 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 3)) void linear_kernel(vcr_lin
 // No VGPRs hold the in-flight slab and there is no ds_write pass.
 struct TileG { float a[BM][32]; float b[BN][32]; };
 
+// Sum over the 16 lanes of a DPP row with VALU-rate DPP moves (quad_perm xor 1, xor 2, then row_ror 4 and 8);
+// every lane ends with the full sum, in a fixed order.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+  return v;
+}
+
 __device__ __forceinline__ void glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// LN_IN : the A operand is LayerNorm(x) of model/transformer.py:141-144, applied on the fly to the fragments read
-//         from LDS: a_k (x - mean) / (std + eps) + b_k with the row statistics rebuilt from per-64-column partial
-//         sums (sum, sum of squares) that the PRODUCING linear wrote from its epilogue (STATS_OUT) -- the separate
-//         LayerNorm launch and its 2 x M x 512 x 4 B round trip disappear.
+// LN_IN : the A operand is LayerNorm(x) of model/transformer.py:141-144 without ever forming it.  With
+//         x_hat = (x - mean) / (std + eps),  W (a * x_hat + b) + bias = inv * (W' x - mean * c) + d  where
+//         W' = W diag(a), c_n = sum_k W'_nk, d = bias + W b are folded once per weight (vcr_fold_layernorm_f32):
+//         the main loop is the plain GEMM on W', the epilogue applies the per-row (mean, inv) rebuilt from the
+//         per-64-column partial sums (sum, sum of squares) that the PRODUCING linear wrote from its epilogue
+//         (STATS_OUT).  The separate LayerNorm launch and its 2 x M x 512 x 4 B round trip disappear
+//          at no cost in the MFMA loop.
 // STATS_OUT: epilogue also writes, per row and per 64-column segment, (sum y, sum y^2) of the final outputs.
 template <bool LN_IN, bool STATS_OUT>
 __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileG* tile = reinterpret_cast<TileG*>(smem);          // [2]
-  float* lnA = reinterpret_cast<float*>(smem + 2 * sizeof(TileG));   // [K] scale, then [K] shift (LN_IN only)
-  float* lnB = lnA + p.K;
+  float* rowst = reinterpret_cast<float*>(smem + 2 * sizeof(TileG));   // [BM][2] (mean, inv) per row (LN_IN only)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -208,8 +220,14 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
     }
   };
   fill(0, 0);
-  if (LN_IN) {
-    for (int i = t; i < p.K; i += 256) { lnA[i] = p.ln_a[i]; lnB[i] = p.ln_b[i]; }
+  if (LN_IN && t < BM) {
+    const float* sp = p.ln_stats_in + (size_t)min(m0 + t, p.M - 1) * p.ln_nseg * 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int sg = 0; sg < p.ln_nseg; ++sg) { s1 += sp[2 * sg]; s2 += sp[2 * sg + 1]; }     // fixed order
+    const float mean = s1 / (float)p.K;
+    const float var = fmaxf((s2 - s1 * mean) / (float)(p.K - 1), 0.f);                      // unbiased, like x.std()
+    rowst[2 * t] = mean;
+    rowst[2 * t + 1] = 1.f / (sqrtf(var) + p.ln_eps);
   }
   __syncthreads();
 
@@ -224,19 +242,6 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
     ra_[i] = wm * 64 + i * 32 + l31; sa[i] = (ra_[i] >> 1) & 7;
     rb_[i] = wn * 64 + i * 32 + l31; sb[i] = (rb_[i] >> 1) & 7;
   }
-  float ln_inv[2] = {1.f, 1.f}, ln_shift[2] = {0.f, 0.f};   // x_hat = x * inv + shift
-  if (LN_IN) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float* sp = p.ln_stats_in + (size_t)min(m0 + ra_[i], p.M - 1) * p.ln_nseg * 2;
-      float s1 = 0.f, s2 = 0.f;
-      for (int sg = 0; sg < p.ln_nseg; ++sg) { s1 += sp[2 * sg]; s2 += sp[2 * sg + 1]; }   // fixed order
-      const float mean = s1 / (float)p.K;
-      const float var = fmaxf((s2 - s1 * mean) / (float)(p.K - 1), 0.f);                    // unbiased, like x.std()
-      ln_inv[i] = 1.f / (sqrtf(var) + p.ln_eps);
-      ln_shift[i] = -mean * ln_inv[i];
-    }
-  }
   const int nk = p.K / 32;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -249,13 +254,6 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
       for (int i = 0; i < 2; ++i) fa[i] = ld4(&T.a[ra_[i]][4 * ((2 * g + half) ^ sa[i])]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[j] = ld4(&T.b[rb_[j]][4 * ((2 * g + half) ^ sb[j])]);
-      if (LN_IN) {
-        const f32x4 a4 = ld4(&lnA[kt * 32 + 8 * g + 4 * half]), b4 = ld4(&lnB[kt * 32 + 8 * g + 4 * half]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) fa[i][e] = fmaf(fmaf(fa[i][e], ln_inv[i], ln_shift[i]), a4[e], b4[e]);
-      }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -270,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
   float* ot = reinterpret_cast<float*>(smem) + wave * 32 * EP;
   const int c4e = (lane & 15) * 4, col = n0 + wn * 64 + c4e;
   const f32x4 bias = (p.bias && col < p.N) ? ld4(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 csum = (LN_IN && col < p.N) ? ld4(p.ln_colsum + col) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -284,15 +283,21 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
         const int rl = ps * 4 + (lane >> 4);
         const int row = m0 + wm * 64 + i * 32 + rl;
         if (row < p.M) {
-          f32x4 v = ld4(&ot[rl * EP + c4e]) + bias;
+          f32x4 v = ld4(&ot[rl * EP + c4e]);
+          if (LN_IN) {
+            const float mean = rowst[2 * (wm * 64 + i * 32 + rl)], inv = rowst[2 * (wm * 64 + i * 32 + rl) + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(inv, fmaf(-mean, csum[e], v[e]), bias[e]);
+          } else {
+            v = v + bias;
+          }
           if (p.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
           if (p.residual) v = v + ld4(p.residual + (size_t)row * p.ldr + col);
           st4(p.y + (size_t)row * p.ldy + col, v);
-          if (STATS_OUT) {                               // the 16 lanes of a row group hold this wave's 64 columns
-            float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+          if (STATS_OUT) {                               // the 16 lanes of a row group (= one DPP row) hold this
+            float s1 = (v[0] + v[1]) + (v[2] + v[3]);    // wave's 64 columns of the row
             float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            s1 = row16_sum(s1); s2 = row16_sum(s2);
             if ((lane & 15) == 0) {
               float* so = p.stats_out + ((size_t)row * (p.N / 64) + (n0 + wn * 64) / 64) * 2;
               so[0] = s1; so[1] = s2;
@@ -325,12 +330,13 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
                   (!a->residual || ((a->ldr % 4 == 0) && ((uintptr_t)a->residual & 15) == 0));
   if (a->ln_stats_in || a->stats_out) {                  // fused LayerNorm prologue / statistics epilogue
     if (!vec || (g_variant & 4)) return VCR_EUNSUPPORTED;
-    if (a->ln_stats_in && (!a->ln_a || !a->ln_b || a->ln_nseg <= 0 || a->K > 2048 || a->K < 2)) return VCR_EINVAL;
+    if (a->ln_stats_in && (!a->ln_colsum || !a->bias || a->ln_nseg <= 0 || a->K < 2 ||
+                           ((uintptr_t)a->ln_colsum & 15))) return VCR_EINVAL;
     if (a->stats_out && (a->N % 64)) return VCR_EINVAL;
   }
   if (!(g_variant & 4) && vec) {   // default: LDS-DMA staging (bit2 of the debug variant selects register staging)
     const bool ln_in = a->ln_stats_in != nullptr, st_out = a->stats_out != nullptr;
-    const int ldsg = 2 * sizeof(TileG) + (ln_in ? 2 * a->K * 4 : 0);
+    const int ldsg = 2 * sizeof(TileG) + (ln_in ? BM * 2 * 4 : 0);
 #define VCR_LIN_LAUNCH(LI, SO)                                                                                          \
   do {                                                                                                                   \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_glds_kernel<LI, SO>),                                \

@@ -274,6 +274,17 @@ class VCRNet(nn.Module):
             mha("dec_cross", d + ".src_attn", True)
             ffn("enc_ffn", e + ".feed_forward"); ffn("dec_ffn", d + ".feed_forward")
             cw.has_pointer = 1
+            if self.linear_mode != "bf16x3":
+                # fp32 mode: LayerNorm folded into the six linears that consume one (linear.hip LN_IN)
+                for site, wk, bk, nk in (("enc_qkv", "enc_self.wqkv", "enc_self.bqkv", "enc_ln0"),
+                                         ("enc_ffn1", "enc_ffn.w_1.weight", "enc_ffn.w_1.bias", "enc_ln1"),
+                                         ("dec_qkv", "dec_self.wqkv", "dec_self.bqkv", "dec_ln0"),
+                                         ("dec_cross_q", "dec_cross.wq", "dec_cross.bq", "dec_ln1"),
+                                         ("dec_cross_kv", "dec_cross.wkv", "dec_cross.bkv", "enc_norm"),
+                                         ("dec_ffn1", "dec_ffn.w_1.weight", "dec_ffn.w_1.bias", "dec_ln2")):
+                    f = native.fold_layernorm(P[wk], P[bk], P[nk + ".a"], P[nk + ".b"])
+                    P["fold." + site] = f
+                    setattr(cw, "fold_" + site, native.FoldedW(*(native.ptr(t) for t in f)))
         else:
             cw.has_pointer = 2 if isinstance(self.pointer, _Identity) else 0
         cw.linear_mode = 1 if self.linear_mode == "bf16x3" else 0

@@ -32,7 +32,7 @@ class KnnArgs(C.Structure):
 class LinearArgs(C.Structure):
     _fields_ = [("x", f32p), ("ldx", C.c_int), ("w", f32p), ("bias", f32p), ("residual", f32p), ("ldr", C.c_int),
                 ("y", f32p), ("ldy", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("relu", C.c_int),
-                ("ln_stats_in", f32p), ("ln_nseg", C.c_int), ("ln_a", f32p), ("ln_b", f32p), ("ln_eps", C.c_float),
+                ("ln_stats_in", f32p), ("ln_nseg", C.c_int), ("ln_colsum", f32p), ("ln_eps", C.c_float),
                 ("stats_out", f32p)]
 
 
@@ -137,6 +137,10 @@ class SplitW(C.Structure):
     _fields_ = [(s, f32p) for s in SPLIT_SITES]
 
 
+class FoldedW(C.Structure):
+    _fields_ = [("w", f32p), ("colsum", f32p), ("bias", f32p)]
+
+
 class VcrnetWeights(C.Structure):
     _fields_ = [("c1_w", f32p), ("c1_b", f32p), ("c2_w", f32p), ("c2_b", f32p),
                 ("dg1_wpq", f32p), ("dg1_bpq", f32p), ("dg2_w", f32p), ("dg2_b", f32p),
@@ -147,6 +151,8 @@ class VcrnetWeights(C.Structure):
                 ("enc_ffn", FfnW), ("dec_ffn", FfnW),
                 ("E", C.c_int), ("F", C.c_int), ("heads", C.c_int), ("k", C.c_int),
                 ("has_pointer", C.c_int), ("head_mode", C.c_int), ("linear_mode", C.c_int), ("split", SplitW),
+                ("fold_enc_qkv", FoldedW), ("fold_enc_ffn1", FoldedW), ("fold_dec_qkv", FoldedW),
+                ("fold_dec_cross_q", FoldedW), ("fold_dec_cross_kv", FoldedW), ("fold_dec_ffn1", FoldedW),
                 ("partial", C.c_int), ("overlap2", C.c_double)]
 
 
@@ -172,7 +178,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 4          # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 5          # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -296,8 +302,9 @@ def knn(x, sq, k):
 
 
 def linear(x, w, bias=None, relu=False, residual=None, out=None, ln=None, want_stats=False):
-    """y = act(x w^T + bias) (+ residual).  ln = (stats [M,nseg,2], a [K], b [K], eps): LayerNorm fused into the
-    A-operand read.  want_stats: also return the [M, N/64, 2] (sum, sum of squares) partials of y."""
+    """y = act(x w^T + bias) (+ residual).  ln = (stats [M,nseg,2], colsum [N], eps) with w / bias folded by
+    fold_layernorm(): y = act(LayerNorm(x) w0^T + bias0).  want_stats: also return the [M, N/64, 2]
+    (sum, sum of squares) partials of y."""
     M, K = x.shape
     N = w.shape[0]
     y = out if out is not None else _f32(M, N, device=x.device)
@@ -305,10 +312,23 @@ def linear(x, w, bias=None, relu=False, residual=None, out=None, ln=None, want_s
     a = LinearArgs(ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(residual),
                    residual.stride(0) if residual is not None else 0, ptr(y), y.stride(0), M, N, K, int(relu))
     if ln is not None:
-        a.ln_stats_in, a.ln_nseg, a.ln_a, a.ln_b, a.ln_eps = ptr(ln[0]), ln[0].shape[1], ptr(ln[1]), ptr(ln[2]), ln[3]
+        a.ln_stats_in, a.ln_nseg, a.ln_colsum, a.ln_eps = ptr(ln[0]), ln[0].shape[1], ptr(ln[1]), ln[2]
     a.stats_out = ptr(stats)
     call("vcr_linear_f32", a)
     return (y, stats) if want_stats else y
+
+
+def fold_layernorm(w, bias, ln_a, ln_b):
+    """vcr_fold_layernorm_f32: (w * a, colsum, bias + w b) for a Linear that consumes LayerNorm(a, b)."""
+    L = lib()
+    N, K = w.shape
+    w = w.contiguous()
+    wf, cs, bf = _f32(N, K, device=w.device), _f32(N, device=w.device), _f32(N, device=w.device)
+    L.vcr_fold_layernorm_f32.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int] + [C.c_void_p] * 4
+    L.vcr_fold_layernorm_f32.restype = C.c_int
+    check(L.vcr_fold_layernorm_f32(ptr(w), ptr(bias), ptr(ln_a), ptr(ln_b), N, K, ptr(wf), ptr(cs), ptr(bf),
+                                   C.c_void_p(stream_ptr())), "vcr_fold_layernorm_f32")
+    return wf, cs, bf
 
 
 def split_bf16x3(w):
