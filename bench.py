@@ -183,9 +183,13 @@ def main():
         if pmcs and (B, N, a.k) == (16, 1024, 20):
             kname = {"linear": "linear_glds_kernel", "sdpa": "sdpa_kernel<false, true>",
                      "edgeconv": "edgeconv_dg_packed_kernel<20>", "softcorr": "pairscore_kernel<0>"}.get(dom)
-            ent = json.load(open(pmcs[-1])).get(kname, {})
-            if "hbm_bytes_per_launch" in ent:
-                roof["traffic"] = ent["hbm_bytes_per_launch"]
+            # a family can be several template instantiations (linear: plain / statistics-out / LayerNorm-in):
+            # launch-weighted mean over the entries whose name starts with the family's kernel name
+            ents = [e for k_, e in json.load(open(pmcs[-1])).items()
+                    if kname and k_.startswith(kname) and "hbm_bytes_per_launch" in e]
+            if ents:
+                nd = [e["FETCH_SIZE"]["dispatches"] for e in ents]
+                roof["traffic"] = sum(e["hbm_bytes_per_launch"] * n for e, n in zip(ents, nd)) / sum(nd)
                 roof["traffic_source"] = os.path.relpath(pmcs[-1], ROOT)
         total_ms = sum(fam_ms.values())
         roof["launches_per_step"] = sum(r[3] for n, r in rows.items() if n.startswith(dom + ":")) // a.steps
