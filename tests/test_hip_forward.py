@@ -69,19 +69,35 @@ def test_whole_vs_reference_golden(name):
     print(f"{name}: max|dR|={np.abs(R.cpu().numpy() - g['it0_R']).max():.2e} max|dt|={np.abs(t.cpu().numpy() - g['it0_t']).max():.2e}")
 
 
-@pytest.mark.parametrize("B,N,kind", [(4, 1024, "object"), (3, 320, "object"), (2, 2048, "uniform")])
+@pytest.mark.parametrize("B,N,kind", [(4, 1024, "object"), (3, 320, "object"), (2, 2048, "uniform"),
+                                      (5, 1000, "object"), (2, 77, "object"), (3, 21, "object")])   # ragged / minimal N
 def test_whole_vs_oracle(B, N, kind):
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import synth
     net, w = build_net()
     src, tgt, _, _, _ = synth.make_batch(200, B, N, kind=kind)
     src_t, tgt_t = torch.from_numpy(src), torch.from_numpy(tgt)
-    ref = oracle.vcrnet_forward(w, src_t, tgt_t, oracle.OracleConfig())
+    rec = {}
+    ref = oracle.vcrnet_forward(w, src_t, tgt_t, oracle.OracleConfig(record=rec))
     with torch.no_grad():
         out = net(src_t.cuda(), tgt_t.cuda())
-    assert_mostly_close(out[1].cpu().numpy(), ref[1].numpy(), atol=5e-4)
-    np.testing.assert_allclose(out[2].cpu().numpy(), ref[2].numpy(), atol=R_TOL)
-    np.testing.assert_allclose(out[3].cpu().numpy(), ref[3].numpy(), atol=T_TOL)
+    # Tensor.topk on the CPU is an unstable nth_element: when the k-th and (k+1)-th neighbour distances of a point
+    # are EXACTLY equal its pick is an artefact of libstdc++'s pivoting (we take the lower index).  Such rows
+    # (about 1 in 10^4 at fp32) legitimately differ, so samples containing one are excluded from the strict check.
+    k = 20
+    amb = torch.zeros(B, dtype=torch.bool)
+    for side in ("emb_src", "emb_tgt"):
+        for key, feat in (("x64", rec[side]["x64"]), ("xyz", src_t if side == "emb_src" else tgt_t)):
+            if N > k + 1:
+                top = torch.topk(oracle.neg_sqdist_knn(feat), k + 2, dim=-1).values
+                amb |= (top[..., k] == top[..., k + 1]).any(1)
+    assert int(amb.sum()) <= max(1, B // 4), amb
+    keep = ~amb
+    # 21 points (N = k+1, the smallest legal cloud): the covariance averages over 21 correspondences only
+    t_tol = 3 * T_TOL if N <= 32 else T_TOL
+    assert_mostly_close(out[1].cpu().numpy()[keep], ref[1].numpy()[keep], atol=5e-4)
+    np.testing.assert_allclose(out[2].cpu().numpy()[keep], ref[2].numpy()[keep], atol=R_TOL)
+    np.testing.assert_allclose(out[3].cpu().numpy()[keep], ref[3].numpy()[keep], atol=t_tol)
 
 
 @pytest.mark.parametrize("name,kw", [("dist_n256_b2", dict(vcp_nn="dist")), ("identity_n256_b2", dict(pointer="identity"))])

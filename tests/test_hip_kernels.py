@@ -65,6 +65,21 @@ def test_pointwise(nat, W):
     torch.testing.assert_close(xyz4.cpu()[..., 3], (x ** 2).sum(1), atol=1e-6, rtol=1e-6)
 
 
+@pytest.mark.parametrize("N", [1024, 1000, 333, 77, 21])
+def test_pointwise_matches_cpu_rounding_bit_for_bit(nat, W, N):
+    """conv1/conv2 (bias-first fma chains) and |feat|^2 in ATen's association -- cascade sum for the points its
+    32-wide vector loop covers, four interleaved accumulators for the last N % 32 -- are bit-identical to the CPU
+    ops the reference runs (multi-threaded, batch >= 2), so the feature-space distance matrix cannot differ."""
+    g = torch.Generator().manual_seed(N)
+    x = torch.rand(4, 3, N, generator=g) * 2 - 1
+    _, f64, sq = nat.pointwise(dev(x), dev(W["emb_nn.conv1_lpd.weight"].view(64, 3)), dev(W["emb_nn.conv1_lpd.bias"]),
+                               dev(W["emb_nn.conv2_lpd.weight"].view(64, 64)), dev(W["emb_nn.conv2_lpd.bias"]))
+    h = F.relu(F.conv1d(x, W["emb_nn.conv1_lpd.weight"], W["emb_nn.conv1_lpd.bias"]))
+    h = F.relu(F.conv1d(h, W["emb_nn.conv2_lpd.weight"], W["emb_nn.conv2_lpd.bias"]))
+    assert torch.equal(f64.cpu(), h.transpose(1, 2))
+    assert torch.equal(sq.cpu(), (h ** 2).sum(1))
+
+
 @pytest.mark.parametrize("N,k", [(256, 20), (1024, 20), (192, 20), (100, 20), (512, 40), (64, 5)])
 def test_knn_feature_space(nat, W, N, k):
     g = golden("whole_n1024_b2")

@@ -59,11 +59,29 @@ __global__ __launch_bounds__(256) void pointwise12_kernel(vcr_pointwise_args a) 
     acc[j] = fmaxf(acc[j], 0.f);
     ss = ss + acc[j] * acc[j];
   }
+  const int base = (threadIdx.x & 63) & ~3;
   {
-    const int base = (threadIdx.x & 63) & ~3;
     const float b0 = __shfl(ss, base, 64), b1 = __shfl(ss, base + 1, 64);
     const float b2 = __shfl(ss, base + 2, 64), b3 = __shfl(ss, base + 3, 64);
     ss = ((b0 + b1) + b2) + b3;
+  }
+  // Ragged N: ATen reduces the last N % 32 points of a cloud (the columns its 32-wide vector loop leaves over) in a
+  // scalar loop with FOUR interleaved accumulators, a_l = sum of channels l, l+4, l+8, ... in ascending order,
+  // combined as ((a0 + a1) + a2) + a3 (established bit-for-bit like the rule above).  The chain runs through the
+  // four threads of a point in turn.
+  const bool tail = live && n >= (a.N & ~31);
+  if (__builtin_amdgcn_ballot_w64(tail) != 0) {
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sgrp = 0; sgrp < 4; ++sgrp) {
+      if (g == sgrp) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a4[j & 3] = a4[j & 3] + acc[j] * acc[j];
+      }
+#pragma unroll
+      for (int l = 0; l < 4; ++l) a4[l] = __shfl(a4[l], base + sgrp, 64);
+    }
+    if (tail) ss = ((a4[0] + a4[1]) + a4[2]) + a4[3];
   }
   if (live) {
     const size_t row = (size_t)b * a.N + n;
