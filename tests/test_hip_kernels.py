@@ -253,6 +253,31 @@ def test_rigid_svd(nat):
     torch.testing.assert_close(tb.cpu(), -torch.matmul(Rr.transpose(1, 2), tr.unsqueeze(2)).squeeze(2), atol=1e-5, rtol=0)
 
 
+def test_rigid_svd_degenerate_pairs_still_give_a_rotation(nat):
+    """Rank-deficient covariances (coplanar, collinear, single-point correspondences) leave R under-determined -- in
+    the reference LAPACK's completion is arbitrary -- but the result must be a proper rotation that still maps the
+    centred source onto the centred correspondences wherever that is defined."""
+    rs = np.random.RandomState(3)
+    B, K = 4, 40
+    src = torch.from_numpy(rs.uniform(-1, 1, (B, K, 3)).astype(np.float32))
+    corr = src.clone()
+    corr[0, :, 2] = 0.25                                             # rank 2: correspondences in a plane
+    line = torch.tensor([0.3, -0.5, 0.8])
+    corr[1] = torch.from_numpy(rs.uniform(-1, 1, (K, 1)).astype(np.float32)) * line + 0.1    # rank 1: on a line
+    corr[2] = torch.tensor([0.2, 0.1, -0.4])                         # rank 0: every source matched to ONE target
+    R, t, Rb, tb = nat.rigid_svd(dev(src), dev(corr))                # sample 3: full rank, R = I
+    R, t = R.cpu(), t.cpu()
+    assert torch.isfinite(R).all() and torch.isfinite(t).all()
+    assert torch.allclose(torch.det(R), torch.ones(B), atol=1e-5)
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(B, 3, 3), atol=1e-5)
+    assert torch.allclose(R[2], torch.eye(3), atol=1e-6) and torch.allclose(R[3], torch.eye(3), atol=1e-5)
+    moved = src @ R.transpose(1, 2) + t.unsqueeze(1)                 # the mean is always matched
+    assert torch.allclose(moved.mean(1), corr.mean(1), atol=1e-5)
+    # rank 2: Kabsch optimum is unique -- compare with the oracle
+    Ro, to = oracle.rigid_svd(src[:1].transpose(1, 2), corr[:1].transpose(1, 2))
+    assert torch.allclose(R[0], Ro[0], atol=1e-4)
+
+
 @pytest.mark.parametrize("name", ["whole_n1024_b2", "whole_n256_b2"])
 def test_feature_space_knn_is_bit_exact_vs_reference(nat, W, name):
     """The discrete step that decides parity: conv1/conv2 features, |x|^2 and the feature-space distance

@@ -57,12 +57,30 @@ __device__ void svd3_rotation(const double H[9], double R[9]) {
     const double inv = sig[c] > 0 ? 1.0 / sig[c] : 0.0;
     for (int i = 0; i < 3; ++i) { U[i][j] = A[i][c] * inv; W[i][j] = V[i][c]; }
   }
-  // a vanishing smallest singular value leaves its left vector undefined: complete the frame
-  // (either sign gives the same R after the determinant rule below)
-  if (sig[ord[2]] <= 1e-12 * sig[ord[0]]) {
-    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
-    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
-    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+  // Vanishing singular values leave their left vectors undefined: complete the frame so that R is always a proper
+  // rotation.  Rank 2 (coplanar pairs): u2 = u0 x u1, either sign gives the same R after the determinant rule
+  // below.  Rank 1 / rank 0 (all pairs on a line / one point; happens when tiny partial clouds collapse in later
+  // vcrnetIter passes): R is not unique -- LAPACK's choice in the reference is arbitrary too -- we take the
+  // completion closest to the coordinate axes, and R = I for H = 0.
+  const double s0 = sig[ord[0]];
+  if (!(s0 > 1e-300)) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) U[i][j] = W[i][j];
+  } else {
+    if (sig[ord[1]] <= 1e-12 * s0) {
+      int e = 0;
+      for (int i = 1; i < 3; ++i) if (fabs(U[i][0]) < fabs(U[e][0])) e = i;
+      double v[3] = {0, 0, 0}, n2 = 0;
+      v[e] = 1.0;
+      const double d = U[e][0];
+      for (int i = 0; i < 3; ++i) { v[i] -= d * U[i][0]; n2 += v[i] * v[i]; }
+      const double inv = 1.0 / sqrt(n2);
+      for (int i = 0; i < 3; ++i) U[i][1] = v[i] * inv;
+    }
+    if (sig[ord[2]] <= 1e-12 * s0) {
+      U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+      U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+      U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+    }
   }
   auto build = [&]() {
     for (int i = 0; i < 3; ++i)
