@@ -116,13 +116,13 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) o[d] = o[d] * alpha;
       }
+      // MFMA group dg owns the head dims d = 4*i + dg (i = the A-operand lane), so ONE ds_read_b128 of
+      // V[key][4*l31 .. 4*l31+3] feeds the four groups of a k-step: 16 wide LDS reads per tile instead of 64 narrow ones.
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
+      for (int r = 0; r < 16; ++r) {
+        const f32x4 vf = ld4(&st[cur].v[acc_row(r, half)][4 * l31]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float vf = st[cur].v[acc_row(r, half)][32 * d + l31];
-          o[d] = mfma32(vf, s[r], o[d]);
-        }
+        for (int d = 0; d < 4; ++d) o[d] = mfma32(vf[d], s[r], o[d]);
       }
     }
     if (tile + 1 < ntiles) stage_write(cur ^ 1);
@@ -140,9 +140,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
     const float inv = 1.f / lt;
     float* ot = reinterpret_cast<float*>(smem) + (size_t)w * 32 * KP;
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[l31 * KP + 32 * d + acc_row(r, half)] = o[d][r] * inv;
+    for (int r = 0; r < 16; ++r)   // o[dg][r] = O[query l31][d = 4*acc_row(r, half) + dg]
+      st4(&ot[l31 * KP + 4 * acc_row(r, half)], f32x4{o[0][r] * inv, o[1][r] * inv, o[2][r] * inv, o[3][r] * inv});
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
