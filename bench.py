@@ -33,6 +33,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="pairs per GPU")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--partial", action="store_true",
+                    help="partial-overlap mode (BASELINE configs[2]): clouds cropped to int(points*0.7507) points, "
+                         "key pruning + selectCom/getCopair heads; combine with --points 1024 --batch 24 --iters 3")
+    ap.add_argument("--iters", type=int, default=1, help="vcrnetIter refinement passes per step (one C call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print the per-launch table to stderr")
     ap.add_argument("--linear-mode", default="fp32", choices=["fp32", "bf16x3"],
@@ -43,35 +47,37 @@ def parse():
     return ap.parse_args()
 
 
-def model_args():
+def model_args(partial=False):
+    from vcrnet_amd import synth
     return SimpleNamespace(emb_dims=512, cycle=False, emb_nn="lpdnet", pointer="transformer", vcp_nn="topK",
-                           partial=False, overlap2=0.75, t3d=False, tfea=False, n_blocks=1, dropout=0.0,
-                           ff_dims=1024, n_heads=4)
+                           partial=partial, overlap2=synth.OVERLAP2_0575 if partial else 0.75, t3d=False, tfea=False,
+                           n_blocks=1, dropout=0.0, ff_dims=1024, n_heads=4)
 
 
-def cpu_baseline(w, B, N, k):
+def cpu_baseline(w, B, N, k, partial=False, iters=1):
     """The CPU oracle (a port of the reference's PyTorch CPU path) timed on this box's host cores on a
     bounded sample of the same workload."""
     import oracle
     from vcrnet_amd import synth
     nthreads = torch.get_num_threads()
-    sample_B = min(B, 8)
-    src, tgt, _, _, _ = synth.make_batch(0, sample_B, N)
+    sample_B = min(B, 8 if N <= 1024 else 2)      # bounded: ~10-30 s of CPU work
+    src, tgt, _, _, _ = synth.make_batch(0, sample_B, N, partial=partial, kind="object" if N <= 2048 else "uniform")
     s, t = torch.from_numpy(src), torch.from_numpy(tgt)
-    cfg = oracle.OracleConfig(k=k)
+    cfg = oracle.OracleConfig(k=k, partial=partial, overlap2=synth.OVERLAP2_0575 if partial else 0.75)
+    run = lambda: oracle.vcrnet_iter(w, s, t, cfg, iters=iters)
     t0 = time.perf_counter()
-    oracle.vcrnet_forward(w, s, t, cfg)           # warm-up
+    run()                                         # warm-up
     warm = time.perf_counter() - t0
     reps = 3 if warm < 8 else 1
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
-        oracle.vcrnet_forward(w, s, t, cfg)
+        run()
         ts.append(time.perf_counter() - t0)
     best = float(np.median(ts))
     return {"value": sample_B / best, "unit": "pairs/s", "cores": nthreads, "kind": "port",
-            "sample": f"oracle.vcrnet_forward, B={sample_B}, N={N}, k={k}, fp32, median of {reps} after 1 warm-up, "
-                      f"torch.set_num_threads={nthreads}"}
+            "sample": f"oracle.vcrnet_iter(iters={iters}{', partial' if partial else ''}), B={sample_B}, N={N}, k={k}, "
+                      f"fp32, median of {reps} after 1 warm-up, torch.set_num_threads={nthreads}"}
 
 
 def main():
@@ -100,7 +106,7 @@ def main():
     from vcrnet_amd.module import VCRNet
 
     w = weights.generate_weights(1234, lpd=weights.load_lpd_fixture())
-    net = VCRNet(model_args())
+    net = VCRNet(model_args(a.partial))
     net.load_state_dict(w)
     net.emb_nn.k = a.k
     net.linear_mode = a.linear_mode
@@ -110,12 +116,14 @@ def main():
     # each rank owns B consecutive items of the global batch (weak scaling); inputs live in HBM
     # object-like clouds have 2048 points (the ModelNet40 convention); larger N (configs 4/5) use uniform clouds
     # built on the device from base clouds + host-drawn permutations / poses (vcr_make_pairs_f32; untimed)
-    src, tgt, _, _, _ = synth.make_batch_device(rank * B, B, N, kind="object" if N <= 2048 else "uniform", device=dev)
+    src, tgt, _, _, _ = synth.make_batch_device(rank * B, B, N, partial=a.partial,
+                                                kind="object" if N <= 2048 else "uniform", device=dev)
+    Nfull, N = N, src.shape[2]                     # partial mode crops the clouds (1024 -> 768)
     assert src.shape == (B, 3, N) and src.is_cuda, src.shape
 
     def step(trace=None):
         with torch.no_grad():
-            out = net._forward_fused(src, tgt, trace=trace)
+            out = net._forward_fused(src, tgt, trace=trace, iters=a.iters)
         pose = torch.cat((out[2].view(B, 9), out[3]), 1)
         if world > 1:
             pose = shard.all_gather_poses(pose, world)
@@ -153,7 +161,7 @@ def main():
     for tr in traces:
         for name, ms in tr.launches():
             fam = name.split(":")[0]
-            fl, by = workmodel.launch_work(name, B, N, a.k)
+            fl, by = workmodel.launch_work(name, B, N, a.k, overlap2=net._overlap2)
             fam_ms[fam] = fam_ms.get(fam, 0.0) + ms
             fam_flops[fam] = fam_flops.get(fam, 0.0) + fl
             fam_bytes[fam] = fam_bytes.get(fam, 0.0) + by
@@ -180,7 +188,7 @@ def main():
         # of this same command, condensed by profiles/summarize.py; null when no summary is committed.
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-        if pmcs and (B, N, a.k) == (16, 1024, 20):
+        if pmcs and (B, N, a.k, a.partial, a.iters) == (16, 1024, 20, False, 1):
             kname = {"linear": "linear_glds_kernel", "sdpa": "sdpa_kernel<false, true>",
                      "edgeconv": "edgeconv_dg_packed_kernel<20>", "softcorr": "pairscore_kernel<0>"}.get(dom)
             # a family can be several template instantiations (linear: plain / statistics-out / LayerNorm-in):
@@ -202,26 +210,32 @@ def main():
         emb_sites = ("pointwise:", "knn:", "edgeconv:", "gathermax:", "linear:dg1_pq", "linear:sn1_pq", "linear:conv3")
         emb_ms = sum(r[0] for n, r in rows.items() if n.startswith(emb_sites)) / a.steps
         emb_bytes = 2.0 * N * (7448 + 784 * a.k) * B
+        emb_gf = sum(workmodel.launch_work(n, B, N, a.k)[0] for n in
+                     ("linear:dg1_pq", "edgeconv:dg1_dg2", "linear:sn1_pq", "linear:conv3")) / 1e9
         emb_stage = {"ms_per_step": emb_ms, "algorithmic_bytes_per_pair": emb_bytes / B,
                      "achieved_gbs": emb_bytes / (emb_ms * 1e-3) / 1e9,
                      "hbm_frac": emb_bytes / (emb_ms * 1e-3) / 1e9 / workmodel.PEAK_HBM_GBS,
-                     "note": "fp32 1x1 convs of this stage are MFMA-bound (SURVEY section 7): 48.8 GF per step alone "
-                             "need 0.31 ms at the fp32 matrix peak, i.e. <= 0.31 of the HBM roofline"}
+                     "note": "fp32 1x1 convs of this stage are MFMA-bound (SURVEY section 7): %.1f GF per step alone "
+                             "need %.2f ms at the fp32 matrix peak, i.e. <= %.2f of the HBM roofline"
+                             % (emb_gf, emb_gf / workmodel.PEAK_MFMA_F32_TFLOPS,
+                                emb_bytes / (emb_gf / workmodel.PEAK_MFMA_F32_TFLOPS * 1e-3) / 1e9 / workmodel.PEAK_HBM_GBS)}
         if a.stages:
             for n, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
                 ms = r[0] / r[3]
                 print(f"{n:28s} {ms:8.3f} ms  {r[1] / ms / 1e9:8.2f} TF/s  {r[2] / ms / 1e6:9.1f} GB/s", file=sys.stderr)
         pairs = B * world * a.steps
         line = {
-            "metric": "point-cloud pairs/sec (N=1024, batch 16 per GPU)", "value": pairs / elapsed, "unit": "pairs/s",
+            "metric": "point-cloud pairs/sec (N=%d, batch %d per GPU)" % (Nfull, B), "value": pairs / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.linear_mode == "fp32" else "f32 (linears as exact bf16x3 splits, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: ModelNet40-like whole-to-whole registration, N=%d, batch=%d "
-                                   "pairs per GPU, LPDNet(k=%d)+Transformer+VcpTopK+SVD, iter=1, fp32; synthetic "
-                                   "object clouds with the reference's transform recipe; LPD-pretrained emb_nn + "
-                                   "seeded Transformer weights" % (N, B, a.k),
+            "config": {"workload": ("BASELINE configs[2]: partial-to-partial overlap 0.575 (clouds cropped %d -> %d "
+                                    "points), " % (Nfull, N) if a.partial else
+                                    "BASELINE configs[1]: ModelNet40-like whole-to-whole registration, ") +
+                                   "N=%d, batch=%d pairs per GPU, LPDNet(k=%d)+Transformer+VcpTopK+SVD, iter=%d, fp32; "
+                                   "synthetic object clouds with the reference's transform recipe; LPD-pretrained "
+                                   "emb_nn + seeded Transformer weights" % (N, B, a.k, a.iters),
                        "num_points": N, "batch_per_gpu": B, "global_batch": B * world, "k": a.k,
                        "parallelism": f"dp{world} (pairs sharded per rank, RCCL all-gather of R,t)"},
             "roofline": roof,
@@ -230,7 +244,7 @@ def main():
             "flops_per_pair_reference": workmodel.reference_flops_per_pair(N, a.k)["total"],
         }
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w, B, N, a.k)
+            line["cpu_baseline"] = cpu_baseline(w, B, Nfull, a.k, a.partial, a.iters)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -12,7 +12,8 @@ PEAK_MFMA_BF16_TFLOPS = 2500.0
 
 # which roofline bounds each kernel family
 FAMILY_BOUND = {"pointwise": "hbm", "knn": "mfma", "linear": "mfma", "edgeconv": "mfma", "gathermax": "hbm",
-                "layernorm": "hbm", "sdpa": "mfma", "softcorr": "mfma", "rigid_svd": "hbm"}
+                "layernorm": "hbm", "sdpa": "mfma", "softcorr": "mfma", "rigid_svd": "hbm",
+                "pairscore": "mfma", "scoremass": "hbm", "select": "hbm", "pose": "hbm"}
 
 _LINEAR_SHAPES = {  # site -> (N_out, K) as multiples resolved below
     "dg1_pq": (256, 64), "sn1_pq": (512, 128), "conv3": ("E", 512),
@@ -22,7 +23,14 @@ _LINEAR_SHAPES = {  # site -> (N_out, K) as multiples resolved below
 }
 
 
-def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1024) -> Tuple[float, float]:
+def overlap_sizes(N: int, overlap2: float) -> Tuple[int, int, int]:
+    """(kept keys, overlap-set size K1, hard pairs K2) of partial mode: transformer.py:41, vcrnet_model.py:208,284."""
+    k1 = int(N * 0.84 * overlap2)
+    return int(N * overlap2), k1, int(k1 * 0.52 * overlap2)
+
+
+def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1024,
+                overlap2: float = 0.765970880926229) -> Tuple[float, float]:
     """(flops, bytes) of one launch called `name` ("family:site") for B pairs of N points."""
     fam, site = name.split(":", 1)
     M1, M2 = B * N, 2 * B * N
@@ -43,12 +51,35 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
     if fam == "layernorm":
         extra = 1 if site.endswith("+res") else 0
         return 8.0 * M2 * E, 4.0 * M2 * E * (2 + extra)
+    keep, K1, K2 = overlap_sizes(N, overlap2)
     if fam == "sdpa":
+        if site == "dec.cross.stats":                      # QK^T + row statistics only
+            return 2.0 * 2 * B * N * N * E, 4.0 * M2 * E * 2
         return 4.0 * 2 * B * N * N * E, 4.0 * M2 * E * 4
+    if fam == "pairscore":
+        if site == "dec.cross.keymass":                    # one head: 128-d scores of every (key, query) pair
+            return 2.0 * 2 * B * N * N * (E // 4), 4.0 * M2 * (E // 4) * 2
+        if site == "head.scores":                          # 512-d scores, stored once
+            return 2.0 * B * N * N * E + 6.0 * B * N * N, 4.0 * (M2 * E + B * N * N)
+        if site == "head.copair":
+            return 2.0 * B * K1 * K1 * E, 4.0 * 2 * B * K1 * E
+        return 2.0 * B * N * N * E, 4.0 * M2 * E           # row/col statistics or mass passes that recompute the scores
+    if fam == "scoremass":
+        return 8.0 * B * N * N, 4.0 * 2 * B * N * N
+    if fam == "select":
+        if site.startswith("gather"):
+            width = E if site.endswith("emb") else 4
+            rows = K1 if ("src_" in site or "tgt_" in site) else K2
+            return 0.0, 4.0 * 2 * B * rows * width
+        n = K1 if site == "head.pairs" else N
+        nb = 2 * B if site == "dec.cross.keys" else B
+        return 1.0 * nb * n * n, 4.0 * nb * n * 2
+    if fam == "pose":
+        return 18.0 * M1, 4.0 * M1 * 6
     if fam == "softcorr":
         return 2.0 * B * N * N * E + 6.0 * B * N * N, 4.0 * (M2 * E + M2 * 4)
     if fam == "rigid_svd":
-        return 18.0 * M1, 4.0 * M1 * 8
+        return 18.0 * M1, 4.0 * M1 * 8                      # (partial mode solves on K2 pairs: even less)
     raise KeyError(name)
 
 
