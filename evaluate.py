@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Evaluation run of the MI355X path on synthetic registration pairs: the counterpart of the reference's
+``main.py --eval`` -> ``testVCRNet`` (model/vcrnet_model.py:768-815), i.e. ``test_one_epoch`` (:546-649) over a
+test set, then the ``==FINAL TEST==`` / ``A--------->B`` log lines.
+
+    python evaluate.py --items 64 --batch 16                       # whole mode, N=1024, iter 1
+    python evaluate.py --partial --iters 3 --batch 24 --items 48   # BASELINE configs[2]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 evaluate.py --items 1024
+
+One process per GPU; items are sharded contiguously over ranks (vcrnet_amd.shard), the per-rank metric sums are
+merged with one all-reduce + one all-gather (EvalAccumulator.merge).  ModelNet40 and the trained VCR-Net weights
+are not available offline: clouds are synthetic and the Transformer weights are seeded, so the
+absolute rot/trans errors are NOT the paper's -- only their agreement with the reference arithmetic is meaningful."""
+import argparse
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--items", type=int, default=64, help="test-set size (pairs)")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--iters", type=int, default=1, help="--iter of the reference (0 = ICP refinement path)")
+    ap.add_argument("--partial", action="store_true")
+    ap.add_argument("--backend", default="nccl")
+    a = ap.parse_args()
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(a.backend, **({"device_id": dev} if a.backend == "nccl" else {}))
+
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import evalmetrics, shard, synth, weights
+    from vcrnet_amd.module import VCRNet, vcrnetIcpNet, vcrnetIter
+
+    args = SimpleNamespace(emb_dims=512, cycle=False, emb_nn="lpdnet", pointer="transformer", vcp_nn="topK",
+                           partial=a.partial, overlap2=synth.OVERLAP2_0575 if a.partial else 0.75, t3d=False, tfea=False,
+                           n_blocks=1, dropout=0.0, ff_dims=1024, n_heads=4, max_iterations=50)
+    w = weights.generate_weights(1234, lpd=weights.load_lpd_fixture())
+    net = VCRNet(args)
+    net.load_state_dict(w)
+    net.emb_nn.k = a.k
+    net = net.to(dev).eval()
+
+    lo, hi = shard.shard_range(a.items, rank, world)
+    acc = evalmetrics.EvalAccumulator()
+    kind = "object" if a.points <= 2048 else "uniform"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for first in range(lo, hi, a.batch):
+        n = min(a.batch, hi - first)
+        src, tgt, R, t, eul = synth.make_batch_device(first, n, a.points, partial=a.partial, kind=kind, device=dev)
+        Rg, tg = torch.from_numpy(R).to(dev), torch.from_numpy(t).to(dev)
+        with torch.no_grad():                                                   # vcrnet_model.py:546-562
+            out = vcrnetIcpNet(args, net, src, tgt) if a.iters == 0 else vcrnetIter(net, src, tgt, iter=a.iters)
+        acc.add_batch(src, tgt, Rg, tg, eul, out)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    merged = acc.merge(world, device=dev if a.backend == "nccl" else "cpu")
+    if rank == 0:
+        m = merged.final()
+        print("==FINAL TEST==")                                                 # vcrnet_model.py:792-799
+        print("A--------->B")
+        print(evalmetrics.EvalAccumulator.format_final(m))
+        print(f"[{merged.num_examples} pairs on {world} GPU(s), {elapsed:.2f} s incl. pair construction and metrics]")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

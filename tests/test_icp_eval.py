@@ -84,3 +84,36 @@ def test_hip_vcrnet_icp_and_eval():
     acc.add_batch(src, tgt, torch.from_numpy(R_gt).cuda(), torch.from_numpy(t_gt).cuda(), eul, out)
     m = acc.final()
     assert np.isfinite(list(m.values())).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("partial,iters", [(False, 1), (False, 3), (True, 1)])
+def test_aggregate_metrics_match_oracle(partial, iters):
+    """over a small test set the reference-style aggregates (rot_MSE in degrees^2, trans_MSE,
+    correspondence MSE) of the HIP path agree with the CPU oracle's: whole mode (1 and 3 refinement passes) to the
+    BASELINE pose tolerance, one partial-overlap pass within 2 %.  (SURVEY asks 1 % for 3 partial passes of the TRAINED
+    network.  With the seeded, untrained Transformer the refinement does not converge -- rot_MSE ~ 3000 deg^2 -- so a
+    single near-tie flip in a discrete selection moves that sample's final pose by degrees; the per-iteration,
+    teacher-forced comparison in test_hip_partial.py is the meaningful check for that path.)"""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import evalmetrics, synth
+    from vcrnet_amd.module import vcrnetIter
+    from test_hip_forward import build_net
+    import oracle
+    o2 = synth.OVERLAP2_0575
+    net, w = build_net(partial=True, overlap2=o2) if partial else build_net()
+    acc, ref = evalmetrics.EvalAccumulator(), evalmetrics.EvalAccumulator()
+    for first in (700, 704, 708):
+        src, tgt, R, t, eul = synth.make_batch(first, 4, 256, partial=partial)
+        s, tt, Rg, tg = (torch.from_numpy(x) for x in (src, tgt, R, t))
+        with torch.no_grad():
+            out = vcrnetIter(net, s.cuda(), tt.cuda(), iter=iters)
+        acc.add_batch(s.cuda(), tt.cuda(), Rg.cuda(), tg.cuda(), eul, out)
+        cfg = oracle.OracleConfig(partial=partial, overlap2=o2 if partial else 0.75)
+        ref.add_batch(s, tt, Rg, tg, eul, oracle.vcrnet_iter(w, s, tt, cfg, iters=iters))
+    m, r = acc.final(), ref.final()
+    tol = 2e-2 if partial else 1e-3
+    for key in ("rot_mse", "trans_mse", "mse", "rot_mae", "trans_mae"):
+        assert abs(m[key] - r[key]) <= tol * abs(r[key]) + 1e-9, (key, m[key], r[key])
+    line = evalmetrics.EvalAccumulator.format_final(m)
+    assert line.startswith("EPOCH:: -1, Loss:") and "rot_MSE" in line and "trans_MAE" in line

@@ -82,3 +82,50 @@ def test_shard_range_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _merge_worker(rank, world, port, q):
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import evalmetrics, shard, synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        total = 7                                            # ragged: ranks own 4 and 3 items
+        lo, hi = shard.shard_range(total, rank, world)
+        acc = evalmetrics.EvalAccumulator()
+        for i in range(lo, hi):                              # one pair per "batch"; poses = ground truth + noise
+            src, tgt, R, t, eul = synth.make_batch(i, 1, 64)
+            s, tt, Rg, tg = (torch.from_numpy(x) for x in (src, tgt, R, t))
+            out = (s, torch.matmul(Rg, s) + tg.unsqueeze(2) + 0.01 * i, Rg, tg + 0.001 * i, Rg.transpose(1, 2),
+                   -torch.matmul(Rg.transpose(1, 2), tg.unsqueeze(2)).squeeze(2))
+            acc.add_batch(s, tt, Rg, tg, eul, out)
+        m = acc.merge(world).final()
+        q.put((rank, m))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eval_accumulator_merge_equals_single_process():
+    """Per-rank metric sums merged over gloo (world 2, ragged 4 + 3 items) equal one process over all 7 items."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import evalmetrics, synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merge_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    one = evalmetrics.EvalAccumulator()
+    for i in range(7):
+        src, tgt, R, t, eul = synth.make_batch(i, 1, 64)
+        s, tt, Rg, tg = (torch.from_numpy(x) for x in (src, tgt, R, t))
+        out = (s, torch.matmul(Rg, s) + tg.unsqueeze(2) + 0.01 * i, Rg, tg + 0.001 * i, Rg.transpose(1, 2),
+               -torch.matmul(Rg.transpose(1, 2), tg.unsqueeze(2)).squeeze(2))
+        one.add_batch(s, tt, Rg, tg, eul, out)
+    ref = one.final()
+    for rank in (0, 1):
+        for k, v in ref.items():
+            assert abs(res[rank][k] - v) <= 1e-6 * max(1.0, abs(v)), (rank, k, res[rank][k], v)

@@ -76,6 +76,37 @@ class EvalAccumulator:
                 "rot_mae": float(np.mean(np.abs(d))), "trans_mse": t_mse, "trans_rmse": float(np.sqrt(t_mse)),
                 "trans_mae": float(np.mean(np.abs(tg - tp)))}
 
+    def merge(self, world: int, device="cpu") -> "EvalAccumulator":
+        """Combine the per-rank accumulators of a process-per-GPU run (the replacement for nn.DataParallel's
+        gather, util/initPara.py:260): one all-reduce of the running sums, one all-gather of the
+        [n,12+12+3] per-pair records (ragged shards padded, rank order kept).  Every rank returns the same
+        merged accumulator; world == 1 returns self."""
+        if world == 1:
+            return self
+        import torch.distributed as dist
+
+        from . import shard
+        keys = sorted(self.sums)
+        vec = torch.tensor([self.sums[k] for k in keys] + [float(self.num_examples)], dtype=torch.float64, device=device)
+        dist.all_reduce(vec)
+        counts = torch.zeros(world, dtype=torch.int64, device=device)
+        counts[dist.get_rank()] = self.num_examples
+        dist.all_reduce(counts)
+        cat = lambda xs, w: (np.concatenate(xs, 0).reshape(-1, w) if xs else np.zeros((0, w), np.float32))
+        rec = np.concatenate((cat(self.R_gt, 9), cat(self.t_gt, 3), cat(self.R_pred, 9), cat(self.t_pred, 3),
+                              cat(self.euler_gt, 3)), 1).astype(np.float32)
+        per = int(counts.max().item())
+        pad = torch.zeros((per, rec.shape[1]), dtype=torch.float32, device=device)
+        pad[: rec.shape[0]] = torch.from_numpy(rec).to(device)
+        g = shard.all_gather_poses(pad, world).view(world, per, -1).cpu().numpy()
+        allrec = np.concatenate([g[r, : int(counts[r].item())] for r in range(world)], 0)
+        out = EvalAccumulator(cycle=self.cycle, num_examples=int(round(vec[-1].item())))
+        out.sums = {k: float(vec[i].item()) for i, k in enumerate(keys)}
+        out.R_gt, out.t_gt = [allrec[:, 0:9].reshape(-1, 3, 3)], [allrec[:, 9:12]]
+        out.R_pred, out.t_pred = [allrec[:, 12:21].reshape(-1, 3, 3)], [allrec[:, 21:24]]
+        out.euler_gt = [allrec[:, 24:27]]
+        return out
+
     @staticmethod
     def format_final(m: Dict[str, float], epoch: int = -1) -> str:
         """The '==FINAL TEST== / A--------->B' line of :792-799."""
