@@ -94,15 +94,25 @@ def test_knn_feature_space(nat, W, N, k):
     assert nbad <= max(2, h.shape[0] * N // 100)
 
 
-@pytest.mark.parametrize("N,k", [(256, 20), (1024, 20), (768, 20), (100, 20), (512, 40), (2048, 20)])
+@pytest.mark.parametrize("N,k", [(256, 20), (1024, 20), (768, 20), (100, 20), (512, 40), (2048, 20), (4096, 40), (21, 20),
+                                 (45, 40), (1000, 5)])
 def test_knn_cartesian(nat, N, k):
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import synth
-    src = torch.from_numpy(synth.make_batch(3, 2, N)[0])
+    src = torch.from_numpy(synth.make_batch(3, 2, N, kind="object" if N <= 2048 else "uniform")[0])
     xyz4 = torch.cat((src.transpose(1, 2), (src ** 2).sum(1).unsqueeze(-1)), -1)
     idx = nat.knn(dev(xyz4), None, k)
     nbad = knn_sets_ok(src, idx, k)
     assert nbad <= max(2, 2 * N // 100)
+    # the candidate split (2 / 4 / 8 waves per 64 queries, chosen from the grid size) must not change any set
+    L = nat.lib()
+    ref = np.sort(idx.cpu().numpy(), -1)
+    for waves in (2, 4, 8):
+        L.vcr_debug_knn3_waves(waves)
+        try:
+            assert (np.sort(nat.knn(dev(xyz4), None, k).cpu().numpy(), -1) == ref).all(), waves
+        finally:
+            L.vcr_debug_knn3_waves(0)
 
 
 def test_knn_duplicates_drop_rank0(nat):

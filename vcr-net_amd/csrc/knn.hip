@@ -16,16 +16,15 @@
 //          (CPU sgemm = k-ascending fma chain; verified), so the feature-space neighbour sets never flip.
 //          Operands go global -> registers (candidate tiles are L2-resident); LDS holds the survivor lists.
 // C == 4 : Cartesian xyz4 rows, one lane per query, candidates broadcast from LDS 16 at a time, VALU.
-//          A block's two waves split the candidates in interleaved halves; two sorted lists A, B merge into
-//          the top-K SET with K compare-selects, C[i] = max(A[i], B[K-1-i]).
+//          A block's 2-8 waves split the candidates in interleaved groups; their sorted lists are combined by a
+//          tree of bitonic sorted merges (merge_sorted).
 #include "common.h"
 
 namespace {
 
 constexpr int PEND = 32;            // survivor slots per (lane) sub-list between merges
 constexpr int TILE = 32;            // candidates per MFMA tile
-// slots of one wave's survivor area ([slot][64 lanes], values + indices); also reused as [KS][64] merge scratch
-template <int KS> constexpr int area_slots() { return KS > PEND ? KS : PEND; }
+template <int KS> constexpr int knn3_slots() { return KS > 24 ? KS : 24; }   // Cartesian kernel: small areas = more waves per CU
 
 __device__ __forceinline__ bool lex_gt(float d, int j, float v, int id) { return d > v || (d == v && j < id); }
 
@@ -57,43 +56,6 @@ struct TopList {
     v[0] = fmaxf(v[0], d);
   }
 };
-
-// Merge this lane's sorted list with another sorted list stored in LDS as [KS][stride] (column `col`):
-// C[i] = max(A[i], B[KS-1-i]) is the top-KS SET of the union; the overall best is A[0] or B[0].
-// Writes the set minus its best element (rank 0) to out[0..k-1].
-// sv/si: [KS][stride] LDS scratch owned by the calling wave (its survivor area, free by now).
-template <int KS>
-__device__ __forceinline__ void merge_and_store(const TopList<KS>& L, const float* bv, const int* bi, float* sv, int* si,
-                                                int stride, int col, int32_t* out, int k) {
-  int w = 0;
-  if (k + 1 == KS) {                                      // the usual case: keep everything but the best
-    const int top = lex_gt(bv[col], bi[col], L.v[0], L.id[0]) ? bi[col] : L.id[0];
-#pragma unroll
-    for (int t = 0; t < KS; ++t) {
-      const float ov = bv[(KS - 1 - t) * stride + col];
-      const int oi = bi[(KS - 1 - t) * stride + col];
-      const int pick = lex_gt(ov, oi, L.v[t], L.id[t]) ? oi : L.id[t];
-      if (pick != top && w < k) out[w++] = pick;
-    }
-    return;
-  }
-  // k + 1 < KS (uncommon): exact ranks inside the unsorted set, through LDS to keep registers free
-#pragma unroll
-  for (int t = 0; t < KS; ++t) {
-    const float ov = bv[(KS - 1 - t) * stride + col];
-    const int oi = bi[(KS - 1 - t) * stride + col];
-    const bool o = lex_gt(ov, oi, L.v[t], L.id[t]);
-    sv[t * stride + col] = o ? ov : L.v[t];
-    si[t * stride + col] = o ? oi : L.id[t];
-  }
-  for (int t = 0; t < KS; ++t) {
-    const float vt = sv[t * stride + col];
-    const int it = si[t * stride + col];
-    int rank = 0;
-    for (int u = 0; u < KS; ++u) rank += lex_gt(sv[u * stride + col], si[u * stride + col], vt, it) ? 1 : 0;
-    if (rank >= 1 && rank <= k && w < k) out[w++] = it;
-  }
-}
 
 // Survivor list of one wave: [slot][lane] so a wave's pushes hit 64 consecutive words.
 struct Pending {
@@ -226,23 +188,60 @@ __global__ __launch_bounds__(256, (KS > 21 ? 1 : 2)) void knn64_kernel(vcr_knn_a
   }
 }
 
-// ---------------------------------------------------------------- C == 4 (xyz4, VALU)
-// Block = 2 waves over the same 64 queries; wave s scans candidate groups s, s+2, ... (16 candidates each).
+// Sorted merge of this lane's list with another sorted list held in LDS as [KS][64] (column `lane`):
+// X[i] = max(A'[i], B'[H-1-i]) over the lists padded with -inf to H entries is a bitonic sequence that holds
+// the top-H of the union; a log2(H)-stage bitonic network sorts it, the first KS entries are the new list.
+// Order: value descending, index ascending (exact, so the result does not depend on how candidates were split).
 template <int KS>
-__global__ __launch_bounds__(128) void knn3_kernel(vcr_knn_args a) {
+__device__ __forceinline__ void merge_sorted(TopList<KS>& L, const float* bv, const int* bi, int lane) {
+  constexpr int H = KS <= 32 ? 32 : 64;
+  float xv[H];
+  int xi[H];
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const int jb = H - 1 - i;
+    const float av = i < KS ? L.v[i] : VCR_NEG_INF;
+    const int ai = i < KS ? L.id[i] : 0x7fffffff;
+    const float ov = jb < KS ? bv[jb * 64 + lane] : VCR_NEG_INF;
+    const int oi = jb < KS ? bi[jb * 64 + lane] : 0x7fffffff;
+    const bool o = lex_gt(ov, oi, av, ai);
+    xv[i] = o ? ov : av;
+    xi[i] = o ? oi : ai;
+  }
+#pragma unroll
+  for (int d = H / 2; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      if ((i & d) == 0) {
+        const bool sw = lex_gt(xv[i + d], xi[i + d], xv[i], xi[i]);
+        const float hv = sw ? xv[i + d] : xv[i], lv = sw ? xv[i] : xv[i + d];
+        const int hi = sw ? xi[i + d] : xi[i], li = sw ? xi[i] : xi[i + d];
+        xv[i] = hv; xi[i] = hi; xv[i + d] = lv; xi[i + d] = li;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < KS; ++t) { L.v[t] = xv[t]; L.id[t] = xi[t]; }
+}
+
+// ---------------------------------------------------------------- C == 4 (xyz4, VALU)
+// Block = 2, 4 or 8 waves over the same 64 queries (one lane per query); wave s scans candidate groups
+// s, s + nw, ... (16 candidates each, fetched as wave-uniform 16-B reads: one L1/L2 broadcast per candidate, no
+// LDS copy of the cloud -- the kernel is latency-bound and LDS is what limits the waves per CU).  The waves'
+// sorted lists are combined by a binary tree of merge_sorted() steps through LDS; wave 0 writes ranks 1..k.
+template <int KS>
+__global__ __launch_bounds__(512) void knn3_kernel(vcr_knn_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, s = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int b = blockIdx.y;
-  constexpr int AS = area_slots<KS>() * 64;
+  constexpr int PEND3 = knn3_slots<KS>();               // survivor slots of this kernel (>= KS for the merge hand-off)
+  constexpr int AS = PEND3 * 64;
   float* pv = reinterpret_cast<float*>(smem) + s * (2 * AS);
   int* pi = reinterpret_cast<int*>(pv + AS);
   int cnt = 0;
-  f32x4* cand = reinterpret_cast<f32x4*>(smem + 2 * 2 * AS * 4);
   const float* xb = a.x + (size_t)b * a.N * a.ldx;
-  for (int i = threadIdx.x; i < a.N; i += 128) cand[i] = ld4(xb + (size_t)i * a.ldx);
-  __syncthreads();
   const int qi = blockIdx.x * 64 + lane;
-  const f32x4 qv = cand[min(qi, a.N - 1)];
+  const f32x4 qv = ld4(xb + (size_t)min(qi, a.N - 1) * a.ldx);
   TopList<KS> L;
   L.init();
   float thr = VCR_NEG_INF;
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(128) void knn3_kernel(vcr_knn_args a) {
     for (int i = 0; __any(i < cnt); ++i) {
       const float d = i < cnt ? dn : VCR_NEG_INF;
       const int j = jn;
-      const int nx = min(i + 1, PEND - 1);
+      const int nx = min(i + 1, PEND3 - 1);
       dn = pv[nx * 64 + lane];
       jn = pi[nx * 64 + lane];
       L.template insert<false>(d, j);                    // this lane's stream is index-sorted
@@ -261,12 +260,14 @@ __global__ __launch_bounds__(128) void knn3_kernel(vcr_knn_args a) {
     thr = L.v[KS - 1];
   };
   const int ngroups = (a.N + 15) / 16;
-  for (int grp = s; grp < ngroups; grp += 2) {
+  int it = 0;
+  for (int grp = s; grp < ngroups; grp += nw, ++it) {
     const int j0 = grp * 16;
-    if (grp < 6 || __any(cnt > PEND - 16)) drain();       // early groups: settle the threshold quickly
+    if (it < 3 || __any(cnt > PEND3 - 16)) drain();       // early groups: settle the threshold quickly
     f32x4 c[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) c[u] = cand[min(j0 + u, a.N - 1)];   // 16 LDS broadcasts in flight
+    for (int u = 0; u < 16; ++u)                          // 16 wave-uniform 16-B reads in flight (L1/L2 broadcasts)
+      c[u] = ld4(xb + (size_t)min(j0 + u, a.N - 1) * a.ldx);
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int j = j0 + u;
@@ -276,15 +277,26 @@ __global__ __launch_bounds__(128) void knn3_kernel(vcr_knn_args a) {
     }
   }
   drain();
-  float* mv = reinterpret_cast<float*>(smem) + 2 * AS;              // wave 1's survivor area, now free
-  int* mi = reinterpret_cast<int*>(mv + AS);
-  if (s == 1) {
+  for (int step = 1; step < nw; step <<= 1) {             // tree merge: wave s absorbs wave s + step
+    if ((s & (2 * step - 1)) == step) {
 #pragma unroll
-    for (int t = 0; t < KS; ++t) { mv[t * 64 + lane] = L.v[t]; mi[t * 64 + lane] = L.id[t]; }
+      for (int t = 0; t < KS; ++t) { pv[t * 64 + lane] = L.v[t]; pi[t * 64 + lane] = L.id[t]; }
+    }
+    __syncthreads();
+    if ((s & (2 * step - 1)) == 0 && s + step < nw) {
+      const float* ov = reinterpret_cast<const float*>(smem) + (s + step) * (2 * AS);
+      merge_sorted<KS>(L, ov, reinterpret_cast<const int*>(ov + AS), lane);
+    }
   }
-  __syncthreads();
-  if (s == 0 && qi < a.N) merge_and_store<KS>(L, mv, mi, pv, pi, 64, lane, a.idx + ((size_t)b * a.N + qi) * a.k, a.k);
+  if (s == 0 && qi < a.N) {
+    int32_t* o = a.idx + ((size_t)b * a.N + qi) * a.k;
+#pragma unroll
+    for (int t = 1; t < KS; ++t)
+      if (t <= a.k) o[t - 1] = L.id[t];
+  }
 }
+
+int g_knn3_waves = 0;   // debug/tuning only (vcr_debug_knn3_waves): 0 = automatic
 
 template <class K>
 int launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const vcr_knn_args& a) {
@@ -295,12 +307,13 @@ int launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const vcr
 
 }  // namespace
 
+extern "C" void vcr_debug_knn3_waves(int w) { g_knn3_waves = w; }
+
 extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->idx) return VCR_EINVAL;
   if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k > 40 || a->k + 1 > a->N || a->N > 65535) return VCR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int ks = a->k <= 20 ? 21 : 41;
-  const size_t pend_bytes = (size_t)2 * (ks > PEND ? ks : PEND) * 64 * 4;   // one wave's survivor area
   if (a->C == 64) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
     dim3 grid((a->N + 127) / 128, a->B);
@@ -310,11 +323,17 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   }
   if (a->C == 4) {
     if (a->ldx < 4 || (a->ldx & 3)) return VCR_EINVAL;
-    const size_t lds = 2 * pend_bytes + (size_t)a->N * 16;
-    if (lds > 160 * 1024) return VCR_EUNSUPPORTED;
+    // Waves per 64 queries.  Splitting the candidates over more waves shortens each wave's serial scan + insert
+    // chain but adds inserts and merge steps in total, so it only pays while the chip is under-filled: keep 2 waves
+    // unless that leaves at most one wave per SIMD (MI355X: 256 CUs x 4 SIMDs), 8 only for very small grids.
+    const long blocks = (long)((a->N + 63) / 64) * a->B;
+    int nw = blocks * 4 <= 1024 ? 8 : blocks * 2 <= 1024 ? 4 : 2;
+    if ((g_knn3_waves & 15) == 2 || (g_knn3_waves & 15) == 4 || (g_knn3_waves & 15) == 8) nw = g_knn3_waves & 15;
+    while (nw > 2 && (size_t)nw * 2 * (ks > 24 ? ks : 24) * 64 * 4 > 160 * 1024) nw >>= 1;
+    const size_t lds = (size_t)nw * 2 * (ks > 24 ? ks : 24) * 64 * 4;
     dim3 grid((a->N + 63) / 64, a->B);
-    if (a->k <= 20) return launch(knn3_kernel<21>, grid, dim3(128), lds, s, *a);
-    return launch(knn3_kernel<41>, grid, dim3(128), lds, s, *a);
+    if (a->k <= 20) return launch(knn3_kernel<21>, grid, dim3(64 * nw), lds, s, *a);
+    return launch(knn3_kernel<41>, grid, dim3(64 * nw), lds, s, *a);
   }
   return VCR_EUNSUPPORTED;
 }
