@@ -82,7 +82,7 @@ struct Pending {
 
 // ---------------------------------------------------------------- C == 64 (MFMA)
 template <int KS>
-__global__ __launch_bounds__(256, (KS > 21 ? 1 : 2)) void knn64_kernel(vcr_knn_args a) {
+__global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, col = lane & 31;
@@ -131,12 +131,16 @@ __global__ __launch_bounds__(256, (KS > 21 ? 1 : 2)) void knn64_kernel(vcr_knn_a
     csq = sqb[c];
   }
   for (int tile = 0; tile < ntiles; ++tile) {
-    f32x4 nraw[16];
+    // k <= 20: the next candidate tile is prefetched as raw rows (64 VGPRs) across the MFMA + selection phase.
+    // k = 40: the 41-entry list leaves no room for that at two waves per SIMD, and two waves hide the load latency
+    // better than one wave with a prefetch (measured), so the tile is loaded after the selection phase instead.
+    constexpr bool PREFETCH = KS <= 21;
+    f32x4 nraw[PREFETCH ? 16 : 1];
     float nsq = 0.f;
-    if (tile + 1 < ntiles) {                            // prefetch next candidate tile (raw rows stay in flight)
+    if (PREFETCH && tile + 1 < ntiles) {                // prefetch next candidate tile (raw rows stay in flight)
       const int c = min((tile + 1) * TILE + col, a.N - 1);
 #pragma unroll
-      for (int m = 0; m < 16; ++m) nraw[m] = ld4(xb + (size_t)c * a.ldx + 4 * m);
+      for (int m = 0; m < (PREFETCH ? 16 : 1); ++m) nraw[m] = ld4(xb + (size_t)c * a.ldx + 4 * m);
       nsq = sqb[c];
     }
     f32x16 acc = {0};
@@ -158,8 +162,22 @@ __global__ __launch_bounds__(256, (KS > 21 ? 1 : 2)) void knn64_kernel(vcr_knn_a
       if (d > thr && j < a.N) pend.push(d, j, lane);
     }
     if (tile + 1 < ntiles) {
-      pick(nraw, cf);
-      csq = nsq;
+      if (PREFETCH) {
+        pick(nraw, cf);
+        csq = nsq;
+      } else {
+        const int c = min((tile + 1) * TILE + col, a.N - 1);
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) {                  // four 64-B quarters of the row: 16 temporaries, not 64
+          f32x4 raw[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) raw[m] = ld4(xb + (size_t)c * a.ldx + 16 * m4 + 4 * m);
+#pragma unroll
+          for (int st = 0; st < 8; ++st)
+            cf[8 * m4 + st] = half ? raw[st >> 1][(st & 1) * 2 + 1] : raw[st >> 1][(st & 1) * 2];
+        }
+        csq = sqb[c];
+      }
     }
   }
   pend.drain(L, lane);
