@@ -242,6 +242,20 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
     ra_[i] = wm * 64 + i * 32 + l31; sa[i] = (ra_[i] >> 1) & 7;
     rb_[i] = wn * 64 + i * 32 + l31; sb[i] = (rb_[i] >> 1) & 7;
   }
+  // The residual tile does not depend on the GEMM: fetch this lane's 16 chunks now, so that the epilogue's
+  // load -> add -> store chain does not start with an HBM round trip (64 VGPRs; the kernel runs 2 waves per SIMD).
+  f32x4 resv[2][8];
+  {
+    const int colr = n0 + wn * 64 + (lane & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int row = m0 + wm * 64 + i * 32 + ps * 4 + (lane >> 4);
+        resv[i][ps] = (p.residual && row < p.M && colr < p.N) ? ld4(p.residual + (size_t)row * p.ldr + colr)
+                                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
   const int nk = p.K / 32;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     if (col < p.N) {
-#pragma unroll 4
+#pragma unroll
       for (int ps = 0; ps < 8; ++ps) {
         const int rl = ps * 4 + (lane >> 4);
         const int row = m0 + wm * 64 + i * 32 + rl;
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
             v = v + bias;
           }
           if (p.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-          if (p.residual) v = v + ld4(p.residual + (size_t)row * p.ldr + col);
+          if (p.residual) v = v + resv[i][ps];
           st4(p.y + (size_t)row * p.ldy + col, v);
           if (STATS_OUT) {                               // the 16 lanes of a row group (= one DPP row) hold this
             float s1 = (v[0] + v[1]) + (v[2] + v[3]);    // wave's 64 columns of the row
