@@ -325,6 +325,139 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
   }
 }
 
+// ---- BK = 16 variant of the LDS-DMA kernel for launches WITHOUT a residual: half-size stages (64-B rows, swizzle
+// pc = lc ^ ((row >> 2) & 3)), 35 KB of LDS per workgroup and ~100 VGPRs, so FOUR workgroups share a CU (4 waves
+// per SIMD from independent workgroups) and the k-step barrier of one is covered by the other three.  Same k order
+// as the BK = 32 kernel: results are bit-identical.
+struct TileG16 { float a[BM][16]; float b[BN][16]; };
+
+template <bool LN_IN, bool STATS_OUT>
+__global__ __launch_bounds__(256, 4) void linear_glds16_kernel(vcr_linear_args p, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  TileG16* tile = reinterpret_cast<TileG16*>(smem);      // [2]
+  float* rowst = reinterpret_cast<float*>(smem + 4 * 32 * 68 * 4);     // [BM][2] (mean, inv) per row (LN_IN only)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, i = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+  }
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // fill mapping: wave w covers rows w*32 + 16i + (lane>>2), physical chunk lane&3 (64-B rows, 16 rows per KiB)
+  const int frow = lane >> 2, fpc = lane & 3;
+  const float* xa[2];
+  const float* wb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wave * 32 + 16 * i + frow;
+    const int lc = fpc ^ ((row >> 2) & 3);
+    xa[i] = p.x + (size_t)min(m0 + row, p.M - 1) * p.ldx + 4 * lc;
+    wb[i] = p.w + (size_t)min(n0 + row, p.N - 1) * p.K + 4 * lc;
+  }
+  auto fill = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      glds16(xa[i] + k0, &tile[buf].a[wave * 32 + 16 * i][0]);
+      glds16(wb[i] + k0, &tile[buf].b[wave * 32 + 16 * i][0]);
+    }
+  };
+  fill(0, 0);
+  if (LN_IN && t < BM) {
+    const float* sp = p.ln_stats_in + (size_t)min(m0 + t, p.M - 1) * p.ln_nseg * 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int sg = 0; sg < p.ln_nseg; ++sg) { s1 += sp[2 * sg]; s2 += sp[2 * sg + 1]; }     // fixed order
+    const float mean = s1 / (float)p.K;
+    const float var = fmaxf((s2 - s1 * mean) / (float)(p.K - 1), 0.f);                      // unbiased, like x.std()
+    rowst[2 * t] = mean;
+    rowst[2 * t + 1] = 1.f / (sqrtf(var) + p.ln_eps);
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
+  int ra_[2], rb_[2], sa[2], sb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ra_[i] = wm * 64 + i * 32 + l31; sa[i] = (ra_[i] >> 2) & 3;
+    rb_[i] = wn * 64 + i * 32 + l31; sb[i] = (rb_[i] >> 2) & 3;
+  }
+  const int nk = p.K / 16;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) fill(cur ^ 1, (kt + 1) * 16);
+    const TileG16& T = tile[cur];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = ld4(&T.a[ra_[i]][4 * ((2 * g + half) ^ sa[i])]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = ld4(&T.b[rb_[j]][4 * ((2 * g + half) ^ sb[j])]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i][s], fb[j][s], acc[i][j]);
+    }
+    __syncthreads();                                     // drains the LDS-DMA (vmcnt(0)) and orders the buffers
+  }
+
+  constexpr int EP = 68;
+  float* ot = reinterpret_cast<float*>(smem) + wave * 32 * EP;
+  const int c4e = (lane & 15) * 4, col = n0 + wn * 64 + c4e;
+  const f32x4 bias = (p.bias && col < p.N) ? ld4(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 csum = (LN_IN && col < p.N) ? ld4(p.ln_colsum + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[acc_row(r, half) * EP + j * 32 + l31] = acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (col < p.N) {
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int rl = ps * 4 + (lane >> 4);
+        const int row = m0 + wm * 64 + i * 32 + rl;
+        if (row < p.M) {
+          f32x4 v = ld4(&ot[rl * EP + c4e]);
+          if (LN_IN) {
+            const float mean = rowst[2 * (wm * 64 + i * 32 + rl)], inv = rowst[2 * (wm * 64 + i * 32 + rl) + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(inv, fmaf(-mean, csum[e], v[e]), bias[e]);
+          } else {
+            v = v + bias;
+          }
+          if (p.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+
+          st4(p.y + (size_t)row * p.ldy + col, v);
+          if (STATS_OUT) {                               // the 16 lanes of a row group (= one DPP row) hold this
+            float s1 = (v[0] + v[1]) + (v[2] + v[3]);    // wave's 64 columns of the row
+            float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            s1 = row16_sum(s1); s2 = row16_sum(s2);
+            if ((lane & 15) == 0) {
+              float* so = p.stats_out + ((size_t)row * (p.N / 64) + (n0 + wn * 64) / 64) * 2;
+              so[0] = s1; so[1] = s2;
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 int g_variant = 0;   // debug/tuning only (vcr_debug_linear_variant): bit0 = BK 16, bit2 = LDS-DMA staging
 
 }  // namespace
@@ -358,10 +491,26 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
     hipLaunchKernelGGL((linear_glds_kernel<LI, SO>), dim3(tiles_m * tiles_n), dim3(256), ldsg, (hipStream_t)stream, *a, \
                        tiles_m, tiles_n);                                                                                \
   } while (0)
-    if (ln_in && st_out) VCR_LIN_LAUNCH(true, true);
+#define VCR_LIN16_LAUNCH(LI, SO)                                                                                        \
+  do {                                                                                                                   \
+    const int lds16g = 4 * 32 * 68 * 4 + (ln_in ? BM * 2 * 4 : 0);                                                       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_glds16_kernel<LI, SO>),                              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds16g);                                      \
+    hipLaunchKernelGGL((linear_glds16_kernel<LI, SO>), dim3(tiles_m * tiles_n), dim3(256), lds16g, (hipStream_t)stream,  \
+                       *a, tiles_m, tiles_n);                                                                            \
+  } while (0)
+    // Without a residual: BK = 16, four workgroups per CU (measured +2-3 % on the qkv / ffn1 / kv projections).
+    // With one: BK = 32 and the residual tile prefetched across the GEMM loop (bit 3 of the debug variant forces BK 32).
+    if (!a->residual && !(g_variant & 8)) {
+      if (ln_in && st_out) VCR_LIN16_LAUNCH(true, true);
+      else if (ln_in) VCR_LIN16_LAUNCH(true, false);
+      else if (st_out) VCR_LIN16_LAUNCH(false, true);
+      else VCR_LIN16_LAUNCH(false, false);
+    } else if (ln_in && st_out) VCR_LIN_LAUNCH(true, true);
     else if (ln_in) VCR_LIN_LAUNCH(true, false);
     else if (st_out) VCR_LIN_LAUNCH(false, true);
     else VCR_LIN_LAUNCH(false, false);
+#undef VCR_LIN16_LAUNCH
 #undef VCR_LIN_LAUNCH
   } else if (g_variant & 1) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
