@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def short(name):
     for key in ("linear_kernel", "sdpa_kernel", "edgeconv_dg_kernel", "softcorr_kernel", "layernorm512_kernel",
                 "knn3_kernel", "knn64_kernel", "gathermax_kernel", "pointwise12_kernel", "rigid_svd_kernel",
-                "rowside_kernel", "linear_glds_kernel", "edgeconv_dg_packed_kernel", "pairscore_kernel", "rankselect_kernel"):
+                "rowside_kernel", "linear_glds16_kernel", "linear_glds_kernel", "edgeconv_dg_packed_kernel", "pairscore_kernel", "rankselect_kernel"):
         if key in name:
             return key + (name[name.index(key) + len(key):].split("(")[0] if "<" in name else "")
     return name[:48]
