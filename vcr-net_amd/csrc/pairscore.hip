@@ -2,11 +2,11 @@
 // head): everything the reference computes from an n_own x n_str score matrix that it materialises
 // and we do not (model/vcrnet_model.py:190-347,402-460, model/transformer.py:35-53).
 //
-// Geometry (same swapped-QK^T scheme as attention.hip): a block owns 32 "owner" points of one sample;
-// their embeddings sit in LDS ([32][E+4], conflict-free ds_read_b128) and are the MFMA B operand, so
-// each lane owns ONE owner column.  The "streamed" points are MFMA rows: wave w walks streamed tiles
-// w, w+4, ... with their embeddings going global -> registers in double-buffered 64-wide chunks.
-// The four waves' per-owner partials are merged through LDS.
+// Geometry (same swapped-QK^T scheme as attention.hip): a block owns 64 (E >= 256) or 32 "owner" points of one
+// sample; their embeddings sit in LDS ([64][E+4], conflict-free ds_read_b128) and are the MFMA B operand, so
+// each lane owns ONE owner column per owner tile.  The "streamed" points are MFMA rows: wave w walks streamed
+// tiles w, w+8, ... with their embeddings going global -> registers in double-buffered 64-wide chunks, each
+// fragment used against both owner tiles.  The waves' per-owner partials are merged through LDS.
 //
 //   op 0  SOFTMAX_PV : corr_o = sum_s softmax_s(score) * xyz_s              (getCopairALL / VcpByDis / DCP)
 //   op 1  STATS      : (max_s score, sum_s exp(score - max), argmax_s)       (row / column soft-max statistics)
@@ -23,32 +23,43 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
-template <int OP>
-__global__ __launch_bounds__(256, 2) void pairscore_kernel(vcr_pairscore_args p) {
+// OT = owner tiles (of 32) per block.  Every block streams ALL streamed rows past its owners, so the L2 traffic per
+// MAC is 1/(32 OT): with one tile the kernel is L2-bandwidth-bound (16 flop/B -> ~6 TB/s at 96 TFLOP/s measured);
+// two tiles, shared by 8 waves, halve that.  Each streamed fragment (MFMA A operand, registers) is then used
+// against both owner tiles (B operand, LDS).
+template <int OP, int OT>
+__global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_kernel(vcr_pairscore_args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NW = 4 * OT;                             // waves per block
+  constexpr int NO = 32 * OT;                            // owners per block
   const int QP = p.E + 4;
-  float* Os = reinterpret_cast<float*>(smem);            // [32][QP] owner embeddings
-  float* mg = Os + 32 * QP;                              // [4 waves][32 owners][5]
+  float* Os = reinterpret_cast<float*>(smem);            // [NO][QP] owner embeddings
+  float* mg = Os + NO * QP;                              // [NW waves][NO owners][5]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.y, o0 = blockIdx.x * 32;
+  const int b = blockIdx.y, o0 = blockIdx.x * NO;
   const int sb = (b + p.str_batch_shift) % p.nbatch;
   const int chunks = p.E / 64;
 
   {
     const int per_row = p.E / 4;
-    for (int i = t; i < 32 * per_row; i += 256) {
+    for (int i = t; i < NO * per_row; i += 64 * NW) {
       const int row = i / per_row, c4 = (i % per_row) * 4;
       const int orow = min(o0 + row, p.n_own - 1);
       st4(&Os[row * QP + c4], ld4(p.own + ((size_t)b * p.n_own + orow) * p.ld_own + c4));
     }
   }
-  const size_t own_row = (size_t)b * p.n_own + min(o0 + l31, p.n_own - 1);
-  const float own_norm = p.score == 1 ? 0.f : p.own_side4[own_row * 4 + 3];
+  size_t own_row[OT];
+  float own_norm[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) {
+    own_row[ot] = (size_t)b * p.n_own + min(o0 + 32 * ot + l31, p.n_own - 1);
+    own_norm[ot] = p.score == 1 ? 0.f : p.own_side4[own_row[ot] * 4 + 3];
+  }
   __syncthreads();
 
   const int ntiles = (p.n_str + 31) / 32;
-  const int my_tiles = (ntiles - w + 3) / 4;             // tiles w, w+4, ...
+  const int my_tiles = (ntiles - w + NW - 1) / NW;       // tiles w, w+NW, ...
   const int nflat = my_tiles * chunks;
   const float* sbase = p.str + (size_t)sb * p.n_str * p.ld_str;
   const float* sside = p.str_side4 ? p.str_side4 + (size_t)sb * p.n_str * 4 : nullptr;
@@ -56,83 +67,98 @@ __global__ __launch_bounds__(256, 2) void pairscore_kernel(vcr_pairscore_args p)
 
   f32x4 bufA[8], bufB[8];
   auto load_chunk = [&](int flat, f32x4* dst) {
-    const int tile = w + 4 * (flat / chunks), c = flat % chunks;
+    const int tile = w + NW * (flat / chunks), c = flat % chunks;
     const int row = min(tile * 32 + l31, p.n_str - 1);
     const float* kp = sbase + (size_t)row * p.ld_str + 64 * c + 4 * half;
 #pragma unroll
     for (int g = 0; g < 8; ++g) dst[g] = ld4(kp + 8 * g);
   };
 
-  float m = VCR_NEG_INF, l = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;   // OP 0/1 state
-  float best = VCR_NEG_INF; int bidx = 0x7fffffff;                 // OP 1 argmax
-  float mass = 0.f;                                                // OP 2
-  f32x16 s = {0};
+  float m[OT], l[OT], ox[OT], oy[OT], oz[OT];            // OP 0/1 state
+  float best[OT]; int bidx[OT];                          // OP 1 argmax
+  float mass[OT];                                        // OP 2
+  f32x16 s[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) {
+    m[ot] = VCR_NEG_INF; l[ot] = ox[ot] = oy[ot] = oz[ot] = 0.f; best[ot] = VCR_NEG_INF; bidx[ot] = 0x7fffffff;
+    mass[ot] = 0.f; s[ot] = f32x16{0};
+  }
   auto compute = [&](int flat, const f32x4* kf) {
-    const int tile = w + 4 * (flat / chunks), c = flat % chunks;
-    if (c == 0) s = f32x16{0};
+    const int tile = w + NW * (flat / chunks), c = flat % chunks;
+    if (c == 0) {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) s[ot] = f32x16{0};
+    }
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-      const f32x4 qv = ld4(&Os[l31 * QP + 64 * c + 8 * g + 4 * half]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s = mfma32(kf[g][e], qv[e], s);
+      for (int ot = 0; ot < OT; ++ot) {
+        const f32x4 qv = ld4(&Os[(32 * ot + l31) * QP + 64 * c + 8 * g + 4 * half]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[ot] = mfma32(kf[g][e], qv[e], s[ot]);
+      }
     }
     if (c != chunks - 1) return;
-    if (p.score == 0) {
-      s = mfma32(half == 0 ? 1.f : 0.f, half == 0 ? -0.5f * own_norm : 0.f, s);
-    } else if (p.score == 2) {
-      const float rn = sside[(size_t)min(tile * 32 + l31, p.n_str - 1) * 4 + 3];
-      s = mfma32(half == 0 ? -0.5f * rn : 0.f, half == 0 ? 1.f : 0.f, s);
-    }
+    float rn = 0.f;
+    if (p.score == 2) rn = sside[(size_t)min(tile * 32 + l31, p.n_str - 1) * 4 + 3];
     f32x4 side[16];
-    float mt = VCR_NEG_INF;
+    if (OP == 0 || p.score == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = tile * 32 + acc_row(r, half);
-      const int jc = min(j, p.n_str - 1);
-      if (OP == 0 || p.score == 0) side[r] = ld4(sside + (size_t)jc * 4);
-      float sc;
-      if (p.score == 0) sc = 2.f * s[r] - side[r][3];
-      else if (p.score == 2) sc = 2.f * s[r] - own_norm;
-      else sc = s[r] * p.scale;
-      s[r] = j < p.n_str ? sc : VCR_NEG_INF;
-      mt = fmaxf(mt, s[r]);
+      for (int r = 0; r < 16; ++r) side[r] = ld4(sside + (size_t)min(tile * 32 + acc_row(r, half), p.n_str - 1) * 4);
     }
-    if (OP == 1 && p.score_out && o0 + l31 < p.n_own) {
-      // keep the scores for the light column / row passes of vcr_scoremass_f32 (the pad past n_str holds -inf)
-      float* srow = p.score_out + (own_row * (size_t)p.ld_score) + tile * 32 + 4 * half;
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) st4(srow + 8 * r4, f32x4{s[4 * r4], s[4 * r4 + 1], s[4 * r4 + 2], s[4 * r4 + 3]});
-    }
-    if (OP == 2) {
+    for (int ot = 0; ot < OT; ++ot) {
+      f32x16& sc16 = s[ot];
+      if (p.score == 0) sc16 = mfma32(half == 0 ? 1.f : 0.f, half == 0 ? -0.5f * own_norm[ot] : 0.f, sc16);
+      else if (p.score == 2) sc16 = mfma32(half == 0 ? -0.5f * rn : 0.f, half == 0 ? 1.f : 0.f, sc16);
+      float mt = VCR_NEG_INF;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = tile * 32 + acc_row(r, half);
-        const int jc = min(j, p.n_str - 1);
-        const float ms = sstat[(size_t)jc * 2], ls = sstat[(size_t)jc * 2 + 1];
-        mass += __builtin_amdgcn_exp2f((s[r] - ms) * LOG2E) / ls;   // exp2(-inf) = 0 past the tail
+        float sc;
+        if (p.score == 0) sc = 2.f * sc16[r] - side[r][3];
+        else if (p.score == 2) sc = 2.f * sc16[r] - own_norm[ot];
+        else sc = sc16[r] * p.scale;
+        sc16[r] = j < p.n_str ? sc : VCR_NEG_INF;
+        mt = fmaxf(mt, sc16[r]);
       }
-      return;
-    }
-    if (OP == 1) {
+      if (OP == 1 && p.score_out && o0 + 32 * ot + l31 < p.n_own) {
+        // keep the scores for the light column / row passes of vcr_scoremass_f32 (the pad past n_str holds -inf)
+        float* srow = p.score_out + (own_row[ot] * (size_t)p.ld_score) + tile * 32 + 4 * half;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+          st4(srow + 8 * r4, f32x4{sc16[4 * r4], sc16[4 * r4 + 1], sc16[4 * r4 + 2], sc16[4 * r4 + 3]});
+      }
+      if (OP == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int jc = min(tile * 32 + acc_row(r, half), p.n_str - 1);
+          const float ms = sstat[(size_t)jc * 2], ls = sstat[(size_t)jc * 2 + 1];
+          mass[ot] += __builtin_amdgcn_exp2f((sc16[r] - ms) * LOG2E) / ls;   // exp2(-inf) = 0 past the tail
+        }
+        continue;
+      }
+      if (OP == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = tile * 32 + acc_row(r, half);
+          if (sc16[r] > best[ot]) { best[ot] = sc16[r]; bidx[ot] = j; }
+        }
+      }
+      mt = fmaxf(mt, xhalf(mt));
+      const float m_new = fmaxf(m[ot], mt);
+      const float alpha = __builtin_amdgcn_exp2f((m[ot] - m_new) * LOG2E);
+      float ls = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int j = tile * 32 + acc_row(r, half);
-        if (s[r] > best) { best = s[r]; bidx = j; }
+        const float pr = __builtin_amdgcn_exp2f((sc16[r] - m_new) * LOG2E);
+        ls += pr;
+        if (OP == 0) { ax = fmaf(pr, side[r][0], ax); ay = fmaf(pr, side[r][1], ay); az = fmaf(pr, side[r][2], az); }
       }
+      l[ot] = l[ot] * alpha + ls;
+      if (OP == 0) { ox[ot] = ox[ot] * alpha + ax; oy[ot] = oy[ot] * alpha + ay; oz[ot] = oz[ot] * alpha + az; }
+      m[ot] = m_new;
     }
-    mt = fmaxf(mt, xhalf(mt));
-    const float m_new = fmaxf(m, mt);
-    const float alpha = __builtin_amdgcn_exp2f((m - m_new) * LOG2E);
-    float ls = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pr = __builtin_amdgcn_exp2f((s[r] - m_new) * LOG2E);
-      ls += pr;
-      if (OP == 0) { ax = fmaf(pr, side[r][0], ax); ay = fmaf(pr, side[r][1], ay); az = fmaf(pr, side[r][2], az); }
-    }
-    l = l * alpha + ls;
-    if (OP == 0) { ox = ox * alpha + ax; oy = oy * alpha + ay; oz = oz * alpha + az; }
-    m = m_new;
   };
 
   if (nflat > 0) load_chunk(0, bufA);
@@ -144,42 +170,45 @@ __global__ __launch_bounds__(256, 2) void pairscore_kernel(vcr_pairscore_args p)
   }
 
   // the two halves of a wave hold disjoint streamed rows of the same owner (same running max)
-  if (OP == 2) {
-    mass += xhalf(mass);
-    if (half == 0) mg[(w * 32 + l31) * 5] = mass;
-  } else {
-    l += xhalf(l);
-    if (OP == 0) { ox += xhalf(ox); oy += xhalf(oy); oz += xhalf(oz); }
-    if (OP == 1) {
-      const float ob = xhalf(best);
-      const int oi = __shfl_xor(bidx, 32, 64);
-      if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-    }
-    if (half == 0) {
-      float* g = mg + (w * 32 + l31) * 5;
-      g[0] = m; g[1] = l;
-      if (OP == 0) { g[2] = ox; g[3] = oy; g[4] = oz; }
-      else { g[2] = best; g[3] = __int_as_float(bidx); }
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) {
+    float* g = mg + (w * NO + 32 * ot + l31) * 5;
+    if (OP == 2) {
+      mass[ot] += xhalf(mass[ot]);
+      if (half == 0) g[0] = mass[ot];
+    } else {
+      l[ot] += xhalf(l[ot]);
+      if (OP == 0) { ox[ot] += xhalf(ox[ot]); oy[ot] += xhalf(oy[ot]); oz[ot] += xhalf(oz[ot]); }
+      if (OP == 1) {
+        const float ob = xhalf(best[ot]);
+        const int oi = __shfl_xor(bidx[ot], 32, 64);
+        if (ob > best[ot] || (ob == best[ot] && oi < bidx[ot])) { best[ot] = ob; bidx[ot] = oi; }
+      }
+      if (half == 0) {
+        g[0] = m[ot]; g[1] = l[ot];
+        if (OP == 0) { g[2] = ox[ot]; g[3] = oy[ot]; g[4] = oz[ot]; }
+        else { g[2] = best[ot]; g[3] = __int_as_float(bidx[ot]); }
+      }
     }
   }
   __syncthreads();
-  if (t < 32 && o0 + t < p.n_own) {
+  if (t < NO && o0 + t < p.n_own) {
     const size_t orow = (size_t)b * p.n_own + o0 + t;
     if (OP == 2) {
       float acc = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc += mg[(i * 32 + t) * 5];
+      for (int i = 0; i < NW; ++i) acc += mg[(i * NO + t) * 5];
       p.mass[orow] = p.accumulate ? p.mass[orow] + acc : acc;
       return;
     }
     float M = VCR_NEG_INF;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) M = fmaxf(M, mg[(i * 32 + t) * 5]);
+    for (int i = 0; i < NW; ++i) M = fmaxf(M, mg[(i * NO + t) * 5]);
     float L = 0.f, X = 0.f, Y = 0.f, Z = 0.f, Bv = VCR_NEG_INF;
     int Bi = 0x7fffffff;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float* g = mg + (i * 32 + t) * 5;
+    for (int i = 0; i < NW; ++i) {
+      const float* g = mg + (i * NO + t) * 5;
       const float a = __builtin_amdgcn_exp2f((g[0] - M) * LOG2E);   // exp2(-inf) = 0 for a wave with no tiles
       L = fmaf(g[1], a, L);
       if (OP == 0) { X = fmaf(g[2], a, X); Y = fmaf(g[3], a, Y); Z = fmaf(g[4], a, Z); }
@@ -246,6 +275,8 @@ __global__ __launch_bounds__(256) void score_rowpass_kernel(vcr_scoremass_args p
   if (lane == 0) p.row_mass[(size_t)b * p.n_rows + i] = acc;
 }
 
+int g_ps_variant = 0;   // debug/tuning only (vcr_debug_pairscore_variant): bit0 = one owner tile per block
+
 int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
   if (!a || !a->own || !a->str) return VCR_EINVAL;
   if (a->nbatch <= 0 || a->n_own <= 0 || a->n_str <= 0 || a->E <= 0 || (a->E % 128) || a->E > 1024) return VCR_EINVAL;
@@ -256,22 +287,29 @@ int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
   if (a->op == 1 && !a->stat2) return VCR_EINVAL;
   if (a->op == 2 && (!a->mass || !a->str_stat2)) return VCR_EINVAL;
   if (a->score_out && (a->op != 1 || (a->ld_score & 3) || a->ld_score < ((a->n_str + 31) & ~31))) return VCR_EINVAL;
-  const int lds = (32 * (a->E + 4) + 4 * 32 * 5) * 4;
+  // two owner tiles per block (8 waves) when their embeddings fit the LDS, one (4 waves) otherwise
+  const int lds2 = (64 * (a->E + 4) + 8 * 64 * 5) * 4, lds1 = (32 * (a->E + 4) + 4 * 32 * 5) * 4;
+  // (narrow scores, E = 128 per attention head: too little MFMA work per block to pay for the half-size grid)
+  const int ot = (lds2 <= 160 * 1024 && a->E >= 256 && !(g_ps_variant & 1)) ? 2 : 1;
+  const int lds = ot == 2 ? lds2 : lds1;
   if (lds > 160 * 1024) return VCR_EUNSUPPORTED;
-  dim3 grid((a->n_own + 31) / 32, a->nbatch);
+  dim3 grid((a->n_own + 32 * ot - 1) / (32 * ot), a->nbatch);
   hipStream_t s = (hipStream_t)stream;
-#define VCR_PS_LAUNCH(OPV)                                                                                              \
+#define VCR_PS_LAUNCH(OPV, OTV)                                                                                         \
   do {                                                                                                                   \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pairscore_kernel<OPV>),                                     \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pairscore_kernel<OPV, OTV>),                                \
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                         \
-    hipLaunchKernelGGL((pairscore_kernel<OPV>), grid, dim3(256), lds, s, *a);                                           \
+    hipLaunchKernelGGL((pairscore_kernel<OPV, OTV>), grid, dim3(256 * OTV), lds, s, *a);                                \
   } while (0)
-  if (a->op == 0) VCR_PS_LAUNCH(0); else if (a->op == 1) VCR_PS_LAUNCH(1); else VCR_PS_LAUNCH(2);
+  if (ot == 2) { if (a->op == 0) VCR_PS_LAUNCH(0, 2); else if (a->op == 1) VCR_PS_LAUNCH(1, 2); else VCR_PS_LAUNCH(2, 2); }
+  else         { if (a->op == 0) VCR_PS_LAUNCH(0, 1); else if (a->op == 1) VCR_PS_LAUNCH(1, 1); else VCR_PS_LAUNCH(2, 1); }
 #undef VCR_PS_LAUNCH
   return VCR_LAUNCH_RC();
 }
 
 }  // namespace
+
+extern "C" void vcr_debug_pairscore_variant(int v) { g_ps_variant = v; }
 
 extern "C" int vcr_pairscore_f32(const vcr_pairscore_args* a, vcr_stream_t stream) { return launch(a, stream); }
 
