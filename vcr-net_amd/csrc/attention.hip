@@ -84,12 +84,14 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
   for (int tile = 0; tile < ntiles; ++tile) {
     if (tile + 1 < ntiles) stage_load(tile + 1);
     f32x16 s = {0};
+    __builtin_amdgcn_s_setprio(2);                       // matrix phases outrank the other workgroup's soft-max VALU
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const f32x4 kf = ld4(&st[cur].k[l31][8 * g + 4 * half]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) s = mfma32(kf[e], qf[g][e], s);
     }
+    __builtin_amdgcn_s_setprio(0);
     float mt = VCR_NEG_INF;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -118,12 +120,14 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
       }
       // MFMA group dg owns the head dims d = 4*i + dg (i = the A-operand lane), so ONE ds_read_b128 of
       // V[key][4*l31 .. 4*l31+3] feeds the four groups of a k-step: 16 wide LDS reads per tile instead of 64 narrow ones.
+      __builtin_amdgcn_s_setprio(2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const f32x4 vf = ld4(&st[cur].v[acc_row(r, half)][4 * l31]);
 #pragma unroll
         for (int d = 0; d < 4; ++d) o[d] = mfma32(vf[d], s[r], o[d]);
       }
+      __builtin_amdgcn_s_setprio(0);
     }
     if (tile + 1 < ntiles) stage_write(cur ^ 1);
     __syncthreads();
