@@ -37,6 +37,8 @@ def parse():
                     help="partial-overlap mode (BASELINE configs[2]): clouds cropped to int(points*0.7507) points, "
                          "key pruning + selectCom/getCopair heads; combine with --points 1024 --batch 24 --iters 3")
     ap.add_argument("--iters", type=int, default=1, help="vcrnetIter refinement passes per step (one C call)")
+    ap.add_argument("--emb-nn", default="lpdnet", choices=["lpdnet", "dgcnn"],
+                    help="feature extractor (--emb_nn of the reference; dgcnn uses seeded weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="print the per-launch table to stderr")
     ap.add_argument("--linear-mode", default="fp32", choices=["fp32", "bf16x3"],
@@ -47,9 +49,9 @@ def parse():
     return ap.parse_args()
 
 
-def model_args(partial=False):
+def model_args(partial=False, emb_nn="lpdnet"):
     from vcrnet_amd import synth
-    return SimpleNamespace(emb_dims=512, cycle=False, emb_nn="lpdnet", pointer="transformer", vcp_nn="topK",
+    return SimpleNamespace(emb_dims=512, cycle=False, emb_nn=emb_nn, pointer="transformer", vcp_nn="topK",
                            partial=partial, overlap2=synth.OVERLAP2_0575 if partial else 0.75, t3d=False, tfea=False,
                            n_blocks=1, dropout=0.0, ff_dims=1024, n_heads=4)
 
@@ -105,8 +107,9 @@ def main():
     from vcrnet_amd import native, shard, synth, weights, workmodel
     from vcrnet_amd.module import VCRNet
 
-    w = weights.generate_weights(1234, lpd=weights.load_lpd_fixture())
-    net = VCRNet(model_args(a.partial))
+    w = (weights.generate_weights(1234, lpd=weights.load_lpd_fixture()) if a.emb_nn == "lpdnet"
+         else weights.generate_weights(1234, emb_nn="dgcnn"))
+    net = VCRNet(model_args(a.partial, a.emb_nn))
     net.load_state_dict(w)
     net.emb_nn.k = a.k
     net.linear_mode = a.linear_mode

@@ -306,6 +306,14 @@ typedef struct {
    * overlap2 is a double because the reference truncates float64 products of it (vcrnet_model.py:208,284). */
   int partial;
   double overlap2;
+  /* emb_kind 1: DGCNN embedding (vcrnet_model.py:90-123 = dcp_model.py:46-79) instead of LPDNet; eval-mode BatchNorm
+   * folded into each bias-free 1x1 conv by the host (w' = w*g/sqrt(var+eps), b' = beta - mean*g/sqrt(var+eps)).
+   * c1_wpq [128,32]: rows 0..63 = conv1 columns 0..2 (neighbour part), rows 64..127 = columns 3..5 (centre part),
+   * K padded 3 -> 32 with zeros; c1_bpq [128] = (0, b1').  c2 [64,64], c3 [128,64], c4 [256,128], c5 [E,512]. */
+  int emb_kind;
+  struct {
+    const float *c1_wpq, *c1_bpq, *c2_w, *c2_b, *c3_w, *c3_b, *c4_w, *c4_b, *c5_w, *c5_b;
+  } dgcnn;
 } vcr_vcrnet_weights;
 
 typedef struct {

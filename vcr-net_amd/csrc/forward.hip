@@ -30,6 +30,8 @@ struct Ws {
   float *rstat, *cstat, *colsum, *rowsum, *score;      // selectCom: [B,N,2] x2, [B,N] x2, [B,N,roundup32(N)]
   int32_t *sel_s, *sel_t, *amax, *pick;                // [B,K1] x3, [B,K2]
   float *so_e, *to_e, *so_s, *to_s, *peak;             // overlap sets: [B,K1,E] x2, [B,K1,4] x2; [B,K1,2]
+  // DGCNN embedding: per-edge activations [2B*N*k, 64 | 64 | 128 | 256]
+  float *eh1, *eh2, *eh3, *eh4;
   // vcrnetIter
   float *cur_cf, *Ri, *ti, *Rb, *tb;
   size_t bytes;
@@ -39,7 +41,7 @@ struct Ws {
 inline int overlap_k1(int N, double o2) { return (int)((double)N * 0.84 * o2); }
 inline int overlap_k2(int N, double o2) { return (int)((double)overlap_k1(N, o2) * 0.52 * o2); }
 
-Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, double o2) {
+Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, double o2, int emb_kind) {
   Bump bp{reinterpret_cast<unsigned char*>(base), 0, 0};
   const size_t M = (size_t)2 * B * N;
   Ws w;
@@ -68,11 +70,27 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
     w.so_s = bp.take<float>(B1 * K1 * 4); w.to_s = bp.take<float>(B1 * K1 * 4);
     w.peak = bp.take<float>(B1 * K1 * 2);
   }
+  if (emb_kind == 1) {
+    const size_t Mk = M * k;
+    w.eh1 = bp.take<float>(Mk * 64); w.eh2 = bp.take<float>(Mk * 64);
+    w.eh3 = bp.take<float>(Mk * 128); w.eh4 = bp.take<float>(Mk * 256);
+  }
   w.cur_cf = bp.take<float>((size_t)B * 3 * N);
   w.Ri = bp.take<float>((size_t)B * 9); w.ti = bp.take<float>((size_t)B * 3);
   w.Rb = bp.take<float>((size_t)B * 9); w.tb = bp.take<float>((size_t)B * 3);
   w.bytes = bp.off + 256;
   return w;
+}
+
+// xin[row][0..31] = (x, y, z, 0, ..., 0): the K = 32 operand of DGCNN's first (split) EdgeConv projection
+__global__ __launch_bounds__(256) void xyz_pad32_kernel(const float* __restrict__ xyz4, float* __restrict__ xin, long M) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;    // one 16-B chunk per thread, 8 chunks per row
+  if (i >= M * 8) return;
+  const long row = i >> 3;
+  const int c = (int)(i & 7);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (c == 0) { v = ld4(xyz4 + row * 4); v[3] = 0.f; }
+  st4(xin + row * 32 + c * 4, v);
 }
 
 struct Runner {
@@ -218,12 +236,56 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     if (W->head_mode != 0 || W->has_pointer != 1) return VCR_EUNSUPPORTED;
     if (!(W->overlap2 > 0.0 && W->overlap2 <= 1.0) || overlap_k2(N, W->overlap2) < 3) return VCR_EINVAL;
   }
-  Ws w = carve(workspace, B, N, k, E, F, W->heads, W->partial, W->overlap2);
+  Ws w = carve(workspace, B, N, k, E, F, W->heads, W->partial, W->overlap2, W->emb_kind);
   if (ws_bytes < w.bytes) return VCR_EWORKSPACE;
   const int M1 = B * N, M2 = 2 * M1;
   Runner R{(hipStream_t)stream, tr};
 #define SP(site) (W->linear_mode == 1 ? W->split.site : nullptr)
 
+  const float* stats_for_ln = (W->has_pointer == 1 && W->linear_mode == 0) ? w.st_emb : nullptr;
+  if (W->emb_kind == 1) {
+    // ---- emb_nn = DGCNN on both clouds (vcrnet_model.py:104-123): one Cartesian kNN, conv1 via the neighbour/centre
+    // split (per-point P/Q + gather), conv2..conv4 as N*k-row GEMMs, max over the k edges after each, conv5 on the
+    // 512-wide concatenation.  BatchNorm (eval mode) is folded into the weights by the host.
+    if (W->linear_mode != 0) return VCR_EUNSUPPORTED;
+    for (int c = 0; c < 2 && R.rc == 0; ++c) {
+      R.mark(c ? "pointwise:tgt" : "pointwise:src");
+      R.ok(vcr_rows4_f32(c ? io->tgt_cf : io->src_cf, w.xyz4 + (size_t)c * M1 * 4, B, N, R.stream));
+    }
+    if (R.rc == 0) {
+      R.mark("knn:xyz");
+      vcr_knn_args a{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3};
+      R.ok(vcr_knn_f32(&a, R.stream));
+    }
+    if (R.rc == 0) {
+      R.mark("pointwise:pad");
+      hipLaunchKernelGGL(xyz_pad32_kernel, dim3((unsigned)(((long)M2 * 8 + 255) / 256)), dim3(256), 0, R.stream, w.xyz4,
+                         w.feat64, (long)M2);
+      R.ok(VCR_LAUNCH_RC());
+    }
+    R.linear("linear:dg_c1_pq", w.feat64, 32, W->dgcnn.c1_wpq, nullptr, W->dgcnn.c1_bpq, w.pq1, 128, M2, 128, 32, 0);
+    const int Mk = M2 * k;
+    auto edge_max = [&](const char* nm, const float* h, int C, int col) {
+      if (R.rc) return;
+      R.mark(nm);
+      vcr_segmax_args a{h, C, M2, k, C, w.cat + col, 512};
+      R.ok(vcr_segmax_f32(&a, R.stream));
+    };
+    if (R.rc == 0) {
+      R.mark("gathermax:dg_c1");
+      vcr_edgerows_args a{w.pq1, 128, 64, w.idx3, k, M2, N, w.eh1, 64};
+      R.ok(vcr_edgerows_f32(&a, R.stream));
+    }
+    edge_max("gathermax:dg_max1", w.eh1, 64, 0);
+    R.linear("linear:dg_c2", w.eh1, 64, W->dgcnn.c2_w, nullptr, W->dgcnn.c2_b, w.eh2, 64, Mk, 64, 64, 1);
+    edge_max("gathermax:dg_max2", w.eh2, 64, 64);
+    R.linear("linear:dg_c3", w.eh2, 64, W->dgcnn.c3_w, nullptr, W->dgcnn.c3_b, w.eh3, 128, Mk, 128, 64, 1);
+    edge_max("gathermax:dg_max3", w.eh3, 128, 128);
+    R.linear("linear:dg_c4", w.eh3, 128, W->dgcnn.c4_w, nullptr, W->dgcnn.c4_b, w.eh4, 256, Mk, 256, 128, 1);
+    edge_max("gathermax:dg_max4", w.eh4, 256, 256);
+    R.linear("linear:conv3", w.cat, 512, W->dgcnn.c5_w, nullptr, W->dgcnn.c5_b, w.emb, E, M2, E, 512, 1, nullptr, 0, nullptr,
+             nullptr, const_cast<float*>(stats_for_ln));
+  } else {
   // ---- emb_nn = LPDNet on both clouds (lpdnet_model.py:103-137)
   for (int c = 0; c < 2 && R.rc == 0; ++c) {
     R.mark(c ? "pointwise:tgt" : "pointwise:src");
@@ -255,6 +317,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   }
   R.linear("linear:conv3", w.cat, 512, W->c3_w, SP(c3), W->c3_b, w.emb, E, M2, E, 512, 1, nullptr, 0, nullptr, nullptr,
            (W->has_pointer == 1 && W->linear_mode == 0) ? w.st_emb : nullptr);
+
+  }
 
   // ---- pointer (transformer.py:264-272) + residual (vcrnet_model.py:504-505)
   const float* head_emb = w.embf;
@@ -386,7 +450,7 @@ __global__ __launch_bounds__(256) void pose_step_kernel(const float* __restrict_
 
 extern "C" size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights* W, int B, int N) {
   if (!W || B <= 0 || N <= 0) return 0;
-  return carve(nullptr, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2).bytes;
+  return carve(nullptr, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind).bytes;
 }
 
 extern "C" int vcr_vcrnet_pairs(const vcr_vcrnet_weights* W, int N) {
@@ -412,7 +476,7 @@ extern "C" int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet
   if (iters == 1) return forward_impl(W, io, ws, bytes, stream, tr);
   const int B = io->B, N = io->N;
   if (B <= 0 || N <= 0) return VCR_EINVAL;
-  const Ws w = carve(ws, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2);
+  const Ws w = carve(ws, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind);
   if (bytes < w.bytes) return VCR_EWORKSPACE;
   for (int it = 0; it < iters; ++it) {
     vcr_vcrnet_io step = *io;
@@ -444,7 +508,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 5; }
+extern "C" int vcr_abi_version(void) { return 6; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

@@ -234,6 +234,23 @@ class VCRNet(nn.Module):
             for k in ("c1_w", "c1_b", "c2_w", "c2_b", "dg1_wpq", "dg1_bpq", "dg2_w", "dg2_b", "sn1_wpq", "sn1_bpq",
                       "c3_w", "c3_b"):
                 setattr(cw, k, native.ptr(P[k]))
+        if self._emb_kind == "dgcnn":
+            # eval-mode BatchNorm folded into the bias-free 1x1 convs (vcrnet_model.py:108-121); conv1 split into its
+            # neighbour / centre halves (get_graph_feature concatenates (x_j, x_i), util.py:197), K padded 3 -> 32
+            def fold(i, eps=1e-5):
+                sc = sd[f"emb_nn.bn{i}.weight"] / torch.sqrt(sd[f"emb_nn.bn{i}.running_var"] + eps)
+                wq = sd[f"emb_nn.conv{i}.weight"].reshape(sd[f"emb_nn.conv{i}.weight"].shape[0], -1)
+                return ((wq * sc.view(-1, 1)).contiguous(),
+                        (sd[f"emb_nn.bn{i}.bias"] - sd[f"emb_nn.bn{i}.running_mean"] * sc).contiguous())
+            w1, b1 = fold(1)
+            wpq = torch.zeros(128, 32, dtype=torch.float32, device=w1.device)
+            wpq[:64, :3], wpq[64:, :3] = w1[:, :3], w1[:, 3:]
+            P["dg.c1_wpq"], P["dg.c1_bpq"] = wpq, torch.cat((torch.zeros_like(b1), b1)).contiguous()
+            for i in (2, 3, 4, 5):
+                P[f"dg.c{i}_w"], P[f"dg.c{i}_b"] = fold(i)
+            cw.emb_kind = 1
+            for f in ("c1_wpq", "c1_bpq", "c2_w", "c2_b", "c3_w", "c3_b", "c4_w", "c4_b", "c5_w", "c5_b"):
+                setattr(cw.dgcnn, f, native.ptr(P["dg." + f]))
         if isinstance(self.pointer, _TransformerParams):
             pre = "pointer.model."
 
@@ -303,7 +320,7 @@ class VCRNet(nn.Module):
         cw.head_mode = 1 if self._vcp == "dist" else 0
         cw.partial, cw.overlap2 = int(self._partial), self._overlap2
         self._packed, self._packed_key = P, key
-        self._cw = cw if self._emb_kind == "lpdnet" else None              # the fused C driver is LPDNet-only
+        self._cw = cw
 
     def _buffers_for(self, B: int, N: int, device) -> Dict[str, torch.Tensor]:
         key = (B, N, device, int(self.emb_nn.k))
@@ -317,7 +334,9 @@ class VCRNet(nn.Module):
     def fused_supported(self) -> bool:
         """True when one vcr_vcrnet_forward_f32 / vcr_vcrnet_iter_f32 call covers this configuration; the other
         variants (DGCNN, VcpAtt, cycle, partial with a non-topK head) run kernel by kernel from composed.py."""
-        if self._emb_kind != "lpdnet" or self.cycle or self._vcp not in ("topK", "dist"):
+        if self.cycle or self._vcp not in ("topK", "dist"):
+            return False
+        if self._emb_kind == "dgcnn" and self.linear_mode == "bf16x3":
             return False
         if self._partial:
             return self._vcp == "topK" and isinstance(self.pointer, _TransformerParams)

@@ -141,6 +141,10 @@ class FoldedW(C.Structure):
     _fields_ = [("w", f32p), ("colsum", f32p), ("bias", f32p)]
 
 
+class DgcnnW(C.Structure):
+    _fields_ = [(n, f32p) for n in ("c1_wpq", "c1_bpq", "c2_w", "c2_b", "c3_w", "c3_b", "c4_w", "c4_b", "c5_w", "c5_b")]
+
+
 class VcrnetWeights(C.Structure):
     _fields_ = [("c1_w", f32p), ("c1_b", f32p), ("c2_w", f32p), ("c2_b", f32p),
                 ("dg1_wpq", f32p), ("dg1_bpq", f32p), ("dg2_w", f32p), ("dg2_b", f32p),
@@ -153,7 +157,7 @@ class VcrnetWeights(C.Structure):
                 ("has_pointer", C.c_int), ("head_mode", C.c_int), ("linear_mode", C.c_int), ("split", SplitW),
                 ("fold_enc_qkv", FoldedW), ("fold_enc_ffn1", FoldedW), ("fold_dec_qkv", FoldedW),
                 ("fold_dec_cross_q", FoldedW), ("fold_dec_cross_kv", FoldedW), ("fold_dec_ffn1", FoldedW),
-                ("partial", C.c_int), ("overlap2", C.c_double)]
+                ("partial", C.c_int), ("overlap2", C.c_double), ("emb_kind", C.c_int), ("dgcnn", DgcnnW)]
 
 
 class VcrnetIo(C.Structure):
@@ -178,7 +182,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 5          # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 6          # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):

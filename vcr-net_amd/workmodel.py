@@ -37,16 +37,25 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
     sym = {"E": E, "2E": 2 * E, "3E": 3 * E, "F": F}
     r = lambda v: sym[v] if isinstance(v, str) else v
     if fam == "pointwise":
+        if site == "pad":
+            return 0.0, 4.0 * M2 * (4 + 32)
         return 2.0 * M1 * (3 * 64 + 64 * 64), 4.0 * M1 * (3 + 4 + 64 + 1)
     if fam == "knn":
         C = 64 if site == "feat64" else 3
         return 2.0 * C * N * N * 2 * B, 4.0 * M2 * ((C if C == 64 else 4) + (1 if C == 64 else 0) + k)
     if fam == "linear":
+        if site.startswith("dg_c"):                        # DGCNN: conv1 split per point, conv2..4 on the N*k edge rows
+            n, kk, rows = {"dg_c1_pq": (128, 32, M2), "dg_c2": (64, 64, M2 * k), "dg_c3": (128, 64, M2 * k),
+                           "dg_c4": (256, 128, M2 * k)}[site]
+            return 2.0 * rows * n * kk, 4.0 * (rows * kk + n * kk + rows * n)
         n, kk = (r(v) for v in _LINEAR_SHAPES[site])
         return 2.0 * M2 * n * kk, 4.0 * (M2 * kk + n * kk + M2 * n)
     if fam == "edgeconv":      # convDG2 on the per-edge features (the per-point half of convDG1 is linear:dg1_pq)
         return 2.0 * M2 * k * 128 * 128, 4.0 * M2 * (k * 128 + 128 + k + 256)
     if fam == "gathermax":
+        if site.startswith("dg_"):
+            C = {"dg_c1": 64, "dg_max1": 64, "dg_max2": 64, "dg_max3": 128, "dg_max4": 256}[site]
+            return 1.0 * M2 * k * C, 4.0 * M2 * (k * C + C)
         return 1.0 * M2 * k * 256, 4.0 * M2 * (k * 256 + 256 + k + 256)
     if fam == "layernorm":
         extra = 1 if site.endswith("+res") else 0
