@@ -287,7 +287,7 @@ typedef struct {
   vcr_ffn_w enc_ffn, dec_ffn;
   int E, F, heads, k;                              /* 512, 1024, 4, 20 */
   int has_pointer;                                 /* 1 transformer, 0 none, 2 identity (emb*2)     */
-  int head_mode;                                   /* 0 neg-distance (topK whole / att), 1 dot/sqrt(E) */
+  int head_mode;                                   /* 0 VcpTopK (neg-distance), 1 VcpByDis / DCP (dot/sqrt(E)), 2 VcpAtt */
   /* linear_mode 0: every 1x1 conv / Linear on v_mfma_f32_32x32x2_f32 (vcr_linear_f32).
    * linear_mode 1: the same products as exact 3-way bf16 splits on the bf16 matrix pipe (vcr_linear_bf16x3_f32);
    * then `split` holds the weights pre-split by vcr_split_bf16x3_f32, in the order of the sites below. */
@@ -300,8 +300,8 @@ typedef struct {
    * vcr_fold_layernorm_f32 (w [N,E], colsum [N], bias [N]).  dec_cross_kv is folded with the ENCODER's final norm. */
   struct vcr_folded { const float *w, *colsum, *bias; } fold_enc_qkv, fold_enc_ffn1, fold_dec_qkv, fold_dec_cross_q,
       fold_dec_cross_kv, fold_dec_ffn1;
-  /* partial-overlap mode (args.partial, vcrnet_model.py:178-187 + transformer.py:35-53; head_mode must be 0):
-   * the decoder's cross-attention keeps the int(N*overlap2) keys with the largest soft-max mass, the head is
+  /* partial-overlap mode (args.partial, vcrnet_model.py:178-187 + transformer.py:35-53): the decoder's
+   * cross-attention keeps the int(N*overlap2) keys with the largest soft-max mass; with head_mode 0 the head is
    * selectCom + getCopair and the outputs hold vcr_vcrnet_pairs() hard pairs per sample instead of N soft ones.
    * overlap2 is a double because the reference truncates float64 products of it (vcrnet_model.py:208,284). */
   int partial;
@@ -314,6 +314,11 @@ typedef struct {
   struct {
     const float *c1_wpq, *c1_bpq, *c2_w, *c2_b, *c3_w, *c3_b, *c4_w, *c4_b, *c5_w, *c5_b;
   } dgcnn;
+  /* head_mode 2: VcpAtt's two Linear(E,E) on the source / target embeddings (head.linears_emb.0/1, [E,E] + [E]) */
+  const float *att_w0, *att_b0, *att_w1, *att_b1;
+  /* args.cycle (vcrnet_model.py:511-513): (R_ba, t_ba) from a second head + solve with the clouds swapped
+   * (soft heads only) instead of the inverse of (R_ab, t_ab) */
+  int cycle;
 } vcr_vcrnet_weights;
 
 typedef struct {
@@ -326,7 +331,7 @@ typedef struct {
 } vcr_vcrnet_io;
 
 size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights*, int B, int N);
-/* Correspondences per sample in corr4/src4: N (whole mode) or int(int(N*0.84*overlap2)*0.52*overlap2) (partial). */
+/* Correspondences per sample in corr4/src4: N, or int(int(N*0.84*overlap2)*0.52*overlap2) for partial + head_mode 0. */
 int vcr_vcrnet_pairs(const vcr_vcrnet_weights*, int N);
 int vcr_vcrnet_forward_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io*, void* workspace,
                            size_t workspace_bytes, vcr_stream_t);

@@ -25,7 +25,8 @@ def check(g, out):
     np.testing.assert_allclose(out[2].cpu().numpy(), g["it0_R"], atol=R_TOL)
     np.testing.assert_allclose(out[3].cpu().numpy(), g["it0_t"], atol=T_TOL)
     np.testing.assert_allclose(out[4].cpu().numpy(), g["it0_R_ba"], atol=R_TOL)
-    np.testing.assert_allclose(out[5].cpu().numpy(), g["it0_t_ba"], atol=T_TOL)
+    # t_ba = -R^T t is derived (vcrnet_model.py:516): it inherits |dR|*|t| + |dt|, so allow 3x the t tolerance
+    np.testing.assert_allclose(out[5].cpu().numpy(), g["it0_t_ba"], atol=3 * T_TOL)
 
 
 def test_dgcnn_embedding():
@@ -78,3 +79,26 @@ def test_dcp_model():
     np.testing.assert_allclose(t_ba.cpu().numpy(), g["t_ba"], atol=T_TOL)
     with pytest.raises(Exception):
         DCP(SimpleNamespace(**{**vars(args), "head": "mlp"}))
+
+
+@pytest.mark.parametrize("kw", [dict(vcp_nn="att"), dict(cycle=True), dict(vcp_nn="dist", cycle=True),
+                                dict(vcp_nn="dist", partial=True, overlap2=0.766), dict(vcp_nn="att", partial=True, overlap2=0.766),
+                                dict(emb_nn="dgcnn", vcp_nn="dist", cycle=True)])
+def test_fused_driver_covers_the_variant_and_matches_kernel_by_kernel(kw):
+    """Head / cycle / partial / embedding variants run as ONE vcr_vcrnet_forward_f32 call and agree with the
+    kernel-by-kernel composition (which the golden tests above pin to the reference)."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import composed, synth
+    net, _ = build_net(**kw)
+    assert net.fused_supported()
+    src, tgt, _, _, _ = synth.make_batch(900, 3, 192)
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    with torch.no_grad():
+        f = net(s, t)
+        c = composed.forward_composed(net, s, t)
+    # the fused driver folds LayerNorm into the linears, the composition runs it as a kernel: fp32-noise apart
+    # (VcpAtt's seeded-random 512x512 projections amplify that noise in the scores: 1e-4 on t for that head)
+    t_tol = 1e-4 if kw.get("vcp_nn") == "att" else 3 * T_TOL
+    for i, tol in ((2, R_TOL), (3, t_tol), (4, R_TOL), (5, t_tol)):
+        np.testing.assert_allclose(f[i].cpu().numpy(), c[i].cpu().numpy(), atol=tol)
+    assert_mostly_close(f[1].cpu().numpy(), c[1].cpu().numpy(), atol=5e-4)

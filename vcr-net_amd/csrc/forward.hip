@@ -232,9 +232,11 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
         W->fold_dec_cross_kv.w && W->fold_dec_ffn1.w))
     return VCR_EINVAL;
   if (((uintptr_t)workspace) & 255) return VCR_EINVAL;
-  if (W->partial) {
-    if (W->head_mode != 0 || W->has_pointer != 1) return VCR_EUNSUPPORTED;
-    if (!(W->overlap2 > 0.0 && W->overlap2 <= 1.0) || overlap_k2(N, W->overlap2) < 3) return VCR_EINVAL;
+  if (W->head_mode < 0 || W->head_mode > 2) return VCR_EINVAL;
+  if (W->partial) {                                      // key pruning in the decoder (+ hard pairs for the topK head)
+    if (W->has_pointer != 1 || (W->cycle && W->head_mode == 0)) return VCR_EUNSUPPORTED;
+    if (!(W->overlap2 > 0.0 && W->overlap2 <= 1.0) || (int)((double)N * W->overlap2) < 1) return VCR_EINVAL;
+    if (W->head_mode == 0 && overlap_k2(N, W->overlap2) < 3) return VCR_EINVAL;
   }
   Ws w = carve(workspace, B, N, k, E, F, W->heads, W->partial, W->overlap2, W->emb_kind);
   if (ws_bytes < w.bytes) return VCR_EWORKSPACE;
@@ -388,19 +390,50 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   }
 
   // ---- head + SVD
-  if (W->partial) {
-    R.partial_head(W, io, w, B, N);
-  } else if (R.rc == 0) {
-    R.mark("softcorr:head");
-    vcr_softcorr_args a{head_emb, E, head_emb + (size_t)M1 * E, E, w.side4, w.side4 + (size_t)M1 * 4,
-                        io->corr4, B, N, N, E, W->head_mode, 1.0f / sqrtf((float)E)};
-    R.ok(vcr_softcorr_f32(&a, R.stream));
+  const bool hard_pairs = W->partial && W->head_mode == 0;       // VcpTopK in partial mode: selectCom + getCopair
+  const float* side = w.side4;
+  if (W->head_mode == 2) {
+    // VcpAtt (vcrnet_model.py:444-449): one Linear per cloud on the final embeddings, then the topK whole-mode scoring
+    // on the projected embeddings (their |.|^2 recomputed); d3 is free once the final LayerNorm has consumed it
+    if (!W->att_w0 || !W->att_w1) return VCR_EINVAL;
+    R.linear("linear:head.att.src", w.embf, E, W->att_w0, nullptr, W->att_b0, w.d3, E, M1, E, E, 0);
+    R.linear("linear:head.att.tgt", w.embf + (size_t)M1 * E, E, W->att_w1, nullptr, W->att_b1, w.d3 + (size_t)M1 * E, E,
+             M1, E, E, 0);
+    if (R.rc == 0) {
+      R.mark("layernorm:rowside.att");
+      vcr_rowside_args a{w.d3, E, M2, E, 1.f, nullptr, E, w.xyz4, w.side4};
+      R.ok(vcr_rowside_f32(&a, R.stream));
+    }
+    head_emb = w.d3;
   }
-  if (R.rc == 0 && !W->partial) {
-    R.mark("rigid_svd:ab");
-    (void)hipMemcpyAsync(io->src4, w.xyz4, (size_t)M1 * 4 * sizeof(float), hipMemcpyDeviceToDevice, R.stream);
-    vcr_rigid_svd_args a{w.xyz4, 4, io->corr4, 4, B, N, io->R_ab, io->t_ab, io->R_ba, io->t_ba, nullptr};
-    R.ok(vcr_rigid_svd_f32(&a, R.stream));
+  auto soft_head = [&](const char* nm, size_t q0, size_t k0, float* corr) {   // rows q0.. are the queries, k0.. the keys
+    if (R.rc) return;
+    R.mark(nm);
+    vcr_softcorr_args a{head_emb + q0 * E, E, head_emb + k0 * E, E, side + q0 * 4, side + k0 * 4,
+                        corr, B, N, N, E, W->head_mode == 1 ? 1 : 0, 1.0f / sqrtf((float)E)};
+    R.ok(vcr_softcorr_f32(&a, R.stream));
+  };
+  if (hard_pairs) {
+    R.partial_head(W, io, w, B, N);
+  } else {
+    soft_head("softcorr:head", 0, (size_t)M1, io->corr4);
+    if (R.rc == 0) {
+      R.mark("rigid_svd:ab");
+      (void)hipMemcpyAsync(io->src4, w.xyz4, (size_t)M1 * 4 * sizeof(float), hipMemcpyDeviceToDevice, R.stream);
+      vcr_rigid_svd_args a{w.xyz4, 4, io->corr4, 4, B, N, io->R_ab, io->t_ab, io->R_ba, io->t_ba, nullptr};
+      R.ok(vcr_rigid_svd_f32(&a, R.stream));
+    }
+    if (W->cycle) {
+      // cycle consistency (vcrnet_model.py:511-513): a second head + solve with the roles swapped gives (R_ba, t_ba)
+      // instead of the inverse of (R_ab, t_ab); the qkv buffer is free and takes the second correspondence set
+      if (!io->R_ba || !io->t_ba) return VCR_EINVAL;
+      soft_head("softcorr:head.ba", (size_t)M1, 0, w.qkv);
+      if (R.rc == 0) {
+        R.mark("rigid_svd:ba");
+        vcr_rigid_svd_args a{w.xyz4 + (size_t)M1 * 4, 4, w.qkv, 4, B, N, io->R_ba, io->t_ba, nullptr, nullptr, nullptr};
+        R.ok(vcr_rigid_svd_f32(&a, R.stream));
+      }
+    }
   }
   if (R.rc == 0 && io->emb_out)
     (void)hipMemcpyAsync(io->emb_out, w.embf, (size_t)M2 * E * sizeof(float), hipMemcpyDeviceToDevice, R.stream);
@@ -455,7 +488,7 @@ extern "C" size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights* W, int B,
 
 extern "C" int vcr_vcrnet_pairs(const vcr_vcrnet_weights* W, int N) {
   if (!W || N <= 0) return 0;
-  return W->partial ? overlap_k2(N, W->overlap2) : N;
+  return (W->partial && W->head_mode == 0) ? overlap_k2(N, W->overlap2) : N;
 }
 
 extern "C" int vcr_vcrnet_forward_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* ws, size_t bytes,
@@ -508,7 +541,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 6; }
+extern "C" int vcr_abi_version(void) { return 7; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

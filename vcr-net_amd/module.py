@@ -317,7 +317,12 @@ class VCRNet(nn.Module):
                     P["split." + site] = native.split_bf16x3(P[key])
                     setattr(cw.split, site, native.ptr(P["split." + site]))
         cw.E, cw.F, cw.heads, cw.k = self.emb_dims, self._ff, self._n_heads, int(self.emb_nn.k)
-        cw.head_mode = 1 if self._vcp == "dist" else 0
+        cw.head_mode = {"topK": 0, "dist": 1, "att": 2}[self._vcp]
+        if self._vcp == "att":
+            for i in (0, 1):
+                P[f"att.w{i}"], P[f"att.b{i}"] = g(f"head.linears_emb.{i}.weight"), g(f"head.linears_emb.{i}.bias")
+                setattr(cw, f"att_w{i}", native.ptr(P[f"att.w{i}"])); setattr(cw, f"att_b{i}", native.ptr(P[f"att.b{i}"]))
+        cw.cycle = int(bool(self.cycle))
         cw.partial, cw.overlap2 = int(self._partial), self._overlap2
         self._packed, self._packed_key = P, key
         self._cw = cw
@@ -332,14 +337,16 @@ class VCRNet(nn.Module):
         return bufs
 
     def fused_supported(self) -> bool:
-        """True when one vcr_vcrnet_forward_f32 / vcr_vcrnet_iter_f32 call covers this configuration; the other
-        variants (DGCNN, VcpAtt, cycle, partial with a non-topK head) run kernel by kernel from composed.py."""
-        if self.cycle or self._vcp not in ("topK", "dist"):
-            return False
+        """True when one vcr_vcrnet_forward_f32 / vcr_vcrnet_iter_f32 call covers this configuration: every
+        embedding / pointer / head / cycle / partial combination except the corner cases below, which run kernel by
+        kernel from composed.py (DGCNN with bf16x3 linears, partial mode without the Transformer, cycle with the
+        partial topK head -- the last one is not defined by the reference either)."""
         if self._emb_kind == "dgcnn" and self.linear_mode == "bf16x3":
             return False
         if self._partial:
-            return self._vcp == "topK" and isinstance(self.pointer, _TransformerParams)
+            if not isinstance(self.pointer, _TransformerParams):
+                return False
+            return not (self.cycle and self._vcp == "topK")
         return True
 
     def _check_call(self, src, tgt):
@@ -389,7 +396,8 @@ class VCRNet(nn.Module):
                                                  C.byref(trace))
         native.check(rc, "vcr_vcrnet_iter_f32" if iters != 1 else "vcr_vcrnet_forward_f32")
         rows = lambda x: x[:, :, :3].transpose(1, 2).contiguous()
-        srcK = rows(src4) if (self._partial or iters != 1) else src      # whole mode returns src itself (:347)
+        hard = self._partial and self._vcp == "topK"
+        srcK = rows(src4) if (hard or iters != 1) else src               # soft heads return src itself (:347)
         out = (srcK, rows(corr4), R_ab, t_ab, R_ba, t_ba)
         return out + (emb,) if want_emb else out
 
