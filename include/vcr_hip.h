@@ -356,6 +356,15 @@ int vcr_vcrnet_forward_traced_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io
 int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io*, int iters, void* workspace,
                         size_t workspace_bytes, vcr_stream_t, vcr_trace* trace);
 
+/* Tuning / test hooks.  PROCESS-GLOBAL and not thread-safe: for benchmarks and tests only (they select between
+ * variants that produce the same results); 0 restores the automatic choice.
+ *   linear   : bit0 register-staged BK 16, bit2 register staging instead of LDS-DMA, bit3 force the BK 32 LDS-DMA kernel
+ *   knn3     : 2 / 4 / 8 = waves per 64 queries of the Cartesian kNN
+ *   pairscore: bit0 one owner tile (32 owners) per block */
+void vcr_debug_linear_variant(int v);
+void vcr_debug_knn3_waves(int w);
+void vcr_debug_pairscore_variant(int v);
+
 /* hipEvent helpers (create / destroy / record / elapsed) bound to the same HIP runtime as the
  * kernels, for hosts without HIP bindings.  Elapsed needs both events completed (synchronise first). */
 int vcr_event_create(void** ev);

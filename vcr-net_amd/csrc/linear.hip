@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 4) void linear_glds16_kernel(vcr_linear_args p
   }
 }
 
-int g_variant = 0;   // debug/tuning only (vcr_debug_linear_variant): bit0 = BK 16, bit2 = LDS-DMA staging
+int g_variant = 0;   // debug/tuning only (vcr_debug_linear_variant, see vcr_hip.h)
 
 }  // namespace
 
