@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
 #pragma unroll
   for (int d = 0; d < 4; ++d) o[d] = f32x16{0};
   float m = VCR_NEG_INF, l = 0.f;
+  const bool fast = DO_PV && p.rowstat == nullptr && p.scale > 0.f;   // wave-uniform
+  const float c2 = p.scale * LOG2E;
 
   stage_load(0);
   stage_write(0);
@@ -92,27 +94,62 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
       for (int e = 0; e < 4; ++e) s = mfma32(kf[e], qf[g][e], s);
     }
     __builtin_amdgcn_s_setprio(0);
-    float mt = VCR_NEG_INF;
+    float mt = VCR_NEG_INF, alpha, ls = 0.f;
+    if (fast) {
+      // no row statistics requested: keep the running maximum in log2 units, m2 = max(raw score) * (scale log2 e),
+      // so that a probability is ONE fma + exp2 of the raw MFMA result (3 VALU ops per score instead of 5)
+      if (!HAS_MASK && tile * 32 + 32 <= p.nk) {         // interior tile: no key to mask (wave-uniform)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = tile * 32 + acc_row(r, half);
-      bool ok = key < p.nk;
-      if (HAS_MASK) ok = ok && p.key_keep[(size_t)kvb * p.nk + min(key, p.nk - 1)] != 0;
-      s[r] = ok ? s[r] * p.scale : VCR_NEG_INF;
-      mt = fmaxf(mt, s[r]);
-    }
-    mt = fmaxf(mt, xhalf(mt));
-    const float m_new = fmaxf(m, mt);
-    const float mref = (m_new == VCR_NEG_INF) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f((m - mref) * LOG2E);
-    float ls = 0.f;
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
+      } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = __builtin_amdgcn_exp2f((s[r] - mref) * LOG2E);
-      ls += s[r];
+        for (int r = 0; r < 16; ++r) {
+          const int key = tile * 32 + acc_row(r, half);
+          bool ok = key < p.nk;
+          if (HAS_MASK) ok = ok && p.key_keep[(size_t)kvb * p.nk + min(key, p.nk - 1)] != 0;
+          s[r] = ok ? s[r] : VCR_NEG_INF;
+          mt = fmaxf(mt, s[r]);
+        }
+      }
+      mt = fmaxf(mt, xhalf(mt)) * c2;
+      const float m_new = fmaxf(m, mt);
+      const float mref = (m_new == VCR_NEG_INF) ? 0.f : m_new;
+      alpha = __builtin_amdgcn_exp2f(m - mref);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -mref));
+        ls += s[r];
+      }
+      m = m_new;
+    } else {
+      if (!HAS_MASK && tile * 32 + 32 <= p.nk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[r] = s[r] * p.scale;
+          mt = fmaxf(mt, s[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = tile * 32 + acc_row(r, half);
+          bool ok = key < p.nk;
+          if (HAS_MASK) ok = ok && p.key_keep[(size_t)kvb * p.nk + min(key, p.nk - 1)] != 0;
+          s[r] = ok ? s[r] * p.scale : VCR_NEG_INF;
+          mt = fmaxf(mt, s[r]);
+        }
+      }
+      mt = fmaxf(mt, xhalf(mt));
+      const float m_new = fmaxf(m, mt);
+      const float mref = (m_new == VCR_NEG_INF) ? 0.f : m_new;
+      alpha = __builtin_amdgcn_exp2f((m - mref) * LOG2E);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __builtin_amdgcn_exp2f((s[r] - mref) * LOG2E);
+        ls += s[r];
+      }
+      m = m_new;
     }
     l = l * alpha + ls;
-    m = m_new;
     if (DO_PV) {
       if (__any(alpha != 1.f)) {
 #pragma unroll
