@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 3)) void linear_kernel(vcr_lin
   constexpr int NPASS = BM / RPP;                        // staging passes per operand
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tile* tile = reinterpret_cast<Tile*>(smem);           // [2]
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS-DMA targets via SALU
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
 
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void linear_glds_kernel(vcr_linear_args p, 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileG* tile = reinterpret_cast<TileG*>(smem);          // [2]
   float* rowst = reinterpret_cast<float*>(smem + 2 * sizeof(TileG));   // [BM][2] (mean, inv) per row (LN_IN only)
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS-DMA targets via SALU
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
   const int nblk = tiles_m * tiles_n;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 4) void linear_glds16_kernel(vcr_linear_args p
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileG16* tile = reinterpret_cast<TileG16*>(smem);      // [2]
   float* rowst = reinterpret_cast<float*>(smem + 4 * 32 * 68 * 4);     // [BM][2] (mean, inv) per row (LN_IN only)
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // scalar: LDS-DMA targets via SALU
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
   const int nblk = tiles_m * tiles_n;
