@@ -154,14 +154,27 @@ int vcr_segmax_f32(const vcr_segmax_args*, vcr_stream_t);
  * kv_batch_shift: keys/values of batch b come from batch (b + shift) % nbatch (decoder cross-attn
  * over the 2B-batched encoder memory).  key_keep: NULL, or uint8 [nbatch, nk] -- keys with 0 are
  * masked out (transformer.py:46-53; exp underflows to exactly 0 for masked_fill(-1e9)).
- * rowstat: NULL or [nbatch,h,nq,2] (max, sum) of the scaled scores -- for the partial path. */
+ * rowstat: NULL or [nbatch,h,nq,2] (max, sum) of the scaled scores -- for the partial path.
+ * score_out: NULL or [nbatch,h,nq,ld_score] -- the scaled scores themselves (needs rowstat; ld_score % 4 == 0 and
+ *            >= nk rounded up to 32, the pad receives -inf), for vcr_keymass_f32. */
 typedef struct {
   const float* q; int ldq; const float* k; int ldk; const float* v; int ldv;
   float* out; int ldo;
   int nbatch, heads, nq, nk; float scale; int kv_batch_shift;
   const uint8_t* key_keep; float* rowstat;
+  float* score_out; int ld_score;
 } vcr_sdpa_args;
 int vcr_sdpa_f32(const vcr_sdpa_args*, vcr_stream_t);
+
+/* ---- key mass of the partial-mode decoder (transformer.py:40): mass[kb][key] = sum over heads and queries of the
+ * soft-max probability that key receives, from the scores and row statistics a statistics-only vcr_sdpa_f32 pass
+ * stored (queries of batch (kb + q_batch_shift) % nbatch attend to the keys of batch kb).  One HBM-bound pass
+ * instead of recomputing the 128-d scores per head. */
+typedef struct {
+  const float* score; int ld; int nbatch, heads, nq, nk;
+  const float* rowstat; int q_batch_shift; float* mass;
+} vcr_keymass_args;
+int vcr_keymass_f32(const vcr_keymass_args*, vcr_stream_t);
 
 /* ---- virtual-correspondence head, whole mode (vcrnet_model.py:334-347, :402-421, dcp_model.py:138-142)
  * corr[i] = sum_j softmax_j(score_ij) * kside4[j].xyz

@@ -91,6 +91,15 @@ def test_attention_key_mass(nat):
     ref_by_qbatch = p.sum(dim=[1, 2])                         # [nb(query batch), N keys]
     ref = torch.roll(ref_by_qbatch, 2, 0)                     # re-index by KEY batch kb = (b+2)%nb
     torch.testing.assert_close(mass.cpu(), ref, atol=2e-4, rtol=2e-5)
+    # the same mass from STORED scores: statistics pass with score_out, then one pass of vcr_keymass_f32
+    xs = torch.full((nb, h, N, (N + 31) // 32 * 32), float("nan"), device="cuda")
+    _, rs2 = nat.sdpa(qd, kd, None, nb, h, N, N, sc, kv_batch_shift=2, want_rowstat=True, pv=False, score_out=xs)
+    assert torch.equal(rs2, rs) and torch.isinf(xs[..., N:]).all()
+    sref = torch.matmul(split(q), split(kk).transpose(-2, -1)) * sc
+    torch.testing.assert_close(xs[..., :N].cpu(), sref, atol=2e-5, rtol=1e-5)
+    mass2 = nat.keymass(xs, rs, N, 2)
+    torch.testing.assert_close(mass2.cpu(), ref, atol=2e-4, rtol=2e-5)
+    torch.testing.assert_close(mass2, mass, atol=1e-4, rtol=1e-5)
 
 
 def _sym_diff(a, b):

@@ -102,13 +102,10 @@ def transformer(net, emb: torch.Tensor, B: int, N: int, rec: Optional[dict] = No
     if net._partial:
         # transformer.py:35-53: soft-max once, total probability mass each KEY receives over heads and queries,
         # keep the int(nk*overlap2) heaviest keys, soft-max again over those only.
-        _, rs = native.sdpa(qc, kvc[:, :E], None, nb, H, N, N, sc, kv_batch_shift=B, want_rowstat=True, pv=False)
-        dk = E // H
-        mass = torch.empty(nb, N, dtype=torch.float32, device=emb.device)
-        for h in range(H):   # owner = keys of batch kb, streamed = queries of batch (kb + B) % nb with their (m, l)
-            native.pairscore(kvc[:, h * dk:(h + 1) * dk], qc[:, h * dk:(h + 1) * dk], nb, N, N, op=2, score=1,
-                             scale=sc, shift=B, str_stat2=rs.view(-1)[h * N * 2:], str_stat_stride=H * N * 2,
-                             mass=mass, accumulate=h > 0)
+        xs = torch.empty(nb, H, N, (N + 31) // 32 * 32, dtype=torch.float32, device=emb.device)
+        _, rs = native.sdpa(qc, kvc[:, :E], None, nb, H, N, N, sc, kv_batch_shift=B, want_rowstat=True, pv=False,
+                            score_out=xs)
+        mass = native.keymass(xs, rs, N, B)               # keys of batch kb are attended by queries of batch (kb+B)%2B
         _, keep = native.rankselect(mass, int(N * net._overlap2), want_order=False, want_mask=True)
         if rec is not None:
             rec.update(key_mass=mass, key_keep=keep)

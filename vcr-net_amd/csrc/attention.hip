@@ -138,6 +138,11 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
           mt = fmaxf(mt, s[r]);
         }
       }
+      if (p.score_out && q < p.nq) {                     // keep the scaled scores for vcr_keymass_f32
+        float* srow = p.score_out + ((((size_t)b * p.heads + head) * p.nq + q) * p.ld_score) + tile * 32 + 4 * half;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) st4(srow + 8 * r4, f32x4{s[4 * r4], s[4 * r4 + 1], s[4 * r4 + 2], s[4 * r4 + 3]});
+      }
       mt = fmaxf(mt, xhalf(mt));
       const float m_new = fmaxf(m, mt);
       const float mref = (m_new == VCR_NEG_INF) ? 0.f : m_new;
@@ -197,13 +202,47 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
   }
 }
 
+// mass[kb][key] = sum_h sum_q exp(S[qb][h][q][key] - m) / l, qb = (kb + shift) % nbatch; 64 keys per block (lanes),
+// the (head, query) rows split over the 4 waves in a fixed order, merged through LDS.
+__global__ __launch_bounds__(256) void keymass_kernel(vcr_keymass_args p) {
+  __shared__ float mg[4][64];
+  const int kb = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int key = blockIdx.x * 64 + lane, kc = min(key, p.nk - 1);
+  const int qb = (kb + p.q_batch_shift) % p.nbatch;
+  const int rows = p.heads * p.nq;                       // (head, query) rows of this query batch, contiguous
+  const float* S = p.score + (size_t)qb * rows * p.ld + kc;
+  const float* rs = p.rowstat + (size_t)qb * rows * 2;
+  const int per = (rows + 3) / 4, r0 = w * per, r1 = min(rows, r0 + per);
+  float acc = 0.f;
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {                          // eight rows in flight per lane; summed in row order
+    float v[8], m8[8], l8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { v[u] = S[(size_t)(r + u) * p.ld]; m8[u] = rs[2 * (r + u)]; l8[u] = rs[2 * (r + u) + 1]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += __builtin_amdgcn_exp2f((v[u] - m8[u]) * LOG2E) / l8[u];
+  }
+  for (; r < r1; ++r) acc += __builtin_amdgcn_exp2f((S[(size_t)r * p.ld] - rs[2 * r]) * LOG2E) / rs[2 * r + 1];
+  mg[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && key < p.nk) p.mass[(size_t)kb * p.nk + key] = ((mg[0][lane] + mg[1][lane]) + mg[2][lane]) + mg[3][lane];
+}
+
 }  // namespace
+
+extern "C" int vcr_keymass_f32(const vcr_keymass_args* a, vcr_stream_t stream) {
+  if (!a || !a->score || !a->rowstat || !a->mass) return VCR_EINVAL;
+  if (a->nbatch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0 || a->ld < a->nk) return VCR_EINVAL;
+  hipLaunchKernelGGL(keymass_kernel, dim3((a->nk + 63) / 64, a->nbatch), dim3(256), 0, (hipStream_t)stream, *a);
+  return VCR_LAUNCH_RC();
+}
 
 extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   if (!a || !a->q || !a->k) return VCR_EINVAL;
   const bool pv = a->out != nullptr;
   if (pv && !a->v) return VCR_EINVAL;
   if (!pv && !a->rowstat) return VCR_EINVAL;
+  if (a->score_out && (!a->rowstat || (a->ld_score & 3) || a->ld_score < ((a->nk + 31) & ~31))) return VCR_EINVAL;
   if (a->nbatch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return VCR_EINVAL;
   if ((a->ldq & 3) || (a->ldk & 3) || (pv && ((a->ldv & 3) || (a->ldo & 3)))) return VCR_EINVAL;
   if (a->ldq < a->heads * 128 || a->ldk < a->heads * 128) return VCR_EINVAL;

@@ -27,6 +27,7 @@ struct Ws {
   float *st_emb, *st_e1, *st_e2, *st_d1, *st_d2;       // [M, E/64, 2] LayerNorm partial sums
   // partial-overlap mode
   float *rowstat, *keymass; uint8_t* keep;             // cross-attention: [2B,H,N,2], [2B,N], [2B,N]
+  float* xscore;                                       // [2B,H,N,roundup32(N)] scaled scores, NULL above 4 GB
   float *rstat, *cstat, *colsum, *rowsum, *score;      // selectCom: [B,N,2] x2, [B,N] x2, [B,N,roundup32(N)]
   int32_t *sel_s, *sel_t, *amax, *pick;                // [B,K1] x3, [B,K2]
   float *so_e, *to_e, *so_s, *to_s, *peak;             // overlap sets: [B,K1,E] x2, [B,K1,4] x2; [B,K1,2]
@@ -44,7 +45,7 @@ inline int overlap_k2(int N, double o2) { return (int)((double)overlap_k1(N, o2)
 Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, double o2, int emb_kind) {
   Bump bp{reinterpret_cast<unsigned char*>(base), 0, 0};
   const size_t M = (size_t)2 * B * N;
-  Ws w;
+  Ws w{};
   w.xyz4 = bp.take<float>(M * 4);   w.feat64 = bp.take<float>(M * 64); w.sq64 = bp.take<float>(M);
   w.idx1 = bp.take<int32_t>(M * k); w.idx3 = bp.take<int32_t>(M * k);
   w.pq1 = bp.take<float>(M * 256);  w.cat = bp.take<float>(M * 512);   w.pq3 = bp.take<float>(M * 512);
@@ -61,6 +62,8 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   if (partial) {
     const size_t K1 = (size_t)overlap_k1(N, o2), K2 = (size_t)overlap_k2(N, o2), B1 = (size_t)B;
     w.rowstat = bp.take<float>(M * heads * 2); w.keymass = bp.take<float>(M); w.keep = bp.take<uint8_t>(M);
+    const size_t xs = M * heads * ((N + 31) & ~31);       // keep the cross-attention scores if they fit 4 GB
+    w.xscore = xs * 4 <= ((size_t)4 << 30) ? bp.take<float>(xs) : nullptr;
     w.rstat = bp.take<float>(B1 * N * 2); w.cstat = bp.take<float>(B1 * N * 2);
     w.colsum = bp.take<float>(B1 * N);    w.rowsum = bp.take<float>(B1 * N);
     w.score = bp.take<float>(B1 * N * ((N + 31) & ~31));
@@ -128,10 +131,11 @@ struct Runner {
   }
   bool sdpa(const char* nm, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
             int ldo, int nb, int heads, int nq, int nk, int shift, const uint8_t* keep = nullptr,
-            float* rowstat = nullptr) {
+            float* rowstat = nullptr, float* score_out = nullptr, int ld_score = 0) {
     if (rc) return false;
     mark(nm);
-    vcr_sdpa_args a{q, ldq, k, ldk, v, ldv, out, ldo, nb, heads, nq, nk, 1.0f / sqrtf(128.f), shift, keep, rowstat};
+    vcr_sdpa_args a{q, ldq, k, ldk, v, ldv, out, ldo, nb, heads, nq, nk, 1.0f / sqrtf(128.f), shift, keep, rowstat,
+                    score_out, ld_score};
     return ok(vcr_sdpa_f32(&a, stream));
   }
   bool pairscore(const char* nm, const vcr_pairscore_args& a) {
@@ -162,14 +166,26 @@ struct Runner {
     const int E = W->E, H = W->heads, nb = 2 * B, dk = E / H;
     const uint8_t* keep = nullptr;
     if (W->partial) {
-      sdpa("sdpa:dec.cross.stats", w.qc, E, w.kvc, 2 * E, nullptr, 0, nullptr, 0, nb, H, N, N, B, nullptr, w.rowstat);
-      for (int h = 0; h < H; ++h) {
-        vcr_pairscore_args a{};
-        a.own = w.kvc + h * dk; a.ld_own = 2 * E; a.str = w.qc + h * dk; a.ld_str = E;
-        a.nbatch = nb; a.n_own = N; a.n_str = N; a.E = dk; a.score = 1; a.scale = 1.0f / sqrtf((float)dk);
-        a.str_batch_shift = B; a.op = 2; a.str_stat2 = w.rowstat + (size_t)h * N * 2;
-        a.str_stat_batch_stride = (long)H * N * 2; a.mass = w.keymass; a.accumulate = h > 0;
-        pairscore("pairscore:dec.cross.keymass", a);
+      if (w.xscore) {
+        // statistics pass that also keeps the scaled scores; the key mass is then one HBM-bound pass over them
+        const int ldS = (N + 31) & ~31;
+        sdpa("sdpa:dec.cross.stats", w.qc, E, w.kvc, 2 * E, nullptr, 0, nullptr, 0, nb, H, N, N, B, nullptr, w.rowstat,
+             w.xscore, ldS);
+        if (rc == 0) {
+          mark("scoremass:dec.cross.keymass");
+          vcr_keymass_args a{w.xscore, ldS, nb, H, N, N, w.rowstat, B, w.keymass};
+          ok(vcr_keymass_f32(&a, stream));
+        }
+      } else {                                           // score matrix too large to keep: recompute it per head
+        sdpa("sdpa:dec.cross.stats", w.qc, E, w.kvc, 2 * E, nullptr, 0, nullptr, 0, nb, H, N, N, B, nullptr, w.rowstat);
+        for (int h = 0; h < H; ++h) {
+          vcr_pairscore_args a{};
+          a.own = w.kvc + h * dk; a.ld_own = 2 * E; a.str = w.qc + h * dk; a.ld_str = E;
+          a.nbatch = nb; a.n_own = N; a.n_str = N; a.E = dk; a.score = 1; a.scale = 1.0f / sqrtf((float)dk);
+          a.str_batch_shift = B; a.op = 2; a.str_stat2 = w.rowstat + (size_t)h * N * 2;
+          a.str_stat_batch_stride = (long)H * N * 2; a.mass = w.keymass; a.accumulate = h > 0;
+          pairscore("pairscore:dec.cross.keymass", a);
+        }
       }
       rank("select:dec.cross.keys", w.keymass, 1, nb, N, (int)((double)N * W->overlap2), nullptr, w.keep, 1);
       keep = w.keep;
@@ -541,7 +557,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 7; }
+extern "C" int vcr_abi_version(void) { return 8; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

@@ -62,7 +62,12 @@ class SdpaArgs(C.Structure):
     _fields_ = [("q", f32p), ("ldq", C.c_int), ("k", f32p), ("ldk", C.c_int), ("v", f32p), ("ldv", C.c_int),
                 ("out", f32p), ("ldo", C.c_int), ("nbatch", C.c_int), ("heads", C.c_int), ("nq", C.c_int),
                 ("nk", C.c_int), ("scale", C.c_float), ("kv_batch_shift", C.c_int), ("key_keep", f32p),
-                ("rowstat", f32p)]
+                ("rowstat", f32p), ("score_out", f32p), ("ld_score", C.c_int)]
+
+
+class KeymassArgs(C.Structure):
+    _fields_ = [("score", f32p), ("ld", C.c_int), ("nbatch", C.c_int), ("heads", C.c_int), ("nq", C.c_int),
+                ("nk", C.c_int), ("rowstat", f32p), ("q_batch_shift", C.c_int), ("mass", f32p)]
 
 
 class SoftcorrArgs(C.Structure):
@@ -176,14 +181,14 @@ _SIGS = {
     "vcr_layernorm_f32": LayerNormArgs, "vcr_rowside_f32": RowsideArgs, "vcr_edgeconv_f32": EdgeconvArgs,
     "vcr_gathermax_f32": GathermaxArgs, "vcr_sdpa_f32": SdpaArgs, "vcr_softcorr_f32": SoftcorrArgs,
     "vcr_rigid_svd_f32": RigidSvdArgs, "vcr_pairscore_f32": PairscoreArgs, "vcr_rankselect_f32": RankselectArgs,
-    "vcr_gather_rows_f32": GatherArgs, "vcr_scoremass_f32": ScoremassArgs, "vcr_make_pairs_f32": MakePairsArgs,
+    "vcr_gather_rows_f32": GatherArgs, "vcr_scoremass_f32": ScoremassArgs, "vcr_keymass_f32": KeymassArgs, "vcr_make_pairs_f32": MakePairsArgs,
     "vcr_edgerows_f32": EdgerowsArgs, "vcr_segmax_f32": SegmaxArgs,
 }
 
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 7          # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 8          # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -393,14 +398,25 @@ def gathermax(pq, Cc, idx, n_per_cloud):
     return y
 
 
-def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None, want_rowstat=False, pv=True):
-    """q [nbatch*nq, >=heads*128] (row views allowed), k/v likewise -> out [nbatch*nq, heads*128]."""
+def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None, want_rowstat=False, pv=True,
+         score_out=None):
+    """q [nbatch*nq, >=heads*128] (row views allowed), k/v likewise -> out [nbatch*nq, heads*128].
+    score_out [nbatch, heads, nq, ld]: also keep the scaled scores (statistics pass of the partial path)."""
     out = _f32(nbatch * nq, heads * 128, device=q.device) if pv else None
     rs = _f32(nbatch, heads, nq, 2, device=q.device) if want_rowstat else None
     call("vcr_sdpa_f32", SdpaArgs(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v) if pv else None,
                                   v.stride(0) if pv else 0, ptr(out), heads * 128 if pv else 0, nbatch, heads, nq, nk,
-                                  scale, kv_batch_shift, ptr(key_keep), ptr(rs)))
+                                  scale, kv_batch_shift, ptr(key_keep), ptr(rs), ptr(score_out),
+                                  score_out.stride(2) if score_out is not None else 0))
     return (out, rs) if want_rowstat else out
+
+
+def keymass(score, rowstat, nk, q_batch_shift):
+    """vcr_keymass_f32: score [nbatch, heads, nq, ld], rowstat [nbatch, heads, nq, 2] -> mass [nbatch, nk] by KEY batch."""
+    nb, h, nq, ld = score.shape
+    mass = _f32(nb, nk, device=score.device)
+    call("vcr_keymass_f32", KeymassArgs(ptr(score), ld, nb, h, nq, nk, ptr(rowstat), q_batch_shift, ptr(mass)))
+    return mass
 
 
 def softcorr(q, k, qside4, kside4, nbatch, nq, nk, mode=0, scale=1.0):

@@ -74,6 +74,8 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
             return 2.0 * B * K1 * K1 * E, 4.0 * 2 * B * K1 * E
         return 2.0 * B * N * N * E, 4.0 * M2 * E           # row/col statistics or mass passes that recompute the scores
     if fam == "scoremass":
+        if site == "dec.cross.keymass":                    # one read of the [2B,H,N,N] scores
+            return 4.0 * 2 * B * 4 * N * N, 4.0 * 2 * B * 4 * N * N
         return 8.0 * B * N * N, 4.0 * 2 * B * N * N
     if fam == "select":
         if site.startswith("gather"):
