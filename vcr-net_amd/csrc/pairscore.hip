@@ -238,13 +238,20 @@ __global__ __launch_bounds__(256) void score_colpass_kernel(vcr_scoremass_args p
   const float* rs = p.row_stat2 + (size_t)b * p.n_rows * 2;
   const int per = (p.n_rows + 3) / 4, i0 = w * per, i1 = min(p.n_rows, i0 + per);
   float cm = VCR_NEG_INF, cl = 0.f, mass = 0.f;
-  for (int i = i0; i < i1; ++i) {
-    const float v = S[(size_t)i * p.ld];
-    const float mi = rs[2 * i], li = rs[2 * i + 1];
+  auto step = [&](float v, float mi, float li) {
     mass += __builtin_amdgcn_exp2f((v - mi) * LOG2E) / li;
     if (v > cm) { cl *= __builtin_amdgcn_exp2f((cm - v) * LOG2E); cm = v; }
     cl += __builtin_amdgcn_exp2f((v - cm) * LOG2E);
+  };
+  int i = i0;
+  for (; i + 8 <= i1; i += 8) {                          // eight rows in flight per lane, consumed in row order
+    float v[8], m8[8], l8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { v[u] = S[(size_t)(i + u) * p.ld]; m8[u] = rs[2 * (i + u)]; l8[u] = rs[2 * (i + u) + 1]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) step(v[u], m8[u], l8[u]);
   }
+  for (; i < i1; ++i) step(S[(size_t)i * p.ld], rs[2 * i], rs[2 * i + 1]);
   mg[w][lane][0] = cm; mg[w][lane][1] = cl; mg[w][lane][2] = mass;
   __syncthreads();
   if (w == 0 && j < p.n_cols) {
@@ -268,6 +275,7 @@ __global__ __launch_bounds__(256) void score_rowpass_kernel(vcr_scoremass_args p
   const float* S = p.score + ((size_t)b * p.n_rows + i) * p.ld;
   const float* cs = p.col_stat2 + (size_t)b * p.n_cols * 2;
   float acc = 0.f;
+#pragma unroll 4
   for (int j = lane; j < p.n_cols; j += 64)
     acc += __builtin_amdgcn_exp2f((S[j] - cs[2 * j]) * LOG2E) / cs[2 * j + 1];
 #pragma unroll
