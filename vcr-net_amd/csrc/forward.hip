@@ -28,6 +28,7 @@ struct Ws {
   // partial-overlap mode
   float *rowstat, *keymass; uint8_t* keep;             // cross-attention: [2B,H,N,2], [2B,N], [2B,N]
   float* xscore;                                       // [2B,H,N,roundup32(N)] scaled scores, NULL above 4 GB
+  int32_t* xorder;                                     // [2B, nkeep] kept keys, heaviest first
   float *rstat, *cstat, *colsum, *rowsum, *score;      // selectCom: [B,N,2] x2, [B,N] x2, [B,N,roundup32(N)]
   int32_t *sel_s, *sel_t, *amax, *pick;                // [B,K1] x3, [B,K2]
   float *so_e, *to_e, *so_s, *to_s, *peak;             // overlap sets: [B,K1,E] x2, [B,K1,4] x2; [B,K1,2]
@@ -64,6 +65,7 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
     w.rowstat = bp.take<float>(M * heads * 2); w.keymass = bp.take<float>(M); w.keep = bp.take<uint8_t>(M);
     const size_t xs = M * heads * ((N + 31) & ~31);       // keep the cross-attention scores if they fit 4 GB
     w.xscore = xs * 4 <= ((size_t)4 << 30) ? bp.take<float>(xs) : nullptr;
+    w.xorder = bp.take<int32_t>(M);
     w.rstat = bp.take<float>(B1 * N * 2); w.cstat = bp.take<float>(B1 * N * 2);
     w.colsum = bp.take<float>(B1 * N);    w.rowsum = bp.take<float>(B1 * N);
     w.score = bp.take<float>(B1 * N * ((N + 31) & ~31));
@@ -187,7 +189,16 @@ struct Runner {
           pairscore("pairscore:dec.cross.keymass", a);
         }
       }
-      rank("select:dec.cross.keys", w.keymass, 1, nb, N, (int)((double)N * W->overlap2), nullptr, w.keep, 1);
+      // the kept keys' K|V rows are gathered into a dense [2B, nkeep, 2E] buffer (hid is free until the FFN) and the
+      // second soft-max runs unmasked over nkeep keys: the same set as masked_fill(-1e9) + softmax, 23 % fewer
+      // score / PV MFMAs at overlap2 = 0.766 and no per-score mask lookups
+      const int nkeep = (int)((double)N * W->overlap2);
+      rank("select:dec.cross.keys", w.keymass, 1, nb, N, nkeep, w.xorder, w.keep, 1);
+      if (W->F >= 2 * E) {                               // hid [2B*N, F] can hold the gathered rows
+        gather("select:gather.kv", w.kvc, 2 * E, N, w.xorder, nb, nkeep, 2 * E, w.hid);
+        sdpa("sdpa:dec.cross", w.qc, E, w.hid, 2 * E, w.hid + E, 2 * E, w.att, E, nb, H, N, nkeep, B);
+        return;
+      }
       keep = w.keep;
     }
     sdpa("sdpa:dec.cross", w.qc, E, w.kvc, 2 * E, w.kvc + E, 2 * E, w.att, E, nb, H, N, N, B, keep);
