@@ -161,7 +161,8 @@ def test_partial_vs_reference_golden(name):
 
 
 def test_partial_module_forward_and_iter():
-    """The nn.Module entry point dispatches partial mode to the composed HIP path; vcrnetIter composes poses."""
+    """The nn.Module entry point runs partial mode through vcr_vcrnet_forward_f32; vcrnetIter (one vcr_vcrnet_iter_f32
+    call) composes the poses on the device."""
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd.module import vcrnetIter
     g = golden("partial_n192_b2_it2")
