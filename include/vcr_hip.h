@@ -54,13 +54,16 @@ int vcr_rows4_f32(const float* x_cf, float* xyz4, int B, int N, vcr_stream_t);
 
 /* ---- kernel 1: fused pairwise-distance + top-k (util/util.py:143-160) ----
  * D_ij = (-sq_j + 2 x_i.x_j) - sq_i ; idx = indices of the k largest D per row after dropping
- * rank 0 ("topk(k+1)[:, :, 1:]"), ties -> lower index first.  C == 64 (feature space, fp32 MFMA)
- * or C == 4 (xyz4 rows; Cartesian, VALU).  k <= 40, N <= 65535. */
+ * rank 0 ("topk(k+1)[:, :, 1:]").  C == 64 (feature space, fp32 MFMA) or C == 4 (xyz4 rows; Cartesian, VALU).
+ * k <= 40, N <= 65535.  Exact ties at the (k+1)-th value: with tie_scratch the kept SET equals what Tensor.topk
+ * (libstdc++ nth_element / partial_sort on the CPU) keeps; without it the lower index wins. */
 typedef struct {
   const float* x; int ldx;            /* [B,N,C] rows                                  */
   const float* sq;                    /* [B,N] squared norms (C==64); ignored for C==4 */
   int B, N, C, k;
   int32_t* idx;                       /* [B,N,k], neighbour index within the cloud     */
+  int32_t* tie_scratch; int tie_cap;  /* optional: [1 + tie_cap] ints of scratch (count, then the rows with a boundary
+                                         tie; 256 entries are plenty: ~1 row in 10^4 ties), N <= 20000 */
 } vcr_knn_args;
 int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
 

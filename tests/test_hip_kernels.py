@@ -363,3 +363,33 @@ def test_linear_with_fused_layernorm(nat):
     assert err <= 5e-5, err
     y_unfused = nat.linear(nat.layernorm(x, dev(a), dev(b)), dev(w1), dev(b1), relu=True)
     assert (y.cpu() - y_unfused.cpu()).abs().max().item() <= 5e-5
+
+
+@pytest.mark.parametrize("N,k", [(1024, 20), (2048, 20), (512, 40), (4096, 40), (333, 5), (1344, 20), (1343, 20)])
+def test_knn_exact_ties_follow_torch_topk(nat, N, k):
+    """Exact distance ties at the k-th neighbour: Tensor.topk on the CPU is libstdc++'s nth_element (or partial_sort
+    when (k+1)*64 <= N) with a value-only comparator; the kernels detect such rows and replay that algorithm, so the
+    neighbour SETS equal the reference's on EVERY row -- here on inputs built to tie massively (integer-grid points
+    and small-integer features, whose distances are exact in fp32)."""
+    rs = np.random.RandomState(N + k)
+    B = 2
+    # Cartesian: distinct points of a coarse integer grid -> thousands of equal distances per row
+    side = int(np.ceil(N ** (1 / 3))) + 1
+    pts = np.stack([rs.permutation(side ** 3)[:N] for _ in range(B)])
+    xyz = np.stack([pts // (side * side), (pts // side) % side, pts % side], 1).astype(np.float32)   # [B,3,N]
+    src = torch.from_numpy(xyz)
+    xyz4 = torch.cat((src.transpose(1, 2), (src ** 2).sum(1).unsqueeze(-1)), -1)
+    got = np.sort(nat.knn(dev(xyz4), None, k).cpu().numpy(), -1)
+    ref = np.sort(oracle.knn_indices(src, k).numpy(), -1)
+    assert (got == ref).all(), f"{int((got != ref).any(-1).sum())} rows differ (xyz)"
+    plain = np.sort(nat.knn(dev(xyz4), None, k, exact_ties=False).cpu().numpy(), -1)
+    assert (plain != ref).any(), "the input was meant to contain boundary ties"
+    # feature space: small non-negative integers in 64 channels (norms and dot products exact in fp32)
+    f = torch.from_numpy(rs.randint(0, 3, size=(B, 64, N)).astype(np.float32))
+    got = np.sort(nat.knn(dev(f.transpose(1, 2)), dev((f ** 2).sum(1)), k).cpu().numpy(), -1)
+    ref = np.sort(oracle.knn_indices(f, k).numpy(), -1)
+    # (duplicate feature vectors make rank 0 itself ambiguous -- exclude rows whose best value is shared)
+    D = oracle.neg_sqdist_knn(f)
+    top2 = torch.topk(D, 2, dim=-1).values
+    ok = (top2[..., 0] != top2[..., 1]).numpy()
+    assert (got == ref)[ok].all(), f"{int((got != ref).any(-1)[ok].sum())} rows differ (features)"

@@ -7,6 +7,12 @@
 //   D_ij = (-sq_j + 2 x_i.x_j) - sq_i      (same association as util.py:157-158)
 //   idx  = top-(k+1) of D_i. by (value desc, index asc), rank 0 dropped (util.py:159); the k kept
 //          indices are written as a SET (unordered) -- every consumer is a max over neighbours.
+//          Exact ties at the (k+1)-th value: Tensor.topk on the CPU is libstdc++'s std::nth_element (or
+//          std::partial_sort when (k+1)*64 <= N) with a value-only comparator, so WHICH of the tied candidates it
+//          keeps is an artefact of introselect's pivoting / the heap's shape.  The lists here carry one entry more
+//          than needed, which makes such a tie visible (about 1 row in 10^4 in fp32); those rows are re-done by
+//          knn_tiebreak_kernel, a sequential replica of the libstdc++ algorithms, so that the neighbour SETS equal
+//          the reference's on every row (validated against torch.topk on tie-heavy inputs).
 //
 // C == 64: v_mfma_f32_32x32x2_f32 with candidates as MFMA rows and queries as MFMA columns, so every lane
 //          owns ONE query column (lanes l and l+32 share a query and split the candidates, their two sorted
@@ -56,6 +62,13 @@ struct TopList {
     v[0] = fmaxf(v[0], d);
   }
 };
+
+// Row whose (k+1)-th and (k+2)-th best values are equal: hand it to knn_tiebreak_kernel (ties[0] = count).
+__device__ __forceinline__ void report_tie(int32_t* ties, int cap, int row) {
+  if (!ties) return;
+  const int pos = atomicAdd(&ties[0], 1);
+  if (pos < cap) ties[1 + pos] = row;
+}
 
 // Survivor list of one wave: [slot][lane] so a wave's pushes hit 64 consecutive words.
 struct Pending {
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
     // k <= 20: the next candidate tile is prefetched as raw rows (64 VGPRs) across the MFMA + selection phase.
     // k = 40: the 41-entry list leaves no room for that at two waves per SIMD, and two waves hide the load latency
     // better than one wave with a prefetch (measured), so the tile is loaded after the selection phase instead.
-    constexpr bool PREFETCH = KS <= 21;
+    constexpr bool PREFETCH = KS <= 22;
     f32x4 nraw[PREFETCH ? 16 : 1];
     float nsq = 0.f;
     if (PREFETCH && tile + 1 < ntiles) {                // prefetch next candidate tile (raw rows stay in flight)
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
     // hipcc (ROCm 7.2) under-pads the MFMA -> v_accvgpr_read hazard of this 16-pass instruction when the
     // accumulator lands in AGPRs (seen only in the 512-register KS=41 build: register 15, the last one written,
     // was read stale).  Tie the wait states to the accumulator itself so they cannot be scheduled away.
-    if (KS > 21) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
+    if (KS > 22) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
 
     if (__any(pend.cnt > PEND - 16)) thr = pend.drain(L, lane);
     const int jbase = tile * TILE;
@@ -199,9 +212,13 @@ __global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
     }
     if (q0 + col < a.N) {
       int32_t* o = a.idx + ((size_t)b * a.N + q0 + col) * a.k;
+      bool tie = false;
 #pragma unroll
-      for (int t = 1; t < KS; ++t)
+      for (int t = 1; t < KS; ++t) {
         if (t <= a.k) o[t - 1] = L.id[t];
+        if (t == a.k + 1) tie = L.v[t] == L.v[t - 1] && L.v[t] > VCR_NEG_INF;   // rank k+2 equals rank k+1
+      }
+      if (tie) report_tie(a.tie_scratch, a.tie_cap, b * a.N + q0 + col);
     }
   }
 }
@@ -308,13 +325,173 @@ __global__ __launch_bounds__(512) void knn3_kernel(vcr_knn_args a) {
   }
   if (s == 0 && qi < a.N) {
     int32_t* o = a.idx + ((size_t)b * a.N + qi) * a.k;
+    bool tie = false;
 #pragma unroll
-    for (int t = 1; t < KS; ++t)
+    for (int t = 1; t < KS; ++t) {
       if (t <= a.k) o[t - 1] = L.id[t];
+      if (t == a.k + 1) tie = L.v[t] == L.v[t - 1] && L.v[t] > VCR_NEG_INF;
+    }
+    if (tie) report_tie(a.tie_scratch, a.tie_cap, b * a.N + qi);
   }
 }
 
 int g_knn3_waves = 0;   // debug/tuning only (vcr_debug_knn3_waves): 0 = automatic
+
+// ---------------------------------------------------------------- exact replica of Tensor.topk's tie-breaking
+// Sequential port of libstdc++'s std::nth_element (__introselect: median-of-three to first, unguarded partition,
+// depth limit 2 log2 n with __heap_select fallback, final insertion sort) and of std::partial_sort's __heap_select,
+// on (value, index) pairs ordered by VALUE ONLY, exactly as ATen's CPU topk runs them (TopKImpl: queue[j] = (x[j], j);
+// partial_sort when k*64 <= n, else nth_element(k-1) + sort of the first k-1).  Only the SET of the first K entries
+// matters here.  One thread per tied row; rows are rare.
+struct PairArr {
+  float* v; int* id;
+  __device__ __forceinline__ bool gt(int a, int b) const { return v[a] > v[b]; }
+  __device__ __forceinline__ void swap(int a, int b) {
+    const float tv = v[a]; v[a] = v[b]; v[b] = tv;
+    const int ti = id[a]; id[a] = id[b]; id[b] = ti;
+  }
+};
+
+__device__ void tb_push_heap(PairArr& q, int first, int hole, int top, float val, int vid) {
+  int parent = (hole - 1) / 2;
+  while (hole > top && q.v[first + parent] > val) {
+    q.v[first + hole] = q.v[first + parent]; q.id[first + hole] = q.id[first + parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  q.v[first + hole] = val; q.id[first + hole] = vid;
+}
+
+__device__ void tb_adjust_heap(PairArr& q, int first, int hole, int len, float val, int vid) {
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (q.v[first + child] > q.v[first + child - 1]) --child;
+    q.v[first + hole] = q.v[first + child]; q.id[first + hole] = q.id[first + child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    q.v[first + hole] = q.v[first + child - 1]; q.id[first + hole] = q.id[first + child - 1];
+    hole = child - 1;
+  }
+  tb_push_heap(q, first, hole, top, val, vid);
+}
+
+__device__ void tb_heap_select(PairArr& q, int first, int middle, int last) {
+  const int len = middle - first;
+  if (len >= 2) {                                        // std::__make_heap
+    for (int parent = (len - 2) / 2;; --parent) {
+      tb_adjust_heap(q, first, parent, len, q.v[first + parent], q.id[first + parent]);
+      if (parent == 0) break;
+    }
+  }
+  for (int i = middle; i < last; ++i) {
+    if (q.v[i] > q.v[first]) {                           // std::__pop_heap(first, middle, i)
+      const float val = q.v[i]; const int vid = q.id[i];
+      q.v[i] = q.v[first]; q.id[i] = q.id[first];
+      tb_adjust_heap(q, first, 0, len, val, vid);
+    }
+  }
+}
+
+__device__ void tb_nth_element(PairArr& q, int n, int nth) {
+  int first = 0, last = n;
+  int depth = 0;
+  for (int m = n; m > 1; m >>= 1) ++depth;               // std::__lg(n)
+  depth *= 2;
+  while (last - first > 3) {
+    if (depth == 0) {
+      tb_heap_select(q, first, nth + 1, last);
+      q.swap(first, nth);
+      return;
+    }
+    --depth;
+    // __unguarded_partition_pivot: median of (first+1, mid, last-1) to first, then partition [first+1, last)
+    const int mid = first + (last - first) / 2, a = first + 1, b = mid, c = last - 1;
+    if (q.gt(a, b)) {
+      if (q.gt(b, c)) q.swap(first, b);
+      else if (q.gt(a, c)) q.swap(first, c);
+      else q.swap(first, a);
+    } else if (q.gt(a, c)) q.swap(first, a);
+    else if (q.gt(b, c)) q.swap(first, c);
+    else q.swap(first, b);
+    int lo = first + 1, hi = last;
+    for (;;) {
+      while (q.gt(lo, first)) ++lo;
+      --hi;
+      while (q.gt(first, hi)) --hi;
+      if (!(lo < hi)) break;
+      q.swap(lo, hi);
+      ++lo;
+    }
+    if (lo <= nth) first = lo; else last = lo;
+  }
+  for (int i = first + 1; i < last; ++i) {               // std::__insertion_sort(first, last)
+    const float val = q.v[i]; const int vid = q.id[i];
+    if (val > q.v[first]) {
+      for (int j = i; j > first; --j) { q.v[j] = q.v[j - 1]; q.id[j] = q.id[j - 1]; }
+      q.v[first] = val; q.id[first] = vid;
+    } else {
+      int j = i;
+      while (val > q.v[j - 1]) { q.v[j] = q.v[j - 1]; q.id[j] = q.id[j - 1]; --j; }
+      q.v[j] = val; q.id[j] = vid;
+    }
+  }
+}
+
+// One block per tied row: all threads recompute the row's N distances with the SAME arithmetic as the main kernels
+// (C == 64: the k-ascending fma chain the MFMA produces, then the -sq_j/2 step, then 2 acc - sq_i; C == 4: the VALU
+// expression of knn3_kernel), thread 0 replays the selection and rewrites the row's k indices.
+__global__ __launch_bounds__(256) void knn_tiebreak_kernel(vcr_knn_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* val = reinterpret_cast<float*>(smem);
+  int* id = reinterpret_cast<int*>(val + a.N);
+  float* qrow = reinterpret_cast<float*>(id + a.N);      // [64]
+  const int count = min(a.tie_scratch[0], a.tie_cap);
+  for (int t = blockIdx.x; t < count; t += gridDim.x) {
+    const int row = a.tie_scratch[1 + t];
+    const int b = row / a.N, qi = row - b * a.N;
+    const float* xb = a.x + (size_t)b * a.N * a.ldx;
+    __syncthreads();
+    if (a.C == 64 && threadIdx.x < 64) qrow[threadIdx.x] = xb[(size_t)qi * a.ldx + threadIdx.x];
+    __syncthreads();
+    for (int j = threadIdx.x; j < a.N; j += blockDim.x) {
+      float d;
+      if (a.C == 64) {
+        const float* c = xb + (size_t)j * a.ldx;
+        f32x4 cr[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) cr[m] = ld4(c + 4 * m);    // the whole row in flight, then the chain
+        float acc = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 64; ++kk) acc = fmaf(cr[kk >> 2][kk & 3], qrow[kk], acc);
+        acc = fmaf(-0.5f * a.sq[(size_t)b * a.N + j], 1.f, acc);
+        d = 2.f * acc - a.sq[(size_t)b * a.N + qi];
+      } else {
+        const f32x4 qv = ld4(xb + (size_t)qi * a.ldx), cv = ld4(xb + (size_t)j * a.ldx);
+        const float dot = fmaf(qv[2], cv[2], fmaf(qv[1], cv[1], qv[0] * cv[0]));
+        d = (2.f * dot - cv[3]) - qv[3];
+      }
+      val[j] = d; id[j] = j;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      PairArr q{val, id};
+      const int K = a.k + 1;                             // topk(k + 1)
+      if ((long)K * 64 <= a.N) tb_heap_select(q, 0, K, a.N);
+      else tb_nth_element(q, a.N, K - 1);
+      int best = 0;                                      // rank 0 = the largest of the K kept (lowest index on ties)
+      for (int i = 1; i < K; ++i)
+        if (val[i] > val[best] || (val[i] == val[best] && id[i] < id[best])) best = i;
+      int32_t* o = a.idx + (size_t)row * a.k;
+      int w = 0;
+      for (int i = 0; i < K; ++i)
+        if (i != best) o[w++] = id[i];
+    }
+  }
+}
 
 template <class K>
 int launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const vcr_knn_args& a) {
@@ -331,15 +508,20 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->idx) return VCR_EINVAL;
   if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k > 40 || a->k + 1 > a->N || a->N > 65535) return VCR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const int ks = a->k <= 20 ? 21 : 41;
+  const int ks = a->k <= 20 ? 22 : 42;                   // k+1 kept entries + one more that exposes boundary ties
+  if (a->tie_scratch) {
+    if (a->tie_cap < 1) return VCR_EINVAL;
+    const hipError_t e = hipMemsetAsync(a->tie_scratch, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  int rc = VCR_EUNSUPPORTED;
   if (a->C == 64) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
     dim3 grid((a->N + 127) / 128, a->B);
     const size_t lds64 = (size_t)4 * 2 * PEND * 64 * 4;
-    if (a->k <= 20) return launch(knn64_kernel<21>, grid, dim3(256), lds64, s, *a);
-    return launch(knn64_kernel<41>, grid, dim3(256), lds64, s, *a);
-  }
-  if (a->C == 4) {
+    rc = a->k <= 20 ? launch(knn64_kernel<22>, grid, dim3(256), lds64, s, *a)
+                    : launch(knn64_kernel<42>, grid, dim3(256), lds64, s, *a);
+  } else if (a->C == 4) {
     if (a->ldx < 4 || (a->ldx & 3)) return VCR_EINVAL;
     // Waves per 64 queries.  Splitting the candidates over more waves shortens each wave's serial scan + insert
     // chain but adds inserts and merge steps in total, so it only pays while the chip is under-filled: keep 2 waves
@@ -350,8 +532,12 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
     while (nw > 2 && (size_t)nw * 2 * (ks > 24 ? ks : 24) * 64 * 4 > 160 * 1024) nw >>= 1;
     const size_t lds = (size_t)nw * 2 * (ks > 24 ? ks : 24) * 64 * 4;
     dim3 grid((a->N + 63) / 64, a->B);
-    if (a->k <= 20) return launch(knn3_kernel<21>, grid, dim3(64 * nw), lds, s, *a);
-    return launch(knn3_kernel<41>, grid, dim3(64 * nw), lds, s, *a);
+    rc = a->k <= 20 ? launch(knn3_kernel<22>, grid, dim3(64 * nw), lds, s, *a)
+                    : launch(knn3_kernel<42>, grid, dim3(64 * nw), lds, s, *a);
   }
-  return VCR_EUNSUPPORTED;
+  if (rc != 0) return rc;
+  // rows with an exact tie at the (k+1)-th value: replay libstdc++'s selection on them (see knn_tiebreak_kernel)
+  const size_t tb_lds = (size_t)a->N * 8 + 256;
+  if (a->tie_scratch && tb_lds <= 160 * 1024) rc = launch(knn_tiebreak_kernel, dim3(64), dim3(256), tb_lds, s, *a);
+  return rc;
 }

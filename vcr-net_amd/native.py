@@ -26,7 +26,7 @@ class PointwiseArgs(C.Structure):
 
 class KnnArgs(C.Structure):
     _fields_ = [("x", f32p), ("ldx", C.c_int), ("sq", f32p), ("B", C.c_int), ("N", C.c_int), ("C", C.c_int),
-                ("k", C.c_int), ("idx", f32p)]
+                ("k", C.c_int), ("idx", f32p), ("tie_scratch", f32p), ("tie_cap", C.c_int)]
 
 
 class LinearArgs(C.Structure):
@@ -188,7 +188,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 8          # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 9          # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -303,11 +303,13 @@ def pointwise(x_cf, w1, b1, w2, b2):
     return xyz4, f64, sq
 
 
-def knn(x, sq, k):
-    """x [B,N,C] rows (C = 64 with sq [B,N], or C = 4 xyz4 rows) -> int32 idx [B,N,k]."""
+def knn(x, sq, k, exact_ties=True):
+    """x [B,N,C] rows (C = 64 with sq [B,N], or C = 4 xyz4 rows) -> int32 idx [B,N,k].  exact_ties: rows whose
+    (k+1)-th and (k+2)-th distances are equal get Tensor.topk's (libstdc++'s) pick instead of the lower index."""
     B, N, Cc = x.shape
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
-    call("vcr_knn_f32", KnnArgs(ptr(x), x.stride(1), ptr(sq), B, N, Cc, k, ptr(idx)))
+    ties = torch.empty(1 + B * N, dtype=torch.int32, device=x.device) if exact_ties else None   # room for every row
+    call("vcr_knn_f32", KnnArgs(ptr(x), x.stride(1), ptr(sq), B, N, Cc, k, ptr(idx), ptr(ties), B * N if exact_ties else 0))
     return idx
 
 
