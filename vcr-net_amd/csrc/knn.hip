@@ -396,11 +396,7 @@ __device__ void tb_heap_select(PairArr& q, int first, int middle, int last) {
   }
 }
 
-__device__ void tb_nth_element(PairArr& q, int n, int nth) {
-  int first = 0, last = n;
-  int depth = 0;
-  for (int m = n; m > 1; m >>= 1) ++depth;               // std::__lg(n)
-  depth *= 2;
+__device__ void tb_nth_element(PairArr& q, int first, int last, int nth, int depth) {
   while (last - first > 3) {
     if (depth == 0) {
       tb_heap_select(q, first, nth + 1, last);
@@ -441,6 +437,79 @@ __device__ void tb_nth_element(PairArr& q, int n, int nth) {
   }
 }
 
+// One __unguarded_partition_pivot pass of introselect on [first, last), run by the whole block with the SAME result
+// as the sequential loop.  With pivot p = v[first] after the median-of-three, the left scan stops at the elements
+// <= p and the right scan at the elements >= p, in order: if A lists the positions > first with v <= p (ascending)
+// and Bd the positions > first with v >= p (descending), the loop swaps A[i] <-> Bd[i] while A[i] < Bd[i] (m swaps)
+// and returns cut = min(A[m], Bd[m-1]) (A[0] when m = 0).  A / Bd are built by an ordered block compaction.
+__device__ int tb_partition_parallel(PairArr& q, int first, int last, int* A, int* Bd, int* red) {
+  const int t = threadIdx.x, nt = blockDim.x;
+  if (t == 0) {
+    const int mid = first + (last - first) / 2, a = first + 1, b = mid, c = last - 1;
+    if (q.gt(a, b)) {
+      if (q.gt(b, c)) q.swap(first, b);
+      else if (q.gt(a, c)) q.swap(first, c);
+      else q.swap(first, a);
+    } else if (q.gt(a, c)) q.swap(first, a);
+    else if (q.gt(b, c)) q.swap(first, c);
+    else q.swap(first, b);
+  }
+  __syncthreads();
+  const float pv = q.v[first];
+  const int n = last - (first + 1);
+  const int per = (n + nt - 1) / nt;
+  const int x0 = first + 1 + t * per, x1 = min(last, x0 + per);
+  int ca = 0, cb = 0;
+  for (int x = x0; x < x1; ++x) { ca += q.v[x] <= pv ? 1 : 0; cb += q.v[x] >= pv ? 1 : 0; }
+  // exclusive prefix of ca over ascending threads, exclusive SUFFIX of cb (threads to the right come first in Bd):
+  // wave-level shuffles + four wave totals through LDS
+  const int lane = t & 63, wv = t >> 6, nwv = nt >> 6;
+  int ia = ca, ib = cb;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int ua = __shfl_up(ia, o, 64), ub = __shfl_down(ib, o, 64);
+    if (lane >= o) ia += ua;
+    if (lane + o < 64) ib += ub;
+  }
+  if (lane == 63) red[wv] = ia;                          // wave totals
+  if (lane == 0) red[8 + wv] = ib;
+  __syncthreads();
+  int offa = ia - ca, offb = ib - cb, sa = 0, sb = 0;
+  for (int i = 0; i < nwv; ++i) {
+    if (i < wv) offa += red[i];
+    if (i > wv) offb += red[8 + i];
+    sa += red[i]; sb += red[8 + i];
+  }
+  __syncthreads();
+  red[16 + t] = offa; red[16 + nt + t] = offb;
+  if (t == 0) { red[2 * nt + 16] = sa; red[2 * nt + 17] = sb; }
+  __syncthreads();
+  const int na = red[2 * nt + 16], nb = red[2 * nt + 17];
+  {
+    int oa = red[16 + t];
+    for (int x = x0; x < x1; ++x) if (q.v[x] <= pv) A[oa++] = x;
+    int ob = red[16 + nt + t];                           // descending order: this chunk's elements from the right
+    for (int x = x1 - 1; x >= x0; --x) if (q.v[x] >= pv) Bd[ob++] = x;
+  }
+  __syncthreads();
+  const int lim = min(na, nb);
+  int mloc = 0;
+  for (int i = t; i < lim; i += nt) mloc += A[i] < Bd[i] ? 1 : 0;   // monotone in i: the count is the first failure
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mloc += __shfl_xor(mloc, o, 64);
+  if (lane == 0) red[wv] = mloc;
+  __syncthreads();
+  int m = 0;
+  for (int i = 0; i < nwv; ++i) m += red[i];
+  int cut;
+  if (m == 0) cut = A[0];
+  else cut = min(m < na ? A[m] : 0x7fffffff, Bd[m - 1]);
+  __syncthreads();                                       // everyone has read A / Bd / red before the swaps reuse LDS
+  for (int i = t; i < m; i += nt) q.swap(A[i], Bd[i]);
+  __syncthreads();
+  return cut;
+}
+
 // One block per tied row: all threads recompute the row's N distances with the SAME arithmetic as the main kernels
 // (C == 64: the k-ascending fma chain the MFMA produces, then the -sq_j/2 step, then 2 acc - sq_i; C == 4: the VALU
 // expression of knn3_kernel), thread 0 replays the selection and rewrites the row's k indices.
@@ -449,6 +518,9 @@ __global__ __launch_bounds__(256) void knn_tiebreak_kernel(vcr_knn_args a) {
   float* val = reinterpret_cast<float*>(smem);
   int* id = reinterpret_cast<int*>(val + a.N);
   float* qrow = reinterpret_cast<float*>(id + a.N);      // [64]
+  int* A = reinterpret_cast<int*>(qrow + 64);            // [N] left stoppers, [N] right stoppers, block scratch
+  int* Bd = A + a.N;
+  int* red = Bd + a.N;                                   // [16 + 2*256 + 2]
   const int count = min(a.tie_scratch[0], a.tie_cap);
   for (int t = blockIdx.x; t < count; t += gridDim.x) {
     const int row = a.tie_scratch[1 + t];
@@ -477,11 +549,26 @@ __global__ __launch_bounds__(256) void knn_tiebreak_kernel(vcr_knn_args a) {
       val[j] = d; id[j] = j;
     }
     __syncthreads();
+    PairArr q{val, id};
+    const int K = a.k + 1;                               // topk(k + 1)
+    const bool use_heap = (long)K * 64 <= a.N;
+    if (!use_heap) {
+      // std::nth_element(K-1): the partition passes over long ranges run on the whole block (see below); the tail
+      // (range <= 64, depth exhaustion, final insertion sort) is finished by thread 0 with the sequential port.
+      int first = 0, last = a.N, depth = 0;
+      for (int m = a.N; m > 1; m >>= 1) ++depth;
+      depth *= 2;
+      while (last - first > 64 && depth > 0) {
+        --depth;
+        const int cut = tb_partition_parallel(q, first, last, A, Bd, red);
+        if (cut <= K - 1) first = cut; else last = cut;
+      }
+      if (threadIdx.x == 0) tb_nth_element(q, first, last, K - 1, depth);
+    } else if (threadIdx.x == 0) {
+      tb_heap_select(q, 0, K, a.N);
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-      PairArr q{val, id};
-      const int K = a.k + 1;                             // topk(k + 1)
-      if ((long)K * 64 <= a.N) tb_heap_select(q, 0, K, a.N);
-      else tb_nth_element(q, a.N, K - 1);
       int best = 0;                                      // rank 0 = the largest of the K kept (lowest index on ties)
       for (int i = 1; i < K; ++i)
         if (val[i] > val[best] || (val[i] == val[best] && id[i] < id[best])) best = i;
@@ -537,7 +624,7 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   }
   if (rc != 0) return rc;
   // rows with an exact tie at the (k+1)-th value: replay libstdc++'s selection on them (see knn_tiebreak_kernel)
-  const size_t tb_lds = (size_t)a->N * 8 + 256;
+  const size_t tb_lds = (size_t)a->N * 16 + 256 + (16 + 2 * 256 + 2) * 4;
   if (a->tie_scratch && tb_lds <= 160 * 1024) rc = launch(knn_tiebreak_kernel, dim3(64), dim3(256), tb_lds, s, *a);
   return rc;
 }
