@@ -437,6 +437,76 @@ __device__ void tb_nth_element(PairArr& q, int first, int last, int nth, int dep
   }
 }
 
+// std::partial_sort's __heap_select(first = 0, middle = K, last = n) with the K-entry heap held ACROSS THE LANES of one
+// wave (lane j = heap[j]; K <= 64): every heap access is a v_readlane / v_writelane with a scalar index instead of a
+// dependent LDS round trip, and the scan over the n - K remaining values tests 64 of them per step.  Same compares,
+// same moves as libstdc++ (__make_heap, then __pop_heap for every v[i] > heap[0]); the values evicted to positions
+// >= K are not written back: nothing reads them again.  Returns with (hv, hid) = the kept set in lanes 0..K-1.
+struct LaneHeap {
+  float hv; int hid; int lane;
+  __device__ __forceinline__ float val(int i) const {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hv), __builtin_amdgcn_readfirstlane(i)));
+  }
+  __device__ __forceinline__ int idx(int i) const {
+    return __builtin_amdgcn_readlane(hid, __builtin_amdgcn_readfirstlane(i));
+  }
+  __device__ __forceinline__ void set(int i, float v, int id) {
+    const int si = __builtin_amdgcn_readfirstlane(i);   // (v, id) are wave-uniform: a lane-select is a writelane
+    hv = lane == si ? v : hv;
+    hid = lane == si ? id : hid;
+  }
+  __device__ void push(int hole, int top, float v, int id) {          // std::__push_heap
+    int parent = (hole - 1) / 2;
+    while (hole > top && val(parent) > v) {
+      set(hole, val(parent), idx(parent));
+      hole = parent;
+      parent = (hole - 1) / 2;
+    }
+    set(hole, v, id);
+  }
+  __device__ void adjust(int hole, int len, float v, int id) {        // std::__adjust_heap
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+      child = 2 * (child + 1);
+      if (val(child) > val(child - 1)) --child;
+      set(hole, val(child), idx(child));
+      hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+      child = 2 * (child + 1);
+      set(hole, val(child - 1), idx(child - 1));
+      hole = child - 1;
+    }
+    push(hole, top, v, id);
+  }
+};
+
+__device__ void tb_heap_select_wave(const float* v, int n, int K, LaneHeap& h, int lane) {
+  h.hv = lane < K ? v[lane] : VCR_NEG_INF;
+  h.hid = lane;
+  h.lane = lane;
+  if (K >= 2) {
+    for (int parent = (K - 2) / 2;; --parent) {
+      h.adjust(parent, K, h.val(parent), h.idx(parent));
+      if (parent == 0) break;
+    }
+  }
+  float top = h.val(0);
+  for (int base = K; base < n; base += 64) {
+    const int x = base + lane;
+    const float c = x < n ? v[x] : VCR_NEG_INF;
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(c > top);
+    while (mask) {
+      const int i = __builtin_ctzll(mask);
+      const float cv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), __builtin_amdgcn_readfirstlane(i)));
+      h.adjust(0, K, cv, base + i);                      // __pop_heap: the candidate replaces the root
+      top = h.val(0);
+      mask = __builtin_amdgcn_ballot_w64(c > top) & ~((2ull << i) - 1ull);
+    }
+  }
+}
+
 // One __unguarded_partition_pivot pass of introselect on [first, last), run by the whole block with the SAME result
 // as the sequential loop.  With pivot p = v[first] after the median-of-three, the left scan stops at the elements
 // <= p and the right scan at the elements >= p, in order: if A lists the positions > first with v <= p (ascending)
@@ -564,8 +634,12 @@ __global__ __launch_bounds__(256) void knn_tiebreak_kernel(vcr_knn_args a) {
         if (cut <= K - 1) first = cut; else last = cut;
       }
       if (threadIdx.x == 0) tb_nth_element(q, first, last, K - 1, depth);
-    } else if (threadIdx.x == 0) {
-      tb_heap_select(q, 0, K, a.N);
+    } else if (threadIdx.x < 64) {
+      // std::partial_sort branch ((k+1)*64 <= N): heap across the lanes of wave 0
+      LaneHeap h;
+      const int lane = threadIdx.x;
+      tb_heap_select_wave(val, a.N, K, h, lane);
+      if (lane < K) { val[lane] = h.hv; id[lane] = h.hid; }           // the kept set, like the sequential port leaves it
     }
     __syncthreads();
     if (threadIdx.x == 0) {
