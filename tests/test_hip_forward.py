@@ -77,29 +77,19 @@ def test_whole_vs_oracle(B, N, kind):
     net, w = build_net()
     src, tgt, _, _, _ = synth.make_batch(200, B, N, kind=kind)
     src_t, tgt_t = torch.from_numpy(src), torch.from_numpy(tgt)
-    rec = {}
-    ref = oracle.vcrnet_forward(w, src_t, tgt_t, oracle.OracleConfig(record=rec))
+    ref = oracle.vcrnet_forward(w, src_t, tgt_t, oracle.OracleConfig())
     with torch.no_grad():
         out = net(src_t.cuda(), tgt_t.cuda())
-    # Tensor.topk on the CPU is an unstable nth_element: when the k-th and (k+1)-th neighbour distances of a point
-    # are EXACTLY equal its pick is an artefact of libstdc++'s pivoting (we take the lower index).  Such rows
-    # (about 1 in 10^4 at fp32) legitimately differ, so samples containing one are excluded from the strict check.
-    k = 20
-    amb = torch.zeros(B, dtype=torch.bool)
-    for side in ("emb_src", "emb_tgt"):
-        for key, feat in (("x64", rec[side]["x64"]), ("xyz", src_t if side == "emb_src" else tgt_t)):
-            if N > k + 1:
-                top = torch.topk(oracle.neg_sqdist_knn(feat), k + 2, dim=-1).values
-                amb |= (top[..., k] == top[..., k + 1]).any(1)
-    assert int(amb.sum()) <= max(1, B // 4), amb
-    keep = ~amb
+    # No sample is excluded: rows whose k-th and (k+1)-th neighbour distances are EXACTLY equal (about 1 in 10^4; the
+    # reference's pick there is an artefact of libstdc++'s nth_element) are replayed by the kNN kernels, so even
+    # those samples match.
     # Tiny clouds (down to N = k+1 = 21, the smallest legal one): the covariance averages over few correspondences,
     # the fp32 oracle itself sits 3e-6 from its fp64 twin there and its multi-threaded rounding varies run to run on
     # the 256-core box, so t gets 3x the tolerance that BASELINE quotes for N >= 768.
     t_tol = 3 * T_TOL if N <= 128 else T_TOL
-    assert_mostly_close(out[1].cpu().numpy()[keep], ref[1].numpy()[keep], atol=5e-4)
-    np.testing.assert_allclose(out[2].cpu().numpy()[keep], ref[2].numpy()[keep], atol=R_TOL)
-    np.testing.assert_allclose(out[3].cpu().numpy()[keep], ref[3].numpy()[keep], atol=t_tol)
+    assert_mostly_close(out[1].cpu().numpy(), ref[1].numpy(), atol=5e-4)
+    np.testing.assert_allclose(out[2].cpu().numpy(), ref[2].numpy(), atol=R_TOL)
+    np.testing.assert_allclose(out[3].cpu().numpy(), ref[3].numpy(), atol=t_tol)
 
 
 @pytest.mark.parametrize("name,kw", [("dist_n256_b2", dict(vcp_nn="dist")), ("identity_n256_b2", dict(pointer="identity"))])

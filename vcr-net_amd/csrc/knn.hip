@@ -624,11 +624,11 @@ __global__ __launch_bounds__(256) void knn_tiebreak_kernel(vcr_knn_args a) {
     const bool use_heap = (long)K * 64 <= a.N;
     if (!use_heap) {
       // std::nth_element(K-1): the partition passes over long ranges run on the whole block (see below); the tail
-      // (range <= 64, depth exhaustion, final insertion sort) is finished by thread 0 with the sequential port.
+      // (range <= 24, depth exhaustion, final insertion sort) is finished by thread 0 with the sequential port.
       int first = 0, last = a.N, depth = 0;
       for (int m = a.N; m > 1; m >>= 1) ++depth;
       depth *= 2;
-      while (last - first > 64 && depth > 0) {
+      while (last - first > 24 && depth > 0) {
         --depth;
         const int cut = tb_partition_parallel(q, first, last, A, Bd, red);
         if (cut <= K - 1) first = cut; else last = cut;
