@@ -10,8 +10,6 @@
 
 namespace {
 
-constexpr int TIE_CAP = 1024;   // rows with an exact k-th-neighbour tie per kNN launch that get libstdc++'s choice
-
 struct Bump {
   unsigned char* base; size_t off, cap;
   template <class T> T* take(size_t n) {
@@ -50,7 +48,7 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   const size_t M = (size_t)2 * B * N;
   Ws w{};
   w.xyz4 = bp.take<float>(M * 4);   w.feat64 = bp.take<float>(M * 64); w.sq64 = bp.take<float>(M);
-  w.idx1 = bp.take<int32_t>(M * k); w.idx3 = bp.take<int32_t>(M * k); w.ties = bp.take<int32_t>(2 * (1 + TIE_CAP));
+  w.idx1 = bp.take<int32_t>(M * k); w.idx3 = bp.take<int32_t>(M * k); w.ties = bp.take<int32_t>(2 * (1 + M));   // a slot for every row
   w.pq1 = bp.take<float>(M * 256);  w.cat = bp.take<float>(M * 512);   w.pq3 = bp.take<float>(M * 512);
   w.emb = bp.take<float>(M * E);
   w.ln = bp.take<float>(M * E);     w.qkv = bp.take<float>(M * 3 * E); w.att = bp.take<float>(M * E);
@@ -285,7 +283,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     }
     if (R.rc == 0) {
       R.mark("knn:xyz");
-      vcr_knn_args a{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + TIE_CAP, TIE_CAP};
+      vcr_knn_args a{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
       R.ok(vcr_knn_f32(&a, R.stream));
     }
     if (R.rc == 0) {
@@ -326,7 +324,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   }
   if (R.rc == 0) {
     R.mark("knn:feat64");
-    vcr_knn_args a{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, TIE_CAP};
+    vcr_knn_args a{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2};
     R.ok(vcr_knn_f32(&a, R.stream));
   }
   R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
@@ -337,7 +335,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   }
   if (R.rc == 0) {
     R.mark("knn:xyz");
-    vcr_knn_args a{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + TIE_CAP, TIE_CAP};
+    vcr_knn_args a{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
     R.ok(vcr_knn_f32(&a, R.stream));
   }
   R.linear("linear:sn1_pq", w.cat + 128, 512, W->sn1_wpq, SP(sn1_pq), W->sn1_bpq, w.pq3, 512, M2, 512, 128, 0);
