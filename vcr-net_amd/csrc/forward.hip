@@ -22,7 +22,7 @@ struct Bump {
 
 struct Ws {
   float *xyz4, *feat64, *sq64, *pq1, *cat, *pq3, *emb;
-  int32_t *idx1, *idx3, *ties;                         // ties: 2 x (count + TIE_CAP rows) for the kNN tie replay
+  int32_t *idx1, *idx3, *ties;                         // ties: 2 x (count + one slot per row) for the kNN tie replay
   float *ln, *qkv, *att, *e1, *e2, *mem, *hid, *d1, *d2, *d3, *qc, *kvc, *embf, *side4;
   float *st_emb, *st_e1, *st_e2, *st_d1, *st_d2;       // [M, E/64, 2] LayerNorm partial sums
   // partial-overlap mode
