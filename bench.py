@@ -132,6 +132,10 @@ def main():
             pose = shard.all_gather_poses(pose, world)
         return pose
 
+    # one-time initialisation, not a warm-up step: the first call loads the code objects, packs / folds the weights,
+    # sizes the workspace and (N > 1) opens the RCCL communicator
+    step()
+    torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     traces = [native.LaunchTrace() for _ in range(a.steps)]
