@@ -154,3 +154,42 @@ def test_bf16x3_linear_mode_vs_reference_golden(name):
     dt = np.abs(out[3].cpu().numpy() - g["it0_t"]).max()
     print(f"{name} bf16x3: max|dR|={dR:.2e} max|dt|={dt:.2e}")
     assert dR <= R_TOL and dt <= T_TOL
+
+
+def test_c_abi_error_codes():
+    """Errors come back as codes (vcr_hip.h): negative for bad arguments / workspace / unsupported shapes, never an
+    exception or a crash across the boundary; vcr_strerror names them."""
+    import ctypes as C
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native, synth
+    L = native.lib()
+    net, _ = build_net()
+    net._pack()
+    src, tgt, _, _, _ = synth.make_batch(0, 2, 128)
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    B, N = 2, 128
+    f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device="cuda")
+    corr4, src4, R, tt, Rb, tb = f(B, N, 4), f(B, N, 4), f(B, 3, 3), f(B, 3), f(B, 3, 3), f(B, 3)
+    io = native.VcrnetIo(native.ptr(s), native.ptr(t), B, N, native.ptr(corr4), native.ptr(src4), native.ptr(R),
+                         native.ptr(tt), native.ptr(Rb), native.ptr(tb), None)
+    need = L.vcr_vcrnet_workspace_bytes(C.byref(net._cw), B, N)
+    ws = torch.empty(need + 256, dtype=torch.uint8, device="cuda")
+    base = ws.data_ptr() + (-ws.data_ptr()) % 256
+    stream = C.c_void_p(native.stream_ptr())
+    call = lambda io_, p, n: L.vcr_vcrnet_forward_f32(C.byref(net._cw), C.byref(io_), C.c_void_p(p), n, stream)
+    assert call(io, base, need) == 0
+    assert call(io, base, need // 2) < 0 and b"workspace" in L.vcr_strerror(call(io, base, need // 2))
+    assert call(io, base + 4, need) < 0                                   # misaligned workspace
+    bad = native.VcrnetIo(native.ptr(s), None, B, N, native.ptr(corr4), native.ptr(src4), native.ptr(R),
+                          native.ptr(tt), native.ptr(Rb), native.ptr(tb), None)
+    assert call(bad, base, need) < 0                                      # NULL input
+    tiny = native.VcrnetIo(native.ptr(s), native.ptr(t), B, 8, native.ptr(corr4), native.ptr(src4), native.ptr(R),
+                           native.ptr(tt), native.ptr(Rb), native.ptr(tb), None)
+    assert call(tiny, base, need) < 0                                     # k + 1 > N
+    # kernel entry points: bad pitch, unsupported width
+    x = f(64, 48)
+    with pytest.raises(native.VcrHipError):
+        native.linear(x, f(32, 48), None)                                 # K % 32 != 0
+    with pytest.raises(native.VcrHipError):
+        native.layernorm(f(16, 256), f(256), f(256))                      # LayerNorm width != 512
+    torch.cuda.synchronize()
