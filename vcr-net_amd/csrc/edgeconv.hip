@@ -110,30 +110,29 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_kernel(vcr_edgeconv_args p
 // multiple of 32, G consecutive points (G*k = 160 rows = 5 MFMA tiles exactly; G = 8 or 4) share the tiles,
 // which removes 37.5 % of the MFMA work.  A tile then spans several points: the row -> point map is a
 // compile-time function of (tile, accumulator register, lane half), so the max over a point's edges folds
-// into G per-point registers with static indexing; x1 (max over H rows, all >= 0 after ReLU) is collected
-// with LDS unsigned-integer atomic max, which orders non-negative floats correctly.
+// into G per-point registers with static indexing; x1 (max over H rows) is collected by a column pass over the
+// staged tile with the same static map.
 template <int KE>
 __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_kernel(vcr_edgeconv_args p) {
   constexpr int G = 160 / KE;                            // points per group
   __shared__ __attribute__((aligned(16))) float Hs[2][32][HP];
-  __shared__ unsigned x1acc[G][128];
+  __shared__ __attribute__((aligned(16))) float x1half[2][G][128];   // per-point column maxima of the two row halves
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int rs = lane >> 3, cg = lane & 7;
   const int ch = 32 * w + 4 * cg;
+  const int colc = threadIdx.x & 127, rowh = threadIdx.x >> 7;       // x1 pass: one channel, 16 rows of the tile
 
   f32x4 wf[16];
 #pragma unroll
   for (int g = 0; g < 16; ++g) wf[g] = ld4(p.w2 + (size_t)(32 * w + l31) * 128 + 8 * g + 4 * half);
   const float bias2 = p.b2[32 * w + l31];
-  for (int i = threadIdx.x; i < G * 128; i += 256) (&x1acc[0][0])[i] = 0u;
 
   const int ngroups = (p.M + G - 1) / G;
   if ((int)blockIdx.x >= ngroups) return;
   const int my_groups = (ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
   f32x4 hr[4];
-  int hp[4];                                             // group-local point of each staged row
   auto gather = [&](int grp, int t) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -144,19 +143,13 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_kernel(vcr_edgeconv
       const int nb = p.idx[(size_t)pt * KE + j];
       const f32x4 v = ld4(p.pq + (size_t)(base + nb) * p.ldpq + ch) + ld4(p.pq + (size_t)pt * p.ldpq + 128 + ch);
       hr[i] = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-      hp[i] = pl;
     }
   };
   auto commit = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      st4(&Hs[buf][rs + 8 * i][ch], hr[i]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) atomicMax(&x1acc[hp[i]][ch + c], __float_as_uint(hr[i][c]));
-    }
+    for (int i = 0; i < 4; ++i) st4(&Hs[buf][rs + 8 * i][ch], hr[i]);
   };
 
-  __syncthreads();                                       // x1acc zeroed
   gather((int)blockIdx.x, 0);
   commit(0);
   __syncthreads();
@@ -164,13 +157,22 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_kernel(vcr_edgeconv
   for (int gi = 0; gi < my_groups; ++gi) {
     const int grp = (int)blockIdx.x + gi * (int)gridDim.x;
     const bool more = gi + 1 < my_groups;
-    float pm[G];
+    float pm[G], cm[G];                                  // per-point maxima: x2 (MFMA rows) and x1 (this thread's channel)
 #pragma unroll
-    for (int q = 0; q < G; ++q) pm[q] = VCR_NEG_INF;
+    for (int q = 0; q < G; ++q) { pm[q] = VCR_NEG_INF; cm[q] = 0.f; }   // H rows are >= 0 after ReLU
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       const bool has_next = t < 4 || more;
       if (has_next) gather(t < 4 ? grp : grp + (int)gridDim.x, t < 4 ? t + 1 : 0);
+      // x1 = max over a point's H rows: a conflict-free column pass over the staged tile (the row -> point map is
+      // static per tile and row half), instead of LDS atomics that collide on (point, channel)
+      if (rowh == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) cm[(32 * t + rr) / KE] = fmaxf(cm[(32 * t + rr) / KE], Hs[cur][rr][colc]);
+      } else {
+#pragma unroll
+        for (int rr = 16; rr < 32; ++rr) cm[(32 * t + rr) / KE] = fmaxf(cm[(32 * t + rr) / KE], Hs[cur][rr][colc]);
+      }
       f32x16 acc = {0};
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
@@ -190,22 +192,22 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_kernel(vcr_edgeconv
         }
       }
       if (t == 4) {
-        // every H row of this group has been committed (its last tile was staged one step ago): emit x1, x2
+        // the group's five tiles are done: emit x2 from the MFMA maxima, x1 from the two row halves' column maxima
 #pragma unroll
         for (int q = 0; q < G; ++q) {
           const int pt = grp * G + q;
           const float v = fmaxf(pm[q], xhalf(pm[q]));
           if (half == 0 && pt < p.M) p.x2[(size_t)pt * p.ldx2 + 32 * w + l31] = fmaxf(v + bias2, 0.f);
+          x1half[rowh][q][colc] = cm[q];
         }
+        __syncthreads();
         for (int i = threadIdx.x; i < G * 32; i += 256) {
           const int q = i >> 5, c4 = (i & 31) * 4, pt = grp * G + q;
-          const f32x4 v = f32x4{__uint_as_float(x1acc[q][c4]), __uint_as_float(x1acc[q][c4 + 1]),
-                                __uint_as_float(x1acc[q][c4 + 2]), __uint_as_float(x1acc[q][c4 + 3])};
-          if (pt < p.M) st4(p.x1 + (size_t)pt * p.ldx1 + c4, v);
+          const f32x4 lo = ld4(&x1half[0][q][c4]), hi = ld4(&x1half[1][q][c4]);
+          if (pt < p.M)
+            st4(p.x1 + (size_t)pt * p.ldx1 + c4, f32x4{fmaxf(lo[0], hi[0]), fmaxf(lo[1], hi[1]), fmaxf(lo[2], hi[2]),
+                                                        fmaxf(lo[3], hi[3])});
         }
-        __syncthreads();                                 // x1acc read out before the next group's rows land
-        for (int i = threadIdx.x; i < G * 128; i += 256) (&x1acc[0][0])[i] = 0u;
-        __syncthreads();
       }
       if (has_next) commit(cur ^ 1);
       __syncthreads();
