@@ -224,8 +224,23 @@ __global__ __launch_bounds__(256) void gathermax_kernel(vcr_gathermax_args p) {
   if (c >= p.C) return;
   const int base = (pt / p.n_per_cloud) * p.n_per_cloud;
   const int32_t* id = p.idx + (size_t)pt * p.k;
-  f32x4 m = ld4(p.pq + (size_t)(base + id[0]) * p.ldpq + c);
-  int j = 1;
+  f32x4 m;
+  int j;
+  if (p.k == 20) {
+    // the path's k: all 20 neighbour rows in flight at once (the kernel is bound by the latency of these L2 gathers)
+    f32x4 a[20];
+#pragma unroll
+    for (int u = 0; u < 20; ++u) a[u] = ld4(p.pq + (size_t)(base + id[u]) * p.ldpq + c);
+    m = a[0];
+#pragma unroll
+    for (int u = 1; u < 20; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], a[u][i]);
+    j = 20;
+  } else {
+    m = ld4(p.pq + (size_t)(base + id[0]) * p.ldpq + c);
+    j = 1;
+  }
   for (; j + 3 < p.k; j += 4) {
     const f32x4 a0 = ld4(p.pq + (size_t)(base + id[j]) * p.ldpq + c);
     const f32x4 a1 = ld4(p.pq + (size_t)(base + id[j + 1]) * p.ldpq + c);
