@@ -193,3 +193,22 @@ def test_c_abi_error_codes():
     with pytest.raises(native.VcrHipError):
         native.layernorm(f(16, 256), f(256), f(256))                      # LayerNorm width != 512
     torch.cuda.synchronize()
+
+
+def test_runs_on_the_callers_stream():
+    """Every launch goes to the stream the caller is on (torch.cuda.current_stream()): the same results on a side
+    stream, and nothing leaks onto the default stream (the output is only valid after the SIDE stream is waited on)."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    net, _ = build_net()
+    src, tgt, _, _, _ = synth.make_batch(321, 2, 256)
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    with torch.no_grad():
+        ref = net(s, t)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            out = net(s, t)
+        side.synchronize()
+    for a, b in zip(out[1:], ref[1:]):
+        assert torch.equal(a, b)
