@@ -212,3 +212,29 @@ def test_runs_on_the_callers_stream():
         side.synchronize()
     for a, b in zip(out[1:], ref[1:]):
         assert torch.equal(a, b)
+
+
+def test_forward_captures_into_a_hip_graph():
+    """vcr_vcrnet_forward_f32 neither allocates nor synchronises, so a whole forward records into ONE HIP graph
+    (torch.cuda.CUDAGraph) and its replay is bit-identical to the eager call."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    net, _ = build_net()
+    src, tgt, _, _, _ = synth.make_batch(77, 2, 256)
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    with torch.no_grad():
+        ref = net(s, t)
+        torch.cuda.synchronize()
+        g, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            net(s, t)                                        # warm the workspace / packed weights on this stream
+            st.synchronize()
+            with torch.cuda.graph(g, stream=st):
+                out = net(s, t)
+        torch.cuda.synchronize()
+        for x in out[1:]:
+            x.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+    for a, b in zip(out[1:], ref[1:]):
+        assert torch.equal(a, b)
