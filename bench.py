@@ -2,17 +2,23 @@
 """Headline benchmark: point-cloud pairs/sec of the VCR-Net registration hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL.)
 
-One "step" = one pass of the whole hot path (VCRNet.forward: LPDNet kNN-graph embedding ->
-Transformer virtual-correspondence block -> soft correspondences -> SVD rigid solve) over one batch
-of 16 synthetic pairs of N=1024 points PER GPU (BASELINE.json configs[1]; weak scaling), inputs already
-resident in HBM, plus -- for N > 1 -- the RCCL all-gather of the per-rank (R, t).
-Prints ONE JSON line on rank 0.
+N > 1: one process per GPU over RCCL.  Either launched by torch.distributed.run (RANK / WORLD_SIZE in the
+environment) or plainly as above, in which case this process only spawns the N rank processes (fresh children started
+BEFORE anything here touches the GPU), waits for them and exits with their worst code; rank 0 prints the line.
+
+One "step" = one pass of the whole hot path (VCRNet.forward: LPDNet kNN-graph embedding -> Transformer
+virtual-correspondence block -> soft correspondences -> SVD rigid solve) over one batch of 16 synthetic pairs of
+N=1024 points PER GPU (BASELINE.json configs[1]; weak scaling), inputs already resident in HBM, plus -- for N > 1 --
+the RCCL all-gather of the per-rank (R, t).  The K-step timed block (barrier + synchronize on both sides, MAX over
+ranks) is repeated until >= 2 s of GPU time have been spent so that external samplers see the load; the MEDIAN block
+is reported and every block's time is listed.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from types import SimpleNamespace
@@ -25,7 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -40,13 +46,19 @@ def parse():
     ap.add_argument("--emb-nn", default="lpdnet", choices=["lpdnet", "dgcnn"],
                     help="feature extractor (--emb_nn of the reference; dgcnn uses seeded weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=75.0,
+                    help="wall-clock budget of the CPU-baseline thread sweep (each thread count: one warm-up, then up "
+                         "to 5 timed runs while the budget lasts)")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="SURVEY 8d protocol without a budget: every thread count, B = --batch, median of 5")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the timed K-step block for this long")
     ap.add_argument("--stages", action="store_true", help="print the per-launch table to stderr")
     ap.add_argument("--linear-mode", default="fp32", choices=["fp32", "bf16x3"],
                     help="fp32: linears on v_mfma_f32_32x32x2_f32 (default).  bf16x3: the same products as exact 3-way "
                          "bf16 splits on the bf16 matrix pipe (fp32-equivalent accuracy)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm); gloo only "
                                                       "for exercising the multi-rank control flow on a 1-GPU box")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def model_args(partial=False, emb_nn="lpdnet"):
@@ -56,39 +68,107 @@ def model_args(partial=False, emb_nn="lpdnet"):
                            n_blocks=1, dropout=0.0, ff_dims=1024, n_heads=4)
 
 
-def cpu_baseline(w, B, N, k, partial=False, iters=1):
-    """The CPU oracle (a port of the reference's PyTorch CPU path) timed on this box's host cores on a
-    bounded sample of the same workload."""
+# ---- N > 1 without torchrun: spawn the ranks ourselves -------------------------------------------------------------
+
+def spawn_ranks(a) -> int:
+    """Start a.gpus fresh rank processes of this script (one per GPU, LOCAL_RANK = rank) and wait for them.  The parent
+    never initialises the GPU: torch.cuda.device_count() does not, and nothing else here touches HIP."""
+    ndev = torch.cuda.device_count()
+    if a.backend == "nccl" and a.gpus > ndev:
+        print(f"bench.py: --gpus {a.gpus} but {ndev} GPU(s) visible: one process per GPU", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ---- CPU baseline ----------------------------------------------------------------------------------------------------
+
+def cpu_baseline(w, B, N, k, partial=False, iters=1, budget_s=75.0, full=False):
+    """The CPU oracle (a port of the reference's PyTorch CPU path) timed on this box's host cores: the
+    bench workload's own batch size, thread counts {1, 8, 16, 32, 64, nproc}, one warm-up then the median of up to 5
+    runs each.  The default run is bounded by `budget_s` (the 1-thread leg uses a 2-pair sample); `full` lifts the
+    bound.  `value` = the best thread count's pairs/s; the whole table is kept."""
     import oracle
     from vcrnet_amd import synth
-    nthreads = torch.get_num_threads()
-    sample_B = min(B, 8 if N <= 1024 else 2)      # bounded: ~10-30 s of CPU work
-    src, tgt, _, _, _ = synth.make_batch(0, sample_B, N, partial=partial, kind="object" if N <= 2048 else "uniform")
-    s, t = torch.from_numpy(src), torch.from_numpy(tgt)
+    ncpu = os.cpu_count() or 1
+    kind = "object" if N < 2048 else "uniform"
     cfg = oracle.OracleConfig(k=k, partial=partial, overlap2=synth.OVERLAP2_0575 if partial else 0.75)
-    run = lambda: oracle.vcrnet_iter(w, s, t, cfg, iters=iters)
-    t0 = time.perf_counter()
-    run()                                         # warm-up
-    warm = time.perf_counter() - t0
-    reps = 3 if warm < 8 else 1
-    ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        run()
-        ts.append(time.perf_counter() - t0)
-    best = float(np.median(ts))
-    return {"value": sample_B / best, "unit": "pairs/s", "cores": nthreads, "kind": "port",
-            "sample": f"oracle.vcrnet_iter(iters={iters}{', partial' if partial else ''}), B={sample_B}, N={N}, k={k}, "
-                      f"fp32, median of {reps} after 1 warm-up, torch.set_num_threads={nthreads}"}
+    full_B = B if N <= 1024 else min(B, 4)
+    data = {}
+
+    def sample(nb):
+        if nb not in data:
+            src, tgt, _, _, _ = synth.make_batch(0, nb, N, partial=partial, kind=kind)
+            data[nb] = (torch.from_numpy(src), torch.from_numpy(tgt))
+        return data[nb]
+
+    threads = sorted({t for t in (1, 8, 16, 32, 64, ncpu) if t <= ncpu})
+    share = budget_s / len(threads)                                    # every thread count gets an equal slice
+    table = {}
+    prev = torch.get_num_threads()
+    try:
+        for th in threads:
+            nb = full_B if (full or th > 1) else min(full_B, 2)
+            s, t = sample(nb)
+            torch.set_num_threads(th)
+            leg = time.perf_counter()
+            oracle.vcrnet_iter(w, s, t, cfg, iters=iters)              # warm-up
+            warm = time.perf_counter() - leg
+            ts = []
+            for _ in range(5):
+                if not full and ts and (time.perf_counter() - leg) + warm > share:
+                    break
+                t0 = time.perf_counter()
+                oracle.vcrnet_iter(w, s, t, cfg, iters=iters)
+                ts.append(time.perf_counter() - t0)
+            table[th] = {"pairs_per_s": nb / float(np.median(ts)), "sample_pairs": nb, "runs": len(ts)}
+    finally:
+        torch.set_num_threads(prev)
+    best = max(table, key=lambda th: table[th]["pairs_per_s"])
+    return {"value": table[best]["pairs_per_s"], "unit": "pairs/s", "cores": ncpu, "threads": best, "kind": "port",
+            "one_thread": table.get(1, {}).get("pairs_per_s"),
+            "by_threads": {str(th): table[th] for th in sorted(table)},
+            "sample": f"oracle.vcrnet_iter(iters={iters}{', partial' if partial else ''}), N={N}, k={k}, fp32, "
+                      f"B={full_B} pairs per run (1-thread leg: {table.get(1, {}).get('sample_pairs', '-')}), one warm-up "
+                      f"then median of <=5 runs per thread count, {'no budget' if full else f'{budget_s:.0f} s budget'}; "
+                      f"best = {best} threads of os.cpu_count()={ncpu}"}
 
 
-def main():
-    a = parse()
+def workload_label(a, Nfull, N, B, kind):
+    if a.partial:
+        base = ("BASELINE configs[2]" if (Nfull, B, a.iters) == (1024, 24, 3) else "partial-overlap (configs[2] recipe)") + \
+            ": partial-to-partial overlap 0.575 (clouds cropped %d -> %d points), " % (Nfull, N)
+    elif kind == "uniform":
+        base = ("BASELINE configs[4]: kNN/EdgeConv stress, " if (N, a.k) == (4096, 40) else
+                "BASELINE configs[3] (one GPU's share): " if N == 2048 else "") + "synthetic random clouds U(-0.5,0.5)^3, "
+    else:
+        base = ("BASELINE configs[1]: " if (N, B) == (1024, 16) else "configs[1] recipe: ") + \
+            "ModelNet40-like whole-to-whole registration, "
+    clouds = ("uniform random clouds" if kind == "uniform" else "synthetic object clouds") + \
+        " with the reference's transform recipe"
+    emb = "LPDNet" if a.emb_nn == "lpdnet" else "DGCNN"
+    wts = "LPD-pretrained emb_nn + seeded Transformer weights" if a.emb_nn == "lpdnet" else "seeded weights"
+    return base + "N=%d, batch=%d pairs per GPU, %s(k=%d)+Transformer+VcpTopK+SVD, iter=%d, fp32; %s; %s" % (
+        N, B, emb, a.k, a.iters, clouds, wts)
+
+
+def run_rank(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     ndev = torch.cuda.device_count()
     if a.backend == "nccl" and world > ndev:
         raise SystemExit(f"{world} ranks but {ndev} GPUs: one process per GPU")
@@ -117,10 +197,10 @@ def main():
 
     B, N = a.batch, a.points
     # each rank owns B consecutive items of the global batch (weak scaling); inputs live in HBM
-    # object-like clouds have 2048 points (the ModelNet40 convention); larger N (configs 4/5) use uniform clouds
+    # object-like clouds have 2048 points (the ModelNet40 convention); larger N (configs 3/4) use uniform clouds
     # built on the device from base clouds + host-drawn permutations / poses (vcr_make_pairs_f32; untimed)
-    src, tgt, _, _, _ = synth.make_batch_device(rank * B, B, N, partial=a.partial,
-                                                kind="object" if N <= 2048 else "uniform", device=dev)
+    kind = "object" if N < 2048 else "uniform"
+    src, tgt, _, _, _ = synth.make_batch_device(rank * B, B, N, partial=a.partial, kind=kind, device=dev)
     Nfull, N = N, src.shape[2]                     # partial mode crops the clouds (1024 -> 768)
     assert src.shape == (B, 3, N) and src.is_cuda, src.shape
 
@@ -152,27 +232,38 @@ def main():
         own = step()[rank * B:(rank + 1) * B]
         assert g.shape == (world * B, 12) and torch.allclose(mine, own)
 
-    fence()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(traces[i].trace)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_block():
+        fence()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(traces[i].trace)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
 
-    # per-launch durations from the HIP events recorded inside the timed region
-    fam_ms, fam_flops, fam_bytes, rows = {}, {}, {}, {}
+    # EXACTLY K steps per block; blocks repeat until min_seconds of load (every rank must agree on the count, so the
+    # decision uses the MAX-reduced times, identical on all ranks)
+    blocks = [timed_block()]
+    while sum(blocks) < a.min_seconds and len(blocks) < 1000:
+        blocks.append(timed_block())
+    elapsed = float(np.median(blocks))
+
+    # per-launch durations from the HIP events recorded inside the (last) timed block
+    fam_ms, fam_flops, fam_bytes, fam_gather, rows = {}, {}, {}, {}, {}
     for tr in traces:
         for name, ms in tr.launches():
             fam = name.split(":")[0]
             fl, by = workmodel.launch_work(name, B, N, a.k, overlap2=net._overlap2)
+            gb = workmodel.gather_bytes(name, B, N, a.k)
             fam_ms[fam] = fam_ms.get(fam, 0.0) + ms
             fam_flops[fam] = fam_flops.get(fam, 0.0) + fl
             fam_bytes[fam] = fam_bytes.get(fam, 0.0) + by
-            r = rows.setdefault(name, [0.0, fl, by, 0])
+            fam_gather[fam] = fam_gather.get(fam, 0.0) + gb
+            r = rows.setdefault(name, [0.0, fl, by, 0, gb])
             r[0] += ms; r[3] += 1
         tr.close()
     if rank == 0:
@@ -195,7 +286,7 @@ def main():
         # of this same command, condensed by profiles/summarize.py; null when no summary is committed.
         import glob
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-        if pmcs and (B, N, a.k, a.partial, a.iters) == (16, 1024, 20, False, 1):
+        if pmcs and (B, N, a.k, a.partial, a.iters, a.emb_nn) == (16, 1024, 20, False, 1, "lpdnet"):
             kname = {"linear": "linear_glds", "sdpa": "sdpa_kernel<false, true>",
                      "edgeconv": "edgeconv_dg_packed_kernel<20>", "softcorr": "pairscore_kernel<0>"}.get(dom)
             # a family can be several template instantiations (linear: plain / statistics-out / LayerNorm-in):
@@ -209,19 +300,25 @@ def main():
         total_ms = sum(fam_ms.values())
         roof["launches_per_step"] = sum(r[3] for n, r in rows.items() if n.startswith(dom + ":")) // a.steps
         roof["avg_launch_ms"] = fam_ms[dom] / max(1, roof["launches_per_step"] * a.steps)
+        # gbs = HBM-compulsory bytes (each distinct row once) over the launch time; l2_gather_gbs = the k-fold
+        # neighbour re-reads the EdgeConv kernels pull through L2 (not HBM traffic: never priced against 8 TB/s)
         stages = {f: {"ms_per_step": fam_ms[f] / a.steps, "share": fam_ms[f] / total_ms,
-                      "tflops": fam_flops[f] / (fam_ms[f] * 1e-3) / 1e12, "gbs": fam_bytes[f] / (fam_ms[f] * 1e-3) / 1e9}
+                      "tflops": fam_flops[f] / (fam_ms[f] * 1e-3) / 1e12, "gbs": fam_bytes[f] / (fam_ms[f] * 1e-3) / 1e9,
+                      **({"l2_gather_gbs": fam_gather[f] / (fam_ms[f] * 1e-3) / 1e9} if fam_gather[f] else {})}
                   for f in sorted(fam_ms, key=fam_ms.get, reverse=True)}
         # the kNN + EdgeConv (emb_nn) stage that BASELINE.json's north_star prices against the HBM roofline:
-        # algorithmic bytes 2*N*(7448 + 784*k) per pair, time = its launches inside the timed region
-        emb_sites = ("pointwise:", "knn:", "edgeconv:", "gathermax:", "linear:dg1_pq", "linear:sn1_pq", "linear:conv3")
+        # algorithmic bytes 2*N*(7448 + 784*k) per pair AND PER ITERATION (kernel-boundary traffic,
+        # gathers included), time = its launches inside the timed region (all iterations)
+        emb_sites = ("pointwise:", "knn:", "edgeconv:", "gathermax:", "linear:dg1_pq", "linear:sn1_pq", "linear:conv3",
+                     "linear:dg_c")
         emb_ms = sum(r[0] for n, r in rows.items() if n.startswith(emb_sites)) / a.steps
-        emb_bytes = 2.0 * N * (7448 + 784 * a.k) * B
-        emb_gf = sum(workmodel.launch_work(n, B, N, a.k)[0] for n in
-                     ("linear:dg1_pq", "edgeconv:dg1_dg2", "linear:sn1_pq", "linear:conv3")) / 1e9
-        emb_stage = {"ms_per_step": emb_ms, "algorithmic_bytes_per_pair": emb_bytes / B,
+        emb_bytes = 2.0 * N * (7448 + 784 * a.k) * B * a.iters
+        emb_gf = a.iters * sum(workmodel.launch_work(n, B, N, a.k)[0] for n in
+                               ("linear:dg1_pq", "edgeconv:dg1_dg2", "linear:sn1_pq", "linear:conv3")) / 1e9
+        emb_stage = {"ms_per_step": emb_ms, "algorithmic_bytes_per_pair": emb_bytes / B / a.iters, "iters": a.iters,
                      "achieved_gbs": emb_bytes / (emb_ms * 1e-3) / 1e9,
                      "hbm_frac": emb_bytes / (emb_ms * 1e-3) / 1e9 / workmodel.PEAK_HBM_GBS,
+                     "knn_ms_per_step": sum(r[0] for n, r in rows.items() if n.startswith("knn:")) / a.steps,
                      "note": "fp32 1x1 convs of this stage are MFMA-bound (SURVEY section 7): %.1f GF per step alone "
                              "need %.2f ms at the fp32 matrix peak, i.e. <= %.2f of the HBM roofline"
                              % (emb_gf, emb_gf / workmodel.PEAK_MFMA_F32_TFLOPS,
@@ -229,7 +326,8 @@ def main():
         if a.stages:
             for n, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
                 ms = r[0] / r[3]
-                print(f"{n:28s} {ms:8.3f} ms  {r[1] / ms / 1e9:8.2f} TF/s  {r[2] / ms / 1e6:9.1f} GB/s", file=sys.stderr)
+                print(f"{n:28s} {ms:8.3f} ms  {r[1] / ms / 1e9:8.2f} TF/s  {r[2] / ms / 1e6:9.1f} GB/s"
+                      + (f"  (+{r[4] / ms / 1e6:8.1f} GB/s L2 gathers)" if r[4] else ""), file=sys.stderr)
         pairs = B * world * a.steps
         line = {
             "metric": "point-cloud pairs/sec (N=%d, batch %d per GPU)" % (Nfull, B), "value": pairs / elapsed, "unit": "pairs/s",
@@ -237,25 +335,29 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.linear_mode == "fp32" else "f32 (linears as exact bf16x3 splits, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[2]: partial-to-partial overlap 0.575 (clouds cropped %d -> %d "
-                                    "points), " % (Nfull, N) if a.partial else
-                                    "BASELINE configs[1]: ModelNet40-like whole-to-whole registration, ") +
-                                   "N=%d, batch=%d pairs per GPU, LPDNet(k=%d)+Transformer+VcpTopK+SVD, iter=%d, fp32; "
-                                   "synthetic object clouds with the reference's transform recipe; LPD-pretrained "
-                                   "emb_nn + seeded Transformer weights" % (N, B, a.k, a.iters),
-                       "num_points": N, "batch_per_gpu": B, "global_batch": B * world, "k": a.k,
+            "config": {"workload": workload_label(a, Nfull, N, B, kind),
+                       "num_points": N, "batch_per_gpu": B, "global_batch": B * world, "k": a.k, "iters": a.iters,
                        "parallelism": f"dp{world} (pairs sharded per rank, RCCL all-gather of R,t)"},
+            "timed_blocks": {"count": len(blocks), "steps_per_block": a.steps, "reported": "median",
+                             "seconds": [round(b, 6) for b in blocks[:64]]},
             "roofline": roof,
             "stages": stages,
             "knn_edgeconv_stage": emb_stage,
             "flops_per_pair_reference": workmodel.reference_flops_per_pair(N, a.k)["total"],
         }
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w, B, Nfull, a.k, a.partial, a.iters)
-        print(json.dumps(line))
+            line["cpu_baseline"] = cpu_baseline(w, B, Nfull, a.k, a.partial, a.iters, a.cpu_budget_s, a.cpu_baseline_full)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(a))               # plain `python bench.py --gpus N`: this process only launches the ranks
+    run_rank(a)
 
 
 if __name__ == "__main__":

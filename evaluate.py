@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(argv=None):
+    """Returns {"ab": A->B metrics, "ba": B->A metrics, "pairs": n} on rank 0 (None elsewhere)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--items", type=int, default=64, help="test-set size (pairs)")
     ap.add_argument("--batch", type=int, default=16)
@@ -32,8 +33,10 @@ def main():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--iters", type=int, default=1, help="--iter of the reference (0 = ICP refinement path)")
     ap.add_argument("--partial", action="store_true")
+    ap.add_argument("--cycle", action="store_true", help="args.cycle: second head for (R_ba, t_ba) + the B->A log line")
+    ap.add_argument("--first-item", type=int, default=0)
     ap.add_argument("--backend", default="nccl")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
@@ -46,7 +49,7 @@ def main():
     from vcrnet_amd import evalmetrics, shard, synth, weights
     from vcrnet_amd.module import VCRNet, vcrnetIcpNet, vcrnetIter
 
-    args = SimpleNamespace(emb_dims=512, cycle=False, emb_nn="lpdnet", pointer="transformer", vcp_nn="topK",
+    args = SimpleNamespace(emb_dims=512, cycle=a.cycle, emb_nn="lpdnet", pointer="transformer", vcp_nn="topK",
                            partial=a.partial, overlap2=synth.OVERLAP2_0575 if a.partial else 0.75, t3d=False, tfea=False,
                            n_blocks=1, dropout=0.0, ff_dims=1024, n_heads=4, max_iterations=50)
     w = weights.generate_weights(1234, lpd=weights.load_lpd_fixture())
@@ -56,7 +59,8 @@ def main():
     net = net.to(dev).eval()
 
     lo, hi = shard.shard_range(a.items, rank, world)
-    acc = evalmetrics.EvalAccumulator()
+    lo, hi = lo + a.first_item, hi + a.first_item
+    acc = evalmetrics.EvalAccumulator(cycle=a.cycle)
     kind = "object" if a.points <= 2048 else "uniform"
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -70,15 +74,22 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     merged = acc.merge(world, device=dev if a.backend == "nccl" else "cpu")
+    result = None
     if rank == 0:
-        m = merged.final()
+        m, mb = merged.final(), merged.final_ba()
         print("==FINAL TEST==")                                                 # vcrnet_model.py:792-799
         print("A--------->B")
         print(evalmetrics.EvalAccumulator.format_final(m))
-        print(f"[{merged.num_examples} pairs on {world} GPU(s), {elapsed:.2f} s incl. pair construction and metrics]")
+        if a.cycle:                                                             # :800-806
+            print("B--------->A")
+            print(evalmetrics.EvalAccumulator.format_final_ba(mb))
+        print(f"[{merged.num_examples} pairs on {world} GPU(s), {elapsed:.2f} s incl. pair construction and metrics]",
+              flush=True)
+        result = {"ab": m, "ba": mb, "pairs": merged.num_examples}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return result
 
 
 if __name__ == "__main__":

@@ -14,7 +14,8 @@
  *     frees or retains pointers, never synchronises, never exits;
  *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*);
  *   - return 0 on success, <0 for an argument error (VCR_E*), >0 = a hipError_t from the launch;
- *   - re-entrant: no global mutable state (safe under nn.DataParallel's thread-per-device).
+ *   - re-entrant: no global mutable state (safe under nn.DataParallel's thread-per-device); tuning / test selectors
+ *     travel in the args structs (`variant`, `waves`), 0 = the automatic choice;
  *   - activations are fp32, point-major ("channels-last"): a [B,N,C] tensor is row-major with one
  *     row per point and an explicit row pitch `ld*` in floats.  Indices are int32.
  */
@@ -64,6 +65,8 @@ typedef struct {
   int32_t* idx;                       /* [B,N,k], neighbour index within the cloud     */
   int32_t* tie_scratch; int tie_cap;  /* optional: [1 + tie_cap] ints of scratch (count, then the rows with a boundary
                                          tie; 256 entries are plenty: ~1 row in 10^4 ties), N <= 20000 */
+  int waves;                          /* tuning / tests: waves that share one query tile's candidates (C == 4: 2, 4 or 8;
+                                         C == 64: 1, 2 or 4); 0 = chosen from the grid size.  Never changes a result. */
 } vcr_knn_args;
 int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
 
@@ -87,6 +90,8 @@ typedef struct {
    *             y = inv_m * (sum_k x[m,k] w[n,k] - mean_m * ln_colsum[n]) + bias[n],  inv = 1 / (std_unbiased + ln_eps). */
   const float* ln_stats_in; int ln_nseg; const float* ln_colsum; float ln_eps;
   float* stats_out;
+  int variant;                        /* tuning / tests, 0 = automatic: bit0 register-staged BK 16, bit2 register staging
+                                         instead of LDS-DMA, bit3 force the BK 32 LDS-DMA kernel (identical results) */
 } vcr_linear_args;
 int vcr_linear_f32(const vcr_linear_args*, vcr_stream_t);
 
@@ -206,6 +211,7 @@ typedef struct {
   const float* str_stat2; long str_stat_batch_stride; float* mass; int accumulate;
   float* score_out; int ld_score;     /* op 1 only, optional: also keep the scores, S[(b*n_own + o)*ld_score + s];
                                          ld_score % 4 == 0 and >= n_str rounded up to 32 (the pad receives -inf) */
+  int variant;                        /* tuning / tests, 0 = automatic: bit0 one owner tile (32 owners) per block */
 } vcr_pairscore_args;
 int vcr_pairscore_f32(const vcr_pairscore_args*, vcr_stream_t);
 
@@ -344,6 +350,18 @@ typedef struct {
   float* src4;                                     /* [B,K,4] the matched src points as rows (x,y,z,|p|^2) */
   float* R_ab; float* t_ab; float* R_ba; float* t_ba;  /* [B,9],[B,3],[B,9],[B,3] */
   float* emb_out;                                  /* optional [2B*N,E] final embeddings (src then tgt), may be NULL */
+  /* Partial-overlap mode only, every pointer optional (NULL = free-running / not wanted): the discrete selections of
+   * the path, in the reference's own order and index spaces.  `force_*` REPLACE the device's ranking with the
+   * caller's (teacher forcing: SURVEY F5 -- one flipped near-tie moves (R, t) by 1e-2, so the 1e-4 / 1e-5 tolerance
+   * is assertable per iteration only on identical selections); `out_*` report what was used.  For
+   * vcr_vcrnet_iter_f32 every array holds one block per iteration, iteration i at offset i * (block size).
+   *   keys    [2B, nkeep]  kept keys of the decoder cross-attention per KEY cloud (src clouds, then tgt clouds),
+   *                        nkeep = int(N*overlap2)                                     (transformer.py:41-42)
+   *   sel_src / sel_tgt [B, K1]  overlap sets of selectCom, K1 = int(N*0.84*overlap2) (vcrnet_model.py:223,245)
+   *   argmax  [B, K1]      arg-max target (position in sel_tgt) of each selected source (vcrnet_model.py:297)
+   *   pairs   [B, K2]      positions in sel_src of the kept sources, K2 = vcr_vcrnet_pairs() (vcrnet_model.py:312) */
+  const int32_t *force_keys, *force_sel_src, *force_sel_tgt, *force_argmax, *force_pairs;
+  int32_t *out_keys, *out_sel_src, *out_sel_tgt, *out_argmax, *out_pairs;
 } vcr_vcrnet_io;
 
 size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights*, int B, int N);
@@ -371,15 +389,6 @@ int vcr_vcrnet_forward_traced_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io
  * No host synchronisation between iterations.  trace may be NULL; launches of all iterations are appended. */
 int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io*, int iters, void* workspace,
                         size_t workspace_bytes, vcr_stream_t, vcr_trace* trace);
-
-/* Tuning / test hooks.  PROCESS-GLOBAL and not thread-safe: for benchmarks and tests only (they select between
- * variants that produce the same results); 0 restores the automatic choice.
- *   linear   : bit0 register-staged BK 16, bit2 register staging instead of LDS-DMA, bit3 force the BK 32 LDS-DMA kernel
- *   knn3     : 2 / 4 / 8 = waves per 64 queries of the Cartesian kNN
- *   pairscore: bit0 one owner tile (32 owners) per block */
-void vcr_debug_linear_variant(int v);
-void vcr_debug_knn3_waves(int w);
-void vcr_debug_pairscore_variant(int v);
 
 /* hipEvent helpers (create / destroy / record / elapsed) bound to the same HIP runtime as the
  * kernels, for hosts without HIP bindings.  Elapsed needs both events completed (synchronise first). */

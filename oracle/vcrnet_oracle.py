@@ -166,7 +166,7 @@ def layer_norm(x: Tensor, a: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
 
 
 def attention(q: Tensor, k: Tensor, v: Tensor, is_src: bool = False, overlap2: float = 0.75,
-              cfg: Optional[OracleConfig] = None) -> Tensor:
+              cfg: Optional[OracleConfig] = None, tag: str = "") -> Tensor:
     """model/transformer.py:13-55 with mask=None, dropout=None.
     q,k,v: [B,h,N,d].  ``is_src`` adds the key-pruning second softmax (:35-53)."""
     d_k = q.size(-1)
@@ -180,6 +180,7 @@ def attention(q: Tensor, k: Tensor, v: Tensor, is_src: bool = False, overlap2: f
         idx = col.topk(k=keep, dim=-1)[1]                                  # :42  [B,1,1,keep]
         if cfg is not None:
             cfg.rec("key_keep", idx.view(bsz, keep))
+            cfg.rec("key_keep" + tag, idx.view(bsz, keep))                 # tag names the cloud whose points are the keys
         mask = torch.zeros(bsz, nk, dtype=torch.bool)
         mask.view(-1)[(idx.view(bsz, keep) + torch.arange(bsz).view(-1, 1) * nk).view(-1)] = True
         scores = scores.masked_fill(~mask.view(bsz, 1, 1, nk), -1e9)       # :46-52
@@ -189,7 +190,7 @@ def attention(q: Tensor, k: Tensor, v: Tensor, is_src: bool = False, overlap2: f
 
 def multi_head_attention(w: Weights, pre: str, q_in: Tensor, k_in: Tensor, v_in: Tensor, h: int,
                          is_src: bool = False, overlap2: float = 0.75,
-                         cfg: Optional[OracleConfig] = None) -> Tensor:
+                         cfg: Optional[OracleConfig] = None, tag: str = "") -> Tensor:
     """model/transformer.py:202-224 (the stored ``self.attn`` side effect, :216-219, is
     plotting-only and not reproduced)."""
     nb = q_in.size(0)
@@ -199,7 +200,7 @@ def multi_head_attention(w: Weights, pre: str, q_in: Tensor, k_in: Tensor, v_in:
     for i, t in enumerate((q_in, k_in, v_in)):
         y = F.linear(t, w[f"{pre}linears.{i}.weight"], w[f"{pre}linears.{i}.bias"])
         proj.append(y.view(nb, -1, h, d_k).transpose(1, 2).contiguous())
-    x = attention(proj[0], proj[1], proj[2], is_src=is_src, overlap2=overlap2, cfg=cfg)
+    x = attention(proj[0], proj[1], proj[2], is_src=is_src, overlap2=overlap2, cfg=cfg, tag=tag)
     x = x.transpose(1, 2).contiguous().view(nb, -1, h * d_k)
     return F.linear(x, w[f"{pre}linears.3.weight"], w[f"{pre}linears.3.bias"])
 
@@ -231,7 +232,7 @@ def encoder_decoder(w: Weights, pre: str, src: Tensor, tgt: Tensor, cfg: OracleC
         x = x + multi_head_attention(w, lp + "self_attn.", y, y, y, h)                       # :183
         y = ln(x, lp + "sublayer.1.norm")
         x = x + multi_head_attention(w, lp + "src_attn.", y, mem, mem, h,                    # :184
-                                     is_src=cfg.partial, overlap2=float(cfg.overlap2), cfg=cfg)
+                                     is_src=cfg.partial, overlap2=float(cfg.overlap2), cfg=cfg, tag=tag)
         x = x + feed_forward(w, lp + "feed_forward.", ln(x, lp + "sublayer.2.norm"))        # :185
     return ln(x, pre + "decoder.norm")                                                        # :131
 
@@ -309,6 +310,7 @@ def head_hard_pairs(src: Tensor, src_emb: Tensor, tgt: Tensor, tgt_emb: Tensor, 
     w = torch.div(val, torch.sum(val, dim=-1, keepdim=True))                # :320-321 (== 1)
     if cfg is not None:
         cfg.rec("pair_src", pick); cfg.rec("pair_tgt", torch.gather(idx.squeeze(-1), 1, pick))
+        cfg.rec("argmax_tgt", idx.squeeze(-1))
     src_corr = _rows(cand * w.transpose(2, 1), pick)                        # :325 (weights are exactly 1)
     return _rows(src, pick), src_corr                                       # :328-330
 
@@ -426,7 +428,9 @@ def vcrnet_iter(w: Weights, src: Tensor, tgt: Tensor, cfg: OracleConfig, iters: 
                 forced_inputs=None, per_iter=None):
     """vcrnetIter, model/vcrnet_model.py:21-43.  ``forced_inputs`` (list of
     transformed_src, one per iteration) teacher-forces each pass (SURVEY F5);
-    ``per_iter`` collects each pass's (R, t, transformed_src_in)."""
+    ``per_iter`` collects each pass's (R, t, transformed_src_in, selections) -- selections = the partial-mode
+    index sets of that pass (kept keys per key cloud, overlap sets, arg-max targets, hard pairs) when
+    ``cfg.record`` is a dict, else {}."""
     cur = src
     R_f = t_f = None
     for i in range(iters):
@@ -434,7 +438,10 @@ def vcrnet_iter(w: Weights, src: Tensor, tgt: Tensor, cfg: OracleConfig, iters: 
             cur = forced_inputs[i]
         srcK, corrK, R, t, _, _ = vcrnet_forward(w, cur, tgt, cfg)
         if per_iter is not None:
-            per_iter.append((R, t, cur))
+            sel = {} if cfg.record is None else {
+                n: cfg.record[n].clone() for n in ("key_keep_src", "key_keep_tgt", "sel_src", "sel_tgt", "argmax_tgt",
+                                                   "pair_src") if n in cfg.record}
+            per_iter.append((R, t, cur, sel))
         cur = transform_point_cloud(cur, R, t)                               # :28
         if R_f is None:
             R_f, t_f = R, t

@@ -7,7 +7,7 @@ reference, only the .npz files this script writes.  Usage:  python tests/golden/
 What it does
   * injects a stub ``pynvml`` (util/util.py:9-16 calls NVML at import; absent on AMD),
   * imports ``model.vcrnet_model`` / ``model.dcp_model`` from /root/reference unmodified,
-  * re-saves pretrained/lpd-pretrained.t7 as ``lpd_pretrained.npz`` (12 fp32 tensors: data),
+  * re-saves pretrained/lpd-pretrained.t7 as ``vcr-net_amd/data/lpd_pretrained.npz`` (12 fp32 tensors: data),
   * builds each variant, loads ``vcrnet_amd.weights.generate_weights(seed=1234, lpd=...)`` into it,
   * feeds ``vcrnet_amd.synth.make_batch`` inputs and records outputs + intermediates:
     every ``Tensor.topk`` result in call order (kNN sets, key-pruning sets, overlap / pair
@@ -95,7 +95,7 @@ def load_into(net, w):
 
 
 def run_vcrnet(name, B, N, first_item, cstride, emb_nn="lpdnet", vcp_nn="topK", partial=False,
-               cycle=False, k=None, iters=1, pointer="transformer"):
+               cycle=False, k=None, iters=1, pointer="transformer", kind="object"):
     overlap2 = synth.OVERLAP2_0575 if partial else 0.75
     args = ref_args(emb_nn=emb_nn, vcp_nn=vcp_nn, partial=partial, overlap2=overlap2, cycle=cycle,
                     pointer=pointer)
@@ -104,7 +104,7 @@ def run_vcrnet(name, B, N, first_item, cstride, emb_nn="lpdnet", vcp_nn="topK", 
     load_into(net, w)
     if k is not None:
         net.emb_nn.k = k
-    src, tgt, R_gt, t_gt, eul = synth.make_batch(first_item, B, N, partial=partial)
+    src, tgt, R_gt, t_gt, eul = synth.make_batch(first_item, B, N, partial=partial, kind=kind)
     src_t, tgt_t = torch.from_numpy(src), torch.from_numpy(tgt)
     out = dict(src=src, tgt=tgt, R_gt=R_gt, t_gt=t_gt, euler_gt=eul, cstride=np.int32(cstride),
                overlap2=np.float64(overlap2), k=np.int32(k or 20), iters=np.int32(iters))
@@ -228,19 +228,34 @@ def run_icp(name, B, N, first_item):
     print(f"{name}: {len(calls)} ICP iterations")
 
 
+CASES = {
+    "whole_n256_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=0, cstride=4),
+    "whole_n1024_b2": lambda n: run_vcrnet(n, B=2, N=1024, first_item=10, cstride=16),
+    "whole_k40_n512_b1": lambda n: run_vcrnet(n, B=1, N=512, first_item=20, cstride=16, k=40),
+    "cycle_n256_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=30, cstride=16, cycle=True),
+    "partial_n192_b2_it2": lambda n: run_vcrnet(n, B=2, N=256, first_item=40, cstride=8, partial=True, iters=2),
+    "partial_n768_b2_it3": lambda n: run_vcrnet(n, B=2, N=1024, first_item=50, cstride=32, partial=True, iters=3),
+    "dgcnn_n256_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=60, cstride=8, emb_nn="dgcnn"),
+    "att_n256_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=70, cstride=16, vcp_nn="att"),
+    "dist_n256_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=80, cstride=16, vcp_nn="dist"),
+    "identity_n256_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=90, cstride=16, pointer="identity"),
+    "dcp_n256_b2": lambda n: run_dcp(n, B=2, N=256, first_item=100, cstride=16),
+    "icp_n256_b2": lambda n: run_icp(n, B=2, N=256, first_item=110),
+    # round 2
+    "attcycle_n256_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=120, cstride=16, vcp_nn="att", cycle=True),
+    "distcycle_n256_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=130, cstride=16, vcp_nn="dist", cycle=True),
+    # BASELINE configs[4] shape: uniform clouds, N=4096, k=40 (LPDNet.k override, lpdnet_model.py:81)
+    "whole_k40_n4096_b2": lambda n: run_vcrnet(n, B=2, N=4096, first_item=140, cstride=128, k=40, kind="uniform"),
+    "dgcnn_partial_n192_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=150, cstride=16, emb_nn="dgcnn",
+                                                   partial=True, iters=1),
+}
+
+
 if __name__ == "__main__":
+    # usage: gen_golden.py [case ...]   (no arguments = every case)
     sd = torch.load(os.path.join(REF, "pretrained", "lpd-pretrained.t7"), map_location="cpu")
-    np.savez(os.path.join(HERE, "lpd_pretrained.npz"), **{k: v.numpy() for k, v in sd.items()})
+    if len(sys.argv) == 1:
+        np.savez(weights.LPD_FIXTURE, **{k: v.numpy() for k, v in sd.items()})
     LPD = weights.load_lpd_fixture()
-    run_vcrnet("whole_n256_b2", B=2, N=256, first_item=0, cstride=4)
-    run_vcrnet("whole_n1024_b2", B=2, N=1024, first_item=10, cstride=16)
-    run_vcrnet("whole_k40_n512_b1", B=1, N=512, first_item=20, cstride=16, k=40)
-    run_vcrnet("cycle_n256_b2", B=2, N=256, first_item=30, cstride=16, cycle=True)
-    run_vcrnet("partial_n192_b2_it2", B=2, N=256, first_item=40, cstride=8, partial=True, iters=2)
-    run_vcrnet("partial_n768_b2_it3", B=2, N=1024, first_item=50, cstride=32, partial=True, iters=3)
-    run_vcrnet("dgcnn_n256_b2", B=2, N=256, first_item=60, cstride=8, emb_nn="dgcnn")
-    run_vcrnet("att_n256_b2", B=2, N=256, first_item=70, cstride=16, vcp_nn="att")
-    run_vcrnet("dist_n256_b2", B=2, N=256, first_item=80, cstride=16, vcp_nn="dist")
-    run_vcrnet("identity_n256_b2", B=2, N=256, first_item=90, cstride=16, pointer="identity")
-    run_dcp("dcp_n256_b2", B=2, N=256, first_item=100, cstride=16)
-    run_icp("icp_n256_b2", B=2, N=256, first_item=110)
+    for name in (sys.argv[1:] or list(CASES)):
+        CASES[name](name)

@@ -32,10 +32,50 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.vcr_abi_version() == 9
+    assert lib.vcr_abi_version() == 10
     assert lib.vcr_strerror(0) == b"ok"
     assert b"invalid" in lib.vcr_strerror(-1)
     assert b"workspace" in lib.vcr_strerror(-2)
+
+
+def test_ctypes_structs_match_the_c_layout(tmp_path):
+    """sizeof + the offset of every field of each args struct, as gcc lays out include/vcr_hip.h, against the ctypes
+    mirrors in vcrnet_amd/native.py (a field added on one side only would silently shift everything after it)."""
+    import subprocess
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native
+    pairs = {"vcr_pointwise_args": native.PointwiseArgs, "vcr_knn_args": native.KnnArgs,
+             "vcr_linear_args": native.LinearArgs, "vcr_layernorm_args": native.LayerNormArgs,
+             "vcr_rowside_args": native.RowsideArgs, "vcr_edgeconv_args": native.EdgeconvArgs,
+             "vcr_gathermax_args": native.GathermaxArgs, "vcr_edgerows_args": native.EdgerowsArgs,
+             "vcr_segmax_args": native.SegmaxArgs, "vcr_sdpa_args": native.SdpaArgs,
+             "vcr_keymass_args": native.KeymassArgs, "vcr_softcorr_args": native.SoftcorrArgs,
+             "vcr_pairscore_args": native.PairscoreArgs, "vcr_scoremass_args": native.ScoremassArgs,
+             "vcr_rankselect_args": native.RankselectArgs, "vcr_gather_args": native.GatherArgs,
+             "vcr_rigid_svd_args": native.RigidSvdArgs, "vcr_icp_args": native.IcpArgs,
+             "vcr_make_pairs_args": native.MakePairsArgs, "vcr_vcrnet_weights": native.VcrnetWeights,
+             "vcr_vcrnet_io": native.VcrnetIo, "vcr_trace": native.Trace}
+    hdr = open(HEADER).read()
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
+    expect = []
+    for cname, ct in pairs.items():
+        body = re.search(r"typedef struct[^{]*\{((?:[^{}]|\{[^{}]*\})*)\}\s*%s;" % cname, hdr)
+        assert body, cname
+        lines.append(f'printf("%zu\\n", sizeof({cname}));')
+        expect.append((cname, "sizeof", ctypes.sizeof(ct)))
+        for fname, _ in ct._fields_:
+            cfield = "in" if fname == "in_" else fname
+            lines.append(f'printf("%zu\\n", offsetof({cname}, {cfield}));')
+            expect.append((cname, fname, getattr(ct, fname).offset))
+    lines.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert len(got) == len(expect)
+    bad = [(c, f, e, g) for (c, f, e), g in zip(expect, got) if e != g]
+    assert not bad, bad
 
 
 def test_argument_errors_do_not_need_a_gpu(lib):

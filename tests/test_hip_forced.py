@@ -1,0 +1,155 @@
+"""Partial-overlap parity of the FUSED driver (vcr_vcrnet_forward_f32 / vcr_vcrnet_iter_f32 -- the calls bench.py
+times at BASELINE configs[2]) at the BASELINE tolerance, on EVERY iteration.
+
+The partial path is discretely chaotic in the reference itself (1 vs 8 CPU threads flip one of 196 hard
+pairs and move R by 3e-3), so the tolerance is assertable only on identical selections.  The C-ABI therefore takes
+the path's five discrete selections as optional inputs (vcr_vcrnet_io.force_*: kept decoder keys, both overlap sets,
+arg-max targets, hard pairs -- model/transformer.py:41-42, model/vcrnet_model.py:223,245,297,312) and reports the ones
+it used (out_*).  These tests
+  (1) teacher-force the reference's recorded selections and assert 1e-4 / 1e-5 on (R, t) for every iteration,
+  (2) run free and report / bound the flips separately, asserting the tolerance whenever nothing flipped."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import golden
+from test_hip_forward import build_net, R_TOL, T_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def golden_selections(g, p):
+    """The reference's selections of iteration prefix p as the `force` dict of VCRNet._forward_fused.
+    keep_dir_src = kept keys of model(src, tgt), whose memory (keys) is the SOURCE cloud -> key clouds 0..B-1."""
+    i32 = lambda a: torch.from_numpy(a.astype(np.int32))
+    return {"keys": torch.cat((i32(g[p + "keep_dir_src"]), i32(g[p + "keep_dir_tgt"])), 0),
+            "sel_src": i32(g[p + "sel_src"]), "sel_tgt": i32(g[p + "sel_tgt"]),
+            "argmax": i32(g[p + "argmax_tgt"]), "pairs": i32(g[p + "pair_src"])}
+
+
+def set_diff(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return sum(len(set(x) ^ set(y)) // 2 for x, y in zip(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])))
+
+
+def count_flips(sel, ref, it=0):
+    """Differences between the device's selections (out_* of iteration `it`) and a reference `force`-style dict:
+    kept keys / overlap sets as SETS, hard pairs as the set of (source point, target point) pairs."""
+    s = {k: v[it].cpu().numpy() for k, v in sel.items()}
+    r = {k: v.numpy() for k, v in ref.items()}
+    B = r["sel_src"].shape[0]
+    pairs = lambda d: {(b, int(d["sel_src"][b, i]), int(d["sel_tgt"][b, d["argmax"][b, i]]))
+                       for b in range(B) for i in d["pairs"][b]}
+    return {"keys": set_diff(s["keys"], r["keys"]), "overlap": set_diff(s["sel_src"], r["sel_src"]) +
+            set_diff(s["sel_tgt"], r["sel_tgt"]), "pairs": len(pairs(s) ^ pairs(r)) // 2, "n_pairs": len(pairs(r))}
+
+
+@pytest.mark.parametrize("name", ["partial_n192_b2_it2", "partial_n768_b2_it3"])
+def test_fused_forward_teacher_forced_every_iteration(name):
+    g = golden(name)
+    net, _ = build_net(partial=True, overlap2=float(g["overlap2"]))
+    assert net.fused_supported()
+    tgt = torch.from_numpy(g["tgt"]).cuda()
+    for it in range(int(g["iters"])):
+        p = f"it{it}_"
+        cur = torch.from_numpy(g[p + "in"]).cuda()
+        force = golden_selections(g, p)
+        with torch.no_grad():
+            srcK, corrK, R, t, R_ba, t_ba, sel = net._forward_fused(cur, tgt, force=force, want_selections=True)
+            free = net._forward_fused(cur, tgt, want_selections=True)
+        for k, v in force.items():                                # the driver reports what it was told to use
+            assert torch.equal(sel[k][0].cpu(), v), k
+        # forced: hard pairs are the reference's points exactly, the pose within the BASELINE tolerance -- every iteration
+        assert np.array_equal(srcK.cpu().numpy(), g[p + "srcK"]) and np.array_equal(corrK.cpu().numpy(), g[p + "corrK"])
+        dR, dt = np.abs(R.cpu().numpy() - g[p + "R"]).max(), np.abs(t.cpu().numpy() - g[p + "t"]).max()
+        assert dR <= R_TOL and dt <= T_TOL, (it, dR, dt)
+        np.testing.assert_allclose(R_ba.cpu().numpy(), g[p + "R_ba"], atol=R_TOL)
+        np.testing.assert_allclose(t_ba.cpu().numpy(), g[p + "t_ba"], atol=3 * T_TOL)
+        # free-running: flips reported separately; identical selections -> the same tolerance
+        fl = count_flips(free[6], force)
+        fR, ft = np.abs(free[2].cpu().numpy() - g[p + "R"]).max(), np.abs(free[3].cpu().numpy() - g[p + "t"]).max()
+        print(f"{name} it{it}: forced max|dR| {dR:.2e} max|dt| {dt:.2e}; free-running flips {fl}, max|dR| {fR:.2e}")
+        B, N = cur.shape[0], cur.shape[2]
+        assert fl["keys"] <= max(2, 2 * B * N // 100) and fl["overlap"] <= max(4, B * N // 50)
+        assert fl["pairs"] <= max(2, fl["n_pairs"] // 20), fl
+        if fl["keys"] == fl["overlap"] == fl["pairs"] == 0:
+            assert fR <= R_TOL and ft <= T_TOL, (it, fR, ft)
+
+
+@pytest.mark.parametrize("name", ["partial_n192_b2_it2", "partial_n768_b2_it3"])
+def test_fused_iter_loop_teacher_forced(name):
+    """ONE vcr_vcrnet_iter_f32 call (device-side loop, poses composed by pose_step) with the reference's selections of
+    every iteration: the composed pose is the reference's within the BASELINE tolerance.  (Each pass here starts from
+    the DEVICE's own moved source, not the recorded one: with identical selections the path is continuous.)"""
+    g = golden(name)
+    iters = int(g["iters"])
+    net, _ = build_net(partial=True, overlap2=float(g["overlap2"]))
+    src, tgt = torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda()
+    per = [golden_selections(g, f"it{it}_") for it in range(iters)]
+    force = {k: torch.stack([d[k] for d in per]) for k in per[0]}
+    with torch.no_grad():
+        srcK, corrK, R, t, R_ba, t_ba, sel = net._forward_fused(src, tgt, iters=iters, force=force, want_selections=True)
+        free = net._forward_fused(src, tgt, iters=iters, want_selections=True)
+    for k, v in force.items():
+        assert torch.equal(sel[k].cpu(), v), k
+    dR, dt = np.abs(R.cpu().numpy() - g["R_final"]).max(), np.abs(t.cpu().numpy() - g["t_final"]).max()
+    print(f"{name}: forced {iters}-iteration loop max|dR| {dR:.2e} max|dt| {dt:.2e}")
+    assert dR <= R_TOL and dt <= T_TOL, (dR, dt)
+    np.testing.assert_allclose(R_ba.cpu().numpy(), np.transpose(g["R_final"], (0, 2, 1)), atol=R_TOL)
+    p = f"it{iters - 1}_"
+    np.testing.assert_allclose(corrK.cpu().numpy(), g[p + "corrK"], atol=0)       # target points: never moved
+    np.testing.assert_allclose(srcK.cpu().numpy(), g[p + "srcK"], atol=2e-4)      # source points moved by the device's own poses
+    # free-running loop: chaotic -- report, and bound loosely
+    fl = [count_flips(free[6], per[it], it) for it in range(iters)]
+    fR = np.abs(free[2].cpu().numpy() - g["R_final"]).max()
+    print(f"{name}: free-running loop flips per iteration {fl}, max|dR| {fR:.2e}")
+    assert fR < 5e-2
+    if all(f["keys"] == f["overlap"] == f["pairs"] == 0 for f in fl):
+        assert fR <= R_TOL
+
+
+def test_config3_single_call_vs_oracle():
+    """BASELINE configs[2] as bench.py runs it: B = 24 pairs, clouds cropped 1024 -> 768, iter = 3, ONE
+    vcr_vcrnet_iter_f32 call, against oracle.vcrnet_iter on the same inputs.  The oracle's own selections of every
+    iteration are forced into the device loop -> every one of the 24 poses within 1e-4 / 1e-5; the free-running call
+    is compared in aggregate (the reference differs from itself at this level)."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    from vcrnet_amd.module import vcrnetIter
+    B, iters = 24, 3
+    net, w = build_net(partial=True, overlap2=synth.OVERLAP2_0575)
+    src, tgt, _, _, _ = synth.make_batch(3000, B, 1024, partial=True)
+    assert src.shape == (B, 3, 768)
+    rec, per = {}, []
+    cfg = oracle.OracleConfig(partial=True, overlap2=synth.OVERLAP2_0575, record=rec)
+    ref = oracle.vcrnet_iter(w, torch.from_numpy(src), torch.from_numpy(tgt), cfg, iters=iters, per_iter=per)
+    i32 = lambda x: x.to(torch.int32)
+    force = {"keys": torch.stack([torch.cat((i32(s["key_keep_src"]), i32(s["key_keep_tgt"])), 0) for *_, s in per]),
+             "sel_src": torch.stack([i32(s["sel_src"]) for *_, s in per]),
+             "sel_tgt": torch.stack([i32(s["sel_tgt"]) for *_, s in per]),
+             "argmax": torch.stack([i32(s["argmax_tgt"]) for *_, s in per]),
+             "pairs": torch.stack([i32(s["pair_src"]) for *_, s in per])}
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    with torch.no_grad():
+        forced = net._forward_fused(s, t, iters=iters, force=force)
+        free = vcrnetIter(net, s, t, iter=iters)              # the public wrapper = the same single C call, free-running
+    dR = np.abs(forced[2].cpu().numpy() - ref[2].numpy()).reshape(B, -1).max(1)
+    dt = np.abs(forced[3].cpu().numpy() - ref[3].numpy()).reshape(B, -1).max(1)
+    print(f"config 3 forced: max|dR| {dR.max():.2e} max|dt| {dt.max():.2e} over {B} pairs")
+    assert dR.max() <= R_TOL and dt.max() <= T_TOL, (dR, dt)
+    fR = np.abs(free[2].cpu().numpy() - ref[2].numpy()).reshape(B, -1).max(1)
+    ft = np.abs(free[3].cpu().numpy() - ref[3].numpy()).reshape(B, -1).max(1)
+    ok = int(((fR <= R_TOL) & (ft <= T_TOL)).sum())
+    print(f"config 3 free-running: {ok}/{B} pairs within tolerance, median|dR| {np.median(fR):.2e}, max|dR| {fR.max():.2e}")
+    assert free[0].shape == (B, 3, 196) and torch.allclose(torch.det(free[2]).cpu(), torch.ones(B), atol=1e-5)
+    assert np.median(fR) < 1e-2 and fR.max() < 0.5
+
+
+def test_forced_selections_are_rejected_in_whole_mode():
+    net, _ = build_net()
+    x = torch.zeros(1, 3, 64).cuda()
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native
+    with torch.no_grad(), pytest.raises(native.VcrHipError):
+        net._forward_fused(x, x, force={"keys": torch.zeros(2, 48, dtype=torch.int32)})

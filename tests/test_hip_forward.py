@@ -44,7 +44,7 @@ def build_net(**kw):
     return net.cuda().eval(), w
 
 
-@pytest.mark.parametrize("name", ["whole_n256_b2", "whole_n1024_b2", "whole_k40_n512_b1"])
+@pytest.mark.parametrize("name", ["whole_n256_b2", "whole_n1024_b2", "whole_k40_n512_b1", "whole_k40_n4096_b2"])
 def test_whole_vs_reference_golden(name):
     g = golden(name)
     net, _ = build_net()
@@ -90,6 +90,25 @@ def test_whole_vs_oracle(B, N, kind):
     assert_mostly_close(out[1].cpu().numpy(), ref[1].numpy(), atol=5e-4)
     np.testing.assert_allclose(out[2].cpu().numpy(), ref[2].numpy(), atol=R_TOL)
     np.testing.assert_allclose(out[3].cpu().numpy(), ref[3].numpy(), atol=t_tol)
+
+
+def test_config5_shape_vs_oracle():
+    """BASELINE configs[4] end to end: uniform clouds, N = 4096, k = 40 (LPDNet.k override, lpdnet_model.py:81), one
+    fused call, against the CPU oracle on fresh inputs (the recorded reference run of the same shape is
+    whole_k40_n4096_b2 above) at the BASELINE tolerance."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    net, w = build_net()
+    net.emb_nn.k = 40
+    src, tgt, _, _, _ = synth.make_batch(5000, 2, 4096, kind="uniform")
+    src_t, tgt_t = torch.from_numpy(src), torch.from_numpy(tgt)
+    ref = oracle.vcrnet_forward(w, src_t, tgt_t, oracle.OracleConfig(k=40))
+    with torch.no_grad():
+        out = net(src_t.cuda(), tgt_t.cuda())
+    dR, dt = np.abs(out[2].cpu().numpy() - ref[2].numpy()).max(), np.abs(out[3].cpu().numpy() - ref[3].numpy()).max()
+    print(f"config 5 shape (N=4096, k=40): max|dR|={dR:.2e} max|dt|={dt:.2e}")
+    assert_mostly_close(out[1].cpu().numpy(), ref[1].numpy(), atol=5e-4)
+    assert dR <= R_TOL and dt <= T_TOL
 
 
 @pytest.mark.parametrize("name,kw", [("dist_n256_b2", dict(vcp_nn="dist")), ("identity_n256_b2", dict(pointer="identity"))])
@@ -139,6 +158,81 @@ def test_iter_wrapper_whole():
         out = vcrnetIter(net, torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), iter=2)
     np.testing.assert_allclose(out[2].cpu().numpy(), ref[2].numpy(), atol=R_TOL)
     np.testing.assert_allclose(out[3].cpu().numpy(), ref[3].numpy(), atol=2 * T_TOL)
+
+
+@pytest.mark.parametrize("iters", [1, 2])
+@pytest.mark.parametrize("vcp", ["topK", "att"])
+def test_iter_wrapper_with_cycle_returns_the_inverse_pose(vcp, iters):
+    """vcrnetIter recomputes (R_ba, t_ba) as the inverse of the composed pose (vcrnet_model.py:40-41) even when
+    args.cycle makes VCRNet.forward return the second head's solve -- also for iter = 1, where the device loop is a
+    single forward."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    from vcrnet_amd.module import vcrnetIter
+    net, w = build_net(cycle=True, vcp_nn=vcp)
+    src, tgt, _, _, _ = synth.make_batch(430, 2, 256)
+    s, t = torch.from_numpy(src), torch.from_numpy(tgt)
+    ref = oracle.vcrnet_iter(w, s, t, oracle.OracleConfig(cycle=True, vcp_nn=vcp), iters=iters)
+    with torch.no_grad():
+        out = vcrnetIter(net, s.cuda(), t.cuda(), iter=iters)
+        fwd = net(s.cuda(), t.cuda())
+    R, tt = out[2].cpu(), out[3].cpu()
+    np.testing.assert_allclose(out[4].cpu().numpy(), R.transpose(1, 2).numpy(), atol=1e-6)
+    np.testing.assert_allclose(out[5].cpu().numpy(), -torch.matmul(R.transpose(1, 2), tt.unsqueeze(2)).squeeze(2).numpy(),
+                               atol=1e-6)
+    tol = 10 if vcp == "att" else 2           # VcpAtt's seeded-random projections amplify fp32 noise (see test_hip_variants)
+    np.testing.assert_allclose(R.numpy(), ref[2].numpy(), atol=R_TOL)
+    np.testing.assert_allclose(tt.numpy(), ref[3].numpy(), atol=tol * T_TOL)
+    np.testing.assert_allclose(out[4].cpu().numpy(), ref[4].numpy(), atol=R_TOL)
+    # the plain forward DOES return the cycle head's pose, which is not the inverse
+    assert np.abs(fwd[4].cpu().numpy() - fwd[2].cpu().transpose(1, 2).numpy()).max() > 1e-4
+
+
+def test_data_parallel_wrapped_net_takes_the_device_loop():
+    """The reference's caller always wraps the net in nn.DataParallel (util/initPara.py:260 -> vcrnet_model.py:26).
+    On one device the wrapper is a pass-through, and vcrnetIter still runs the single-call device loop."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    from vcrnet_amd.module import VCRNet, vcrnetIter
+    net, _ = build_net()
+    dp = torch.nn.DataParallel(net, device_ids=[0])
+    src, tgt, _, _, _ = synth.make_batch(440, 3, 256)
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    calls = []
+    orig = VCRNet.forward_iter
+    VCRNet.forward_iter = lambda self, *a: (calls.append(1), orig(self, *a))[1]
+    try:
+        with torch.no_grad():
+            a = vcrnetIter(net, s, t, iter=2)
+            b = vcrnetIter(dp, s, t, iter=2)
+            c = dp(s, t)
+            d = net(s, t)
+    finally:
+        VCRNet.forward_iter = orig
+    assert len(calls) == 2                                  # both took forward_iter (one vcr_vcrnet_iter_f32 call each)
+    for x, y in zip(a[1:], b[1:]):
+        assert torch.equal(x, y)
+    for x, y in zip(c[1:], d[1:]):
+        assert torch.equal(x, y)
+    # a checkpoint saved through the wrapper carries the "module." prefix and loads back (SURVEY section 5 gotcha)
+    net2, _ = build_net()
+    net2.load_state_dict(dp.state_dict(), strict=True)
+
+
+def test_module_on_its_own_device_without_set_device():
+    """A module and inputs on cuda:0 run on cuda:0's stream whatever the current device is (the guard that matters on
+    multi-GPU boxes: net.to('cuda:1')(x) without torch.cuda.set_device(1)); a device mismatch raises."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native, synth
+    net, _ = build_net()
+    src, tgt, _, _, _ = synth.make_batch(450, 2, 128)
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    with torch.no_grad():
+        out = net(s, t)
+        with pytest.raises(native.VcrHipError):
+            net(s, t.cpu())
+    assert out[2].device == s.device
+    assert native.stream_ptr(s.device) == torch.cuda.current_stream(s.device).cuda_stream
 
 
 @pytest.mark.parametrize("name", ["whole_n256_b2", "whole_n1024_b2"])

@@ -105,14 +105,9 @@ def test_knn_cartesian(nat, N, k):
     nbad = knn_sets_ok(src, idx, k)
     assert nbad <= max(2, 2 * N // 100)
     # the candidate split (2 / 4 / 8 waves per 64 queries, chosen from the grid size) must not change any set
-    L = nat.lib()
     ref = np.sort(idx.cpu().numpy(), -1)
     for waves in (2, 4, 8):
-        L.vcr_debug_knn3_waves(waves)
-        try:
-            assert (np.sort(nat.knn(dev(xyz4), None, k).cpu().numpy(), -1) == ref).all(), waves
-        finally:
-            L.vcr_debug_knn3_waves(0)
+        assert (np.sort(nat.knn(dev(xyz4), None, k, waves=waves).cpu().numpy(), -1) == ref).all(), waves
 
 
 def test_knn_duplicates_drop_rank0(nat):

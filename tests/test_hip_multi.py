@@ -1,0 +1,135 @@
+"""The multi-GPU path on the hardware a 1-GPU box offers (replaces nn.DataParallel,
+util/initPara.py:260):
+  * RCCL itself initialises next to libvcr_hip.so (two HIP runtimes in one image: torch's bundled ROCm and the system
+    one hipcc links) and shard.all_gather_poses runs on cuda:0 through backend "nccl" -- world size 1 in this process;
+  * `python bench.py --gpus 2` with no launcher spawns its own ranks (two processes sharing the one GPU, gloo for the
+    rendezvous) and rank 0 prints the n_gpus = 2 line;
+  * evaluate.main, the counterpart of main.py --eval -> testVCRNet, over a sharded test set, against the CPU oracle's
+    metrics."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import cfg_weights
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_rccl_world1_all_gather_next_to_libvcr_hip():
+    import torch.distributed as dist
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native, shard, synth
+    from test_hip_forward import build_net
+    native.lib()                                             # libvcr_hip.so is mapped BEFORE the communicator opens
+    net, _ = build_net()
+    src, tgt, _, _, _ = synth.make_batch(10, 2, 128)
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    with torch.no_grad():
+        out = net(s, t)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl"
+        pose = shard.pack_pose(out[2], out[3])
+        # world == 1 short-circuits in all_gather_poses; drive the collective itself
+        got = torch.empty_like(pose)
+        dist.all_gather_into_tensor(got, pose.contiguous())
+        assert torch.equal(got, pose)
+        tt = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        assert float(tt.item()) == 1.5
+        dist.barrier()
+        with torch.no_grad():                                # and the HIP path still runs after RCCL came up
+            again = net(s, t)
+        assert torch.equal(again[2], out[2])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run: the parent spawns the two rank processes before it
+    touches the GPU.  On this 1-GPU box both ranks share cuda:0 and rendezvous over gloo (--backend gloo); with 2+ GPUs
+    the same command line without --backend is the RCCL run the driver's scaling sweep performs."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3",
+                        "--warmup", "1", "--batch", "4", "--points", "256", "--min-seconds", "0.2"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["scaling"] == "weak"
+    assert j["value"] > 0 and "roofline" in j and "cpu_baseline" not in j
+    assert j["timed_blocks"]["count"] >= 1 and j["timed_blocks"]["steps_per_block"] == 3
+
+
+def test_bench_under_torchrun_still_works():
+    port = _free_port()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--points", "256", "--min-seconds", "0.1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2
+
+
+def test_evaluate_main_matches_oracle_metrics(capsys):
+    """evaluate.main over 32 synthetic items (two batches of 16, N = 256): the ==FINAL TEST== figures equal the ones
+    the same accumulator computes from the CPU oracle's poses (whole mode: every pose within 1e-4 / 1e-5, so the
+    aggregates agree to 1e-3 relative)."""
+    sys.path.insert(0, ROOT)
+    import evaluate
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import evalmetrics, synth
+    res = evaluate.main(["--items", "32", "--batch", "16", "--points", "256", "--first-item", "6000", "--cycle"])
+    text = capsys.readouterr().out
+    assert "==FINAL TEST==" in text and "A--------->B" in text and "B--------->A" in text
+    assert res["pairs"] == 32
+    w = cfg_weights()
+    ref = evalmetrics.EvalAccumulator(cycle=True)
+    for first in (6000, 6016):
+        src, tgt, R, t, eul = synth.make_batch(first, 16, 256)
+        s, tt, Rg, tg = (torch.from_numpy(x) for x in (src, tgt, R, t))
+        ref.add_batch(s, tt, Rg, tg, eul, oracle.vcrnet_iter(w, s, tt, oracle.OracleConfig(cycle=True), iters=1))
+    ma, mb = ref.final(), ref.final_ba()
+    for key in ("loss", "mse", "mae", "rot_mse", "rot_mae", "trans_mse", "trans_mae"):
+        assert abs(res["ab"][key] - ma[key]) <= 1e-3 * abs(ma[key]) + 1e-9, ("ab", key, res["ab"][key], ma[key])
+    for key in ("mse", "rot_mse", "rot_mae", "trans_mse", "trans_mae"):
+        assert abs(res["ba"][key] - mb[key]) <= 1e-3 * abs(mb[key]) + 1e-9, ("ba", key, res["ba"][key], mb[key])
+    line = [ln for ln in text.splitlines() if ln.startswith("EPOCH:: -1")][0]
+    assert ("rot_MSE: %f" % res["ab"]["rot_mse"]) in line
+
+
+def test_evaluate_sharded_two_ranks_equals_one():
+    """Two evaluate.py ranks (sharing the GPU, gloo) print the same FINAL line as one process: contiguous shards +
+    EvalAccumulator.merge (one all-reduce, one all-gather) lose nothing."""
+    cmd = [os.path.join(ROOT, "evaluate.py"), "--items", "12", "--batch", "4", "--points", "256", "--first-item", "6100"]
+    one = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + cmd + ["--backend", "gloo"],
+                         capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    pick = lambda out: [ln for ln in out.splitlines() if ln.startswith("EPOCH:: -1")][0]
+    a = np.array([float(x.split(":")[-1]) for x in pick(one.stdout).split(",")[1:]])
+    b = np.array([float(x.split(":")[-1]) for x in pick(two.stdout).split(",")[1:]])
+    np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6)

@@ -54,8 +54,40 @@ def test_vcp_att_head():
     check(*run("att_n256_b2", vcp_nn="att"))
 
 
-def test_cycle_consistency():
-    check(*run("cycle_n256_b2", cycle=True))
+@pytest.mark.parametrize("name,kw", [("cycle_n256_b2", {}), ("distcycle_n256_b2", dict(vcp_nn="dist")),
+                                     ("attcycle_n256_b2", dict(vcp_nn="att"))])
+def test_cycle_consistency(name, kw):
+    """args.cycle: (R_ba, t_ba) from a second head + solve with the roles swapped (vcrnet_model.py:511-513).  With the
+    VcpAtt head the swap also swaps which Linear sees which cloud: linears_emb[0] projects the TARGET embeddings in
+    the second pass (vcrnet_model.py:444-445)."""
+    g, out = run(name, cycle=True, **kw)
+    print(name, "max|dt|", np.abs(out[3].cpu().numpy() - g["it0_t"]).max(), "max|dt_ba|",
+          np.abs(out[5].cpu().numpy() - g["it0_t_ba"]).max(), "max|dR_ba|", np.abs(out[4].cpu().numpy() - g["it0_R_ba"]).max())
+    if kw.get("vcp_nn") == "att":
+        # VcpAtt's seeded-random 512x512 projections amplify fp32 noise in the 512-d scores (see below): t gets 1e-4
+        assert_mostly_close(out[1].cpu().numpy(), g["it0_corrK"], atol=5e-4)
+        np.testing.assert_allclose(out[2].cpu().numpy(), g["it0_R"], atol=R_TOL)
+        np.testing.assert_allclose(out[4].cpu().numpy(), g["it0_R_ba"], atol=R_TOL)
+        np.testing.assert_allclose(out[3].cpu().numpy(), g["it0_t"], atol=1e-4)
+        np.testing.assert_allclose(out[5].cpu().numpy(), g["it0_t_ba"], atol=1e-4)
+    else:
+        check(g, out)
+    # and the second pose is NOT merely the inverse of the first
+    assert np.abs(out[4].cpu().numpy() - np.transpose(out[2].cpu().numpy(), (0, 2, 1))).max() > 1e-4
+
+
+def test_dgcnn_partial_vs_golden():
+    """emb_nn = dgcnn with the partial-overlap heads, reference selections forced: BASELINE tolerance."""
+    from test_hip_forced import golden_selections
+    g = golden("dgcnn_partial_n192_b2")
+    net, _ = build_net(emb_nn="dgcnn", partial=True, overlap2=float(g["overlap2"]))
+    assert net.fused_supported()
+    s, t = torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda()
+    with torch.no_grad():
+        out = net._forward_fused(s, t, force=golden_selections(g, "it0_"))
+    assert np.array_equal(out[0].cpu().numpy(), g["it0_srcK"]) and np.array_equal(out[1].cpu().numpy(), g["it0_corrK"])
+    np.testing.assert_allclose(out[2].cpu().numpy(), g["it0_R"], atol=R_TOL)
+    np.testing.assert_allclose(out[3].cpu().numpy(), g["it0_t"], atol=T_TOL)
 
 
 def test_dcp_model():

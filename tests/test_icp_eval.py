@@ -49,6 +49,21 @@ def test_eval_metrics_known_answers():
     assert abs(m2["trans_mae"] - 0.01) < 1e-6 and abs(m2["trans_rmse"] - 0.01) < 1e-6
     line = evalmetrics.EvalAccumulator.format_final(m2)
     assert line.startswith("EPOCH:: -1, Loss: ") and "rot_MSE: " in line and line.count(",") == 12
+    # B -> A (vcrnet_model.py:781-790): the exact inverse pose scores zero against the loader's B -> A labels -- this
+    # pins the 'xyz' Euler order of :781 to euler_ba = -euler_ab[::-1] of util/data.py:295 -- ...
+    mb = acc.final_ba()
+    for k in ("rot_mse", "rot_mae", "trans_mse", "trans_mae"):     # (mse_ba compares independently permuted clouds, :583,629)
+        assert abs(mb[k]) < 1e-4, (k, mb[k])
+    # ... and a known error shows up where it should: +2 degrees about x in the B -> A rotation, -0.02 on t_ba
+    Rb2 = np.stack([Rotation.from_euler("xyz", np.degrees(-e[::-1]) + [2.0, 0, 0], degrees=True).as_matrix()
+                    for e in eul]).astype(np.float32)
+    acc3 = evalmetrics.EvalAccumulator()
+    acc3.add_batch(T(src), T(tgt), T(R), T(t), T(eul), (T(src), corr, T(R), T(t), T(Rb2), tb - 0.02))
+    mb3 = acc3.final_ba()
+    assert abs(mb3["rot_mae"] - 2.0 / 3.0) < 1e-3 and abs(mb3["trans_mae"] - 0.02) < 1e-6
+    assert abs(acc3.final()["rot_mae"]) < 1e-4                     # the A -> B figures do not see it
+    lb = evalmetrics.EvalAccumulator.format_final_ba(mb3)
+    assert lb.startswith("EPOCH:: -1, Loss: ") and lb.count(",") == 11
 
 
 @pytest.mark.gpu

@@ -48,17 +48,25 @@ def check_common(g, rec, out, p="it0_", cs=None, lpd=True, pointer=True):
     np.testing.assert_allclose(t_ba.numpy(), g[p + "t_ba"], atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["whole_n256_b2", "whole_n1024_b2", "whole_k40_n512_b1"])
+@pytest.mark.parametrize("name", ["whole_n256_b2", "whole_n1024_b2", "whole_k40_n512_b1", "whole_k40_n4096_b2"])
 def test_whole(name):
     g, w, cfg, rec = run_case(name)
     out = oracle.vcrnet_forward(w, torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]), cfg)
     check_common(g, rec, out)
 
 
-def test_cycle():
-    g, w, cfg, rec = run_case("cycle_n256_b2", cycle=True)
+@pytest.mark.parametrize("name,kw", [("cycle_n256_b2", {}), ("attcycle_n256_b2", dict(vcp_nn="att")),
+                                     ("distcycle_n256_b2", dict(vcp_nn="dist"))])
+def test_cycle(name, kw):
+    """args.cycle (vcrnet_model.py:511-513): the second head runs with the ROLES swapped -- for VcpAtt that means
+    linears_emb[0] on the target embeddings -- and its solve is (R_ba, t_ba)."""
+    g, w, cfg, rec = run_case(name, cycle=True, **kw)
     out = oracle.vcrnet_forward(w, torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]), cfg)
     check_common(g, rec, out)
+    # vcrnetIter discards the cycle head's pose and returns the inverse of the composed one (vcrnet_model.py:40-41)
+    it = oracle.vcrnet_iter(w, torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]), cfg, iters=1)
+    np.testing.assert_allclose(it[4].numpy(), np.transpose(g["it0_R"], (0, 2, 1)), atol=1e-4)
+    assert np.abs(it[4].numpy() - g["it0_R_ba"]).max() > 1e-3      # ... which is NOT the cycle head's
 
 
 @pytest.mark.parametrize("name,kw", [("att_n256_b2", dict(vcp_nn="att")), ("dist_n256_b2", dict(vcp_nn="dist")),
@@ -89,11 +97,24 @@ def test_partial_teacher_forced(name):
         assert set_mismatch(rec["sel_tgt"].numpy(), g[p + "sel_tgt"]) == 0
         assert set_mismatch(rec["sel_src"].numpy(), g[p + "sel_src"]) == 0
         assert np.array_equal(rec["pair_src"].numpy(), g[p + "pair_src"])
+        # decoder key pruning, named by the cloud whose points are the keys (model(src,tgt): memory = enc(src))
+        assert set_mismatch(rec["key_keep_src"].numpy(), g[p + "keep_dir_src"]) == 0
+        assert set_mismatch(rec["key_keep_tgt"].numpy(), g[p + "keep_dir_tgt"]) == 0
+        assert np.array_equal(rec["argmax_tgt"].numpy(), g[p + "argmax_tgt"])
         check_common(g, rec, out, p=p)
     # free-running iteration reproduces the composed pose too (same machine, same primitives)
     fr = oracle.vcrnet_iter(w, torch.from_numpy(g["src"]), tgt, cfg, iters=iters)
     np.testing.assert_allclose(fr[2].numpy(), g["R_final"], atol=1e-4)
     np.testing.assert_allclose(fr[3].numpy(), g["t_final"], atol=1e-5)
+
+
+def test_dgcnn_partial():
+    g, w, cfg, rec = run_case("dgcnn_partial_n192_b2", emb_nn="dgcnn", partial=True)
+    out = oracle.vcrnet_forward(w, torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]), cfg)
+    assert set_mismatch(rec["sel_tgt"].numpy(), g["it0_sel_tgt"]) == 0
+    assert set_mismatch(rec["sel_src"].numpy(), g["it0_sel_src"]) == 0
+    assert np.array_equal(rec["pair_src"].numpy(), g["it0_pair_src"])
+    check_common(g, rec, out, lpd=False)
 
 
 def test_dcp():

@@ -251,8 +251,7 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
 #define VCR_SDPA_LAUNCH(M, P)                                                                                         \
   do {                                                                                                                 \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sdpa_kernel<M, P>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                        lds);                                                                                          \
+    VCR_DYN_LDS((sdpa_kernel<M, P>), lds);                                                                             \
     hipLaunchKernelGGL((sdpa_kernel<M, P>), grid, dim3(256), lds, s, *a);                                             \
   } while (0)
   if (a->key_keep) { if (pv) VCR_SDPA_LAUNCH(true, true); else VCR_SDPA_LAUNCH(true, false); }

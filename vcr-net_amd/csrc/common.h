@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <atomic>
 #include "../../include/vcr_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -10,6 +11,28 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define VCR_LAUNCH_RC() ((int)hipGetLastError())
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is sticky per (kernel, device): raise it when a launch needs more than
+// any earlier launch on that device did, not on every launch.  The cache is a per-call-site static of atomics (a
+// monotone maximum), so the entry points stay re-entrant: two threads may both issue the same idempotent
+// hipFuncSetAttribute, neither can lower the limit.
+struct vcr_lds_cache { std::atomic<int> cur[16]; };
+inline void vcr_raise_dyn_lds(const void* kernel, int bytes, vcr_lds_cache& c) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return;
+  }
+  int seen = c.cur[dev].load(std::memory_order_acquire);
+  if (seen >= bytes) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  while (seen < bytes && !c.cur[dev].compare_exchange_weak(seen, bytes, std::memory_order_release)) {}
+}
+#define VCR_DYN_LDS(kernel, bytes)                                                   \
+  do {                                                                               \
+    static vcr_lds_cache vcr_lds_cache_;                                             \
+    vcr_raise_dyn_lds(reinterpret_cast<const void*>(kernel), (bytes), vcr_lds_cache_); \
+  } while (0)
 #define VCR_NEG_INF (-__builtin_huge_valf())
 
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];

@@ -164,11 +164,23 @@ struct Runner {
   // KEY receives over heads and queries, keep the int(nk*overlap2) heaviest keys, soft-max again over those.
   // The first soft-max is never written: a statistics pass leaves (max, sum) per query row, the mass pass
   // streams the queries past each key block (owner = keys of batch b, streamed = queries of batch (b+B) % 2B).
-  void cross_attention(const vcr_vcrnet_weights* W, const Ws& w, int B, int N) {
+  // device-to-device copy of a forced / reported selection (tiny; stays on the stream)
+  void copy_idx(const char* nm, int32_t* dst, const int32_t* src, size_t n) {
+    if (rc) return;
+    mark(nm);
+    ok((int)hipMemcpyAsync(dst, src, n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+  }
+
+  void cross_attention(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, const Ws& w, int B, int N) {
     const int E = W->E, H = W->heads, nb = 2 * B, dk = E / H;
     const uint8_t* keep = nullptr;
     if (W->partial) {
-      if (w.xscore) {
+      const int nkeep = (int)((double)N * W->overlap2);
+      if (io->force_keys) {
+        // teacher forcing: the caller's kept keys replace the mass ranking (both passes that only feed it are skipped)
+        if (W->F < 2 * E) { ok(VCR_EUNSUPPORTED); return; }
+        copy_idx("select:dec.cross.keys.forced", w.xorder, io->force_keys, (size_t)nb * nkeep);
+      } else if (w.xscore) {
         // statistics pass that also keeps the scaled scores; the key mass is then one HBM-bound pass over them
         const int ldS = (N + 31) & ~31;
         sdpa("sdpa:dec.cross.stats", w.qc, E, w.kvc, 2 * E, nullptr, 0, nullptr, 0, nb, H, N, N, B, nullptr, w.rowstat,
@@ -192,8 +204,8 @@ struct Runner {
       // the kept keys' K|V rows are gathered into a dense [2B, nkeep, 2E] buffer (hid is free until the FFN) and the
       // second soft-max runs unmasked over nkeep keys: the same set as masked_fill(-1e9) + softmax, 23 % fewer
       // score / PV MFMAs at overlap2 = 0.766 and no per-score mask lookups
-      const int nkeep = (int)((double)N * W->overlap2);
-      rank("select:dec.cross.keys", w.keymass, 1, nb, N, nkeep, w.xorder, w.keep, 1);
+      if (!io->force_keys) rank("select:dec.cross.keys", w.keymass, 1, nb, N, nkeep, w.xorder, w.keep, 1);
+      if (io->out_keys) copy_idx("select:dec.cross.keys.out", io->out_keys, w.xorder, (size_t)nb * nkeep);
       if (W->F >= 2 * E) {                               // hid [2B*N, F] can hold the gathered rows
         gather("select:gather.kv", w.kvc, 2 * E, N, w.xorder, nb, nkeep, 2 * E, w.hid);
         sdpa("sdpa:dec.cross", w.qc, E, w.hid, 2 * E, w.hid + E, 2 * E, w.att, E, nb, H, N, nkeep, B);
@@ -223,21 +235,33 @@ struct Runner {
     // statistics (dim=2); the column statistics (dim=1) and both probability masses come from two HBM-bound
     // passes over it
     const int ldS = (N + 31) & ~31;
-    stats("pairscore:head.scores", se, te, ss, ts, N, N, w.rstat, nullptr, w.score, ldS);
-    if (rc == 0) {
-      mark("scoremass:head");
-      vcr_scoremass_args a{w.score, ldS, B, N, N, w.rstat, w.cstat, w.colsum, w.rowsum};             // :222, :244
-      ok(vcr_scoremass_f32(&a, stream));
+    const bool forced_sets = io->force_sel_src && io->force_sel_tgt;
+    if (!forced_sets) {
+      stats("pairscore:head.scores", se, te, ss, ts, N, N, w.rstat, nullptr, w.score, ldS);
+      if (rc == 0) {
+        mark("scoremass:head");
+        vcr_scoremass_args a{w.score, ldS, B, N, N, w.rstat, w.cstat, w.colsum, w.rowsum};           // :222, :244
+        ok(vcr_scoremass_f32(&a, stream));
+      }
     }
-    rank("select:head.tgt", w.colsum, 1, B, N, K1, w.sel_t, nullptr, 1);                             // :223
-    rank("select:head.src", w.rowsum, 1, B, N, K1, w.sel_s, nullptr, 1);                             // :245
+    if (io->force_sel_tgt) copy_idx("select:head.tgt.forced", w.sel_t, io->force_sel_tgt, (size_t)B * K1);
+    else rank("select:head.tgt", w.colsum, 1, B, N, K1, w.sel_t, nullptr, 1);                        // :223
+    if (io->force_sel_src) copy_idx("select:head.src.forced", w.sel_s, io->force_sel_src, (size_t)B * K1);
+    else rank("select:head.src", w.rowsum, 1, B, N, K1, w.sel_s, nullptr, 1);                        // :245
+    if (io->out_sel_tgt) copy_idx("select:head.tgt.out", io->out_sel_tgt, w.sel_t, (size_t)B * K1);
+    if (io->out_sel_src) copy_idx("select:head.src.out", io->out_sel_src, w.sel_s, (size_t)B * K1);
     gather("select:gather.src_emb", se, E, N, w.sel_s, B, K1, E, w.so_e);                            // :251-260
     gather("select:gather.tgt_emb", te, E, N, w.sel_t, B, K1, E, w.to_e);                            // :235-238
     gather("select:gather.src_xyz", ss, 4, N, w.sel_s, B, K1, 4, w.so_s);
     gather("select:gather.tgt_xyz", ts, 4, N, w.sel_t, B, K1, 4, w.to_s);
     // getCopair on the overlap sets: peak soft-max probability = 1/l and its arg-max target (:295-298)
-    stats("pairscore:head.copair", w.so_e, w.to_e, w.so_s, w.to_s, K1, K1, w.peak, w.amax, nullptr, 0);
-    rank("select:head.pairs", w.peak + 1, 2, B, K1, K2, w.pick, nullptr, 0);   // largest peak prob == smallest l (:312)
+    if (!(io->force_argmax && io->force_pairs))
+      stats("pairscore:head.copair", w.so_e, w.to_e, w.so_s, w.to_s, K1, K1, w.peak, w.amax, nullptr, 0);
+    if (io->force_argmax) copy_idx("select:head.argmax.forced", w.amax, io->force_argmax, (size_t)B * K1);
+    if (io->force_pairs) copy_idx("select:head.pairs.forced", w.pick, io->force_pairs, (size_t)B * K2);
+    else rank("select:head.pairs", w.peak + 1, 2, B, K1, K2, w.pick, nullptr, 0);   // largest peak prob == smallest l (:312)
+    if (io->out_argmax) copy_idx("select:head.argmax.out", io->out_argmax, w.amax, (size_t)B * K1);
+    if (io->out_pairs) copy_idx("select:head.pairs.out", io->out_pairs, w.pick, (size_t)B * K2);
     gather("select:gather.srcK", w.so_s, 4, K1, w.pick, B, K2, 4, io->src4);                         // :328-330
     gather("select:gather.corrK", w.to_s, 4, K1, w.pick, B, K2, 4, io->corr4, w.amax, K1);           // :325 (weights == 1)
     if (rc) return;
@@ -265,6 +289,9 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     if (!(W->overlap2 > 0.0 && W->overlap2 <= 1.0) || (int)((double)N * W->overlap2) < 1) return VCR_EINVAL;
     if (W->head_mode == 0 && overlap_k2(N, W->overlap2) < 3) return VCR_EINVAL;
   }
+  if (!W->partial && (io->force_keys || io->force_sel_src || io->force_sel_tgt || io->force_argmax || io->force_pairs))
+    return VCR_EINVAL;                                   // there is nothing discrete to force in whole mode
+  if ((io->force_sel_src != nullptr) != (io->force_sel_tgt != nullptr)) return VCR_EINVAL;
   Ws w = carve(workspace, B, N, k, E, F, W->heads, W->partial, W->overlap2, W->emb_kind);
   if (ws_bytes < w.bytes) return VCR_EWORKSPACE;
   const int M1 = B * N, M2 = 2 * M1;
@@ -377,7 +404,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
              w.st_d1, W->fold_dec_cross_q.colsum);
     R.linear("linear:dec.cross.kv", w.e2, E, W->fold_dec_cross_kv.w, nullptr, W->fold_dec_cross_kv.bias, w.kvc, 2 * E, M2, 2 * E, E, 0,
              nullptr, 0, w.st_e2, W->fold_dec_cross_kv.colsum);
-    R.cross_attention(W, w, B, N);
+    R.cross_attention(W, io, w, B, N);
     R.linear("linear:dec.cross.wo", w.att, E, W->dec_cross.wo, nullptr, W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E,
              nullptr, nullptr, w.st_d2);
     R.linear("linear:dec.ffn1", w.d2, E, W->fold_dec_ffn1.w, nullptr, W->fold_dec_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
@@ -403,7 +430,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     R.norm("layernorm:dec.sub1", w.d1, W->dec_ln1, w.ln, M2, E);
     R.linear("linear:dec.cross.q", w.ln, E, W->dec_cross.wq, SP(dec_cross_q), W->dec_cross.bq, w.qc, E, M2, E, E, 0);
     R.linear("linear:dec.cross.kv", w.mem, E, W->dec_cross.wkv, SP(dec_cross_kv), W->dec_cross.bkv, w.kvc, 2 * E, M2, 2 * E, E, 0);
-    R.cross_attention(W, w, B, N);
+    R.cross_attention(W, io, w, B, N);
     R.linear("linear:dec.cross.wo", w.att, E, W->dec_cross.wo, SP(dec_cross_wo), W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E);
     R.norm("layernorm:dec.sub2", w.d2, W->dec_ln2, w.ln, M2, E);
     R.linear("linear:dec.ffn1", w.ln, E, W->dec_ffn.w1, SP(dec_ffn1), W->dec_ffn.b1, w.hid, F, M2, F, E, 1);
@@ -454,6 +481,20 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       // cycle consistency (vcrnet_model.py:511-513): a second head + solve with the roles swapped gives (R_ba, t_ba)
       // instead of the inverse of (R_ab, t_ab); the qkv buffer is free and takes the second correspondence set
       if (!io->R_ba || !io->t_ba) return VCR_EINVAL;
+      if (W->head_mode == 2) {
+        // VcpAtt with the roles swapped, head(tgt_emb, src_emb, tgt, src) (vcrnet_model.py:511-513 -> :444-445):
+        // linears_emb[0] now projects the TARGET embeddings (the queries) and linears_emb[1] the SOURCE embeddings
+        // (the keys) -- not the ab pass's projections with the roles exchanged.  d2 is free after the decoder.
+        R.linear("linear:head.att.ba.src", w.embf, E, W->att_w1, nullptr, W->att_b1, w.d2, E, M1, E, E, 0);
+        R.linear("linear:head.att.ba.tgt", w.embf + (size_t)M1 * E, E, W->att_w0, nullptr, W->att_b0, w.d2 + (size_t)M1 * E,
+                 E, M1, E, E, 0);
+        if (R.rc == 0) {
+          R.mark("layernorm:rowside.att.ba");
+          vcr_rowside_args a{w.d2, E, M2, E, 1.f, nullptr, E, w.xyz4, w.side4};
+          R.ok(vcr_rowside_f32(&a, R.stream));
+        }
+        head_emb = w.d2;
+      }
       soft_head("softcorr:head.ba", (size_t)M1, 0, w.qkv);
       if (R.rc == 0) {
         R.mark("rigid_svd:ba");
@@ -471,7 +512,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
 
 // One step of vcrnetIter's bookkeeping (vcrnet_model.py:32-38) for sample blockIdx.y:
 //   out = R_i in + t_i              transform_point_cloud (util/util.py:91-96), skipped when out == NULL
-//   R_f <- R_i R_f,  t_f <- R_i t_f + t_i,  R_ba = R_f^T,  t_ba = -R_ba t_f      (block x == 0, when compose != 0)
+//   R_f <- R_i R_f,  t_f <- R_i t_f + t_i,  R_ba = R_f^T,  t_ba = -R_ba t_f      (block x == 0, when compose == 1)
+//   R_ba = R_i^T, t_ba = -R_ba t_i                                                (block x == 0, when compose == 2)
 // Products are k-ascending fma chains like the reference's CPU matmul.
 __global__ __launch_bounds__(256) void pose_step_kernel(const float* __restrict__ Ri, const float* __restrict__ ti,
                                                         const float* in_cf, float* out_cf, int N, int compose,
@@ -489,7 +531,12 @@ __global__ __launch_bounds__(256) void pose_step_kernel(const float* __restrict_
       for (int c = 0; c < 3; ++c) o[(size_t)c * N] = fmaf(r[c * 3 + 2], z, fmaf(r[c * 3 + 1], y, r[c * 3] * x)) + t[c];
     }
   }
-  if (compose && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (compose == 2 && blockIdx.x == 0 && threadIdx.x == 0) {          // (R_ba, t_ba) = inverse of (R_i, t_i) only
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) Rba[b * 9 + i * 3 + j] = r[j * 3 + i];
+      tba[b * 3 + i] = -fmaf(r[6 + i], t[2], fmaf(r[3 + i], t[1], r[i] * t[0]));
+    }
+  } else if (compose && blockIdx.x == 0 && threadIdx.x == 0) {
     float f[9], g[3], nf[9], ng[3];
     for (int i = 0; i < 9; ++i) f[i] = Rf[b * 9 + i];
     for (int i = 0; i < 3; ++i) g[i] = tf[b * 3 + i];
@@ -533,15 +580,37 @@ extern "C" int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet
                                    size_t bytes, vcr_stream_t stream, vcr_trace* tr) {
   if (!W || !io || iters < 1 || !io->R_ba || !io->t_ba) return VCR_EINVAL;
   if (tr) tr->count = 0;
-  if (iters == 1) return forward_impl(W, io, ws, bytes, stream, tr);
   const int B = io->B, N = io->N;
   if (B <= 0 || N <= 0) return VCR_EINVAL;
+  if (iters == 1) {
+    // vcrnetIter ALWAYS returns the inverse of the composed pose (vcrnet_model.py:40-41), also when args.cycle made
+    // the forward itself return the second head's (R_ba, t_ba)
+    const int rc = forward_impl(W, io, ws, bytes, stream, tr, !W->cycle);
+    if (rc || !W->cycle) return rc;
+    Runner R{(hipStream_t)stream, tr};
+    R.mark("pose:inverse");
+    hipLaunchKernelGGL(pose_step_kernel, dim3(1, B), dim3(64), 0, (hipStream_t)stream, io->R_ab, io->t_ab, nullptr, nullptr, N,
+                       2, nullptr, nullptr, io->R_ba, io->t_ba);
+    const int lrc = VCR_LAUNCH_RC();
+    R.finish();
+    return lrc;
+  }
   const Ws w = carve(ws, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind);
   if (bytes < w.bytes) return VCR_EWORKSPACE;
+  const size_t nkeys = W->partial ? (size_t)2 * B * (int)((double)N * W->overlap2) : 0;
+  const size_t nsel = W->partial ? (size_t)B * overlap_k1(N, W->overlap2) : 0;
+  const size_t npair = W->partial ? (size_t)B * overlap_k2(N, W->overlap2) : 0;
   for (int it = 0; it < iters; ++it) {
     vcr_vcrnet_io step = *io;
     if (it > 0) { step.src_cf = w.cur_cf; step.R_ab = w.Ri; step.t_ab = w.ti; step.R_ba = w.Rb; step.t_ba = w.tb; }
     if (it + 1 < iters) step.emb_out = nullptr;
+    // forced / reported selections: one block per iteration
+    auto at = [it](auto* p, size_t n) { return p ? p + (size_t)it * n : p; };
+    step.force_keys = at(io->force_keys, nkeys);       step.out_keys = at(io->out_keys, nkeys);
+    step.force_sel_src = at(io->force_sel_src, nsel);  step.out_sel_src = at(io->out_sel_src, nsel);
+    step.force_sel_tgt = at(io->force_sel_tgt, nsel);  step.out_sel_tgt = at(io->out_sel_tgt, nsel);
+    step.force_argmax = at(io->force_argmax, nsel);    step.out_argmax = at(io->out_argmax, nsel);
+    step.force_pairs = at(io->force_pairs, npair);     step.out_pairs = at(io->out_pairs, npair);
     const bool last = it + 1 == iters;
     const int rc = forward_impl(W, &step, ws, bytes, stream, tr, false);
     if (rc) return rc;
@@ -568,7 +637,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 9; }
+extern "C" int vcr_abi_version(void) { return 10; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

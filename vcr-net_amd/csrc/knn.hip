@@ -335,8 +335,6 @@ __global__ __launch_bounds__(512) void knn3_kernel(vcr_knn_args a) {
   }
 }
 
-int g_knn3_waves = 0;   // debug/tuning only (vcr_debug_knn3_waves): 0 = automatic
-
 // ---------------------------------------------------------------- exact replica of Tensor.topk's tie-breaking
 // Sequential port of libstdc++'s std::nth_element (__introselect: median-of-three to first, unguarded partition,
 // depth limit 2 log2 n with __heap_select fallback, final insertion sort) and of std::partial_sort's __heap_select,
@@ -654,16 +652,14 @@ __global__ __launch_bounds__(256) void knn_tiebreak_kernel(vcr_knn_args a) {
   }
 }
 
-template <class K>
-int launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const vcr_knn_args& a) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kernel, grid, block, lds, s, a);
+template <auto Kernel>
+int launch(dim3 grid, dim3 block, size_t lds, hipStream_t s, const vcr_knn_args& a) {
+  VCR_DYN_LDS(Kernel, (int)lds);                         // one cache per kernel: Kernel is a template argument
+  hipLaunchKernelGGL(Kernel, grid, block, lds, s, a);
   return VCR_LAUNCH_RC();
 }
 
 }  // namespace
-
-extern "C" void vcr_debug_knn3_waves(int w) { g_knn3_waves = w; }
 
 extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->idx) return VCR_EINVAL;
@@ -680,8 +676,8 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
     dim3 grid((a->N + 127) / 128, a->B);
     const size_t lds64 = (size_t)4 * 2 * PEND * 64 * 4;
-    rc = a->k <= 20 ? launch(knn64_kernel<22>, grid, dim3(256), lds64, s, *a)
-                    : launch(knn64_kernel<42>, grid, dim3(256), lds64, s, *a);
+    rc = a->k <= 20 ? launch<knn64_kernel<22>>(grid, dim3(256), lds64, s, *a)
+                    : launch<knn64_kernel<42>>(grid, dim3(256), lds64, s, *a);
   } else if (a->C == 4) {
     if (a->ldx < 4 || (a->ldx & 3)) return VCR_EINVAL;
     // Waves per 64 queries.  Splitting the candidates over more waves shortens each wave's serial scan + insert
@@ -689,16 +685,16 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
     // unless that leaves at most one wave per SIMD (MI355X: 256 CUs x 4 SIMDs), 8 only for very small grids.
     const long blocks = (long)((a->N + 63) / 64) * a->B;
     int nw = blocks * 4 <= 1024 ? 8 : blocks * 2 <= 1024 ? 4 : 2;
-    if ((g_knn3_waves & 15) == 2 || (g_knn3_waves & 15) == 4 || (g_knn3_waves & 15) == 8) nw = g_knn3_waves & 15;
+    if (a->waves == 2 || a->waves == 4 || a->waves == 8) nw = a->waves;   // caller's override (tests / tuning)
     while (nw > 2 && (size_t)nw * 2 * (ks > 24 ? ks : 24) * 64 * 4 > 160 * 1024) nw >>= 1;
     const size_t lds = (size_t)nw * 2 * (ks > 24 ? ks : 24) * 64 * 4;
     dim3 grid((a->N + 63) / 64, a->B);
-    rc = a->k <= 20 ? launch(knn3_kernel<22>, grid, dim3(64 * nw), lds, s, *a)
-                    : launch(knn3_kernel<42>, grid, dim3(64 * nw), lds, s, *a);
+    rc = a->k <= 20 ? launch<knn3_kernel<22>>(grid, dim3(64 * nw), lds, s, *a)
+                    : launch<knn3_kernel<42>>(grid, dim3(64 * nw), lds, s, *a);
   }
   if (rc != 0) return rc;
   // rows with an exact tie at the (k+1)-th value: replay libstdc++'s selection on them (see knn_tiebreak_kernel)
   const size_t tb_lds = (size_t)a->N * 16 + 256 + (16 + 2 * 256 + 2) * 4;
-  if (a->tie_scratch && tb_lds <= 160 * 1024) rc = launch(knn_tiebreak_kernel, dim3(64), dim3(256), tb_lds, s, *a);
+  if (a->tie_scratch && tb_lds <= 160 * 1024) rc = launch<knn_tiebreak_kernel>(dim3(64), dim3(256), tb_lds, s, *a);
   return rc;
 }

@@ -458,15 +458,12 @@ __global__ __launch_bounds__(256, 4) void linear_glds16_kernel(vcr_linear_args p
   }
 }
 
-int g_variant = 0;   // debug/tuning only (vcr_debug_linear_variant, see vcr_hip.h)
-
 }  // namespace
-
-extern "C" void vcr_debug_linear_variant(int v) { g_variant = v; }
 
 extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->w || !a->y) return VCR_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % 32) != 0) return VCR_EINVAL;
+  const int variant = a->variant;                    // tuning / test selector carried by the call (see vcr_hip.h)
   if ((a->ldx & 3) || a->ldx < a->K || a->ldy < a->N || (a->residual && a->ldr < a->N)) return VCR_EINVAL;
   if (((uintptr_t)a->x | (uintptr_t)a->w) & 15) return VCR_EINVAL;
   const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
@@ -476,32 +473,30 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
                   (!a->bias || ((uintptr_t)a->bias & 15) == 0) &&
                   (!a->residual || ((a->ldr % 4 == 0) && ((uintptr_t)a->residual & 15) == 0));
   if (a->ln_stats_in || a->stats_out) {                  // fused LayerNorm prologue / statistics epilogue
-    if (!vec || (g_variant & 4)) return VCR_EUNSUPPORTED;
+    if (!vec || (variant & 4)) return VCR_EUNSUPPORTED;
     if (a->ln_stats_in && (!a->ln_colsum || !a->bias || a->ln_nseg <= 0 || a->K < 2 ||
                            ((uintptr_t)a->ln_colsum & 15))) return VCR_EINVAL;
     if (a->stats_out && (a->N % 64)) return VCR_EINVAL;
   }
-  if (!(g_variant & 4) && vec) {   // default: LDS-DMA staging (bit2 of the debug variant selects register staging)
+  if (!(variant & 4) && vec) {   // default: LDS-DMA staging (bit2 of the debug variant selects register staging)
     const bool ln_in = a->ln_stats_in != nullptr, st_out = a->stats_out != nullptr;
     const int ldsg = 2 * sizeof(TileG) + (ln_in ? BM * 2 * 4 : 0);
 #define VCR_LIN_LAUNCH(LI, SO)                                                                                          \
   do {                                                                                                                   \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_glds_kernel<LI, SO>),                                \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, ldsg);                                        \
+    VCR_DYN_LDS((linear_glds_kernel<LI, SO>), ldsg);                                                                     \
     hipLaunchKernelGGL((linear_glds_kernel<LI, SO>), dim3(tiles_m * tiles_n), dim3(256), ldsg, (hipStream_t)stream, *a, \
                        tiles_m, tiles_n);                                                                                \
   } while (0)
 #define VCR_LIN16_LAUNCH(LI, SO)                                                                                        \
   do {                                                                                                                   \
     const int lds16g = 4 * 32 * 68 * 4 + (ln_in ? BM * 2 * 4 : 0);                                                       \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_glds16_kernel<LI, SO>),                              \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds16g);                                      \
+    VCR_DYN_LDS((linear_glds16_kernel<LI, SO>), lds16g);                                                                 \
     hipLaunchKernelGGL((linear_glds16_kernel<LI, SO>), dim3(tiles_m * tiles_n), dim3(256), lds16g, (hipStream_t)stream,  \
                        *a, tiles_m, tiles_n);                                                                            \
   } while (0)
     // Without a residual: BK = 16, four workgroups per CU (measured +2-3 % on the qkv / ffn1 / kv projections).
     // With one: BK = 32 and the residual tile prefetched across the GEMM loop (bit 3 of the debug variant forces BK 32).
-    if (!a->residual && !(g_variant & 8)) {
+    if (!a->residual && !(variant & 8)) {
       if (ln_in && st_out) VCR_LIN16_LAUNCH(true, true);
       else if (ln_in) VCR_LIN16_LAUNCH(true, false);
       else if (st_out) VCR_LIN16_LAUNCH(false, true);
@@ -512,12 +507,12 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
     else VCR_LIN_LAUNCH(false, false);
 #undef VCR_LIN16_LAUNCH
 #undef VCR_LIN_LAUNCH
-  } else if (g_variant & 1) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+  } else if (variant & 1) {
+    VCR_DYN_LDS(linear_kernel<16>, lds16);
     hipLaunchKernelGGL(linear_kernel<16>, dim3(tiles_m * tiles_n), dim3(256), lds16, (hipStream_t)stream, *a, tiles_m,
                        tiles_n, vec);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
+    VCR_DYN_LDS(linear_kernel<32>, lds32);
     hipLaunchKernelGGL(linear_kernel<32>, dim3(tiles_m * tiles_n), dim3(256), lds32, (hipStream_t)stream, *a, tiles_m,
                        tiles_n, vec);
   }

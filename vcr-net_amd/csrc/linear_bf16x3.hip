@@ -212,7 +212,7 @@ extern "C" int vcr_linear_bf16x3_f32(const vcr_linear_args* a, const void* w_pla
   const int tiles_m = (a->M + TM - 1) / TM, tiles_n = (a->N + TN - 1) / TN;
   const int lds = 2 * sizeof(Stage3);
   static_assert(2 * sizeof(Stage3) >= 8 * 32 * 68 * 4, "epilogue slices fit");
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  VCR_DYN_LDS(linear_bf16x3_kernel, lds);
   hipLaunchKernelGGL(linear_bf16x3_kernel, dim3(tiles_m * tiles_n), dim3(512), lds, (hipStream_t)stream, *a,
                      reinterpret_cast<const short*>(w_planes), tiles_m, tiles_n);
   return VCR_LAUNCH_RC();

@@ -75,8 +75,7 @@ extern "C" int vcr_make_pairs_f32(const vcr_make_pairs_args* a, vcr_stream_t str
     return VCR_EINVAL;
   if (a->B <= 0 || a->N < 2 || a->N > 4096 || a->P < a->N || a->keep < 1 || a->keep > a->N) return VCR_EINVAL;
   const int lds = a->N * 4 * (int)sizeof(double);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(make_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            lds);
+  VCR_DYN_LDS(make_pairs_kernel, lds);
   hipLaunchKernelGGL(make_pairs_kernel, dim3(2, a->B), dim3(256), lds, (hipStream_t)stream, *a);
   return VCR_LAUNCH_RC();
 }

@@ -283,8 +283,6 @@ __global__ __launch_bounds__(256) void score_rowpass_kernel(vcr_scoremass_args p
   if (lane == 0) p.row_mass[(size_t)b * p.n_rows + i] = acc;
 }
 
-int g_ps_variant = 0;   // debug/tuning only (vcr_debug_pairscore_variant): bit0 = one owner tile per block
-
 int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
   if (!a || !a->own || !a->str) return VCR_EINVAL;
   if (a->nbatch <= 0 || a->n_own <= 0 || a->n_str <= 0 || a->E <= 0 || (a->E % 128) || a->E > 1024) return VCR_EINVAL;
@@ -298,15 +296,14 @@ int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
   // two owner tiles per block (8 waves) when their embeddings fit the LDS, one (4 waves) otherwise
   const int lds2 = (64 * (a->E + 4) + 8 * 64 * 5) * 4, lds1 = (32 * (a->E + 4) + 4 * 32 * 5) * 4;
   // (narrow scores, E = 128 per attention head: too little MFMA work per block to pay for the half-size grid)
-  const int ot = (lds2 <= 160 * 1024 && a->E >= 256 && !(g_ps_variant & 1)) ? 2 : 1;
+  const int ot = (lds2 <= 160 * 1024 && a->E >= 256 && !(a->variant & 1)) ? 2 : 1;
   const int lds = ot == 2 ? lds2 : lds1;
   if (lds > 160 * 1024) return VCR_EUNSUPPORTED;
   dim3 grid((a->n_own + 32 * ot - 1) / (32 * ot), a->nbatch);
   hipStream_t s = (hipStream_t)stream;
 #define VCR_PS_LAUNCH(OPV, OTV)                                                                                         \
   do {                                                                                                                   \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pairscore_kernel<OPV, OTV>),                                \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                         \
+    VCR_DYN_LDS((pairscore_kernel<OPV, OTV>), lds);                                                                      \
     hipLaunchKernelGGL((pairscore_kernel<OPV, OTV>), grid, dim3(256 * OTV), lds, s, *a);                                \
   } while (0)
   if (ot == 2) { if (a->op == 0) VCR_PS_LAUNCH(0, 2); else if (a->op == 1) VCR_PS_LAUNCH(1, 2); else VCR_PS_LAUNCH(2, 2); }
@@ -316,8 +313,6 @@ int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
 }
 
 }  // namespace
-
-extern "C" void vcr_debug_pairscore_variant(int v) { g_ps_variant = v; }
 
 extern "C" int vcr_pairscore_f32(const vcr_pairscore_args* a, vcr_stream_t stream) { return launch(a, stream); }
 

@@ -33,6 +33,8 @@ class EvalAccumulator:
     R_pred: List[np.ndarray] = field(default_factory=list)
     t_pred: List[np.ndarray] = field(default_factory=list)
     euler_gt: List[np.ndarray] = field(default_factory=list)
+    Rba_pred: List[np.ndarray] = field(default_factory=list)
+    tba_pred: List[np.ndarray] = field(default_factory=list)
 
     def add_batch(self, src, tgt, R_ab, t_ab, euler_ab, out) -> None:
         """``out`` = (srcK, src_corrK, R_ab_pred, t_ab_pred, R_ba_pred, t_ba_pred) of vcrnetIter."""
@@ -59,6 +61,24 @@ class EvalAccumulator:
         self.R_gt.append(R_ab.detach().cpu().numpy()); self.t_gt.append(t_ab.detach().cpu().numpy())
         self.R_pred.append(Rp.detach().cpu().numpy()); self.t_pred.append(tp.detach().cpu().numpy())
         self.euler_gt.append(np.asarray(euler_ab.cpu() if torch.is_tensor(euler_ab) else euler_ab))
+        self.Rba_pred.append(Rbp.detach().cpu().numpy()); self.tba_pred.append(tbp.detach().cpu().numpy())   # :577-580
+
+    def final_ba(self) -> Dict[str, float]:
+        """testVCRNet's B -> A figures, :775,781-790: the predicted inverse pose against the loader's B -> A labels
+        (R_ba = R_ab^T, t_ba = -R_ba t_ab, euler_ba = -euler_ab[::-1]; util/data.py:278,286,295), Euler angles of the
+        prediction taken in 'xyz' order (:781)."""
+        n = max(1, self.num_examples)
+        Rg, tg, eg = np.concatenate(self.R_gt, 0), np.concatenate(self.t_gt, 0), np.concatenate(self.euler_gt, 0)
+        Rb, tb = np.concatenate(self.Rba_pred, 0), np.concatenate(self.tba_pred, 0)
+        t_ba = -np.einsum("bji,bj->bi", Rg, tg)                             # -R_ab^T t_ab
+        d = npmat2euler(Rb, "xyz") - np.degrees(-eg[:, ::-1])
+        r_mse = float(np.mean(d ** 2))
+        t_mse = float(np.mean((t_ba - tb) ** 2))
+        mse_ba = self.sums["mse_ba"] / n
+        return {"loss": self.sums["loss_vcr"] / n, "loss_pose": self.sums["loss"] / n, "mse": mse_ba,
+                "rmse": float(np.sqrt(mse_ba)), "mae": self.sums["mae_ba"] / n, "rot_mse": r_mse,
+                "rot_rmse": float(np.sqrt(r_mse)), "rot_mae": float(np.mean(np.abs(d))), "trans_mse": t_mse,
+                "trans_rmse": float(np.sqrt(t_mse)), "trans_mae": float(np.mean(np.abs(t_ba - tb)))}
 
     def final(self) -> Dict[str, float]:
         """testVCRNet, :769-790 (A -> B direction)."""
@@ -79,7 +99,7 @@ class EvalAccumulator:
     def merge(self, world: int, device="cpu") -> "EvalAccumulator":
         """Combine the per-rank accumulators of a process-per-GPU run (the replacement for nn.DataParallel's
         gather, util/initPara.py:260): one all-reduce of the running sums, one all-gather of the
-        [n,12+12+3] per-pair records (ragged shards padded, rank order kept).  Every rank returns the same
+        [n,12+12+3+12] per-pair records (ragged shards padded, rank order kept).  Every rank returns the same
         merged accumulator; world == 1 returns self."""
         if world == 1:
             return self
@@ -94,7 +114,7 @@ class EvalAccumulator:
         dist.all_reduce(counts)
         cat = lambda xs, w: (np.concatenate(xs, 0).reshape(-1, w) if xs else np.zeros((0, w), np.float32))
         rec = np.concatenate((cat(self.R_gt, 9), cat(self.t_gt, 3), cat(self.R_pred, 9), cat(self.t_pred, 3),
-                              cat(self.euler_gt, 3)), 1).astype(np.float32)
+                              cat(self.euler_gt, 3), cat(self.Rba_pred, 9), cat(self.tba_pred, 3)), 1).astype(np.float32)
         per = int(counts.max().item())
         pad = torch.zeros((per, rec.shape[1]), dtype=torch.float32, device=device)
         pad[: rec.shape[0]] = torch.from_numpy(rec).to(device)
@@ -105,6 +125,7 @@ class EvalAccumulator:
         out.R_gt, out.t_gt = [allrec[:, 0:9].reshape(-1, 3, 3)], [allrec[:, 9:12]]
         out.R_pred, out.t_pred = [allrec[:, 12:21].reshape(-1, 3, 3)], [allrec[:, 21:24]]
         out.euler_gt = [allrec[:, 24:27]]
+        out.Rba_pred, out.tba_pred = [allrec[:, 27:36].reshape(-1, 3, 3)], [allrec[:, 36:39]]
         return out
 
     @staticmethod
@@ -114,3 +135,13 @@ class EvalAccumulator:
                 "rot_RMSE: %f, rot_MAE: %f, trans_MSE: %f, trans_RMSE: %f, trans_MAE: %f"
                 % (epoch, m["loss"], m["loss_pose"], m["cycle_loss"], m["mse"], m["rmse"], m["mae"], m["rot_mse"],
                    m["rot_rmse"], m["rot_mae"], m["trans_mse"], m["trans_rmse"], m["trans_mae"]))
+
+    @staticmethod
+    def format_final_ba(m: Dict[str, float], epoch: int = -1) -> str:
+        """The 'B--------->A' line of :800-806, printed when args.cycle.  (The reference's format string there has one
+        conversion fewer than arguments -- 'test_LossPose' lost its ': %f' -- so the reference itself raises TypeError
+        on this line; the twelve values it passes are printed here with the missing conversion restored.)"""
+        return ("EPOCH:: %d, Loss: %f, test_LossPose: %f, MSE: %f, RMSE: %f, MAE: %f, rot_MSE: %f, rot_RMSE: %f, "
+                "rot_MAE: %f, trans_MSE: %f, trans_RMSE: %f, trans_MAE: %f"
+                % (epoch, m["loss"], m["loss_pose"], m["mse"], m["rmse"], m["mae"], m["rot_mse"], m["rot_rmse"],
+                   m["rot_mae"], m["trans_mse"], m["trans_rmse"], m["trans_mae"]))

@@ -353,6 +353,10 @@ class VCRNet(nn.Module):
         if not (src.is_cuda and tgt.is_cuda):
             raise native.VcrHipError("vcrnet_amd.VCRNet runs on the MI355X HIP path only; move inputs to cuda "
                                      "(there is no CPU fallback by design)")
+        p0 = next(self.parameters())
+        if not (src.device == tgt.device == p0.device):
+            raise native.VcrHipError(f"src ({src.device}), tgt ({tgt.device}) and the parameters ({p0.device}) must "
+                                     "live on one device")
         if self.training or torch.is_grad_enabled():
             raise native.VcrHipError("inference only: call .eval() and wrap in torch.no_grad() "
                                      "(model/vcrnet_model.py:546); backward kernels are out of scope")
@@ -361,17 +365,36 @@ class VCRNet(nn.Module):
     def forward(self, *input):
         src, tgt = input[0], input[1]
         self._check_call(src, tgt)
-        self._pack()
-        if not self.fused_supported():
-            from .composed import forward_composed
-            return forward_composed(self, src, tgt)
-        return self._forward_fused(src, tgt)
+        # HIP launches go to the CURRENT device's stream: make the tensors' device current for the whole call (a module
+        # moved with .to('cuda:1') but called without torch.cuda.set_device(1), or an nn.DataParallel replica)
+        with torch.cuda.device(src.device):
+            self._pack()
+            if not self.fused_supported():
+                from .composed import forward_composed
+                return forward_composed(self, src, tgt)
+            return self._forward_fused(src, tgt)
 
-    def _forward_fused(self, src, tgt, trace: Optional[native.Trace] = None, want_emb: bool = False, iters: int = 1):
-        """One C-ABI call: VCRNet.forward (iters == 1) or the whole vcrnetIter loop (iters > 1)."""
+    def selection_sizes(self, N: int) -> Dict[str, int]:
+        """Per-sample lengths of the partial-mode selections (transformer.py:41, vcrnet_model.py:208,284)."""
+        k1 = int(N * 0.84 * self._overlap2)
+        return {"keys": int(N * self._overlap2), "sel_src": k1, "sel_tgt": k1, "argmax": k1,
+                "pairs": int(k1 * 0.52 * self._overlap2)}
+
+    def _forward_fused(self, src, tgt, trace: Optional[native.Trace] = None, want_emb: bool = False, iters: int = 1,
+                       force: Optional[Dict[str, torch.Tensor]] = None, want_selections: bool = False):
+        """One C-ABI call: VCRNet.forward (iters == 1) or the whole vcrnetIter loop (iters > 1).
+
+        Partial mode only: ``force`` = {"keys": [iters, 2B, nkeep], "sel_src" / "sel_tgt": [iters, B, K1],
+        "argmax": [iters, B, K1], "pairs": [iters, B, K2]} int32 (any subset; the leading dimension may be omitted for
+        iters == 1) replaces the device's rankings by the caller's -- teacher forcing for the parity tests;
+        ``want_selections`` appends a dict of the selections that were used, one block per iteration."""
+        with torch.cuda.device(src.device):
+            return self._forward_fused_on(src, tgt, trace, want_emb, iters, force, want_selections)
+
+    def _forward_fused_on(self, src, tgt, trace, want_emb, iters, force, want_selections):
         self._pack()
         B, _, N = src.shape
-        dev = src.device
+        dev = native.same_device(src, tgt, next(self.parameters()))
         srcc, tgtc = src.contiguous().float(), tgt.contiguous().float()
         bufs = self._buffers_for(B, N, dev)
         ws = bufs["ws"]
@@ -384,7 +407,21 @@ class VCRNet(nn.Module):
         emb = f(2 * B * N, self.emb_dims) if want_emb else None
         io = native.VcrnetIo(native.ptr(srcc), native.ptr(tgtc), B, N, native.ptr(corr4), native.ptr(src4),
                              native.ptr(R_ab), native.ptr(t_ab), native.ptr(R_ba), native.ptr(t_ba), native.ptr(emb))
-        stream = C.c_void_p(native.stream_ptr())
+        keepalive, sel = [], {}
+        if force or want_selections:
+            if not self._partial:
+                raise native.VcrHipError("forced / reported selections exist in partial mode only")
+            sizes = self.selection_sizes(N)
+            for name in native.SELECTION_FIELDS:
+                rows = 2 * B if name == "keys" else B
+                if force and name in force:
+                    t = force[name].to(device=dev, dtype=torch.int32).reshape(iters, rows, sizes[name]).contiguous()
+                    keepalive.append(t)
+                    setattr(io, "force_" + name, native.ptr(t))
+                if want_selections and (self._vcp == "topK" or name == "keys"):
+                    sel[name] = torch.empty(iters, rows, sizes[name], dtype=torch.int32, device=dev)
+                    setattr(io, "out_" + name, native.ptr(sel[name]))
+        stream = C.c_void_p(native.stream_ptr(dev))
         wsp = C.c_void_p(ws.data_ptr() + off)
         if iters != 1:
             rc = L.vcr_vcrnet_iter_f32(C.byref(self._cw), C.byref(io), iters, wsp, ws.numel() - off, stream,
@@ -399,13 +436,14 @@ class VCRNet(nn.Module):
         hard = self._partial and self._vcp == "topK"
         srcK = rows(src4) if (hard or iters != 1) else src               # soft heads return src itself (:347)
         out = (srcK, rows(corr4), R_ab, t_ab, R_ba, t_ba)
-        return out + (emb,) if want_emb else out
+        if want_emb:
+            out = out + (emb,)
+        return out + (sel,) if want_selections else out
 
     def forward_iter(self, src, tgt, iters: int):
         """vcrnetIter (model/vcrnet_model.py:21-43) as ONE device-side loop when the fused driver covers this
         configuration; None otherwise (the caller then loops over forward())."""
         self._check_call(src, tgt)
-        self._pack()
         if not self.fused_supported():
             return None
         return self._forward_fused(src, tgt, iters=int(iters))
@@ -469,9 +507,14 @@ def vcrnetIcpNet(args, net, src, tgt):
 
 def vcrnetIter(net, src, tgt, iter=1):
     """model/vcrnet_model.py:21-43: run ``iter`` passes, composing the poses on the device."""
+    # The reference's caller always wraps the net in nn.DataParallel (util/initPara.py:260).  With one visible device
+    # (or inputs already on the wrapped module's device and a single device id) DataParallel.forward just calls
+    # module(*inputs), so the device-side loop of the wrapped module is the same computation without the wrapper's
+    # scatter; with several device ids the wrapper must do its scatter / replicate, and the Python loop below drives it.
     inner = net.module if isinstance(net, nn.DataParallel) else net
-    if isinstance(inner, VCRNet) and inner is net and iter >= 1:
-        out = net.forward_iter(src, tgt, iter)
+    single = inner is net or len(getattr(net, "device_ids", ())) <= 1
+    if isinstance(inner, VCRNet) and single and iter >= 1:
+        out = inner.forward_iter(src, tgt, iter)
         if out is not None:
             return out
     cur = src

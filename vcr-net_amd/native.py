@@ -26,14 +26,14 @@ class PointwiseArgs(C.Structure):
 
 class KnnArgs(C.Structure):
     _fields_ = [("x", f32p), ("ldx", C.c_int), ("sq", f32p), ("B", C.c_int), ("N", C.c_int), ("C", C.c_int),
-                ("k", C.c_int), ("idx", f32p), ("tie_scratch", f32p), ("tie_cap", C.c_int)]
+                ("k", C.c_int), ("idx", f32p), ("tie_scratch", f32p), ("tie_cap", C.c_int), ("waves", C.c_int)]
 
 
 class LinearArgs(C.Structure):
     _fields_ = [("x", f32p), ("ldx", C.c_int), ("w", f32p), ("bias", f32p), ("residual", f32p), ("ldr", C.c_int),
                 ("y", f32p), ("ldy", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("relu", C.c_int),
                 ("ln_stats_in", f32p), ("ln_nseg", C.c_int), ("ln_colsum", f32p), ("ln_eps", C.c_float),
-                ("stats_out", f32p)]
+                ("stats_out", f32p), ("variant", C.c_int)]
 
 
 class LayerNormArgs(C.Structure):
@@ -82,7 +82,7 @@ class PairscoreArgs(C.Structure):
                 ("score", C.c_int), ("scale", C.c_float), ("str_batch_shift", C.c_int), ("op", C.c_int),
                 ("corr4", f32p), ("stat2", f32p), ("argmax", f32p), ("str_stat2", f32p),
                 ("str_stat_batch_stride", C.c_long), ("mass", f32p), ("accumulate", C.c_int),
-                ("score_out", f32p), ("ld_score", C.c_int)]
+                ("score_out", f32p), ("ld_score", C.c_int), ("variant", C.c_int)]
 
 
 class MakePairsArgs(C.Structure):
@@ -168,7 +168,13 @@ class VcrnetWeights(C.Structure):
 
 class VcrnetIo(C.Structure):
     _fields_ = [("src_cf", f32p), ("tgt_cf", f32p), ("B", C.c_int), ("N", C.c_int), ("corr4", f32p), ("src4", f32p),
-                ("R_ab", f32p), ("t_ab", f32p), ("R_ba", f32p), ("t_ba", f32p), ("emb_out", f32p)]
+                ("R_ab", f32p), ("t_ab", f32p), ("R_ba", f32p), ("t_ba", f32p), ("emb_out", f32p),
+                ("force_keys", f32p), ("force_sel_src", f32p), ("force_sel_tgt", f32p), ("force_argmax", f32p),
+                ("force_pairs", f32p), ("out_keys", f32p), ("out_sel_src", f32p), ("out_sel_tgt", f32p),
+                ("out_argmax", f32p), ("out_pairs", f32p)]
+
+
+SELECTION_FIELDS = ("keys", "sel_src", "sel_tgt", "argmax", "pairs")
 
 
 class Trace(C.Structure):
@@ -188,7 +194,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 9          # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 10         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -280,12 +286,43 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
-def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def stream_ptr(device=None) -> int:
+    """The current HIP stream of `device` (default: the current device).  Kernels must be enqueued on a stream of the
+    device that owns their pointers: every wrapper below runs under on_device(tensor), so `net.to('cuda:1')(x)`
+    without torch.cuda.set_device(1) launches on cuda:1, not on the current device."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def on_device(t: torch.Tensor):
+    """Context manager: make t's device current (HIP launches go to the CURRENT device's stream)."""
+    if not t.is_cuda:
+        raise VcrHipError("vcr-net_amd kernels take device tensors only (no CPU fallback)")
+    return torch.cuda.device(t.device)
+
+
+def same_device(*tensors) -> torch.device:
+    devs = {t.device for t in tensors if t is not None}
+    if len(devs) != 1:
+        raise VcrHipError(f"all tensors of one call must live on one device, got {sorted(map(str, devs))}")
+    return next(iter(devs))
 
 
 def call(name: str, args: C.Structure) -> None:
     check(getattr(lib(), name)(C.byref(args), C.c_void_p(stream_ptr())), name)
+
+
+def _guarded(fn):
+    """Run a tensor-level wrapper with its first device tensor's device made current."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **kw):
+        for x in list(a) + list(kw.values()):
+            if isinstance(x, torch.Tensor) and x.is_cuda:
+                with torch.cuda.device(x.device):
+                    return fn(*a, **kw)
+        return fn(*a, **kw)
+    return wrapper
 
 
 # ---- thin tensor-level wrappers (used by the tests and by the module for the non-fused variants) -------------
@@ -294,6 +331,7 @@ def _f32(*shape, device):
     return torch.empty(*shape, dtype=torch.float32, device=device)
 
 
+@_guarded
 def pointwise(x_cf, w1, b1, w2, b2):
     B, _, N = x_cf.shape
     x_cf = x_cf.contiguous()
@@ -303,17 +341,19 @@ def pointwise(x_cf, w1, b1, w2, b2):
     return xyz4, f64, sq
 
 
-def knn(x, sq, k, exact_ties=True):
+@_guarded
+def knn(x, sq, k, exact_ties=True, waves=0):
     """x [B,N,C] rows (C = 64 with sq [B,N], or C = 4 xyz4 rows) -> int32 idx [B,N,k].  exact_ties: rows whose
     (k+1)-th and (k+2)-th distances are equal get Tensor.topk's (libstdc++'s) pick instead of the lower index."""
     B, N, Cc = x.shape
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
     ties = torch.empty(1 + B * N, dtype=torch.int32, device=x.device) if exact_ties else None   # room for every row
-    call("vcr_knn_f32", KnnArgs(ptr(x), x.stride(1), ptr(sq), B, N, Cc, k, ptr(idx), ptr(ties), B * N if exact_ties else 0))
+    call("vcr_knn_f32", KnnArgs(ptr(x), x.stride(1), ptr(sq), B, N, Cc, k, ptr(idx), ptr(ties), B * N if exact_ties else 0, waves))
     return idx
 
 
-def linear(x, w, bias=None, relu=False, residual=None, out=None, ln=None, want_stats=False):
+@_guarded
+def linear(x, w, bias=None, relu=False, residual=None, out=None, ln=None, want_stats=False, variant=0):
     """y = act(x w^T + bias) (+ residual).  ln = (stats [M,nseg,2], colsum [N], eps) with w / bias folded by
     fold_layernorm(): y = act(LayerNorm(x) w0^T + bias0).  want_stats: also return the [M, N/64, 2]
     (sum, sum of squares) partials of y."""
@@ -326,10 +366,12 @@ def linear(x, w, bias=None, relu=False, residual=None, out=None, ln=None, want_s
     if ln is not None:
         a.ln_stats_in, a.ln_nseg, a.ln_colsum, a.ln_eps = ptr(ln[0]), ln[0].shape[1], ptr(ln[1]), ln[2]
     a.stats_out = ptr(stats)
+    a.variant = variant
     call("vcr_linear_f32", a)
     return (y, stats) if want_stats else y
 
 
+@_guarded
 def fold_layernorm(w, bias, ln_a, ln_b):
     """vcr_fold_layernorm_f32: (w * a, colsum, bias + w b) for a Linear that consumes LayerNorm(a, b)."""
     L = lib()
@@ -343,6 +385,7 @@ def fold_layernorm(w, bias, ln_a, ln_b):
     return wf, cs, bf
 
 
+@_guarded
 def split_bf16x3(w):
     """fp32 tensor -> int16 [3, numel] bf16 planes (hi, mid, lo) with hi + mid + lo == w exactly."""
     L = lib()
@@ -354,6 +397,7 @@ def split_bf16x3(w):
     return planes
 
 
+@_guarded
 def linear_bf16x3(x, w_planes, n_out, bias=None, relu=False, residual=None, out=None):
     L = lib()
     M, K = x.shape
@@ -366,6 +410,7 @@ def linear_bf16x3(x, w_planes, n_out, bias=None, relu=False, residual=None, out=
     return y
 
 
+@_guarded
 def layernorm(x, a, b, eps=1e-6, residual=None, xyz4=None):
     M, Cc = x.shape
     y = _f32(M, Cc, device=x.device)
@@ -376,6 +421,7 @@ def layernorm(x, a, b, eps=1e-6, residual=None, xyz4=None):
     return (y, side4) if xyz4 is not None else y
 
 
+@_guarded
 def rowside(x, xyz4, scale=1.0):
     M, Cc = x.shape
     y, side4 = _f32(M, Cc, device=x.device), _f32(M, 4, device=x.device)
@@ -383,6 +429,7 @@ def rowside(x, xyz4, scale=1.0):
     return y, side4
 
 
+@_guarded
 def edgeconv(pq, idx, n_per_cloud, w2, b2):
     M = pq.shape[0]
     k = idx.shape[-1]
@@ -392,6 +439,7 @@ def edgeconv(pq, idx, n_per_cloud, w2, b2):
     return x1, x2
 
 
+@_guarded
 def gathermax(pq, Cc, idx, n_per_cloud):
     M = pq.shape[0]
     k = idx.shape[-1]
@@ -400,6 +448,7 @@ def gathermax(pq, Cc, idx, n_per_cloud):
     return y
 
 
+@_guarded
 def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None, want_rowstat=False, pv=True,
          score_out=None):
     """q [nbatch*nq, >=heads*128] (row views allowed), k/v likewise -> out [nbatch*nq, heads*128].
@@ -413,6 +462,7 @@ def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None,
     return (out, rs) if want_rowstat else out
 
 
+@_guarded
 def keymass(score, rowstat, nk, q_batch_shift):
     """vcr_keymass_f32: score [nbatch, heads, nq, ld], rowstat [nbatch, heads, nq, 2] -> mass [nbatch, nk] by KEY batch."""
     nb, h, nq, ld = score.shape
@@ -421,6 +471,7 @@ def keymass(score, rowstat, nk, q_batch_shift):
     return mass
 
 
+@_guarded
 def softcorr(q, k, qside4, kside4, nbatch, nq, nk, mode=0, scale=1.0):
     corr4 = _f32(nbatch * nq, 4, device=q.device)
     call("vcr_softcorr_f32", SoftcorrArgs(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(qside4), ptr(kside4),
@@ -428,6 +479,7 @@ def softcorr(q, k, qside4, kside4, nbatch, nq, nk, mode=0, scale=1.0):
     return corr4
 
 
+@_guarded
 def rigid_svd(src, corr, want_h=False):
     """src/corr [B,K,>=3] rows -> R [B,3,3], t [B,3], R_ba, t_ba (and H when asked)."""
     B, K, _ = src.shape
@@ -439,9 +491,10 @@ def rigid_svd(src, corr, want_h=False):
     return (R, t, Rb, tb, H) if want_h else (R, t, Rb, tb)
 
 
+@_guarded
 def pairscore(own, strm, nbatch, n_own, n_str, op, score=0, scale=1.0, own_side4=None, str_side4=None,
               shift=0, str_stat2=None, str_stat_stride=None, mass=None, accumulate=False, want_argmax=False,
-              score_out=None):
+              score_out=None, variant=0):
     """vcr_pairscore_f32: op 0 -> corr4; op 1 -> (stat2 [nbatch*n_own,2], argmax or None); op 2 -> mass.
     score_out (op 1): [nbatch, n_own, ld] buffer that also receives the scores."""
     dev = own.device
@@ -454,7 +507,7 @@ def pairscore(own, strm, nbatch, n_own, n_str, op, score=0, scale=1.0, own_side4
         ptr(own), own.stride(0), ptr(strm), strm.stride(0), ptr(own_side4), ptr(str_side4), nbatch, n_own, n_str,
         own.shape[1], score, scale, shift, op, ptr(corr4), ptr(stat2), ptr(amax), ptr(str_stat2),
         int(str_stat_stride if str_stat_stride is not None else n_str * 2), ptr(mass), int(accumulate),
-        ptr(score_out), score_out.stride(1) if score_out is not None else 0))
+        ptr(score_out), score_out.stride(1) if score_out is not None else 0, variant))
     if op == 0:
         return corr4
     if op == 1:
@@ -462,6 +515,7 @@ def pairscore(own, strm, nbatch, n_own, n_str, op, score=0, scale=1.0, own_side4
     return mass
 
 
+@_guarded
 def scoremass(score, n_cols, row_stat2):
     """vcr_scoremass_f32 on score [nbatch, n_rows, ld]: (col_stat2 [nbatch,n_cols,2], col_mass, row_mass)."""
     nb, n_rows, ld = score.shape
@@ -471,6 +525,7 @@ def scoremass(score, n_cols, row_stat2):
     return cs, cm, rm
 
 
+@_guarded
 def make_pairs(cloud, R_ab, t_ab, pick, perm_src, perm_tgt, keep):
     """vcr_make_pairs_f32: cloud [B,P,3] f32, R_ab [B,3,3] / t_ab [B,3] f64, index maps [B,N] int32 ->
     (src [B,3,keep], tgt [B,3,keep])."""
@@ -492,6 +547,7 @@ class IcpArgs(C.Structure):
                 ("R_ba", f32p), ("t_ba", f32p), ("iterations", f32p)]
 
 
+@_guarded
 def to_rows4(x_cf):
     """[B,3,N] channels-first points -> [B,N,4] rows (x, y, z, |p|^2) (layout plumbing for the C-ABI)."""
     L = lib()
@@ -503,6 +559,7 @@ def to_rows4(x_cf):
     return out
 
 
+@_guarded
 def icp(src_cf, dst_cf, max_iterations=10, tolerance=0.001):
     """ICP.forward (model/icp_model.py:26-48) on the device: returns (final [B,3,N], R, t, R_ba, t_ba, iters)."""
     L = lib()
@@ -524,6 +581,7 @@ def icp(src_cf, dst_cf, max_iterations=10, tolerance=0.001):
     return final4[:, :, :3].transpose(1, 2).contiguous(), R, t, Rb, tb, iters
 
 
+@_guarded
 def edgerows(pq, Cc, idx, n_per_cloud):
     """pq [M, 2C] (P | Q), idx [M,k] -> per-edge rows relu(P[nbr] + Q[i]) as [M*k, C]."""
     M, k = idx.shape
@@ -532,6 +590,7 @@ def edgerows(pq, Cc, idx, n_per_cloud):
     return h
 
 
+@_guarded
 def segmax(x, M, k, out=None):
     """x [M*k, C] edge rows -> [M, C] max over each point's k rows (out may be a strided row view)."""
     Cc = x.shape[1]
@@ -540,6 +599,7 @@ def segmax(x, M, k, out=None):
     return y
 
 
+@_guarded
 def rankselect(values, K, want_order=True, want_mask=False, largest=True):
     """values [nbatch, n] (any element stride along n, e.g. one column of a [nbatch, n, 2] record)."""
     nb, n = values.shape
@@ -552,6 +612,7 @@ def rankselect(values, K, want_order=True, want_mask=False, largest=True):
     return order, mask
 
 
+@_guarded
 def gather_rows(x, idx, nbatch, n_in, via=None):
     """x [nbatch*n_in, C] rows, idx [nbatch, n_out] int32 -> [nbatch*n_out, C]; with via [nbatch, n_via] int32 the
     row taken is via[b][idx[b][r]]."""

@@ -108,6 +108,14 @@ def draw_pair(item: int, num_points: int = 1024, factor: float = 4.0, kind: str 
                  perm_src.astype(np.int32), perm_tgt.astype(np.int32))
 
 
+def inverse_labels(R_ab: np.ndarray, t_ab: np.ndarray, euler_ab: np.ndarray):
+    """The B -> A ground truth the reference's loader returns next to (R_ab, t_ab, euler_ab): R_ba = R_ab^T,
+    t_ba = -R_ba t_ab, euler_ba = -euler_ab[::-1] (util/data.py:278,286,295).  Batched [B,...] or single."""
+    R_ba = np.swapaxes(R_ab, -1, -2)
+    t_ba = -np.einsum("...ij,...j->...i", R_ba, t_ab)
+    return R_ba, t_ba, -euler_ab[..., ::-1]
+
+
 def make_pair(item: int, num_points: int = 1024, partial: bool = False, reserve: float = RESERVE_0575,
               factor: float = 4.0, kind: str = "object") -> Pair:
     """One evaluation item on the host (util/data.py:258-303)."""

@@ -18,7 +18,9 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LPD_FIXTURE = os.path.join(os.path.dirname(_HERE), "tests", "golden", "lpd_pretrained.npz")
+# the reference's only shipped checkpoint (pretrained/lpd-pretrained.t7: 12 fp32 emb_nn.* tensors, 1.46 MB) re-saved as
+# .npz by tests/golden/gen_golden.py -- data the product needs, so it lives in the package, not under tests/
+LPD_FIXTURE = os.path.join(_HERE, "data", "lpd_pretrained.npz")
 
 
 def param_shapes(emb_nn: str = "lpdnet", pointer: str = "transformer", vcp_nn: str = "topK",

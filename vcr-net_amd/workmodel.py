@@ -1,7 +1,13 @@
 """Algorithmic work per kernel launch of the whole-path forward (SURVEY.md section 8d figures):
 FLOPs and kernel-boundary bytes as functions of (B pairs, N points, k, E, F).  Used by bench.py to
 turn measured launch durations into roofline fractions.  Peaks from MI355X_MICROARCH.md:
-fp32 matrix (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s, HBM3E 8 TB/s."""
+fp32 matrix (v_mfma_f32_32x32x2_f32) 157.3 TFLOP/s, HBM3E 8 TB/s.
+
+Bytes come in two kinds.  ``launch_work`` returns the HBM-COMPULSORY bytes of a launch: every distinct input row
+read once, every output written once.  The neighbour gathers of the EdgeConv kernels re-read each row ~k times;
+those re-reads are served by L2 / MALL, not HBM, and are returned separately by ``gather_bytes`` (SURVEY 8d counts
+them as kernel-boundary traffic, which is why its per-pair figure -- used for the kNN+EdgeConv stage line -- is
+larger than the sum of the compulsory bytes).  Pricing the gathers against the HBM peak gave >8 TB/s in round 1."""
 from __future__ import annotations
 
 from typing import Dict, Tuple
@@ -48,16 +54,23 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
             n, kk, rows = {"dg_c1_pq": (128, 32, M2), "dg_c2": (64, 64, M2 * k), "dg_c3": (128, 64, M2 * k),
                            "dg_c4": (256, 128, M2 * k)}[site]
             return 2.0 * rows * n * kk, 4.0 * (rows * kk + n * kk + rows * n)
+        if site.startswith("head.att"):                    # VcpAtt's two Linear(E,E), one cloud each
+            return 2.0 * M1 * E * E, 4.0 * (2 * M1 * E + E * E)
         n, kk = (r(v) for v in _LINEAR_SHAPES[site])
         return 2.0 * M2 * n * kk, 4.0 * (M2 * kk + n * kk + M2 * n)
     if fam == "edgeconv":      # convDG2 on the per-edge features (the per-point half of convDG1 is linear:dg1_pq)
-        return 2.0 * M2 * k * 128 * 128, 4.0 * M2 * (k * 128 + 128 + k + 256)
+        # compulsory: P|Q rows [M2,256] once, idx, x1 and x2 out
+        return 2.0 * M2 * k * 128 * 128, 4.0 * M2 * (256 + k + 256)
     if fam == "gathermax":
-        if site.startswith("dg_"):
-            C = {"dg_c1": 64, "dg_max1": 64, "dg_max2": 64, "dg_max3": 128, "dg_max4": 256}[site]
+        if site == "dg_c1":                                # edge rows materialised: P|Q once, idx, [M2*k,64] out
+            return 1.0 * M2 * k * 64, 4.0 * M2 * (128 + k + k * 64)
+        if site.startswith("dg_"):                         # segmented max over stored edge rows: streamed once
+            C = {"dg_max1": 64, "dg_max2": 64, "dg_max3": 128, "dg_max4": 256}[site]
             return 1.0 * M2 * k * C, 4.0 * M2 * (k * C + C)
-        return 1.0 * M2 * k * 256, 4.0 * M2 * (k * 256 + 256 + k + 256)
+        return 1.0 * M2 * k * 256, 4.0 * M2 * (512 + k + 256)   # P|Q rows [M2,512] once, idx, x3 out
     if fam == "layernorm":
+        if site.startswith("rowside"):
+            return 2.0 * M2 * E, 4.0 * M2 * E * 2
         extra = 1 if site.endswith("+res") else 0
         return 8.0 * M2 * E, 4.0 * M2 * E * (2 + extra)
     keep, K1, K2 = overlap_sizes(N, overlap2)
@@ -78,6 +91,8 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
             return 4.0 * 2 * B * 4 * N * N, 4.0 * 2 * B * 4 * N * N
         return 8.0 * B * N * N, 4.0 * 2 * B * N * N
     if fam == "select":
+        if site.endswith(".forced") or site.endswith(".out"):   # device-to-device copy of an index block
+            return 0.0, 8.0 * 2 * B * N
         if site.startswith("gather"):
             width = E if site.endswith("emb") else 4
             rows = K1 if ("src_" in site or "tgt_" in site) else K2
@@ -92,6 +107,21 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
     if fam == "rigid_svd":
         return 18.0 * M1, 4.0 * M1 * 8                      # (partial mode solves on K2 pairs: even less)
     raise KeyError(name)
+
+
+def gather_bytes(name: str, B: int, N: int, k: int = 20) -> float:
+    """Bytes a launch moves through L2 for its neighbour gathers (k rows per point, each row re-read ~k times across
+    the cloud): NOT HBM traffic.  edgeconv gathers 128-float P rows, gathermax:sn1 256-float rows, DGCNN's
+    edge-row builder 64-float rows."""
+    fam, site = name.split(":", 1)
+    M2 = 2 * B * N
+    if fam == "edgeconv":
+        return 4.0 * M2 * k * 128
+    if fam == "gathermax" and site == "sn1":
+        return 4.0 * M2 * k * 256
+    if fam == "gathermax" and site == "dg_c1":
+        return 4.0 * M2 * k * 64
+    return 0.0
 
 
 def reference_flops_per_pair(N: int, k: int = 20, E: int = 512, F: int = 1024) -> Dict[str, float]:
