@@ -381,17 +381,20 @@ class VCRNet(nn.Module):
                 "pairs": int(k1 * 0.52 * self._overlap2)}
 
     def _forward_fused(self, src, tgt, trace: Optional[native.Trace] = None, want_emb: bool = False, iters: int = 1,
-                       force: Optional[Dict[str, torch.Tensor]] = None, want_selections: bool = False):
+                       force: Optional[Dict[str, torch.Tensor]] = None, want_selections: bool = False,
+                       iter_api: bool = False):
         """One C-ABI call: VCRNet.forward (iters == 1) or the whole vcrnetIter loop (iters > 1).
 
         Partial mode only: ``force`` = {"keys": [iters, 2B, nkeep], "sel_src" / "sel_tgt": [iters, B, K1],
         "argmax": [iters, B, K1], "pairs": [iters, B, K2]} int32 (any subset; the leading dimension may be omitted for
         iters == 1) replaces the device's rankings by the caller's -- teacher forcing for the parity tests;
-        ``want_selections`` appends a dict of the selections that were used, one block per iteration."""
+        ``want_selections`` appends a dict of the selections that were used, one block per iteration.
+        ``iter_api``: use vcr_vcrnet_iter_f32 also for iters == 1 (vcrnetIter's contract: (R_ba, t_ba) is ALWAYS the
+        inverse of the composed pose, vcrnet_model.py:40-41, even when args.cycle gives forward() a second head)."""
         with torch.cuda.device(src.device):
-            return self._forward_fused_on(src, tgt, trace, want_emb, iters, force, want_selections)
+            return self._forward_fused_on(src, tgt, trace, want_emb, iters, force, want_selections, iter_api)
 
-    def _forward_fused_on(self, src, tgt, trace, want_emb, iters, force, want_selections):
+    def _forward_fused_on(self, src, tgt, trace, want_emb, iters, force, want_selections, iter_api):
         self._pack()
         B, _, N = src.shape
         dev = native.same_device(src, tgt, next(self.parameters()))
@@ -423,7 +426,7 @@ class VCRNet(nn.Module):
                     setattr(io, "out_" + name, native.ptr(sel[name]))
         stream = C.c_void_p(native.stream_ptr(dev))
         wsp = C.c_void_p(ws.data_ptr() + off)
-        if iters != 1:
+        if iters != 1 or iter_api:
             rc = L.vcr_vcrnet_iter_f32(C.byref(self._cw), C.byref(io), iters, wsp, ws.numel() - off, stream,
                                        C.byref(trace) if trace is not None else None)
         elif trace is None:
@@ -431,7 +434,7 @@ class VCRNet(nn.Module):
         else:
             rc = L.vcr_vcrnet_forward_traced_f32(C.byref(self._cw), C.byref(io), wsp, ws.numel() - off, stream,
                                                  C.byref(trace))
-        native.check(rc, "vcr_vcrnet_iter_f32" if iters != 1 else "vcr_vcrnet_forward_f32")
+        native.check(rc, "vcr_vcrnet_iter_f32" if (iters != 1 or iter_api) else "vcr_vcrnet_forward_f32")
         rows = lambda x: x[:, :, :3].transpose(1, 2).contiguous()
         hard = self._partial and self._vcp == "topK"
         srcK = rows(src4) if (hard or iters != 1) else src               # soft heads return src itself (:347)
@@ -446,7 +449,7 @@ class VCRNet(nn.Module):
         self._check_call(src, tgt)
         if not self.fused_supported():
             return None
-        return self._forward_fused(src, tgt, iters=int(iters))
+        return self._forward_fused(src, tgt, iters=int(iters), iter_api=True)
 
 
 class DCP(VCRNet):
