@@ -90,8 +90,13 @@ typedef struct {
    *             y = inv_m * (sum_k x[m,k] w[n,k] - mean_m * ln_colsum[n]) + bias[n],  inv = 1 / (std_unbiased + ln_eps). */
   const float* ln_stats_in; int ln_nseg; const float* ln_colsum; float ln_eps;
   float* stats_out;
-  int variant;                        /* tuning / tests, 0 = automatic: bit0 register-staged BK 16, bit2 register staging
-                                         instead of LDS-DMA, bit3 force the BK 32 LDS-DMA kernel (identical results) */
+  int variant;                        /* tuning / tests, 0 = automatic (LDS-DMA staging, one 128x128 tile per workgroup:
+                                         BK 16 and four workgroups per CU without a residual, BK 32 with one).
+                                         bit3 (8) force BK 32, bit6 (64) force BK 16; bit2 (4) register staging instead of
+                                         LDS-DMA, bit0 (1) register-staged BK 16; bit5 (32) persistent workgroups with the
+                                         epilogue deferred under the next tile's MFMAs (measured slower; no alignment
+                                         requirement on y / bias / residual).  Same GEMM results in every variant; bit5
+                                         sums the row statistics of stats_out in a different fixed order. */
 } vcr_linear_args;
 int vcr_linear_f32(const vcr_linear_args*, vcr_stream_t);
 

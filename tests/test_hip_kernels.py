@@ -142,6 +142,39 @@ def test_linear(nat, M, N, K, relu, res):
     assert err <= 4e-6 * math.sqrt(K) + 1e-6, err            # fp32 fma-chain error ~ eps * sqrt(K) * |a.b|
 
 
+@pytest.mark.parametrize("M,N,K,relu,res,ln", [(33000, 512, 512, False, True, False),   # 1032 tiles on 512 persistent workgroups
+                                                 (20000, 1536, 512, True, False, True),    # LayerNorm-in, 6 tiles per workgroup
+                                                 (66000, 256, 64, False, False, False),    # K = 64: two k-steps, slices flushed
+                                                 (70001, 128, 32, True, True, False),      # K = 32: one k-step; ragged M
+                                                 (513, 200, 96, False, True, False)])      # ragged N, odd row pitches
+def test_linear_persistent_equals_one_tile_per_workgroup(nat, M, N, K, relu, res, ln):
+    """The opt-in persistent kernel (variant 32: workgroups walk over their tiles, the epilogue of tile i is issued
+    under the MFMAs of tile i+1 straight from the accumulator registers) against the default one-tile-per-workgroup
+    kernels: the same k order and the same epilogue arithmetic, so y is BIT-identical; the row statistics are summed
+    in a different fixed order."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = dev(torch.randn(M, K, generator=g))
+    w = dev(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = dev(torch.randn(N, generator=g))
+    r = dev(torch.randn(M, N + 3, generator=g))[:, :N] if res else None       # ldr = N + 3: unaligned residual rows
+    lnarg = None
+    if ln:
+        a_, b_ = dev(torch.rand(K, generator=g) + 0.5), dev(torch.randn(K, generator=g))
+        _, st = nat.linear(x, dev(torch.eye(K)), None, want_stats=True)   # row statistics of x itself
+        w, cs, b = nat.fold_layernorm(w, b, a_, b_)
+        lnarg = (st, cs, 1e-6)
+    stats_ok = N % 64 == 0
+    vec_ok = N % 4 == 0 and not res                         # the default kernels need 16-B aligned rows (else they fall
+    if ln or stats_ok and vec_ok:                           # back to the register-staged sibling by themselves)
+        y0, s0 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg, want_stats=True)
+        y1, s1 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg, want_stats=True, variant=32)
+        torch.testing.assert_close(s1, s0, rtol=2e-5, atol=2e-4)
+    else:
+        y0 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg)
+        y1 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg, variant=32)
+    assert torch.equal(y0, y1), (y0 - y1).abs().max().item()
+
+
 def test_layernorm(nat):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1000, 512, generator=g) * 3 + 0.5
