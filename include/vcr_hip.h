@@ -57,7 +57,8 @@ int vcr_rows4_f32(const float* x_cf, float* xyz4, int B, int N, vcr_stream_t);
  * D_ij = (-sq_j + 2 x_i.x_j) - sq_i ; idx = indices of the k largest D per row after dropping
  * rank 0 ("topk(k+1)[:, :, 1:]").  C == 64 (feature space, fp32 MFMA) or C == 4 (xyz4 rows; Cartesian, VALU).
  * k <= 40, N <= 65535.  Exact ties at the (k+1)-th value: with tie_scratch the kept SET equals what Tensor.topk
- * (libstdc++ nth_element / partial_sort on the CPU) keeps; without it the lower index wins. */
+ * (libstdc++ nth_element / partial_sort on the CPU) keeps; without it one of the tied candidates is kept
+ * (deterministically, but not by a documented rule). */
 typedef struct {
   const float* x; int ldx;            /* [B,N,C] rows                                  */
   const float* sq;                    /* [B,N] squared norms (C==64); ignored for C==4 */
@@ -65,8 +66,8 @@ typedef struct {
   int32_t* idx;                       /* [B,N,k], neighbour index within the cloud     */
   int32_t* tie_scratch; int tie_cap;  /* optional: [1 + tie_cap] ints of scratch (count, then the rows with a boundary
                                          tie; 256 entries are plenty: ~1 row in 10^4 ties), N <= 20000 */
-  int waves;                          /* tuning / tests: waves that share one query tile's candidates (C == 4: 2, 4 or 8;
-                                         C == 64: 1, 2 or 4); 0 = chosen from the grid size.  Never changes a result. */
+  int waves;                          /* tuning / tests: waves of a workgroup that share one group of queries and split its
+                                         candidates (1, 2 or 4); 0 = chosen from the grid size.  Never changes a result. */
 } vcr_knn_args;
 int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
 

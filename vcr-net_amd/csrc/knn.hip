@@ -5,55 +5,71 @@
 // survivor (~k ln(N/k) per query), not per candidate.
 //
 //   D_ij = (-sq_j + 2 x_i.x_j) - sq_i      (same association as util.py:157-158)
-//   idx  = top-(k+1) of D_i. by (value desc, index asc), rank 0 dropped (util.py:159); the k kept
-//          indices are written as a SET (unordered) -- every consumer is a max over neighbours.
+//   idx  = top-(k+1) of D_i. by value, rank 0 dropped (util.py:159); the k kept indices are written as a SET
+//          (unordered) -- every consumer is a max over neighbours.
 //          Exact ties at the (k+1)-th value: Tensor.topk on the CPU is libstdc++'s std::nth_element (or
 //          std::partial_sort when (k+1)*64 <= N) with a value-only comparator, so WHICH of the tied candidates it
 //          keeps is an artefact of introselect's pivoting / the heap's shape.  The lists here carry one entry more
 //          than needed, which makes such a tie visible (about 1 row in 10^4 in fp32); those rows are re-done by
-//          knn_tiebreak_kernel, a sequential replica of the libstdc++ algorithms, so that the neighbour SETS equal
-//          the reference's on every row (validated against torch.topk on tie-heavy inputs).
+//          knn_tiebreak_kernel, a replica of the libstdc++ algorithms, so that the neighbour SETS equal the
+//          reference's on every row (validated against torch.topk on tie-heavy inputs).  A row WITHOUT a boundary tie
+//          has a set that depends on the values only, so the order in which equal values entered the list is
+//          irrelevant; without tie_scratch a boundary tie keeps one of the tied candidates, deterministically.
 //
-// C == 64: v_mfma_f32_32x32x2_f32 with candidates as MFMA rows and queries as MFMA columns, so every lane
-//          owns ONE query column (lanes l and l+32 share a query and split the candidates, their two sorted
-//          lists are merged at the end).  The k order of the MFMA chain is the natural one (step s multiplies
-//          k = 2s, 2s+1) and -sq_j/2 rides along as a 33rd k-step: together with the pointwise kernel's
-//          reference-ordered features and norms the distance matrix is BIT-IDENTICAL to the reference's
-//          (CPU sgemm = k-ascending fma chain; verified), so the feature-space neighbour sets never flip.
-//          Operands go global -> registers (candidate tiles are L2-resident); LDS holds the survivor lists.
-// C == 4 : Cartesian xyz4 rows, one lane per query, candidates broadcast from LDS 16 at a time, VALU.
-//          A block's 2-8 waves split the candidates in interleaved groups; their sorted lists are combined by a
-//          tree of bitonic sorted merges (merge_sorted).
+// Round 2: ONE sorted list per query, spread over the lanes that share the query, instead of one full list per lane
+// and a candidate split that multiplied the lists (and with them the k ln(N/k) insertions: 2 lists per query in the
+// feature-space kernel, 4-8 in the Cartesian one).  Lane segment s holds ranks [s*T, (s+1)*T); an insertion of d runs
+// on every segment at once, segment s taking min(d, last element of segment s-1) -- the element that falls off the
+// segment above, known BEFORE the insertion -- so the segments need one cross-lane move per insertion and no chain.
+//
+// C == 64: v_mfma_f32_32x32x2_f32 with candidates as MFMA rows and queries as MFMA columns: lanes l and l+32 own one
+//          query column and 16 candidate rows each; they hold the two halves of the query's list (exchange:
+//          v_permlane32_swap).  The k order of the MFMA chain is the natural one (step s multiplies k = 2s, 2s+1) and
+//          -sq_j/2 rides along as a 33rd k-step: together with the pointwise kernel's reference-ordered features and
+//          norms the distance matrix is BIT-IDENTICAL to the reference's (CPU sgemm = k-ascending fma chain;
+//          verified), so the feature-space neighbour sets never flip.  S waves of a workgroup share a query tile and
+//          split the candidate tiles (S = 2 fills two waves per SIMD at BASELINE configs[1]); their lists are folded
+//          into one at the end.
+// C == 4 : Cartesian xyz4 rows on the VALU: four lanes (one DPP quad) per query, 16 queries per wave, each lane
+//          scanning every fourth candidate; segments exchange through DPP quad_perm.
 #include "common.h"
 
 namespace {
 
-constexpr int PEND = 32;            // survivor slots per (lane) sub-list between merges
 constexpr int TILE = 32;            // candidates per MFMA tile
-template <int KS> constexpr int knn3_slots() { return KS > 24 ? KS : 24; }   // Cartesian kernel: small areas = more waves per CU
 
-__device__ __forceinline__ bool lex_gt(float d, int j, float v, int id) { return d > v || (d == v && j < id); }
+#ifdef VCR_TIMELINE
+// Experiment-only (profiles/timeline_knn.py, -DVCR_TIMELINE builds): wave 0 of every workgroup accumulates the 100 MHz
+// wall clock over the phases of its scan.
+__device__ unsigned long long vcr_tl_knn[4096 * 8];
+#define KTL_DECL unsigned long long ktl_t = wall_clock64(), ktl_acc[6] = {0, 0, 0, 0, 0, 0}
+#define KTL(slot) do { const unsigned long long n_ = wall_clock64(); ktl_acc[slot] += n_ - ktl_t; ktl_t = n_; } while (0)
+#define KTL_FLUSH do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) for (int i_ = 0; i_ < 6; ++i_) vcr_tl_knn[blockIdx.x * 8 + i_] = ktl_acc[i_]; } while (0)
+#else
+#define KTL_DECL ((void)0)
+#define KTL(slot) ((void)0)
+#define KTL_FLUSH ((void)0)
+#endif
 
-template <int KS>
-struct TopList {
-  float v[KS];
-  int id[KS];
+// A sorted-descending segment of T (value, index) entries in registers.
+template <int T>
+struct Seg {
+  float v[T];
+  int id[T];
   __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int t = 0; t < KS; ++t) { v[t] = VCR_NEG_INF; id[t] = 0x7fffffff; }
+    for (int t = 0; t < T; ++t) { v[t] = VCR_NEG_INF; id[t] = 0x7fffffff; }
   }
-  // Sorted-descending insert.  Values move with ONE v_med3_f32 per slot: for v[t-1] >= v[t] the new
-  // slot value is median(v[t-1], d, v[t]).  Indices follow with one compare per slot (the compare of
-  // slot t-1 is the "shift" condition of slot t).  LEX = exact (value desc, index asc) order for streams
-  // that are not index-sorted; otherwise strict '>' keeps the earlier (= lower index) entry on ties.
-  // Inserting -inf is a no-op, which lets callers run the network unconditionally (no divergent branch
-  // around 2*KS live registers).
-  template <bool LEX>
+  // Insert d: values move with ONE v_med3_f32 per slot (for v[t-1] >= v[t] the new slot value is
+  // median(v[t-1], d, v[t])), indices follow with one compare per slot (the compare of slot t-1 is the "shift"
+  // condition of slot t).  Strict '>': an equal value goes behind the entry already there.  Inserting -inf (or any
+  // value <= the last entry) is a no-op, which lets callers run the network unconditionally (no divergent branch
+  // around 2*T live registers).
   __device__ __forceinline__ void insert(float d, int j) {
-    bool c_hi = LEX ? lex_gt(d, j, v[KS - 1], id[KS - 1]) : d > v[KS - 1];
+    bool c_hi = d > v[T - 1];
 #pragma unroll
-    for (int t = KS - 1; t >= 1; --t) {
-      const bool c_lo = LEX ? lex_gt(d, j, v[t - 1], id[t - 1]) : d > v[t - 1];
+    for (int t = T - 1; t >= 1; --t) {
+      const bool c_lo = d > v[t - 1];
       id[t] = c_lo ? id[t - 1] : (c_hi ? j : id[t]);
       v[t] = __builtin_amdgcn_fmed3f(v[t - 1], d, v[t]);
       c_hi = c_lo;
@@ -70,42 +86,31 @@ __device__ __forceinline__ void report_tie(int32_t* ties, int cap, int row) {
   if (pos < cap) ties[1 + pos] = row;
 }
 
-// Survivor list of one wave: [slot][lane] so a wave's pushes hit 64 consecutive words.
-struct Pending {
-  float* pv; int* pi; int cnt;
-  __device__ __forceinline__ void push(float d, int j, int lane) {
-    pv[cnt * 64 + lane] = d; pi[cnt * 64 + lane] = j; ++cnt;
-  }
-  template <int KS>
-  __device__ __forceinline__ float drain(TopList<KS>& L, int lane) {
-    float dn = pv[lane];
-    int jn = pi[lane];
-    for (int i = 0; __any(i < cnt); ++i) {               // branch-free body: idle lanes insert -inf (a no-op)
-      const float d = i < cnt ? dn : VCR_NEG_INF;
-      const int j = jn;
-      const int nx = min(i + 1, PEND - 1);
-      dn = pv[nx * 64 + lane];
-      jn = pi[nx * 64 + lane];
-      L.template insert<false>(d, j);
-    }
-    cnt = 0;
-    return L.v[KS - 1];
-  }
-};
+// values of the other 32-lane half (v_permlane32_swap: result 0 = the lower half's values in both halves, 1 = the upper's)
+__device__ __forceinline__ int other_half(int x, int half) {
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return half ? r[0] : r[1];
+}
+__device__ __forceinline__ float other_half(float x, int half) {
+  return __int_as_float(other_half(__float_as_int(x), half));
+}
 
 // ---------------------------------------------------------------- C == 64 (MFMA)
-template <int KS>
+// Workgroup = 4 waves = 4/S query tiles of 32 queries; wave (qt, part) scans candidate tiles part, part+S, ...
+// KS = list length (k+2 rounded to 22 / 42), one half of it per lane.
+template <int KS, int S>
 __global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
+  constexpr int T = KS / 2;                              // list entries per lane (lane half h holds ranks h*T ..)
+  constexpr int PEND = 64;                               // survivor slots per query between drains (a tile adds <= 32)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int b = blockIdx.y;
-  const int q0 = (blockIdx.x * 4 + wave) * 32;          // this wave's 32 queries
-  if (q0 >= a.N) return;                                // wave-uniform
-  Pending pend;
-  pend.pv = reinterpret_cast<float*>(smem) + wave * (2 * PEND * 64);
-  pend.pi = reinterpret_cast<int*>(pend.pv + PEND * 64);
-  pend.cnt = 0;
+  const int qt = wave / S, part = wave % S;
+  const int q0 = (blockIdx.x * (4 / S) + qt) * 32;       // this wave's 32 queries (may lie beyond N: clamped, not written)
+  float* pv = reinterpret_cast<float*>(smem) + wave * (2 * PEND * 32);       // [slot][32 queries]
+  int* pi = reinterpret_cast<int*>(pv + PEND * 32);
+  int cnt = 0;                                           // survivors parked for this lane's query (same in both halves)
 
   const float* xb = a.x + (size_t)b * a.N * a.ldx;
   const float* sqb = a.sq + (size_t)b * a.N;
@@ -128,30 +133,56 @@ __global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
   }
   const float sq_q = sqb[q];
 
-  TopList<KS> L;
+  Seg<T> L;
   L.init();
-  float thr = VCR_NEG_INF;
+  float thr = VCR_NEG_INF;                               // the list's last value: nothing <= thr can enter
+  // One insertion into the query's list, both halves at once.  When d displaces the upper segment's last entry
+  // (d > that entry, known before either insertion), that entry falls into the lower segment -- at its FRONT,
+  // unconditionally: it is >= everything there, and a compare-based insertion would drop it on an exact tie with the
+  // lower segment's own entries while the upper segment has already let go of it.
+  auto insert_one = [&](float d, int j) {
+    const float ob = other_half(L.v[T - 1], half);
+    const int oj = other_half(L.id[T - 1], half);
+    const bool take = half && d > ob;
+    L.insert(take ? __builtin_huge_valf() : d, take ? oj : j);
+    if (take) L.v[0] = ob;
+  };
+  auto drain = [&]() {
+    float dn = pv[col];
+    int jn = pi[col];
+    for (int i = 0; __any(i < cnt); ++i) {               // branch-free body: idle lanes insert -inf (a no-op)
+      const float d = i < cnt ? dn : VCR_NEG_INF;
+      const int j = jn;
+      const int nx = min(i + 1, PEND - 1);
+      dn = pv[nx * 32 + col];
+      jn = pi[nx * 32 + col];
+      insert_one(d, j);
+    }
+    cnt = 0;
+    const float ol = other_half(L.v[T - 1], half);
+    thr = half ? L.v[T - 1] : ol;                        // the LOWER segment's last value, in both halves
+  };
 
   const int ntiles = (a.N + TILE - 1) / TILE;
   float cf[32];
-  float csq;
-  {
-    const int c = min(col, a.N - 1);
+  float csq = 0.f;
+  if (part < ntiles) {
+    const int c = min(part * TILE + col, a.N - 1);
     f32x4 raw[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) raw[m] = ld4(xb + (size_t)c * a.ldx + 4 * m);
     pick(raw, cf);
     csq = sqb[c];
   }
-  for (int tile = 0; tile < ntiles; ++tile) {
+  KTL_DECL;
+  for (int tile = part; tile < ntiles; tile += S) {
     // k <= 20: the next candidate tile is prefetched as raw rows (64 VGPRs) across the MFMA + selection phase.
-    // k = 40: the 41-entry list leaves no room for that at two waves per SIMD, and two waves hide the load latency
-    // better than one wave with a prefetch (measured), so the tile is loaded after the selection phase instead.
+    // k = 40: the longer list leaves no room for that at two waves per SIMD; the tile is loaded after the selection.
     constexpr bool PREFETCH = KS <= 22;
     f32x4 nraw[PREFETCH ? 16 : 1];
     float nsq = 0.f;
-    if (PREFETCH && tile + 1 < ntiles) {                // prefetch next candidate tile (raw rows stay in flight)
-      const int c = min((tile + 1) * TILE + col, a.N - 1);
+    if (PREFETCH && tile + S < ntiles) {
+      const int c = min((tile + S) * TILE + col, a.N - 1);
 #pragma unroll
       for (int m = 0; m < (PREFETCH ? 16 : 1); ++m) nraw[m] = ld4(xb + (size_t)c * a.ldx + 4 * m);
       nsq = sqb[c];
@@ -162,29 +193,50 @@ __global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
     // 33rd k-step: A[cand][k*] = -sq_cand/2 (half 0), B[k*][q] = 1  ->  acc = dot - sq_j/2, rounded once
     acc = mfma32(half == 0 ? -0.5f * csq : 0.f, half == 0 ? 1.f : 0.f, acc);
     // hipcc (ROCm 7.2) under-pads the MFMA -> v_accvgpr_read hazard of this 16-pass instruction when the
-    // accumulator lands in AGPRs (seen only in the 512-register KS=41 build: register 15, the last one written,
-    // was read stale).  Tie the wait states to the accumulator itself so they cannot be scheduled away.
+    // accumulator lands in AGPRs (seen in the k = 40 build: register 15, the last one written, was read stale).
+    // Tie the wait states to the accumulator itself so they cannot be scheduled away.
     if (KS > 22) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
+#ifdef VCR_TIMELINE
+    asm volatile("" : "+v"(acc));
+    { const float fence_ = acc[15]; asm volatile("" :: "v"(fence_)); }
+#endif
+    KTL(0);                                              // prefetch issue + MFMA chain
 
-    if (__any(pend.cnt > PEND - 16)) thr = pend.drain(L, lane);
     const int jbase = tile * TILE;
+    float dd[16];
+    unsigned m = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int j = jbase + acc_row(r, half);
-      const float d = 2.f * acc[r] - sq_q;              // (-sq_j + 2 dot) - sq_i
-      if (d > thr && j < a.N) pend.push(d, j, lane);
+      dd[r] = 2.f * acc[r] - sq_q;                       // (-sq_j + 2 dot) - sq_i
+      m |= (dd[r] > thr && jbase + acc_row(r, half) < a.N) ? (1u << r) : 0u;
     }
-    if (tile + 1 < ntiles) {
+    const unsigned om = (unsigned)other_half((int)m, half);
+    if (__any(m != 0)) {                                 // both halves of a column append to ONE list: upper half first
+      const int base = cnt + (half ? __popc(om) : 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (m & (1u << r)) {
+          const int pos = base + __popc(m & ((1u << r) - 1u));
+          pv[pos * 32 + col] = dd[r];
+          pi[pos * 32 + col] = jbase + acc_row(r, half);
+        }
+      }
+    }
+    cnt += __popc(m) + __popc(om);
+    KTL(1);                                              // filter + push
+    if (__any(cnt > PEND - 32)) drain();
+    KTL(2);                                              // drain
+    if (tile + S < ntiles) {
       if (PREFETCH) {
         pick(nraw, cf);
         csq = nsq;
       } else {
-        const int c = min((tile + 1) * TILE + col, a.N - 1);
+        const int c = min((tile + S) * TILE + col, a.N - 1);
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4) {                  // four 64-B quarters of the row: 16 temporaries, not 64
           f32x4 raw[4];
 #pragma unroll
-          for (int m = 0; m < 4; ++m) raw[m] = ld4(xb + (size_t)c * a.ldx + 16 * m4 + 4 * m);
+          for (int mm = 0; mm < 4; ++mm) raw[mm] = ld4(xb + (size_t)c * a.ldx + 16 * m4 + 4 * mm);
 #pragma unroll
           for (int st = 0; st < 8; ++st)
             cf[8 * m4 + st] = half ? raw[st >> 1][(st & 1) * 2 + 1] : raw[st >> 1][(st & 1) * 2];
@@ -192,146 +244,179 @@ __global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
         csq = sqb[c];
       }
     }
+    KTL(3);                                              // operand pick (waits for the prefetched rows)
   }
-  pend.drain(L, lane);
+  drain();
+  KTL(4);
+  KTL_FLUSH;
 
-  // merge the two half-lists of each query: half 1 hands its list over through LDS
-  float* mv = pend.pv;                                  // reuse: [KS][32]
-  int* mi = pend.pi;
-  if (half == 1) {
+  // ---- the S waves of a query tile fold their lists into wave part 0's, which writes ranks 1..k
+  float* lv = pv;                                        // reuse the wave's survivor area: [KS][32]
+  int* li = pi;
+  auto dump = [&]() {
 #pragma unroll
-    for (int t = 0; t < KS; ++t) { mv[t * 32 + col] = L.v[t]; mi[t * 32 + col] = L.id[t]; }
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): same-wave LDS hand-off
-  __builtin_amdgcn_wave_barrier();
-  if (half == 0) {
-    for (int t = 0; t < KS; ++t) {
-      const float d = mv[t * 32 + col];
-      const int j = mi[t * 32 + col];
-      if (d > L.v[KS - 1] || (d == L.v[KS - 1] && j < L.id[KS - 1])) L.template insert<true>(d, j);
+    for (int t = 0; t < T; ++t) { lv[(half * T + t) * 32 + col] = L.v[t]; li[(half * T + t) * 32 + col] = L.id[t]; }
+  };
+  if (S > 1) {
+    if (part != 0) dump();
+    __syncthreads();
+    if (part == 0) {
+      for (int p = 1; p < S; ++p) {
+        const float* ov = reinterpret_cast<const float*>(smem) + (wave + p) * (2 * PEND * 32);
+        const int* oi = reinterpret_cast<const int*>(ov + PEND * 32);
+        for (int t = 0; t < KS; ++t) insert_one(ov[t * 32 + col], oi[t * 32 + col]);
+      }
     }
+  }
+  if (part == 0) {
+    dump();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): same-wave LDS hand-off
+    __builtin_amdgcn_wave_barrier();
     if (q0 + col < a.N) {
       int32_t* o = a.idx + ((size_t)b * a.N + q0 + col) * a.k;
-      bool tie = false;
-#pragma unroll
-      for (int t = 1; t < KS; ++t) {
-        if (t <= a.k) o[t - 1] = L.id[t];
-        if (t == a.k + 1) tie = L.v[t] == L.v[t - 1] && L.v[t] > VCR_NEG_INF;   // rank k+2 equals rank k+1
-      }
-      if (tie) report_tie(a.tie_scratch, a.tie_cap, b * a.N + q0 + col);
-    }
-  }
-}
-
-// Sorted merge of this lane's list with another sorted list held in LDS as [KS][64] (column `lane`):
-// X[i] = max(A'[i], B'[H-1-i]) over the lists padded with -inf to H entries is a bitonic sequence that holds
-// the top-H of the union; a log2(H)-stage bitonic network sorts it, the first KS entries are the new list.
-// Order: value descending, index ascending (exact, so the result does not depend on how candidates were split).
-template <int KS>
-__device__ __forceinline__ void merge_sorted(TopList<KS>& L, const float* bv, const int* bi, int lane) {
-  constexpr int H = KS <= 32 ? 32 : 64;
-  float xv[H];
-  int xi[H];
-#pragma unroll
-  for (int i = 0; i < H; ++i) {
-    const int jb = H - 1 - i;
-    const float av = i < KS ? L.v[i] : VCR_NEG_INF;
-    const int ai = i < KS ? L.id[i] : 0x7fffffff;
-    const float ov = jb < KS ? bv[jb * 64 + lane] : VCR_NEG_INF;
-    const int oi = jb < KS ? bi[jb * 64 + lane] : 0x7fffffff;
-    const bool o = lex_gt(ov, oi, av, ai);
-    xv[i] = o ? ov : av;
-    xi[i] = o ? oi : ai;
-  }
-#pragma unroll
-  for (int d = H / 2; d >= 1; d >>= 1) {
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-      if ((i & d) == 0) {
-        const bool sw = lex_gt(xv[i + d], xi[i + d], xv[i], xi[i]);
-        const float hv = sw ? xv[i + d] : xv[i], lv = sw ? xv[i] : xv[i + d];
-        const int hi = sw ? xi[i + d] : xi[i], li = sw ? xi[i] : xi[i + d];
-        xv[i] = hv; xi[i] = hi; xv[i + d] = lv; xi[i + d] = li;
+      for (int t = 1 + half; t <= a.k; t += 2) o[t - 1] = li[t * 32 + col];    // rank 0 dropped (util.py:159)
+      if (half == 0) {
+        const float vk = lv[a.k * 32 + col], vk1 = lv[(a.k + 1) * 32 + col];   // ranks k+1 and k+2
+        if (vk1 == vk && vk1 > VCR_NEG_INF) report_tie(a.tie_scratch, a.tie_cap, b * a.N + q0 + col);
       }
     }
   }
-#pragma unroll
-  for (int t = 0; t < KS; ++t) { L.v[t] = xv[t]; L.id[t] = xi[t]; }
 }
 
 // ---------------------------------------------------------------- C == 4 (xyz4, VALU)
-// Block = 2, 4 or 8 waves over the same 64 queries (one lane per query); wave s scans candidate groups
-// s, s + nw, ... (16 candidates each, fetched as wave-uniform 16-B reads: one L1/L2 broadcast per candidate, no
-// LDS copy of the cloud -- the kernel is latency-bound and LDS is what limits the waves per CU).  The waves'
-// sorted lists are combined by a binary tree of merge_sorted() steps through LDS; wave 0 writes ranks 1..k.
-template <int KS>
-__global__ __launch_bounds__(512) void knn3_kernel(vcr_knn_args a) {
+// Wave = 16 queries x 4 lanes (DPP quad = query); lane s of the quad computes the distances of candidates j = 4u + s
+// and holds ranks [s*T, (s+1)*T) of the query's list (T = 6 for k <= 20: 24 entries, T = 11 for k <= 40: 44).
+// S waves of a workgroup may split the candidates of a query group (small grids); their lists are folded at the end.
+__device__ __forceinline__ int quad_from_prev(int x) {   // lane s <- lane s-1 of its quad (lane 0: itself)
+  return __builtin_amdgcn_mov_dpp(x, 0x90, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int quad_from_prev2(int x) {  // lane s <- lane s-2 (lanes 0, 1: themselves)
+  return __builtin_amdgcn_mov_dpp(x, 0x44, 0xF, 0xF, true);
+}
+__device__ __forceinline__ int quad_bcast3(int x) { return __builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true); }
+
+template <int KS, int S>
+__global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
+  constexpr int T = (KS + 3) / 4;                        // entries per lane; the list holds 4T >= KS entries
+  constexpr int PEND = 64;                               // survivor slots per query between drains (a step adds <= 16)
+  constexpr int TL = (KS - 1) / T, TS = (KS - 1) % T;    // lane / slot of rank KS-1: the threshold
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63, s = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 3, qd = lane >> 2;
   const int b = blockIdx.y;
-  constexpr int PEND3 = knn3_slots<KS>();               // survivor slots of this kernel (>= KS for the merge hand-off)
-  constexpr int AS = PEND3 * 64;
-  float* pv = reinterpret_cast<float*>(smem) + s * (2 * AS);
-  int* pi = reinterpret_cast<int*>(pv + AS);
+  const int grp = wave / S, part = wave % S;
+  const int q0 = (blockIdx.x * (4 / S) + grp) * 16;
+  float* pv = reinterpret_cast<float*>(smem) + wave * (2 * PEND * 16);       // [slot][16 queries]
+  int* pi = reinterpret_cast<int*>(pv + PEND * 16);
   int cnt = 0;
   const float* xb = a.x + (size_t)b * a.N * a.ldx;
-  const int qi = blockIdx.x * 64 + lane;
+  const int qi = q0 + qd;
   const f32x4 qv = ld4(xb + (size_t)min(qi, a.N - 1) * a.ldx);
-  TopList<KS> L;
+  Seg<T> L;
   L.init();
   float thr = VCR_NEG_INF;
+  // segment s takes min(d, last entry of segment s-1); when that is the entry falling off the segment above it goes to
+  // the FRONT unconditionally (see knn64_kernel: a compare-based insertion would lose it on an exact tie)
+  auto insert_one = [&](float d, int j) {
+    const float pb = __int_as_float(quad_from_prev(__float_as_int(L.v[T - 1])));
+    const int pj = quad_from_prev(L.id[T - 1]);
+    const bool take = s && d > pb;
+    L.insert(take ? __builtin_huge_valf() : d, take ? pj : j);
+    if (take) L.v[0] = pb;
+  };
   auto drain = [&]() {
-    float dn = pv[lane];
-    int jn = pi[lane];
+    float dn = pv[qd];
+    int jn = pi[qd];
     for (int i = 0; __any(i < cnt); ++i) {
       const float d = i < cnt ? dn : VCR_NEG_INF;
       const int j = jn;
-      const int nx = min(i + 1, PEND3 - 1);
-      dn = pv[nx * 64 + lane];
-      jn = pi[nx * 64 + lane];
-      L.template insert<false>(d, j);                    // this lane's stream is index-sorted
+      const int nx = min(i + 1, PEND - 1);
+      dn = pv[nx * 16 + qd];
+      jn = pi[nx * 16 + qd];
+      insert_one(d, j);
     }
     cnt = 0;
-    thr = L.v[KS - 1];
+    // rank KS-1 lives in lane TL of the quad, slot TS: broadcast it
+    float tv = L.v[TS];
+    if (TL == 3) tv = __int_as_float(quad_bcast3(__float_as_int(tv)));
+    else tv = __shfl(tv, (lane & ~3) + TL, 64);
+    thr = tv;
   };
-  const int ngroups = (a.N + 15) / 16;
+  // 16 candidates per step, 4 per lane: j = j0 + 4u + s (the quad reads 64 contiguous bytes per load)
+  const int nsteps = (a.N + 15) / 16;
   int it = 0;
-  for (int grp = s; grp < ngroups; grp += nw, ++it) {
-    const int j0 = grp * 16;
-    if (it < 3 || __any(cnt > PEND3 - 16)) drain();       // early groups: settle the threshold quickly
-    f32x4 c[16];
+  KTL_DECL;
+  for (int st = part; st < nsteps; st += S, ++it) {
+    const int j0 = st * 16;
+    if (it < 3 || __any(cnt > PEND - 16)) drain();       // early steps: settle the threshold quickly
+    KTL(2);
+    f32x4 c[4];
 #pragma unroll
-    for (int u = 0; u < 16; ++u)                          // 16 wave-uniform 16-B reads in flight (L1/L2 broadcasts)
-      c[u] = ld4(xb + (size_t)min(j0 + u, a.N - 1) * a.ldx);
+    for (int u = 0; u < 4; ++u) c[u] = ld4(xb + (size_t)min(j0 + 4 * u + s, a.N - 1) * a.ldx);
+    float dd[4];
+    unsigned m = 0;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int j = j0 + u;
+    for (int u = 0; u < 4; ++u) {
       const float dot = fmaf(qv[2], c[u][2], fmaf(qv[1], c[u][1], qv[0] * c[u][0]));
-      const float d = (2.f * dot - c[u][3]) - qv[3];
-      if (d > thr && j < a.N) { pv[cnt * 64 + lane] = d; pi[cnt * 64 + lane] = j; ++cnt; }
+      dd[u] = (2.f * dot - c[u][3]) - qv[3];
+      m |= (dd[u] > thr && j0 + 4 * u + s < a.N) ? (1u << u) : 0u;
     }
+    // the quad appends to ONE list: exclusive prefix of the lanes' survivor counts
+    // (DPP reads of lanes that are switched off return 0: every cross-lane move is issued with all lanes active and
+    // only its RESULT is selected per lane)
+    const int c0 = __popc(m);
+    const int p1 = quad_from_prev(c0);
+    int inc = c0 + (s >= 1 ? p1 : 0);
+    const int p2 = quad_from_prev2(inc);
+    inc += s >= 2 ? p2 : 0;
+    const int total = quad_bcast3(inc);
+    if (m) {
+      const int base = cnt + inc - c0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (m & (1u << u)) {
+          const int pos = base + __popc(m & ((1u << u) - 1u));
+          pv[pos * 16 + qd] = dd[u];
+          pi[pos * 16 + qd] = j0 + 4 * u + s;
+        }
+      }
+    }
+    cnt += total;
+    KTL(1);                                              // prefix + push
   }
   drain();
-  for (int step = 1; step < nw; step <<= 1) {             // tree merge: wave s absorbs wave s + step
-    if ((s & (2 * step - 1)) == step) {
+  KTL(4);
+  KTL_FLUSH;
+
+  float* lv = pv;                                        // [4T][16]
+  int* li = pi;
+  auto dump = [&]() {
 #pragma unroll
-      for (int t = 0; t < KS; ++t) { pv[t * 64 + lane] = L.v[t]; pi[t * 64 + lane] = L.id[t]; }
-    }
+    for (int t = 0; t < T; ++t) { lv[(s * T + t) * 16 + qd] = L.v[t]; li[(s * T + t) * 16 + qd] = L.id[t]; }
+  };
+  if (S > 1) {
+    if (part != 0) dump();
     __syncthreads();
-    if ((s & (2 * step - 1)) == 0 && s + step < nw) {
-      const float* ov = reinterpret_cast<const float*>(smem) + (s + step) * (2 * AS);
-      merge_sorted<KS>(L, ov, reinterpret_cast<const int*>(ov + AS), lane);
+    if (part == 0) {
+      for (int p = 1; p < S; ++p) {
+        const float* ov = reinterpret_cast<const float*>(smem) + (wave + p) * (2 * PEND * 16);
+        const int* oi = reinterpret_cast<const int*>(ov + PEND * 16);
+        for (int t = 0; t < KS; ++t) insert_one(ov[t * 16 + qd], oi[t * 16 + qd]);
+      }
     }
   }
-  if (s == 0 && qi < a.N) {
-    int32_t* o = a.idx + ((size_t)b * a.N + qi) * a.k;
-    bool tie = false;
-#pragma unroll
-    for (int t = 1; t < KS; ++t) {
-      if (t <= a.k) o[t - 1] = L.id[t];
-      if (t == a.k + 1) tie = L.v[t] == L.v[t - 1] && L.v[t] > VCR_NEG_INF;
+  if (part == 0) {
+    dump();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (qi < a.N) {
+      int32_t* o = a.idx + ((size_t)b * a.N + qi) * a.k;
+      for (int t = 1 + s; t <= a.k; t += 4) o[t - 1] = li[t * 16 + qd];
+      if (s == 0) {
+        const float vk = lv[a.k * 16 + qd], vk1 = lv[(a.k + 1) * 16 + qd];
+        if (vk1 == vk && vk1 > VCR_NEG_INF) report_tie(a.tie_scratch, a.tie_cap, b * a.N + qi);
+      }
     }
-    if (tie) report_tie(a.tie_scratch, a.tie_cap, b * a.N + qi);
   }
 }
 
@@ -661,36 +746,47 @@ int launch(dim3 grid, dim3 block, size_t lds, hipStream_t s, const vcr_knn_args&
 
 }  // namespace
 
+#ifdef VCR_TIMELINE
+extern "C" int vcr_dbg_timeline_knn(unsigned long long* host_dst, int clear) {
+  if (clear) {
+    static unsigned long long zeros[4096 * 8];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(vcr_tl_knn), zeros, sizeof(zeros));
+  }
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(vcr_tl_knn), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif
+
 extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->idx) return VCR_EINVAL;
   if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k > 40 || a->k + 1 > a->N || a->N > 65535) return VCR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const int ks = a->k <= 20 ? 22 : 42;                   // k+1 kept entries + one more that exposes boundary ties
   if (a->tie_scratch) {
     if (a->tie_cap < 1) return VCR_EINVAL;
     const hipError_t e = hipMemsetAsync(a->tie_scratch, 0, sizeof(int32_t), s);
     if (e != hipSuccess) return (int)e;
   }
   int rc = VCR_EUNSUPPORTED;
+  const bool k20 = a->k <= 20;                           // list of k+2 entries (one more than topk(k+1): exposes boundary ties)
+  // S waves of a workgroup share one group of queries and split its candidates.  One list per query keeps the
+  // insertion work minimal, so S stays 1 whenever that alone gives every SIMD (MI355X: 1024) two waves.
+  auto pick_s = [&](long groups) { return a->waves == 1 || a->waves == 2 || a->waves == 4 ? a->waves
+                                          : groups >= 2048 ? 1 : groups >= 1024 ? 2 : 4; };
   if (a->C == 64) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
-    dim3 grid((a->N + 127) / 128, a->B);
-    const size_t lds64 = (size_t)4 * 2 * PEND * 64 * 4;
-    rc = a->k <= 20 ? launch<knn64_kernel<22>>(grid, dim3(256), lds64, s, *a)
-                    : launch<knn64_kernel<42>>(grid, dim3(256), lds64, s, *a);
+    const int S = pick_s((long)((a->N + 31) / 32) * a->B);
+    const dim3 grid((a->N + 32 * (4 / S) - 1) / (32 * (4 / S)), a->B);
+    const size_t lds = (size_t)4 * 2 * 64 * 32 * 4;
+#define VCR_KNN64(SV) (k20 ? launch<knn64_kernel<22, SV>>(grid, dim3(256), lds, s, *a) : launch<knn64_kernel<42, SV>>(grid, dim3(256), lds, s, *a))
+    rc = S == 1 ? VCR_KNN64(1) : S == 2 ? VCR_KNN64(2) : VCR_KNN64(4);
+#undef VCR_KNN64
   } else if (a->C == 4) {
     if (a->ldx < 4 || (a->ldx & 3)) return VCR_EINVAL;
-    // Waves per 64 queries.  Splitting the candidates over more waves shortens each wave's serial scan + insert
-    // chain but adds inserts and merge steps in total, so it only pays while the chip is under-filled: keep 2 waves
-    // unless that leaves at most one wave per SIMD (MI355X: 256 CUs x 4 SIMDs), 8 only for very small grids.
-    const long blocks = (long)((a->N + 63) / 64) * a->B;
-    int nw = blocks * 4 <= 1024 ? 8 : blocks * 2 <= 1024 ? 4 : 2;
-    if (a->waves == 2 || a->waves == 4 || a->waves == 8) nw = a->waves;   // caller's override (tests / tuning)
-    while (nw > 2 && (size_t)nw * 2 * (ks > 24 ? ks : 24) * 64 * 4 > 160 * 1024) nw >>= 1;
-    const size_t lds = (size_t)nw * 2 * (ks > 24 ? ks : 24) * 64 * 4;
-    dim3 grid((a->N + 63) / 64, a->B);
-    rc = a->k <= 20 ? launch<knn3_kernel<22>>(grid, dim3(64 * nw), lds, s, *a)
-                    : launch<knn3_kernel<42>>(grid, dim3(64 * nw), lds, s, *a);
+    const int S = pick_s((long)((a->N + 15) / 16) * a->B);
+    const dim3 grid((a->N + 16 * (4 / S) - 1) / (16 * (4 / S)), a->B);
+    const size_t lds = (size_t)4 * 2 * 64 * 16 * 4;
+#define VCR_KNN3(SV) (k20 ? launch<knn3_kernel<22, SV>>(grid, dim3(256), lds, s, *a) : launch<knn3_kernel<42, SV>>(grid, dim3(256), lds, s, *a))
+    rc = S == 1 ? VCR_KNN3(1) : S == 2 ? VCR_KNN3(2) : VCR_KNN3(4);
+#undef VCR_KNN3
   }
   if (rc != 0) return rc;
   // rows with an exact tie at the (k+1)-th value: replay libstdc++'s selection on them (see knn_tiebreak_kernel)
