@@ -22,8 +22,8 @@ def main():
     L.vcr_dbg_timeline_knn.restype = C.c_int
     g = torch.Generator().manual_seed(0)
     buf = np.zeros((4096, 8), np.uint64)
-    names = {"feat64": ["prefetch+MFMA", "filter+push", "drain", "pick", "final drain"],
-             "xyz": ["loads+dist", "prefix+push", "drain", "-", "final drain"]}
+    names = {"feat64": ["prefetch issue", "MFMA wait+filter", "make_room", "pick", "log push", "drain", "-", "-"],
+             "xyz": ["dist+filter", "log+drain", "-", "-", "-", "-", "-", "-"]}
     for B, N, k in ((32, 1024, 20), (64, 4096, 40)):
         f = torch.randn(B, N, 64, generator=g).cuda()
         sq = (f ** 2).sum(-1).contiguous()

@@ -1,83 +1,60 @@
 // Kernel 1: fused pairwise-distance + top-k (util/util.py:143-160).  The N x N distance matrix is
 // never written: distances are produced tile by tile in registers and filtered against each
-// query's current k-th best; survivors are parked in a per-query LDS list and merged into a
-// register-resident sorted list in wave-synchronous batches, so the insertion network is paid per
-// survivor (~k ln(N/k) per query), not per candidate.
+// query's current (k+2)-th best value; survivors are logged per query in LDS.
 //
 //   D_ij = (-sq_j + 2 x_i.x_j) - sq_i      (same association as util.py:157-158)
 //   idx  = top-(k+1) of D_i. by value, rank 0 dropped (util.py:159); the k kept indices are written as a SET
 //          (unordered) -- every consumer is a max over neighbours.
 //          Exact ties at the (k+1)-th value: Tensor.topk on the CPU is libstdc++'s std::nth_element (or
 //          std::partial_sort when (k+1)*64 <= N) with a value-only comparator, so WHICH of the tied candidates it
-//          keeps is an artefact of introselect's pivoting / the heap's shape.  The lists here carry one entry more
-//          than needed, which makes such a tie visible (about 1 row in 10^4 in fp32); those rows are re-done by
+//          keeps is an artefact of introselect's pivoting / the heap's shape.  The value lists here carry one entry
+//          more than needed, which makes such a tie visible (about 1 row in 10^4 in fp32); those rows are re-done by
 //          knn_tiebreak_kernel, a replica of the libstdc++ algorithms, so that the neighbour SETS equal the
 //          reference's on every row (validated against torch.topk on tie-heavy inputs).  A row WITHOUT a boundary tie
-//          has a set that depends on the values only, so the order in which equal values entered the list is
-//          irrelevant; without tie_scratch a boundary tie keeps one of the tied candidates, deterministically.
+//          has a set that depends on the values only; without tie_scratch a boundary tie keeps the tied candidates
+//          that were scanned first.
 //
-// Round 2: ONE sorted list per query, spread over the lanes that share the query, instead of one full list per lane
-// and a candidate split that multiplied the lists (and with them the k ln(N/k) insertions: 2 lists per query in the
-// feature-space kernel, 4-8 in the Cartesian one).  Lane segment s holds ranks [s*T, (s+1)*T); an insertion of d runs
-// on every segment at once, segment s taking min(d, last element of segment s-1) -- the element that falls off the
-// segment above, known BEFORE the insertion -- so the segments need one cross-lane move per insertion and no chain.
+// Selection, round 2 (measured on the round-1 kernels: 40 % of their time went into the sorted-insert network that
+// moved (value, index) pairs through 22-42 register slots, ~100 issue slots per insertion):
+//   * registers hold the sorted top-KS VALUES only: an insertion is one v_med3_f32 per slot, no compares, no index
+//     traffic.  The list of a query is spread over the lanes that share the query (2 for the MFMA layout, 4 in the
+//     Cartesian kernel); lane segment s takes min(d, last value of segment s-1) -- what falls off the segment above,
+//     known before the insertion -- so the segments need one cross-lane move per insertion and no chain;
+//   * every candidate that passed the filter stays in the query's LDS log as (value, index).  The log is compacted
+//     in place against the current KS-th best value whenever it runs out of room (entries strictly above it, at most
+//     KS-1, plus as many equal ones as the list itself holds), and once more at the end against the (k+2)-th best
+//     value: what is left ARE the k+1 neighbours.
 //
 // C == 64: v_mfma_f32_32x32x2_f32 with candidates as MFMA rows and queries as MFMA columns: lanes l and l+32 own one
-//          query column and 16 candidate rows each; they hold the two halves of the query's list (exchange:
-//          v_permlane32_swap).  The k order of the MFMA chain is the natural one (step s multiplies k = 2s, 2s+1) and
-//          -sq_j/2 rides along as a 33rd k-step: together with the pointwise kernel's reference-ordered features and
-//          norms the distance matrix is BIT-IDENTICAL to the reference's (CPU sgemm = k-ascending fma chain;
-//          verified), so the feature-space neighbour sets never flip.  S waves of a workgroup share a query tile and
-//          split the candidate tiles (S = 2 fills two waves per SIMD at BASELINE configs[1]); their lists are folded
-//          into one at the end.
+//          query column and 16 candidate rows each (cross-lane: v_permlane32_swap).  The k order of the MFMA chain is
+//          the natural one (step s multiplies k = 2s, 2s+1) and -sq_j/2 rides along as a 33rd k-step: together with
+//          the pointwise kernel's reference-ordered features and norms the distance matrix is BIT-IDENTICAL to the
+//          reference's (CPU sgemm = k-ascending fma chain; verified), so the feature-space neighbour sets never flip.
+//          S waves of a workgroup may share a query tile and split the candidate tiles (k <= 20; S = 2 puts two waves
+//          on every SIMD at BASELINE configs[1]); their value lists and logs are folded at the end.
 // C == 4 : Cartesian xyz4 rows on the VALU: four lanes (one DPP quad) per query, 16 queries per wave, each lane
-//          scanning every fourth candidate; segments exchange through DPP quad_perm.
+//          scanning every fourth candidate (cross-lane: DPP quad_perm).
 #include "common.h"
 
 namespace {
 
 constexpr int TILE = 32;            // candidates per MFMA tile
+// log entries per query: room for the KS-1 entries a compaction can leave, the <= 16 a step adds, and slack so that
+// compactions stay rare
+template <int KS> constexpr int pend_of() { return KS <= 22 ? 64 : 96; }
 
 #ifdef VCR_TIMELINE
 // Experiment-only (profiles/timeline_knn.py, -DVCR_TIMELINE builds): wave 0 of every workgroup accumulates the 100 MHz
 // wall clock over the phases of its scan.
 __device__ unsigned long long vcr_tl_knn[4096 * 8];
-#define KTL_DECL unsigned long long ktl_t = wall_clock64(), ktl_acc[6] = {0, 0, 0, 0, 0, 0}
+#define KTL_DECL unsigned long long ktl_t = wall_clock64(), ktl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define KTL(slot) do { const unsigned long long n_ = wall_clock64(); ktl_acc[slot] += n_ - ktl_t; ktl_t = n_; } while (0)
-#define KTL_FLUSH do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) for (int i_ = 0; i_ < 6; ++i_) vcr_tl_knn[blockIdx.x * 8 + i_] = ktl_acc[i_]; } while (0)
+#define KTL_FLUSH do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) for (int i_ = 0; i_ < 8; ++i_) vcr_tl_knn[blockIdx.x * 8 + i_] = ktl_acc[i_]; } while (0)
 #else
 #define KTL_DECL ((void)0)
 #define KTL(slot) ((void)0)
 #define KTL_FLUSH ((void)0)
 #endif
-
-// A sorted-descending segment of T (value, index) entries in registers.
-template <int T>
-struct Seg {
-  float v[T];
-  int id[T];
-  __device__ __forceinline__ void init() {
-#pragma unroll
-    for (int t = 0; t < T; ++t) { v[t] = VCR_NEG_INF; id[t] = 0x7fffffff; }
-  }
-  // Insert d: values move with ONE v_med3_f32 per slot (for v[t-1] >= v[t] the new slot value is
-  // median(v[t-1], d, v[t])), indices follow with one compare per slot (the compare of slot t-1 is the "shift"
-  // condition of slot t).  Strict '>': an equal value goes behind the entry already there.  Inserting -inf (or any
-  // value <= the last entry) is a no-op, which lets callers run the network unconditionally (no divergent branch
-  // around 2*T live registers).
-  __device__ __forceinline__ void insert(float d, int j) {
-    bool c_hi = d > v[T - 1];
-#pragma unroll
-    for (int t = T - 1; t >= 1; --t) {
-      const bool c_lo = d > v[t - 1];
-      id[t] = c_lo ? id[t - 1] : (c_hi ? j : id[t]);
-      v[t] = __builtin_amdgcn_fmed3f(v[t - 1], d, v[t]);
-      c_hi = c_lo;
-    }
-    id[0] = c_hi ? j : id[0];
-    v[0] = fmaxf(v[0], d);
-  }
-};
 
 // Row whose (k+1)-th and (k+2)-th best values are equal: hand it to knn_tiebreak_kernel (ties[0] = count).
 __device__ __forceinline__ void report_tie(int32_t* ties, int cap, int row) {
@@ -86,31 +63,212 @@ __device__ __forceinline__ void report_tie(int32_t* ties, int cap, int row) {
   if (pos < cap) ties[1 + pos] = row;
 }
 
-// values of the other 32-lane half (v_permlane32_swap: result 0 = the lower half's values in both halves, 1 = the upper's)
-__device__ __forceinline__ int other_half(int x, int half) {
-  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-  return half ? r[0] : r[1];
+// ---- lane geometry of a query's lanes.  Every cross-lane move is issued with all lanes active and only its RESULT
+// is selected per lane (DPP / permlane reads of switched-off lanes return 0).
+struct GeomMfma {                    // 32 query columns, lanes l and l+32 share one: segment = lane >> 5
+  static constexpr int COLS = 32, LPQ = 2;
+  __device__ static __forceinline__ int col(int lane) { return lane & 31; }
+  __device__ static __forceinline__ int seg(int lane) { return lane >> 5; }
+  // x of segment `which` (0 / 1), in every lane of the column (v_permlane32_swap: result 0 = the lower half's values
+  // in both halves, result 1 = the upper half's)
+  __device__ static __forceinline__ int from_seg(int x, int which) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return which ? r[1] : r[0];
+  }
+  __device__ static __forceinline__ int from_prev(int x, int) { return from_seg(x, 0); }   // only segment 1 has a predecessor
+  __device__ static __forceinline__ int col_sum(int x, int sg) { return x + from_seg(x, sg ^ 1); }
+};
+struct GeomQuad {                    // 16 queries, one DPP quad each: segment = lane & 3
+  static constexpr int COLS = 16, LPQ = 4;
+  __device__ static __forceinline__ int col(int lane) { return lane >> 2; }
+  __device__ static __forceinline__ int seg(int lane) { return lane & 3; }
+  __device__ static __forceinline__ int from_seg(int x, int which) {
+    const int a = __builtin_amdgcn_mov_dpp(x, 0x00, 0xF, 0xF, true), b = __builtin_amdgcn_mov_dpp(x, 0x55, 0xF, 0xF, true);
+    const int c = __builtin_amdgcn_mov_dpp(x, 0xAA, 0xF, 0xF, true), d = __builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true);
+    return which == 0 ? a : which == 1 ? b : which == 2 ? c : d;
+  }
+  __device__ static __forceinline__ int from_prev(int x, int) { return __builtin_amdgcn_mov_dpp(x, 0x90, 0xF, 0xF, true); }
+  __device__ static __forceinline__ int col_sum(int x, int) {
+    x += __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    return x;
+  }
+};
+template <class G> __device__ __forceinline__ float gf_from_seg(float x, int which) {
+  return __int_as_float(G::from_seg(__float_as_int(x), which));
 }
-__device__ __forceinline__ float other_half(float x, int half) {
-  return __int_as_float(other_half(__float_as_int(x), half));
+
+// ---- per-query selection state of one wave: sorted top-KS values in registers (T per lane), (value, index) log in LDS
+template <class G, int KS>
+struct Selector {
+  static constexpr int PEND = pend_of<KS>();
+  static constexpr int T = (KS + G::LPQ - 1) / G::LPQ;   // values per lane; the list holds LPQ*T >= KS values
+  static constexpr int TL = (KS - 1) / T, TS = (KS - 1) % T;   // segment / slot of rank KS-1: the filter threshold
+  float v[T];
+  float* lv; int* li;                                    // log [PEND + 1][COLS]; row PEND swallows the writes of lanes
+                                                         // that have nothing to log (branch-free appends)
+  int cnt, done;                                         // entries logged / already inserted (same in a query's lanes)
+  float thr;                                             // rank KS-1 value: nothing <= thr can be a neighbour
+  int col, sg;
+
+  __device__ __forceinline__ void init(float* lv_, int* li_, int lane) {
+    lv = lv_; li = li_; cnt = 0; done = 0; thr = VCR_NEG_INF; col = G::col(lane); sg = G::seg(lane);
+#pragma unroll
+    for (int t = 0; t < T; ++t) v[t] = VCR_NEG_INF;
+  }
+  // one value into the query's list, all segments at once (inserting -inf or anything <= the last value is a no-op)
+  __device__ __forceinline__ void insert(float d) {
+    const float pb = __int_as_float(G::from_prev(__float_as_int(v[T - 1]), sg));
+    d = sg ? fminf(d, pb) : d;
+#pragma unroll
+    for (int t = T - 1; t >= 1; --t) v[t] = __builtin_amdgcn_fmed3f(v[t - 1], d, v[t]);
+    v[0] = fmaxf(v[0], d);
+  }
+  __device__ __forceinline__ void refresh_thr() {
+    const float mine = v[TS];
+    thr = gf_from_seg<G>(mine, TL);
+  }
+  // value at global rank r (wave-uniform r) in every lane of the column
+  __device__ __forceinline__ float rank_value(int r) const {
+    const int rs = r / T, rt = r % T;
+    int bits = 0;                                        // (an OR of masked words: a select chain over v[] would be
+#pragma unroll                                           // turned into a dynamically indexed scratch array)
+    for (int t = 0; t < T; ++t) bits |= (rt == t ? -1 : 0) & __float_as_int(v[t]);
+    return gf_from_seg<G>(__int_as_float(bits), rs);
+  }
+  // insert the values logged since the last drain.  Four log reads are in flight per round trip: the loop is bound by
+  // LDS latency, not by the 1-med3-per-slot network.
+  __device__ __forceinline__ void drain() {
+    int i = done;
+    while (__any(i < cnt)) {
+      float d[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) d[u] = lv[min(i + u, PEND - 1) * G::COLS + col];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) insert(i + u < cnt ? d[u] : VCR_NEG_INF);      // idle lanes insert -inf: a no-op
+      i += 4;
+    }
+    done = cnt;
+    refresh_thr();
+  }
+  // keep the log entries above x, plus at most `emax` equal to x (the earliest logged); cnt = done = kept
+  __device__ __forceinline__ void compact(float x, int emax) {
+    int w = 0, ne = 0;
+    for (int i = 0; __any(i < cnt); i += 4) {
+      float d[4];
+      int j[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {                      // all four entries are in registers before any is rewritten
+        const int ii = min(i + u, PEND - 1);
+        d[u] = lv[ii * G::COLS + col];
+        j[u] = li[ii * G::COLS + col];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool eq = d[u] == x && ne < emax;
+        const bool keep = i + u < cnt && (d[u] > x || eq);
+        const int wr = keep ? w : PEND;                  // w <= i + u: in place (the lanes of a column write the same words)
+        lv[wr * G::COLS + col] = d[u];
+        li[wr * G::COLS + col] = j[u];
+        w += keep ? 1 : 0;
+        ne += (keep && eq) ? 1 : 0;
+      }
+    }
+    cnt = done = w;
+  }
+  __device__ __forceinline__ int count_above(float x) const {
+    int c = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) c += v[t] > x ? 1 : 0;
+    return G::col_sum(c, sg);
+  }
+  // make room for the next step (<= 16 new entries per query)
+  __device__ __forceinline__ void make_room() {
+    if (__any(cnt > PEND - 16)) {
+      drain();
+      compact(thr, KS - count_above(thr));
+    }
+  }
+};
+
+// Final stage shared by both kernels: the log holds every candidate above the (k+2)-th best value; fold the lists /
+// logs of the S waves of a query group into wave part 0, reduce the log to the k+1 best, drop rank 0, write the set.
+template <class G, int KS, int S>
+__device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args& a, int b, int q, int wave, int part,
+                                       unsigned char* smem) {
+  constexpr int T = Selector<G, KS>::T;
+  constexpr int PEND = Selector<G, KS>::PEND;
+  constexpr int AREA = 2 * (PEND + 1) * G::COLS;         // floats per wave
+  sel.drain();
+  if (S > 1) {
+    // every wave first shrinks its log to its own top-KS and parks its sorted values behind it (KS <= 22: 22 + 24 <= 64)
+    sel.compact(sel.thr, KS - sel.count_above(sel.thr));
+#pragma unroll
+    for (int t = 0; t < T; ++t) sel.lv[(PEND - G::LPQ * T + sel.sg * T + t) * G::COLS + sel.col] = sel.v[t];
+    if (sel.sg == 0) sel.li[(PEND - 1) * G::COLS + sel.col] = sel.cnt;
+    __syncthreads();
+    if (part == 0) {
+      for (int p = 1; p < S; ++p) {
+        const float* ov = reinterpret_cast<const float*>(smem) + (size_t)(wave + p) * AREA;
+        for (int t = 0; t < KS; ++t) sel.insert(ov[(PEND - G::LPQ * T + t) * G::COLS + sel.col]);
+      }
+      sel.refresh_thr();
+    }
+  }
+  if (part != 0) return;
+  const float vk = sel.rank_value(a.k), vk1 = sel.rank_value(a.k + 1);       // ranks k+1 and k+2 (KS >= k+2)
+  const int need = a.k + 1 - sel.count_above(vk1);      // neighbours that EQUAL the (k+2)-th value: 0 unless tied
+  sel.compact(vk1, need);
+  if (S > 1) {                                           // append the other waves' qualifying entries
+    int ne = 0;
+    for (int i = 0; i < sel.cnt; ++i) ne += sel.lv[i * G::COLS + sel.col] == vk1 ? 1 : 0;
+    for (int p = 1; p < S; ++p) {
+      const float* ov = reinterpret_cast<const float*>(smem) + (size_t)(wave + p) * AREA;
+      const int* oi = reinterpret_cast<const int*>(ov + (PEND + 1) * G::COLS);
+      const int oc = oi[(PEND - 1) * G::COLS + sel.col];
+      for (int i = 0; __any(i < oc); ++i) {
+        const int ii = min(i, PEND - 1);
+        const float d = ov[ii * G::COLS + sel.col];
+        const int j = oi[ii * G::COLS + sel.col];
+        const bool eq = d == vk1 && ne < need;
+        const bool keep = i < oc && (d > vk1 || eq) && sel.cnt < PEND;
+        if (keep) { sel.lv[sel.cnt * G::COLS + sel.col] = d; sel.li[sel.cnt * G::COLS + sel.col] = j; }
+        sel.cnt += keep ? 1 : 0;
+        ne += (keep && eq) ? 1 : 0;
+      }
+    }
+  }
+  // rank 0 = the largest value (the point itself; the first logged on an exact tie, e.g. duplicate points): dropped
+  int imax = 0;
+  float vmax = VCR_NEG_INF;
+  for (int i = 0; __any(i < sel.cnt); ++i) {
+    const float d = i < sel.cnt ? sel.lv[min(i, PEND - 1) * G::COLS + sel.col] : VCR_NEG_INF;
+    if (d > vmax) { vmax = d; imax = i; }
+  }
+  if (q < a.N) {
+    int32_t* o = a.idx + ((size_t)b * a.N + q) * a.k;
+    for (int i = sel.sg; i < sel.cnt && i <= a.k; i += G::LPQ)
+      if (i != imax) o[i - (i > imax ? 1 : 0)] = sel.li[i * G::COLS + sel.col];
+    if (sel.sg == 0 && vk1 == vk && vk1 > VCR_NEG_INF) report_tie(a.tie_scratch, a.tie_cap, b * a.N + q);
+  }
 }
 
 // ---------------------------------------------------------------- C == 64 (MFMA)
-// Workgroup = 4 waves = 4/S query tiles of 32 queries; wave (qt, part) scans candidate tiles part, part+S, ...
-// KS = list length (k+2 rounded to 22 / 42), one half of it per lane.
-template <int KS, int S>
-__global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
-  constexpr int T = KS / 2;                              // list entries per lane (lane half h holds ranks h*T ..)
-  constexpr int PEND = 64;                               // survivor slots per query between drains (a tile adds <= 32)
+// Workgroup = W waves = W/S query tiles of 32 queries; wave (qt, part) scans candidate tiles part, part+S, ...
+// (W = 4, or 2 for k > 20 whose longer logs would otherwise leave one workgroup per CU)
+template <int KS, int S, int W>
+__global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
+  using G = GeomMfma;
+  constexpr int PEND = pend_of<KS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int b = blockIdx.y;
   const int qt = wave / S, part = wave % S;
-  const int q0 = (blockIdx.x * (4 / S) + qt) * 32;       // this wave's 32 queries (may lie beyond N: clamped, not written)
-  float* pv = reinterpret_cast<float*>(smem) + wave * (2 * PEND * 32);       // [slot][32 queries]
-  int* pi = reinterpret_cast<int*>(pv + PEND * 32);
-  int cnt = 0;                                           // survivors parked for this lane's query (same in both halves)
+  const int q0 = (blockIdx.x * (W / S) + qt) * 32;       // this wave's 32 queries (may lie beyond N: clamped, not written)
+  float* lv = reinterpret_cast<float*>(smem) + wave * (2 * (PEND + 1) * 32);
+  Selector<G, KS> sel;
+  sel.init(lv, reinterpret_cast<int*>(lv + (PEND + 1) * 32), lane);
 
   const float* xb = a.x + (size_t)b * a.N * a.ldx;
   const float* sqb = a.sq + (size_t)b * a.N;
@@ -133,36 +291,6 @@ __global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
   }
   const float sq_q = sqb[q];
 
-  Seg<T> L;
-  L.init();
-  float thr = VCR_NEG_INF;                               // the list's last value: nothing <= thr can enter
-  // One insertion into the query's list, both halves at once.  When d displaces the upper segment's last entry
-  // (d > that entry, known before either insertion), that entry falls into the lower segment -- at its FRONT,
-  // unconditionally: it is >= everything there, and a compare-based insertion would drop it on an exact tie with the
-  // lower segment's own entries while the upper segment has already let go of it.
-  auto insert_one = [&](float d, int j) {
-    const float ob = other_half(L.v[T - 1], half);
-    const int oj = other_half(L.id[T - 1], half);
-    const bool take = half && d > ob;
-    L.insert(take ? __builtin_huge_valf() : d, take ? oj : j);
-    if (take) L.v[0] = ob;
-  };
-  auto drain = [&]() {
-    float dn = pv[col];
-    int jn = pi[col];
-    for (int i = 0; __any(i < cnt); ++i) {               // branch-free body: idle lanes insert -inf (a no-op)
-      const float d = i < cnt ? dn : VCR_NEG_INF;
-      const int j = jn;
-      const int nx = min(i + 1, PEND - 1);
-      dn = pv[nx * 32 + col];
-      jn = pi[nx * 32 + col];
-      insert_one(d, j);
-    }
-    cnt = 0;
-    const float ol = other_half(L.v[T - 1], half);
-    thr = half ? L.v[T - 1] : ol;                        // the LOWER segment's last value, in both halves
-  };
-
   const int ntiles = (a.N + TILE - 1) / TILE;
   float cf[32];
   float csq = 0.f;
@@ -176,9 +304,8 @@ __global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
   }
   KTL_DECL;
   for (int tile = part; tile < ntiles; tile += S) {
-    // k <= 20: the next candidate tile is prefetched as raw rows (64 VGPRs) across the MFMA + selection phase.
-    // k = 40: the longer list leaves no room for that at two waves per SIMD; the tile is loaded after the selection.
-    constexpr bool PREFETCH = KS <= 22;
+    // the next candidate tile is prefetched as raw rows (64 VGPRs) across the MFMA + selection phase
+    constexpr bool PREFETCH = true;
     f32x4 nraw[PREFETCH ? 16 : 1];
     float nsq = 0.f;
     if (PREFETCH && tile + S < ntiles) {
@@ -196,36 +323,45 @@ __global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
     // accumulator lands in AGPRs (seen in the k = 40 build: register 15, the last one written, was read stale).
     // Tie the wait states to the accumulator itself so they cannot be scheduled away.
     if (KS > 22) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
-#ifdef VCR_TIMELINE
-    asm volatile("" : "+v"(acc));
-    { const float fence_ = acc[15]; asm volatile("" :: "v"(fence_)); }
-#endif
     KTL(0);                                              // prefetch issue + MFMA chain
 
     const int jbase = tile * TILE;
-    float dd[16];
-    unsigned m = 0;
+    const bool ragged = jbase + TILE > a.N;              // only the last tile can hold rows beyond N
+    // two steps of 16 rows per query (8 per lane): the log has room for 16 new entries, never for 32
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      dd[r] = 2.f * acc[r] - sq_q;                       // (-sq_j + 2 dot) - sq_i
-      m |= (dd[r] > thr && jbase + acc_row(r, half) < a.N) ? (1u << r) : 0u;
-    }
-    const unsigned om = (unsigned)other_half((int)m, half);
-    if (__any(m != 0)) {                                 // both halves of a column append to ONE list: upper half first
-      const int base = cnt + (half ? __popc(om) : 0);
+    for (int hs = 0; hs < 2; ++hs) {
+      sel.make_room();
+      KTL(2);
+      float dd[8];
+      unsigned m = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (m & (1u << r)) {
-          const int pos = base + __popc(m & ((1u << r) - 1u));
-          pv[pos * 32 + col] = dd[r];
-          pi[pos * 32 + col] = jbase + acc_row(r, half);
+      for (int r = 0; r < 8; ++r) {
+        dd[r] = 2.f * acc[8 * hs + r] - sq_q;            // (-sq_j + 2 dot) - sq_i
+        m |= dd[r] > sel.thr ? (1u << r) : 0u;
+      }
+      if (ragged) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) m &= (jbase + acc_row(8 * hs + r, half) < a.N) ? ~0u : ~(1u << r);
+      }
+      const unsigned om = (unsigned)G::from_seg((int)m, half ^ 1);
+#ifdef VCR_TIMELINE
+      asm volatile("" :: "v"(om));
+#endif
+      KTL(1);
+      if (__any(m != 0)) {                               // the two lanes of a column append to ONE log: upper half first
+        const int base = sel.cnt + (half ? __popc(om) : 0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {                    // branch-free: a lane without a survivor in row r writes the trash row
+          const int pos = (m & (1u << r)) ? base + __popc(m & ((1u << r) - 1u)) : PEND;
+          sel.lv[pos * 32 + col] = dd[r];
+          sel.li[pos * 32 + col] = jbase + acc_row(8 * hs + r, half);
         }
       }
+      sel.cnt += __popc(m) + __popc(om);
+      KTL(4);
+      if (__any(sel.cnt - sel.done > 16)) sel.drain();   // keep the threshold fresh
+      KTL(5);
     }
-    cnt += __popc(m) + __popc(om);
-    KTL(1);                                              // filter + push
-    if (__any(cnt > PEND - 32)) drain();
-    KTL(2);                                              // drain
     if (tile + S < ntiles) {
       if (PREFETCH) {
         pick(nraw, cf);
@@ -246,178 +382,77 @@ __global__ __launch_bounds__(256, 2) void knn64_kernel(vcr_knn_args a) {
     }
     KTL(3);                                              // operand pick (waits for the prefetched rows)
   }
-  drain();
-  KTL(4);
   KTL_FLUSH;
-
-  // ---- the S waves of a query tile fold their lists into wave part 0's, which writes ranks 1..k
-  float* lv = pv;                                        // reuse the wave's survivor area: [KS][32]
-  int* li = pi;
-  auto dump = [&]() {
-#pragma unroll
-    for (int t = 0; t < T; ++t) { lv[(half * T + t) * 32 + col] = L.v[t]; li[(half * T + t) * 32 + col] = L.id[t]; }
-  };
-  if (S > 1) {
-    if (part != 0) dump();
-    __syncthreads();
-    if (part == 0) {
-      for (int p = 1; p < S; ++p) {
-        const float* ov = reinterpret_cast<const float*>(smem) + (wave + p) * (2 * PEND * 32);
-        const int* oi = reinterpret_cast<const int*>(ov + PEND * 32);
-        for (int t = 0; t < KS; ++t) insert_one(ov[t * 32 + col], oi[t * 32 + col]);
-      }
-    }
-  }
-  if (part == 0) {
-    dump();
-    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): same-wave LDS hand-off
-    __builtin_amdgcn_wave_barrier();
-    if (q0 + col < a.N) {
-      int32_t* o = a.idx + ((size_t)b * a.N + q0 + col) * a.k;
-      for (int t = 1 + half; t <= a.k; t += 2) o[t - 1] = li[t * 32 + col];    // rank 0 dropped (util.py:159)
-      if (half == 0) {
-        const float vk = lv[a.k * 32 + col], vk1 = lv[(a.k + 1) * 32 + col];   // ranks k+1 and k+2
-        if (vk1 == vk && vk1 > VCR_NEG_INF) report_tie(a.tie_scratch, a.tie_cap, b * a.N + q0 + col);
-      }
-    }
-  }
+  finish<G, KS, S>(sel, a, b, q0 + col, wave, part, smem);
 }
 
 // ---------------------------------------------------------------- C == 4 (xyz4, VALU)
-// Wave = 16 queries x 4 lanes (DPP quad = query); lane s of the quad computes the distances of candidates j = 4u + s
-// and holds ranks [s*T, (s+1)*T) of the query's list (T = 6 for k <= 20: 24 entries, T = 11 for k <= 40: 44).
-// S waves of a workgroup may split the candidates of a query group (small grids); their lists are folded at the end.
-__device__ __forceinline__ int quad_from_prev(int x) {   // lane s <- lane s-1 of its quad (lane 0: itself)
-  return __builtin_amdgcn_mov_dpp(x, 0x90, 0xF, 0xF, true);
-}
-__device__ __forceinline__ int quad_from_prev2(int x) {  // lane s <- lane s-2 (lanes 0, 1: themselves)
-  return __builtin_amdgcn_mov_dpp(x, 0x44, 0xF, 0xF, true);
-}
-__device__ __forceinline__ int quad_bcast3(int x) { return __builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true); }
-
+// Wave = 16 queries x 4 lanes (DPP quad = query); lane s of the quad computes the distances of candidates j = 4u + s.
+// S waves of a workgroup may split the candidates of a query group (small grids, k <= 20).
 template <int KS, int S>
 __global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
-  constexpr int T = (KS + 3) / 4;                        // entries per lane; the list holds 4T >= KS entries
-  constexpr int PEND = 64;                               // survivor slots per query between drains (a step adds <= 16)
-  constexpr int TL = (KS - 1) / T, TS = (KS - 1) % T;    // lane / slot of rank KS-1: the threshold
+  using G = GeomQuad;
+  constexpr int PEND = pend_of<KS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = lane & 3, qd = lane >> 2;
   const int b = blockIdx.y;
   const int grp = wave / S, part = wave % S;
   const int q0 = (blockIdx.x * (4 / S) + grp) * 16;
-  float* pv = reinterpret_cast<float*>(smem) + wave * (2 * PEND * 16);       // [slot][16 queries]
-  int* pi = reinterpret_cast<int*>(pv + PEND * 16);
-  int cnt = 0;
+  float* lv = reinterpret_cast<float*>(smem) + wave * (2 * (PEND + 1) * 16);
+  Selector<G, KS> sel;
+  sel.init(lv, reinterpret_cast<int*>(lv + (PEND + 1) * 16), lane);
   const float* xb = a.x + (size_t)b * a.N * a.ldx;
   const int qi = q0 + qd;
   const f32x4 qv = ld4(xb + (size_t)min(qi, a.N - 1) * a.ldx);
-  Seg<T> L;
-  L.init();
-  float thr = VCR_NEG_INF;
-  // segment s takes min(d, last entry of segment s-1); when that is the entry falling off the segment above it goes to
-  // the FRONT unconditionally (see knn64_kernel: a compare-based insertion would lose it on an exact tie)
-  auto insert_one = [&](float d, int j) {
-    const float pb = __int_as_float(quad_from_prev(__float_as_int(L.v[T - 1])));
-    const int pj = quad_from_prev(L.id[T - 1]);
-    const bool take = s && d > pb;
-    L.insert(take ? __builtin_huge_valf() : d, take ? pj : j);
-    if (take) L.v[0] = pb;
-  };
-  auto drain = [&]() {
-    float dn = pv[qd];
-    int jn = pi[qd];
-    for (int i = 0; __any(i < cnt); ++i) {
-      const float d = i < cnt ? dn : VCR_NEG_INF;
-      const int j = jn;
-      const int nx = min(i + 1, PEND - 1);
-      dn = pv[nx * 16 + qd];
-      jn = pi[nx * 16 + qd];
-      insert_one(d, j);
-    }
-    cnt = 0;
-    // rank KS-1 lives in lane TL of the quad, slot TS: broadcast it
-    float tv = L.v[TS];
-    if (TL == 3) tv = __int_as_float(quad_bcast3(__float_as_int(tv)));
-    else tv = __shfl(tv, (lane & ~3) + TL, 64);
-    thr = tv;
-  };
-  // 16 candidates per step, 4 per lane: j = j0 + 4u + s (the quad reads 64 contiguous bytes per load)
+  // 16 candidates per step, 4 per lane: j = j0 + 4u + s (the quad reads 64 contiguous bytes per load); the next
+  // step's rows are in flight while this one is filtered
   const int nsteps = (a.N + 15) / 16;
-  int it = 0;
+  f32x4 c[4], cn[4];
+  auto load = [&](f32x4* dst, int st) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dst[u] = ld4(xb + (size_t)min(st * 16 + 4 * u + s, a.N - 1) * a.ldx);
+  };
+  if (part < nsteps) load(c, part);
   KTL_DECL;
+  int it = 0;
   for (int st = part; st < nsteps; st += S, ++it) {
     const int j0 = st * 16;
-    if (it < 3 || __any(cnt > PEND - 16)) drain();       // early steps: settle the threshold quickly
-    KTL(2);
-    f32x4 c[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) c[u] = ld4(xb + (size_t)min(j0 + 4 * u + s, a.N - 1) * a.ldx);
+    if (st + S < nsteps) load(cn, st + S);
+    sel.make_room();
     float dd[4];
     unsigned m = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float dot = fmaf(qv[2], c[u][2], fmaf(qv[1], c[u][1], qv[0] * c[u][0]));
       dd[u] = (2.f * dot - c[u][3]) - qv[3];
-      m |= (dd[u] > thr && j0 + 4 * u + s < a.N) ? (1u << u) : 0u;
+      m |= (dd[u] > sel.thr && j0 + 4 * u + s < a.N) ? (1u << u) : 0u;
     }
-    // the quad appends to ONE list: exclusive prefix of the lanes' survivor counts
-    // (DPP reads of lanes that are switched off return 0: every cross-lane move is issued with all lanes active and
-    // only its RESULT is selected per lane)
+    KTL(0);                                              // distances + filter
+    // the quad appends to ONE log: exclusive prefix of the lanes' survivor counts
     const int c0 = __popc(m);
-    const int p1 = quad_from_prev(c0);
+    const int p1 = __builtin_amdgcn_mov_dpp(c0, 0x90, 0xF, 0xF, true);     // lane s <- lane s-1 (lane 0: itself)
     int inc = c0 + (s >= 1 ? p1 : 0);
-    const int p2 = quad_from_prev2(inc);
+    const int p2 = __builtin_amdgcn_mov_dpp(inc, 0x44, 0xF, 0xF, true);    // lane s <- lane s-2 (lanes 0, 1: themselves)
     inc += s >= 2 ? p2 : 0;
-    const int total = quad_bcast3(inc);
-    if (m) {
-      const int base = cnt + inc - c0;
+    const int total = G::from_seg(inc, 3);
+    if (__any(m != 0)) {
+      const int base = sel.cnt + inc - c0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (m & (1u << u)) {
-          const int pos = base + __popc(m & ((1u << u) - 1u));
-          pv[pos * 16 + qd] = dd[u];
-          pi[pos * 16 + qd] = j0 + 4 * u + s;
-        }
+      for (int u = 0; u < 4; ++u) {                      // branch-free: lanes without a survivor write the trash row
+        const int pos = (m & (1u << u)) ? base + __popc(m & ((1u << u) - 1u)) : PEND;
+        sel.lv[pos * 16 + qd] = dd[u];
+        sel.li[pos * 16 + qd] = j0 + 4 * u + s;
       }
     }
-    cnt += total;
-    KTL(1);                                              // prefix + push
+    sel.cnt += total;
+    if (it < 3 || __any(sel.cnt - sel.done > 12)) sel.drain();   // early steps: settle the threshold quickly
+    KTL(1);                                              // log + drains
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = cn[u];
   }
-  drain();
-  KTL(4);
   KTL_FLUSH;
-
-  float* lv = pv;                                        // [4T][16]
-  int* li = pi;
-  auto dump = [&]() {
-#pragma unroll
-    for (int t = 0; t < T; ++t) { lv[(s * T + t) * 16 + qd] = L.v[t]; li[(s * T + t) * 16 + qd] = L.id[t]; }
-  };
-  if (S > 1) {
-    if (part != 0) dump();
-    __syncthreads();
-    if (part == 0) {
-      for (int p = 1; p < S; ++p) {
-        const float* ov = reinterpret_cast<const float*>(smem) + (wave + p) * (2 * PEND * 16);
-        const int* oi = reinterpret_cast<const int*>(ov + PEND * 16);
-        for (int t = 0; t < KS; ++t) insert_one(ov[t * 16 + qd], oi[t * 16 + qd]);
-      }
-    }
-  }
-  if (part == 0) {
-    dump();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (qi < a.N) {
-      int32_t* o = a.idx + ((size_t)b * a.N + qi) * a.k;
-      for (int t = 1 + s; t <= a.k; t += 4) o[t - 1] = li[t * 16 + qd];
-      if (s == 0) {
-        const float vk = lv[a.k * 16 + qd], vk1 = lv[(a.k + 1) * 16 + qd];
-        if (vk1 == vk && vk1 > VCR_NEG_INF) report_tie(a.tie_scratch, a.tie_cap, b * a.N + qi);
-      }
-    }
-  }
+  finish<G, KS, S>(sel, a, b, qi, wave, part, smem);
 }
 
 // ---------------------------------------------------------------- exact replica of Tensor.topk's tie-breaking
@@ -767,26 +802,30 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   }
   int rc = VCR_EUNSUPPORTED;
   const bool k20 = a->k <= 20;                           // list of k+2 entries (one more than topk(k+1): exposes boundary ties)
-  // S waves of a workgroup share one group of queries and split its candidates.  One list per query keeps the
-  // insertion work minimal, so S stays 1 whenever that alone gives every SIMD (MI355X: 1024) two waves.
-  auto pick_s = [&](long groups) { return a->waves == 1 || a->waves == 2 || a->waves == 4 ? a->waves
-                                          : groups >= 2048 ? 1 : groups >= 1024 ? 2 : 4; };
+  // S waves of a workgroup share one group of queries and split its candidates.  The selection work grows with the
+  // number of lists (S per query), and measured on MI355X a second wave per SIMD bought with S = 2 only breaks even, so
+  // S stays 1 as soon as that gives every SIMD (1024 of them) one wave; smaller grids split to fill the chip.
+  // (the fold of S > 1 waves parks the value lists behind the logs: there is room for that with k <= 20 only)
+  auto pick_s = [&](long groups) { return !k20 ? 1 : a->waves == 1 || a->waves == 2 || a->waves == 4 ? a->waves
+                                          : groups >= 1024 ? 1 : groups >= 512 ? 2 : 4; };
   if (a->C == 64) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
-    const int S = pick_s((long)((a->N + 31) / 32) * a->B);
-    const dim3 grid((a->N + 32 * (4 / S) - 1) / (32 * (4 / S)), a->B);
-    const size_t lds = (size_t)4 * 2 * 64 * 32 * 4;
-#define VCR_KNN64(SV) (k20 ? launch<knn64_kernel<22, SV>>(grid, dim3(256), lds, s, *a) : launch<knn64_kernel<42, SV>>(grid, dim3(256), lds, s, *a))
-    rc = S == 1 ? VCR_KNN64(1) : S == 2 ? VCR_KNN64(2) : VCR_KNN64(4);
-#undef VCR_KNN64
+    const int S = pick_s((long)((a->N + 31) / 32) * a->B), W = k20 ? 4 : 2;
+    const dim3 grid((a->N + 32 * (W / S) - 1) / (32 * (W / S)), a->B);
+    const size_t lds = (size_t)W * 2 * ((k20 ? pend_of<22>() : pend_of<42>()) + 1) * 32 * 4;
+    rc = !k20 ? launch<knn64_kernel<42, 1, 2>>(grid, dim3(128), lds, s, *a)
+         : S == 1 ? launch<knn64_kernel<22, 1, 4>>(grid, dim3(256), lds, s, *a)
+         : S == 2 ? launch<knn64_kernel<22, 2, 4>>(grid, dim3(256), lds, s, *a)
+                  : launch<knn64_kernel<22, 4, 4>>(grid, dim3(256), lds, s, *a);
   } else if (a->C == 4) {
     if (a->ldx < 4 || (a->ldx & 3)) return VCR_EINVAL;
     const int S = pick_s((long)((a->N + 15) / 16) * a->B);
     const dim3 grid((a->N + 16 * (4 / S) - 1) / (16 * (4 / S)), a->B);
-    const size_t lds = (size_t)4 * 2 * 64 * 16 * 4;
-#define VCR_KNN3(SV) (k20 ? launch<knn3_kernel<22, SV>>(grid, dim3(256), lds, s, *a) : launch<knn3_kernel<42, SV>>(grid, dim3(256), lds, s, *a))
-    rc = S == 1 ? VCR_KNN3(1) : S == 2 ? VCR_KNN3(2) : VCR_KNN3(4);
-#undef VCR_KNN3
+    const size_t lds = (size_t)4 * 2 * ((k20 ? pend_of<22>() : pend_of<42>()) + 1) * 16 * 4;
+    rc = !k20 ? launch<knn3_kernel<42, 1>>(grid, dim3(256), lds, s, *a)
+         : S == 1 ? launch<knn3_kernel<22, 1>>(grid, dim3(256), lds, s, *a)
+         : S == 2 ? launch<knn3_kernel<22, 2>>(grid, dim3(256), lds, s, *a)
+                  : launch<knn3_kernel<22, 4>>(grid, dim3(256), lds, s, *a);
   }
   if (rc != 0) return rc;
   // rows with an exact tie at the (k+1)-th value: replay libstdc++'s selection on them (see knn_tiebreak_kernel)
