@@ -68,6 +68,12 @@ typedef struct {
                                          tie; 256 entries are plenty: ~1 row in 10^4 ties), N <= 20000 */
   int waves;                          /* tuning / tests: waves of a workgroup that share one group of queries and split its
                                          candidates (1, 2 or 4); 0 = chosen from the grid size.  Never changes a result. */
+  /* Optional overlap of the tie replay (a latency-bound kernel that keeps ~4 CUs busy for ~25 us) with whatever the
+   * caller enqueues next on `stream`: with tie_stream and two caller-owned event handles (vcr_event_create) the replay
+   * is enqueued on tie_stream, fenced by tie_events[0] (recorded on `stream` after the main kernel); idx is final once
+   * tie_events[1] has completed -- the caller makes its consumer wait for it (vcr_stream_wait_event).
+   * tie_zeroed != 0: the caller guarantees tie_scratch[0] == 0 on entry (no memset is enqueued here). */
+  vcr_stream_t tie_stream; void* tie_events[2]; int tie_zeroed;
 } vcr_knn_args;
 int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
 
@@ -368,6 +374,12 @@ typedef struct {
    *   pairs   [B, K2]      positions in sel_src of the kept sources, K2 = vcr_vcrnet_pairs() (vcrnet_model.py:312) */
   const int32_t *force_keys, *force_sel_src, *force_sel_tgt, *force_argmax, *force_pairs;
   int32_t *out_keys, *out_sel_src, *out_sel_tgt, *out_argmax, *out_pairs;
+  /* Optional second stream + four caller-owned events (vcr_event_create): the two kNN tie replays then run beside the
+   * GEMMs that follow them instead of in front of them (measured on MI355X: the two cross-stream joins cost as much
+   * as the ~50 us they hide, so the host module leaves this off by default).  Everything is joined
+   * back into `stream` before the call returns control of the outputs: the caller only ever synchronises `stream`.
+   * NULL = everything on `stream`. */
+  vcr_stream_t aux_stream; void* aux_events[4];
 } vcr_vcrnet_io;
 
 size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights*, int B, int N);
@@ -402,6 +414,7 @@ int vcr_event_create(void** ev);
 int vcr_event_destroy(void* ev);
 int vcr_event_record(void* ev, vcr_stream_t stream);
 int vcr_event_elapsed_ms(void* start, void* stop, float* ms);
+int vcr_stream_wait_event(vcr_stream_t stream, void* ev);   /* work enqueued on stream after this call waits for ev */
 
 #ifdef __cplusplus
 }

@@ -164,6 +164,24 @@ struct Runner {
   // KEY receives over heads and queries, keep the int(nk*overlap2) heaviest keys, soft-max again over those.
   // The first soft-max is never written: a statistics pass leaves (max, sum) per query row, the mass pass
   // streams the queries past each key block (owner = keys of batch b, streamed = queries of batch (b+B) % 2B).
+  // kNN launch `which` (0 = feature space, 1 = Cartesian): the tie counters were zeroed together at the start of the
+  // forward; with an auxiliary stream the tie replay runs there, and knn_join(which) makes this stream wait for it
+  // right before the first consumer of the indices
+  const vcr_vcrnet_io* io_ = nullptr;
+  void knn(const char* nm, vcr_knn_args a, int which) {
+    if (rc) return;
+    mark(nm);
+    a.tie_zeroed = 1;
+    if (io_ && io_->aux_stream && io_->aux_events[2 * which] && io_->aux_events[2 * which + 1]) {
+      a.tie_stream = io_->aux_stream; a.tie_events[0] = io_->aux_events[2 * which]; a.tie_events[1] = io_->aux_events[2 * which + 1];
+    }
+    ok(vcr_knn_f32(&a, stream));
+  }
+  void knn_join(int which) {
+    if (rc || !io_ || !io_->aux_stream || !io_->aux_events[2 * which + 1]) return;
+    ok((int)hipStreamWaitEvent(stream, (hipEvent_t)io_->aux_events[2 * which + 1], 0));
+  }
+
   // device-to-device copy of a forced / reported selection (tiny; stays on the stream)
   void copy_idx(const char* nm, int32_t* dst, const int32_t* src, size_t n) {
     if (rc) return;
@@ -296,6 +314,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (ws_bytes < w.bytes) return VCR_EWORKSPACE;
   const int M1 = B * N, M2 = 2 * M1;
   Runner R{(hipStream_t)stream, tr};
+  R.io_ = io;
+  R.ok((int)hipMemsetAsync(w.ties, 0, (size_t)(M2 + 2) * sizeof(int32_t), R.stream));   // both tie counters (and the first block)
 #define SP(site) (W->linear_mode == 1 ? W->split.site : nullptr)
 
   const float* stats_for_ln = (W->has_pointer == 1 && W->linear_mode == 0) ? w.st_emb : nullptr;
@@ -308,11 +328,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       R.mark(c ? "pointwise:tgt" : "pointwise:src");
       R.ok(vcr_rows4_f32(c ? io->tgt_cf : io->src_cf, w.xyz4 + (size_t)c * M1 * 4, B, N, R.stream));
     }
-    if (R.rc == 0) {
-      R.mark("knn:xyz");
-      vcr_knn_args a{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
-      R.ok(vcr_knn_f32(&a, R.stream));
-    }
+    R.knn("knn:xyz", vcr_knn_args{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2}, 1);
     if (R.rc == 0) {
       R.mark("pointwise:pad");
       hipLaunchKernelGGL(xyz_pad32_kernel, dim3((unsigned)(((long)M2 * 8 + 255) / 256)), dim3(256), 0, R.stream, w.xyz4,
@@ -327,6 +343,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       vcr_segmax_args a{h, C, M2, k, C, w.cat + col, 512};
       R.ok(vcr_segmax_f32(&a, R.stream));
     };
+    R.knn_join(1);
     if (R.rc == 0) {
       R.mark("gathermax:dg_c1");
       vcr_edgerows_args a{w.pq1, 128, 64, w.idx3, k, M2, N, w.eh1, 64};
@@ -349,23 +366,19 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
                          w.xyz4 + (size_t)c * M1 * 4, w.feat64 + (size_t)c * M1 * 64, w.sq64 + (size_t)c * M1};
     R.ok(vcr_pointwise_f32(&a, R.stream));
   }
-  if (R.rc == 0) {
-    R.mark("knn:feat64");
-    vcr_knn_args a{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2};
-    R.ok(vcr_knn_f32(&a, R.stream));
-  }
+  // The Cartesian kNN (lpdnet_model.py:129) needs nothing but xyz: it goes first, so that its tie replay -- and, with an
+  // auxiliary stream, the feature-space one too -- sits beside the kernels that do not read the indices.
+  R.knn("knn:xyz", vcr_knn_args{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2}, 1);
+  R.knn("knn:feat64", vcr_knn_args{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2}, 0);
   R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
+  R.knn_join(0);
   if (R.rc == 0) {
     R.mark("edgeconv:dg1_dg2");
     vcr_edgeconv_args a{w.pq1, 256, w.idx1, k, M2, N, W->dg2_w, W->dg2_b, w.cat, 512, w.cat + 128, 512};
     R.ok(vcr_edgeconv_f32(&a, R.stream));
   }
-  if (R.rc == 0) {
-    R.mark("knn:xyz");
-    vcr_knn_args a{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
-    R.ok(vcr_knn_f32(&a, R.stream));
-  }
   R.linear("linear:sn1_pq", w.cat + 128, 512, W->sn1_wpq, SP(sn1_pq), W->sn1_bpq, w.pq3, 512, M2, 512, 128, 0);
+  R.knn_join(1);
   if (R.rc == 0) {
     R.mark("gathermax:sn1");
     vcr_gathermax_args a{w.pq3, 512, 256, w.idx3, k, M2, N, w.cat + 256, 512};
@@ -637,7 +650,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 10; }
+extern "C" int vcr_abi_version(void) { return 11; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.
@@ -651,6 +664,9 @@ extern "C" int vcr_event_create(void** ev) {
 extern "C" int vcr_event_destroy(void* ev) { return ev ? (int)hipEventDestroy((hipEvent_t)ev) : VCR_EINVAL; }
 extern "C" int vcr_event_record(void* ev, vcr_stream_t stream) {
   return ev ? (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) : VCR_EINVAL;
+}
+extern "C" int vcr_stream_wait_event(vcr_stream_t stream, void* ev) {
+  return ev ? (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0) : VCR_EINVAL;
 }
 extern "C" int vcr_event_elapsed_ms(void* start, void* stop, float* ms) {
   if (!start || !stop || !ms) return VCR_EINVAL;

@@ -797,8 +797,11 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   if (a->tie_scratch) {
     if (a->tie_cap < 1) return VCR_EINVAL;
-    const hipError_t e = hipMemsetAsync(a->tie_scratch, 0, sizeof(int32_t), s);
-    if (e != hipSuccess) return (int)e;
+    if (a->tie_stream && (!a->tie_events[0] || !a->tie_events[1])) return VCR_EINVAL;
+    if (!a->tie_zeroed) {
+      const hipError_t e = hipMemsetAsync(a->tie_scratch, 0, sizeof(int32_t), s);
+      if (e != hipSuccess) return (int)e;
+    }
   }
   int rc = VCR_EUNSUPPORTED;
   const bool k20 = a->k <= 20;                           // list of k+2 entries (one more than topk(k+1): exposes boundary ties)
@@ -830,6 +833,17 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   if (rc != 0) return rc;
   // rows with an exact tie at the (k+1)-th value: replay libstdc++'s selection on them (see knn_tiebreak_kernel)
   const size_t tb_lds = (size_t)a->N * 16 + 256 + (16 + 2 * 256 + 2) * 4;
-  if (a->tie_scratch && tb_lds <= 160 * 1024) rc = launch<knn_tiebreak_kernel>(dim3(64), dim3(256), tb_lds, s, *a);
+  if (a->tie_scratch && tb_lds <= 160 * 1024) {
+    if (a->tie_stream) {                                 // replay beside the caller's next launches (see vcr_hip.h)
+      hipStream_t ts = (hipStream_t)a->tie_stream;
+      hipError_t e = hipEventRecord((hipEvent_t)a->tie_events[0], s);
+      if (e == hipSuccess) e = hipStreamWaitEvent(ts, (hipEvent_t)a->tie_events[0], 0);
+      if (e != hipSuccess) return (int)e;
+      rc = launch<knn_tiebreak_kernel>(dim3(64), dim3(256), tb_lds, ts, *a);
+      if (rc == 0) rc = (int)hipEventRecord((hipEvent_t)a->tie_events[1], ts);
+    } else {
+      rc = launch<knn_tiebreak_kernel>(dim3(64), dim3(256), tb_lds, s, *a);
+    }
+  }
   return rc;
 }
