@@ -164,6 +164,11 @@ def workload_label(a, Nfull, N, B, kind):
 
 
 def run_rank(a):
+    # stdout carries exactly ONE line, the JSON: libraries that chat on file descriptor 1 (gloo's "Rank 0 is connected
+    # ...", RCCL's version banner) are sent to stderr for the life of the process; the line goes out through a copy
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -347,7 +352,7 @@ def run_rank(a):
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, B, Nfull, a.k, a.partial, a.iters, a.cpu_budget_s, a.cpu_baseline_full)
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

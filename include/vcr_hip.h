@@ -97,6 +97,11 @@ typedef struct {
    *             y = inv_m * (sum_k x[m,k] w[n,k] - mean_m * ln_colsum[n]) + bias[n],  inv = 1 / (std_unbiased + ln_eps). */
   const float* ln_stats_in; int ln_nseg; const float* ln_colsum; float ln_eps;
   float* stats_out;
+  /* Optional EdgeConv max-pool fused into the epilogue (DGCNN's x.max(dim=-1), vcrnet_model.py:112-118): the rows are
+   * edges, seg_k consecutive rows per point; segmax_out[row / seg_k][n] = max(segmax_out[..][n], y[row][n]) by integer
+   * atomic max -- needs relu != 0 (values >= 0) and segmax_out pre-set to 0 (vcr_edgerows_f32 does that).  y may then
+   * be NULL: the per-edge activations of the last conv are never written.  LDS-DMA kernels (variant 0) only. */
+  float* segmax_out; int ld_segmax; int seg_k;
   int variant;                        /* tuning / tests, 0 = automatic (LDS-DMA staging, one 128x128 tile per workgroup:
                                          BK 16 and four workgroups per CU without a residual, BK 32 with one).
                                          bit3 (8) force BK 32, bit6 (64) force BK 16; bit2 (4) register staging instead of
@@ -161,6 +166,9 @@ int vcr_gathermax_f32(const vcr_gathermax_args*, vcr_stream_t);
  * ([M*k, C], feeding vcr_linear_f32 for conv2..conv4) and the max over each point's k edge rows. */
 typedef struct {
   const float* pq; int ldpq; int C; const int32_t* idx; int k; int M; int n_per_cloud; float* h; int ldh;
+  /* optional (C == 64): ymax[i][0:C] = max_j h[(i,j)] written by the same pass (x1 of vcrnet_model.py:109), and
+   * ymax[i][C:zero_to] = 0 -- the base the fused maxima of the following convs accumulate into (vcr_linear_args.segmax_out) */
+  float* ymax; int ldymax; int zero_to;
 } vcr_edgerows_args;
 int vcr_edgerows_f32(const vcr_edgerows_args*, vcr_stream_t);
 typedef struct {

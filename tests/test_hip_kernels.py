@@ -175,6 +175,43 @@ def test_linear_persistent_equals_one_tile_per_workgroup(nat, M, N, K, relu, res
     assert torch.equal(y0, y1), (y0 - y1).abs().max().item()
 
 
+@pytest.mark.parametrize("M,k,K,N,store", [(700, 20, 64, 128, True), (300, 40, 128, 256, False), (129, 7, 64, 64, True)])
+def test_linear_with_fused_edge_max(nat, M, k, K, N, store):
+    """DGCNN's x.max(dim=-1) (vcrnet_model.py:112-118) folded into the producing GEMM's epilogue: the max over each
+    point's k consecutive edge rows, by integer atomic max on the post-ReLU values -- bit-equal to the separate
+    segmax pass over the stored rows, with and without storing the per-edge rows themselves."""
+    g = torch.Generator().manual_seed(M + k)
+    x = dev(torch.randn(M * k, K, generator=g))
+    w = dev(torch.randn(N, K, generator=g) / math.sqrt(K))
+    b = dev(torch.randn(N, generator=g))
+    y_ref = nat.linear(x, w, b, relu=True)
+    ref = nat.segmax(y_ref, M, k)
+    cat = torch.full((M, 512), float("nan"), device="cuda")
+    out = cat[:, 192:192 + N]
+    out.zero_()
+    y = nat.linear(x, w, b, relu=True, segmax=(out, k), store=store)
+    assert torch.equal(out, ref)
+    assert torch.isnan(cat[:, :192]).all() and torch.isnan(cat[:, 192 + N:]).all()
+    if store:
+        assert torch.equal(y, y_ref)
+
+
+def test_edgerows_with_max_and_zero_base(nat):
+    g = torch.Generator().manual_seed(3)
+    B, N, k = 2, 300, 20
+    pq = dev(torch.randn(B * N, 128, generator=g))
+    idx = dev(torch.randint(0, N, (B * N, k), generator=g).int())
+    h0 = nat.edgerows(pq, 64, idx, N)
+    cat = torch.full((B * N, 512), float("nan"), device="cuda")
+    h1 = nat.edgerows(pq, 64, idx, N, ymax=cat, zero_to=512)
+    assert torch.equal(h0, h1)
+    assert torch.equal(cat[:, :64], nat.segmax(h0, B * N, k)) and (cat[:, 64:] == 0).all()
+    P, Q = pq[:, :64].cpu(), pq[:, 64:].cpu()
+    nbr = (idx.cpu().long() + (torch.arange(B * N) // N * N).view(-1, 1))
+    ref = torch.relu(P[nbr] + Q[:, None, :]).reshape(B * N * k, 64)
+    assert torch.equal(h0.cpu(), ref)
+
+
 def test_layernorm(nat):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1000, 512, generator=g) * 3 + 0.5

@@ -73,8 +73,8 @@ def test_bench_spawns_its_own_ranks():
                         "--warmup", "1", "--batch", "4", "--points", "256", "--min-seconds", "0.2"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, r.stdout                          # stdout = the ONE JSON line (library chatter goes to stderr)
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["scaling"] == "weak"
     assert j["value"] > 0 and "roofline" in j and "cpu_baseline" not in j

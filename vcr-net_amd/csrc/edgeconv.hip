@@ -277,6 +277,40 @@ __global__ __launch_bounds__(256) void edge_rows_kernel(vcr_edgerows_args p) {
   }
 }
 
+// C == 64: one wave per POINT, four edge rows per step (16 lanes x 16 B each); the same pass writes the max over the
+// point's k rows (x1, vcrnet_model.py:109) and zeroes the columns that the fused maxima of conv2..conv4 will
+// accumulate into with atomic max (vcr_linear_args.segmax_out)
+__global__ __launch_bounds__(256) void edge_rows64_kernel(vcr_edgerows_args p) {
+  const int lane = threadIdx.x & 63;
+  const int pt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pt >= p.M) return;
+  const int base = (pt / p.n_per_cloud) * p.n_per_cloud;
+  const int c = (lane & 15) * 4, rg = lane >> 4;
+  const f32x4 q = ld4(p.pq + (size_t)pt * p.ldpq + 64 + c);
+  f32x4 m = {0.f, 0.f, 0.f, 0.f};                        // post-ReLU values are >= 0
+  for (int j0 = 0; j0 < p.k; j0 += 4) {
+    const int j = j0 + rg;
+    if (j < p.k) {
+      const int nb = p.idx[(size_t)pt * p.k + j];
+      const f32x4 v = ld4(p.pq + (size_t)(base + nb) * p.ldpq + c) + q;
+      const f32x4 h = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+      st4(p.h + ((size_t)pt * p.k + j) * p.ldh + c, h);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], h[i]);
+    }
+  }
+  if (p.ymax) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      m[i] = fmaxf(m[i], __shfl_xor(m[i], 16, 64));
+      m[i] = fmaxf(m[i], __shfl_xor(m[i], 32, 64));
+    }
+    float* yr = p.ymax + (size_t)pt * p.ldymax;
+    if (rg == 0) st4(yr + c, m);
+    for (int z = 64 + lane * 4; z < p.zero_to; z += 256) st4(yr + z, f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+}
+
 // y[i] = max_j x[(i,j)]   (x.max(dim=-1) of vcrnet_model.py:109-118)
 __global__ __launch_bounds__(256) void segmax_kernel(vcr_segmax_args p) {
   const int lane = threadIdx.x & 63;
@@ -299,8 +333,13 @@ extern "C" int vcr_edgerows_f32(const vcr_edgerows_args* a, vcr_stream_t stream)
   if (!a || !a->pq || !a->idx || !a->h) return VCR_EINVAL;
   if (a->M <= 0 || a->k <= 0 || a->C <= 0 || (a->C & 3) || (a->ldpq & 3) || (a->ldh & 3) || a->ldpq < 2 * a->C) return VCR_EINVAL;
   if (a->n_per_cloud <= 0 || (a->M % a->n_per_cloud)) return VCR_EINVAL;
+  if (a->ymax && (a->C != 64 || (a->ldymax & 3) || a->ldymax < a->zero_to || (a->zero_to & 3) ||
+                  (a->zero_to && a->zero_to < 64))) return VCR_EINVAL;
   const long rows = (long)a->M * a->k;
-  hipLaunchKernelGGL(edge_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  if (a->C == 64)
+    hipLaunchKernelGGL(edge_rows64_kernel, dim3((unsigned)((a->M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL(edge_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
   return VCR_LAUNCH_RC();
 }
 

@@ -32,8 +32,8 @@ struct Ws {
   float *rstat, *cstat, *colsum, *rowsum, *score;      // selectCom: [B,N,2] x2, [B,N] x2, [B,N,roundup32(N)]
   int32_t *sel_s, *sel_t, *amax, *pick;                // [B,K1] x3, [B,K2]
   float *so_e, *to_e, *so_s, *to_s, *peak;             // overlap sets: [B,K1,E] x2, [B,K1,4] x2; [B,K1,2]
-  // DGCNN embedding: per-edge activations [2B*N*k, 64 | 64 | 128 | 256]
-  float *eh1, *eh2, *eh3, *eh4;
+  // DGCNN embedding: per-edge activations [2B*N*k, 64 | 64 | 128]
+  float *eh1, *eh2, *eh3;
   // vcrnetIter
   float *cur_cf, *Ri, *ti, *Rb, *tb;
   size_t bytes;
@@ -78,7 +78,7 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   if (emb_kind == 1) {
     const size_t Mk = M * k;
     w.eh1 = bp.take<float>(Mk * 64); w.eh2 = bp.take<float>(Mk * 64);
-    w.eh3 = bp.take<float>(Mk * 128); w.eh4 = bp.take<float>(Mk * 256);
+    w.eh3 = bp.take<float>(Mk * 128);                      // (conv4's [M*k, 256] output is only ever max-reduced: never stored)
   }
   w.cur_cf = bp.take<float>((size_t)B * 3 * N);
   w.Ri = bp.take<float>((size_t)B * 9); w.ti = bp.take<float>((size_t)B * 3);
@@ -337,25 +337,26 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     }
     R.linear("linear:dg_c1_pq", w.feat64, 32, W->dgcnn.c1_wpq, nullptr, W->dgcnn.c1_bpq, w.pq1, 128, M2, 128, 32, 0);
     const int Mk = M2 * k;
-    auto edge_max = [&](const char* nm, const float* h, int C, int col) {
+    // Every x.max(dim=-1) of vcrnet_model.py:109-118 rides on the kernel that produces the per-edge rows: the edge-row
+    // builder writes x1 (and the zero base of x2..x4), conv2..conv4 fold the max over each point's k rows into their
+    // epilogues (integer atomic max on post-ReLU values), and conv4's 256-wide per-edge activations are never written.
+    auto conv_max = [&](const char* nm, const float* x, int K, const float* wt, const float* bias, float* y, int Nout,
+                        int col) {
       if (R.rc) return;
       R.mark(nm);
-      vcr_segmax_args a{h, C, M2, k, C, w.cat + col, 512};
-      R.ok(vcr_segmax_f32(&a, R.stream));
+      vcr_linear_args a{x, K, wt, bias, nullptr, 0, y, Nout, Mk, Nout, K, 1};
+      a.segmax_out = w.cat + col; a.ld_segmax = 512; a.seg_k = k;
+      R.ok(vcr_linear_f32(&a, R.stream));
     };
     R.knn_join(1);
     if (R.rc == 0) {
       R.mark("gathermax:dg_c1");
-      vcr_edgerows_args a{w.pq1, 128, 64, w.idx3, k, M2, N, w.eh1, 64};
+      vcr_edgerows_args a{w.pq1, 128, 64, w.idx3, k, M2, N, w.eh1, 64, w.cat, 512, 512};
       R.ok(vcr_edgerows_f32(&a, R.stream));
     }
-    edge_max("gathermax:dg_max1", w.eh1, 64, 0);
-    R.linear("linear:dg_c2", w.eh1, 64, W->dgcnn.c2_w, nullptr, W->dgcnn.c2_b, w.eh2, 64, Mk, 64, 64, 1);
-    edge_max("gathermax:dg_max2", w.eh2, 64, 64);
-    R.linear("linear:dg_c3", w.eh2, 64, W->dgcnn.c3_w, nullptr, W->dgcnn.c3_b, w.eh3, 128, Mk, 128, 64, 1);
-    edge_max("gathermax:dg_max3", w.eh3, 128, 128);
-    R.linear("linear:dg_c4", w.eh3, 128, W->dgcnn.c4_w, nullptr, W->dgcnn.c4_b, w.eh4, 256, Mk, 256, 128, 1);
-    edge_max("gathermax:dg_max4", w.eh4, 256, 256);
+    conv_max("linear:dg_c2", w.eh1, 64, W->dgcnn.c2_w, W->dgcnn.c2_b, w.eh2, 64, 64);
+    conv_max("linear:dg_c3", w.eh2, 64, W->dgcnn.c3_w, W->dgcnn.c3_b, w.eh3, 128, 128);
+    conv_max("linear:dg_c4", w.eh3, 128, W->dgcnn.c4_w, W->dgcnn.c4_b, nullptr, 256, 256);
     R.linear("linear:conv3", w.cat, 512, W->dgcnn.c5_w, nullptr, W->dgcnn.c5_b, w.emb, E, M2, E, 512, 1, nullptr, 0, nullptr,
              nullptr, const_cast<float*>(stats_for_ln));
   } else {

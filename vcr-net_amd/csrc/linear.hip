@@ -316,6 +316,16 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_kernel(vc
   const int c4e = (lane & 15) * 4, col = n0 + wn * 64 + c4e;
   const f32x4 bias = (p.bias && col < p.N) ? ld4(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
   const f32x4 csum = (LN_IN && col < p.N) ? ld4(p.ln_colsum + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  int run_pt = -1;                                       // fused max-pool state (segmax_out only)
+  f32x4 run_mx = {0.f, 0.f, 0.f, 0.f};
+  auto seg_flush = [&]() {
+    if (run_pt >= 0 && (lane >> 4) == 0 && col < p.N) {
+      int* o = reinterpret_cast<int*>(p.segmax_out + (size_t)run_pt * p.ld_segmax + col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicMax(o + e, __float_as_int(run_mx[e]));
+    }
+    run_pt = -1;
+  };
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -324,7 +334,44 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_kernel(vc
       for (int r = 0; r < 16; ++r) ot[acc_row(r, half) * EP + j * 32 + l31] = acc[i][j][r];
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    if (col < p.N) {
+    if (p.segmax_out) {
+      // (uniform) fused EdgeConv max-pool, DGCNN conv2..conv4 -- no LayerNorm / residual / statistics here.  Rows are
+      // edges, seg_k consecutive rows per point.  The wave walks its 64 rows in ascending order (i, then ps, then
+      // lane >> 4); the maximum of a point is kept in registers while the point lasts -- folded over the four lane
+      // groups of a ps step when they share the point -- and goes out as ONE integer atomic max per column and run
+      // (post-ReLU values are >= 0: their bit patterns order like ints; the target was pre-set to 0 by vcr_edgerows_f32).
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int rl = ps * 4 + (lane >> 4);
+        const int row0 = m0 + wm * 64 + i * 32 + ps * 4, row = row0 + (lane >> 4);   // row0: wave-uniform
+        f32x4 v = ld4(&ot[rl * EP + c4e]) + bias;
+        v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        if (row >= p.M || col >= p.N) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        else if (p.y) st4(p.y + (size_t)row * p.ldy + col, v);
+        if (row0 >= p.M) continue;
+        const int pa = row0 / p.seg_k, pb = min(row0 + 3, p.M - 1) / p.seg_k;
+        if (pa == pb) {                                  // the four rows of this step belong to one point
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = fmaxf(v[e], __shfl_xor(v[e], 16, 64));
+            v[e] = fmaxf(v[e], __shfl_xor(v[e], 32, 64));
+          }
+          if (pa != run_pt) { seg_flush(); run_pt = pa; run_mx = v; }
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) run_mx[e] = fmaxf(run_mx[e], v[e]);
+          }
+        } else {                                         // a point boundary inside the step: every row for itself
+          seg_flush();
+          if (row < p.M && col < p.N) {
+            int* o = reinterpret_cast<int*>(p.segmax_out + (size_t)(row / p.seg_k) * p.ld_segmax + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicMax(o + e, __float_as_int(v[e]));
+          }
+        }
+      }
+      if (i == 1) seg_flush();
+    } else if (col < p.N) {
 #pragma unroll
       for (int ps = 0; ps < 8; ++ps) {
         const int rl = ps * 4 + (lane >> 4);
@@ -651,15 +698,18 @@ extern "C" int vcr_dbg_timeline(unsigned long long* host_dst, int clear) {
 #endif
 
 extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
-  if (!a || !a->x || !a->w || !a->y) return VCR_EINVAL;
+  if (!a || !a->x || !a->w || (!a->y && !a->segmax_out)) return VCR_EINVAL;
+  if (a->segmax_out && (a->seg_k <= 0 || !a->relu || a->residual || a->ln_stats_in || a->stats_out || (a->ld_segmax & 3) ||
+                        a->ld_segmax < a->N || ((uintptr_t)a->segmax_out & 15) || (a->variant & (1 | 4 | 32))))
+    return VCR_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % 32) != 0) return VCR_EINVAL;
   const int variant = a->variant;                    // tuning / test selector carried by the call (see vcr_hip.h)
-  if ((a->ldx & 3) || a->ldx < a->K || a->ldy < a->N || (a->residual && a->ldr < a->N)) return VCR_EINVAL;
+  if ((a->ldx & 3) || a->ldx < a->K || (a->y && a->ldy < a->N) || (a->residual && a->ldr < a->N)) return VCR_EINVAL;
   if (((uintptr_t)a->x | (uintptr_t)a->w) & 15) return VCR_EINVAL;
   const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
   const int lds32 = 2 * sizeof(TileT<32>), lds16 = 2 * sizeof(TileT<16>);
   static_assert(2 * sizeof(TileT<16>) >= 4 * 32 * 68 * 4, "epilogue slice fits the staging buffers");
-  const int vec = (a->N % 4 == 0) && (a->ldy % 4 == 0) && (((uintptr_t)a->y & 15) == 0) &&
+  const int vec = (a->N % 4 == 0) && (!a->y || ((a->ldy % 4 == 0) && (((uintptr_t)a->y & 15) == 0))) &&
                   (!a->bias || ((uintptr_t)a->bias & 15) == 0) &&
                   (!a->residual || ((a->ldr % 4 == 0) && ((uintptr_t)a->residual & 15) == 0));
   const bool persist = (variant & 32) != 0;
@@ -692,6 +742,7 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
 #undef VCR_LINP_LAUNCH
     return VCR_LAUNCH_RC();
   }
+  if (a->segmax_out && !vec) return VCR_EUNSUPPORTED;
   if (!(variant & 4) && vec) {   // LDS-DMA staging, one tile per workgroup
     const bool ln_in = a->ln_stats_in != nullptr, st_out = a->stats_out != nullptr;
     hipStream_t s = (hipStream_t)stream;

@@ -405,6 +405,12 @@ class VCRNet(nn.Module):
         srcc, tgtc = src.contiguous().float(), tgt.contiguous().float()
         bufs = self._buffers_for(B, N, dev)
         ws = bufs["ws"]
+        # the workspace is shared by consecutive calls: a call on ANOTHER stream first waits for the previous user
+        cur = torch.cuda.current_stream(dev)
+        prev = bufs.get("stream")
+        if prev is not None and prev != cur:
+            cur.wait_stream(prev)
+        bufs["stream"] = cur
         off = (-ws.data_ptr()) % 256
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         L = native.lib()

@@ -34,7 +34,8 @@ class LinearArgs(C.Structure):
     _fields_ = [("x", f32p), ("ldx", C.c_int), ("w", f32p), ("bias", f32p), ("residual", f32p), ("ldr", C.c_int),
                 ("y", f32p), ("ldy", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("relu", C.c_int),
                 ("ln_stats_in", f32p), ("ln_nseg", C.c_int), ("ln_colsum", f32p), ("ln_eps", C.c_float),
-                ("stats_out", f32p), ("variant", C.c_int)]
+                ("stats_out", f32p), ("segmax_out", f32p), ("ld_segmax", C.c_int), ("seg_k", C.c_int),
+                ("variant", C.c_int)]
 
 
 class LayerNormArgs(C.Structure):
@@ -109,7 +110,8 @@ class GatherArgs(C.Structure):
 
 class EdgerowsArgs(C.Structure):
     _fields_ = [("pq", f32p), ("ldpq", C.c_int), ("C", C.c_int), ("idx", f32p), ("k", C.c_int), ("M", C.c_int),
-                ("n_per_cloud", C.c_int), ("h", f32p), ("ldh", C.c_int)]
+                ("n_per_cloud", C.c_int), ("h", f32p), ("ldh", C.c_int), ("ymax", f32p), ("ldymax", C.c_int),
+                ("zero_to", C.c_int)]
 
 
 class SegmaxArgs(C.Structure):
@@ -376,16 +378,20 @@ def knn(x, sq, k, exact_ties=True, waves=0):
 
 
 @_guarded
-def linear(x, w, bias=None, relu=False, residual=None, out=None, ln=None, want_stats=False, variant=0):
+def linear(x, w, bias=None, relu=False, residual=None, out=None, ln=None, want_stats=False, variant=0, segmax=None,
+           store=True):
     """y = act(x w^T + bias) (+ residual).  ln = (stats [M,nseg,2], colsum [N], eps) with w / bias folded by
     fold_layernorm(): y = act(LayerNorm(x) w0^T + bias0).  want_stats: also return the [M, N/64, 2]
     (sum, sum of squares) partials of y."""
     M, K = x.shape
     N = w.shape[0]
-    y = out if out is not None else _f32(M, N, device=x.device)
+    y = None if not store else out if out is not None else _f32(M, N, device=x.device)
     stats = _f32(M, N // 64, 2, device=x.device) if want_stats else None
     a = LinearArgs(ptr(x), x.stride(0), ptr(w), ptr(bias), ptr(residual),
-                   residual.stride(0) if residual is not None else 0, ptr(y), y.stride(0), M, N, K, int(relu))
+                   residual.stride(0) if residual is not None else 0, ptr(y), y.stride(0) if y is not None else N,
+                   M, N, K, int(relu))
+    if segmax is not None:       # (out [M / seg_k, >= N] row view pre-set to 0, seg_k): fused max over each point's edge rows
+        a.segmax_out, a.ld_segmax, a.seg_k = ptr(segmax[0]), segmax[0].stride(0), int(segmax[1])
     if ln is not None:
         a.ln_stats_in, a.ln_nseg, a.ln_colsum, a.ln_eps = ptr(ln[0]), ln[0].shape[1], ptr(ln[1]), ln[2]
     a.stats_out = ptr(stats)
@@ -605,11 +611,13 @@ def icp(src_cf, dst_cf, max_iterations=10, tolerance=0.001):
 
 
 @_guarded
-def edgerows(pq, Cc, idx, n_per_cloud):
-    """pq [M, 2C] (P | Q), idx [M,k] -> per-edge rows relu(P[nbr] + Q[i]) as [M*k, C]."""
+def edgerows(pq, Cc, idx, n_per_cloud, ymax=None, zero_to=0):
+    """pq [M, 2C] (P | Q), idx [M,k] -> per-edge rows relu(P[nbr] + Q[i]) as [M*k, C].  ymax (row view [M, >= zero_to]):
+    also the max over each point's k rows in columns 0..C-1, and zeros in columns C..zero_to-1."""
     M, k = idx.shape
     h = _f32(M * k, Cc, device=pq.device)
-    call("vcr_edgerows_f32", EdgerowsArgs(ptr(pq), pq.stride(0), Cc, ptr(idx), k, M, n_per_cloud, ptr(h), Cc))
+    call("vcr_edgerows_f32", EdgerowsArgs(ptr(pq), pq.stride(0), Cc, ptr(idx), k, M, n_per_cloud, ptr(h), Cc,
+                                          ptr(ymax), ymax.stride(0) if ymax is not None else 0, zero_to))
     return h
 
 

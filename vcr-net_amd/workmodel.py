@@ -53,7 +53,8 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
         if site.startswith("dg_c"):                        # DGCNN: conv1 split per point, conv2..4 on the N*k edge rows
             n, kk, rows = {"dg_c1_pq": (128, 32, M2), "dg_c2": (64, 64, M2 * k), "dg_c3": (128, 64, M2 * k),
                            "dg_c4": (256, 128, M2 * k)}[site]
-            return 2.0 * rows * n * kk, 4.0 * (rows * kk + n * kk + rows * n)
+            out_rows = M2 if site == "dg_c4" else rows     # conv4's per-edge rows are never stored: only the fused max
+            return 2.0 * rows * n * kk, 4.0 * (rows * kk + n * kk + out_rows * n)
         if site.startswith("head.att"):                    # VcpAtt's two Linear(E,E), one cloud each
             return 2.0 * M1 * E * E, 4.0 * (2 * M1 * E + E * E)
         n, kk = (r(v) for v in _LINEAR_SHAPES[site])
@@ -62,8 +63,8 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
         # compulsory: P|Q rows [M2,256] once, idx, x1 and x2 out
         return 2.0 * M2 * k * 128 * 128, 4.0 * M2 * (256 + k + 256)
     if fam == "gathermax":
-        if site == "dg_c1":                                # edge rows materialised: P|Q once, idx, [M2*k,64] out
-            return 1.0 * M2 * k * 64, 4.0 * M2 * (128 + k + k * 64)
+        if site == "dg_c1":                                # edge rows materialised: P|Q once, idx, [M2*k,64] out, x1 + zero base
+            return 1.0 * M2 * k * 64, 4.0 * M2 * (128 + k + k * 64 + 512)
         if site.startswith("dg_"):                         # segmented max over stored edge rows: streamed once
             C = {"dg_max1": 64, "dg_max2": 64, "dg_max3": 128, "dg_max4": 256}[site]
             return 1.0 * M2 * k * C, 4.0 * M2 * (k * C + C)
