@@ -19,7 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def short(name):
     for key in ("linear_kernel", "sdpa_kernel", "edgeconv_dg_kernel", "softcorr_kernel", "layernorm512_kernel",
                 "knn3_kernel", "knn64_kernel", "gathermax_kernel", "pointwise12_kernel", "rigid_svd_kernel",
-                "rowside_kernel", "linear_glds16_kernel", "linear_glds_kernel", "edgeconv_dg_packed_kernel", "pairscore_kernel", "rankselect_kernel"):
+                "rowside_kernel", "linear_glds16_kernel", "linear_glds_kernel", "linear_persist_kernel",
+                "edgeconv_dg_packed_kernel", "pairscore_kernel", "rankselect_kernel", "knn_tiebreak_kernel"):
         if key in name:
             return key + (name[name.index(key) + len(key):].split("(")[0] if "<" in name else "")
     return name[:48]
@@ -34,10 +35,10 @@ def main():
             rows.append((short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]),
                          float(r["Percentage"]), float(r["MinNs"]), float(r["MaxNs"])))
     rows.sort(key=lambda r: -r[2])
-    with open(os.path.join(HERE, f"{tag}_kernel_stats.csv"), "w") as fh:
-        fh.write("kernel,calls,total_ns,avg_ns,percent,min_ns,max_ns\n")
-        for r in rows:
-            fh.write(",".join(str(x) for x in r) + "\n")
+    with open(os.path.join(HERE, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
+        wr = csv.writer(fh)                                # (kernel names carry template commas: quoted)
+        wr.writerow(["kernel", "calls", "total_ns", "avg_ns", "percent", "min_ns", "max_ns"])
+        wr.writerows(rows)
     pmc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     for d in pmc_dirs:
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
