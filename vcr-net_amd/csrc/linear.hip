@@ -25,8 +25,10 @@ __device__ __forceinline__ void tl_mark(int slot) {
   if (threadIdx.x == 0 && blockIdx.x < 4096 && slot < 16) vcr_tl[blockIdx.x * 16 + slot] = wall_clock64();
 }
 #define TL(slot) tl_mark(slot)
+#define VCR_TL_EXTRA_LDS(variant, stage) (((variant) & 256) ? 90 * 1024 - (stage) : 0)   /* experiment: one workgroup per CU */
 #else
 #define TL(slot) ((void)0)
+#define VCR_TL_EXTRA_LDS(variant, stage) 0
 #endif
 
 template <int BK> struct TileT { float a[BM][BK + 4]; float b[BN][BK + 4]; };
@@ -288,6 +290,37 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_kernel(vc
       }
   }
   const int nk = p.K / BK;
+#ifdef VCR_TIMELINE
+  if (p.variant & 512) {                                 // experiment: fragments of group g+1 requested before the MFMAs of g
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) fill(cur ^ 1, (kt + 1) * BK);
+      const Tile& T = tile[cur];
+      f32x4 fa[2][2], fb[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[0][i] = ld4(&T.a[ra_[i]][4 * ((half) ^ sa[i])]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[0][j] = ld4(&T.b[rb_[j]][4 * ((half) ^ sb[j])]);
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        if (g + 1 < BK / 8) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) fa[(g + 1) & 1][i] = ld4(&T.a[ra_[i]][4 * ((2 * (g + 1) + half) ^ sa[i])]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) fb[(g + 1) & 1][j] = ld4(&T.b[rb_[j]][4 * ((2 * (g + 1) + half) ^ sb[j])]);
+        }
+        __builtin_amdgcn_sched_barrier(0);               // keep the reads ABOVE this group's MFMAs
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[g & 1][i][s], fb[g & 1][j][s], acc[i][j]);
+      }
+      __syncthreads();
+    }
+  } else
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) fill(cur ^ 1, (kt + 1) * BK);
@@ -750,7 +783,7 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
 #define VCR_LIN_LAUNCH(BKV, LI, SO)                                                                                     \
   do {                                                                                                                   \
     const int stage = 2 * (int)sizeof(TileGT<BKV>) > 4 * 32 * 68 * 4 ? 2 * (int)sizeof(TileGT<BKV>) : 4 * 32 * 68 * 4;    \
-    const int lds = stage + (LI ? BM * 2 * 4 : 0);                                                                       \
+    const int lds = stage + (LI ? BM * 2 * 4 : 0) + VCR_TL_EXTRA_LDS(variant, stage);                                   \
     VCR_DYN_LDS((linear_glds_kernel<BKV, LI, SO>), lds);                                                                 \
     hipLaunchKernelGGL((linear_glds_kernel<BKV, LI, SO>), grid, dim3(256), lds, s, *a, tiles_m, tiles_n);               \
   } while (0)
