@@ -147,7 +147,7 @@ def test_linear(nat, M, N, K, relu, res):
                                                  (66000, 256, 64, False, False, False),    # K = 64: two k-steps, slices flushed
                                                  (70001, 128, 32, True, True, False),      # K = 32: one k-step; ragged M
                                                  (513, 200, 96, False, True, False)])      # ragged N, odd row pitches
-def test_linear_persistent_equals_one_tile_per_workgroup(nat, M, N, K, relu, res, ln):
+def test_linear_persistent_equals_one_tile_per_workgroup(nat, M, N, K, relu, res, ln, pv=32):
     """The opt-in persistent kernel (variant 32: workgroups walk over their tiles, the epilogue of tile i is issued
     under the MFMAs of tile i+1 straight from the accumulator registers) against the default one-tile-per-workgroup
     kernels: the same k order and the same epilogue arithmetic, so y is BIT-identical; the row statistics are summed
@@ -167,11 +167,11 @@ def test_linear_persistent_equals_one_tile_per_workgroup(nat, M, N, K, relu, res
     vec_ok = N % 4 == 0 and not res                         # the default kernels need 16-B aligned rows (else they fall
     if ln or stats_ok and vec_ok:                           # back to the register-staged sibling by themselves)
         y0, s0 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg, want_stats=True)
-        y1, s1 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg, want_stats=True, variant=32)
+        y1, s1 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg, want_stats=True, variant=pv)
         torch.testing.assert_close(s1, s0, rtol=2e-5, atol=2e-4)
     else:
         y0 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg)
-        y1 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg, variant=32)
+        y1 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg, variant=pv)
     assert torch.equal(y0, y1), (y0 - y1).abs().max().item()
 
 
