@@ -1,7 +1,10 @@
 // Kernel 4: centred 3x3 cross-covariance + SVD rigid solve (model/vcrnet_model.py:356-399).
 // The reference loops over the batch in Python with one LAPACK call and one host sync (det < 0) per
-// sample; here one 256-thread block per sample reduces the covariance (fp64 accumulation of the fp32
-// inputs) and a single lane finishes with a one-sided Jacobi SVD in fp64.
+// sample; here one 256-thread block per sample reduces the means and the covariance (fp64 accumulation of the fp32
+// inputs; all six / all nine sums cross the block together: four barriers in total), and the first quad of wave 0 runs
+// the one-sided Jacobi SVD in fp64 cooperatively: lane i owns row i of A and V, the column inner products of a
+// rotation are summed over the quad with DPP, every lane rotates its own row.  Lane 0 gathers the rows for the tail
+// (ordering, rank completion, R = V U^T, determinant rule).
 //   H = sum_k (s_k - s_mean)(c_k - c_mean)^T,  H = U S V^T,  R = V U^T,
 //   det R < 0  ->  flip the column of V that belongs to the SMALLEST singular value (torch.svd sorts
 //   descending, so the reference's V @ diag(1,1,-1) is exactly that; :382-386),  t = -R s_mean + c_mean.
@@ -11,40 +14,72 @@
 
 namespace {
 
-__device__ __forceinline__ double block_sum(double v, double* red) {
+__device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// NV sums across the block at once: wave trees, one LDS hand-off, fixed order over the four waves
+template <int NV>
+__device__ __forceinline__ void block_sums(double (&v)[NV], double* red) {
   const int w = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < NV; ++e) v[e] = wave_sum_f64(v[e]);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[w] = v;
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int e = 0; e < NV; ++e) red[w * NV + e] = v[e];
   __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+#pragma unroll
+  for (int e = 0; e < NV; ++e) v[e] = ((red[e] + red[NV + e]) + red[2 * NV + e]) + red[3 * NV + e];
+}
+// sum over the four lanes of a DPP quad (two butterflies on the 32-bit halves of a double); same value in every lane
+__device__ __forceinline__ double quad_xor(double v, int ctrl_is_1) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if (ctrl_is_1) { lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); }
+  else { lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); }
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_sum(double v) {
+  v += quad_xor(v, 1);                                   // lanes (0,1) (2,3)
+  v += quad_xor(v, 0);                                   // + the other pair: (x0 + x1) + (x2 + x3) in every lane
+  return v;
+}
+__device__ __forceinline__ double quad_get(double v, int lane_in_quad) {   // lane_in_quad: compile-time 0..2
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  const int c = lane_in_quad == 0 ? 0x00 : lane_in_quad == 1 ? 0x55 : 0xAA;
+  if (lane_in_quad == 0) { lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xF, 0xF, true); }
+  else if (lane_in_quad == 1) { lo = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xF, 0xF, true); }
+  else { lo = __builtin_amdgcn_mov_dpp(lo, 0xAA, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xAA, 0xF, 0xF, true); }
+  (void)c;
+  return __hiloint2double(hi, lo);
 }
 
-__device__ void svd3_rotation(const double H[9], double R[9]) {
-  double A[3][3], V[3][3];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) { A[i][j] = H[3 * i + j]; V[i][j] = (i == j) ? 1.0 : 0.0; }
+// One-sided Jacobi sweeps on the quad: lane i < 3 holds a[0..2] = row i of A (initially H) and v[0..2] = row i of V
+// (initially I); lane 3 holds zeros.  The control flow is uniform over the quad (the inner products are quad sums).
+__device__ __forceinline__ void jacobi_sweeps_quad(double (&a)[3], double (&v)[3]) {
   for (int sweep = 0; sweep < 40; ++sweep) {
     double off = 0.0;
+#pragma unroll
     for (int pq = 0; pq < 3; ++pq) {
       const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
-      double al = 0, be = 0, ga = 0;
-      for (int i = 0; i < 3; ++i) { al += A[i][p] * A[i][p]; be += A[i][q] * A[i][q]; ga += A[i][p] * A[i][q]; }
+      const double al = quad_sum(a[p] * a[p]), be = quad_sum(a[q] * a[q]), ga = quad_sum(a[p] * a[q]);
       if (fabs(ga) <= 1e-30 + 1e-17 * sqrt(al * be)) continue;
       off = fmax(off, fabs(ga) / sqrt(al * be + 1e-300));
       const double zeta = (be - al) / (2.0 * ga);
       const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
       const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
-      for (int i = 0; i < 3; ++i) {
-        const double ap = A[i][p], aq = A[i][q];
-        A[i][p] = c * ap - s * aq; A[i][q] = s * ap + c * aq;
-        const double vp = V[i][p], vq = V[i][q];
-        V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
-      }
+      const double ap = a[p], aq = a[q];
+      a[p] = c * ap - s * aq; a[q] = s * ap + c * aq;
+      const double vp = v[p], vq = v[q];
+      v[p] = c * vp - s * vq; v[q] = s * vp + c * vq;
     }
     if (off < 1e-15) break;
   }
+}
+
+// Tail of the solve on one lane, from the converged A (columns = singular vectors times singular values) and V
+__device__ void svd3_finish(const double A[3][3], const double V[3][3], double R[9]) {
   double sig[3];
   int ord[3] = {0, 1, 2};
   for (int j = 0; j < 3; ++j) sig[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
@@ -96,17 +131,17 @@ __device__ void svd3_rotation(const double H[9], double R[9]) {
 }
 
 __global__ __launch_bounds__(256) void rigid_svd_kernel(vcr_rigid_svd_args p) {
-  __shared__ double red[4];
+  __shared__ double red[4 * 9];
   const int b = blockIdx.x, t = threadIdx.x;
   const float* S = p.src + (size_t)b * p.K * p.lds;
   const float* C = p.corr + (size_t)b * p.K * p.ldc;
-  double sm[3] = {0, 0, 0}, cm[3] = {0, 0, 0};
+  double mean[6] = {0, 0, 0, 0, 0, 0};
   for (int i = t; i < p.K; i += 256)
-    for (int c = 0; c < 3; ++c) { sm[c] += S[(size_t)i * p.lds + c]; cm[c] += C[(size_t)i * p.ldc + c]; }
-  for (int c = 0; c < 3; ++c) { sm[c] = block_sum(sm[c], red) / p.K; cm[c] = block_sum(cm[c], red) / p.K; }
+    for (int c = 0; c < 3; ++c) { mean[c] += S[(size_t)i * p.lds + c]; mean[3 + c] += C[(size_t)i * p.ldc + c]; }
+  block_sums<6>(mean, red);
   // the reference centres in fp32 (src - src.mean): round the means to fp32 like it does
   float smf[3], cmf[3];
-  for (int c = 0; c < 3; ++c) { smf[c] = (float)sm[c]; cmf[c] = (float)cm[c]; }
+  for (int c = 0; c < 3; ++c) { smf[c] = (float)(mean[c] / p.K); cmf[c] = (float)(mean[3 + c] / p.K); }
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = t; i < p.K; i += 256) {
     float sc[3], cc[3];
@@ -114,10 +149,25 @@ __global__ __launch_bounds__(256) void rigid_svd_kernel(vcr_rigid_svd_args p) {
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) H[3 * r + c] += (double)sc[r] * (double)cc[c];
   }
-  for (int e = 0; e < 9; ++e) H[e] = block_sum(H[e], red);
+  block_sums<9>(H, red);
+  if (t >= 64) return;                                   // wave 0 finishes; its first quad runs the Jacobi sweeps together
+  const int li = t & 3;
+  double a[3], v[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    a[j] = li == 0 ? H[j] : li == 1 ? H[3 + j] : li == 2 ? H[6 + j] : 0.0;
+    v[j] = li == j ? 1.0 : 0.0;
+  }
+  jacobi_sweeps_quad(a, v);
+  double A[3][3], V[3][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {                          // gather the rows (lane i of the quad = row i)
+    A[0][j] = quad_get(a[j], 0); A[1][j] = quad_get(a[j], 1); A[2][j] = quad_get(a[j], 2);
+    V[0][j] = quad_get(v[j], 0); V[1][j] = quad_get(v[j], 1); V[2][j] = quad_get(v[j], 2);
+  }
   if (t == 0) {
     double R[9];
-    svd3_rotation(H, R);
+    svd3_finish(A, V, R);
     float* Ro = p.R + (size_t)b * 9;
     float* to = p.t + (size_t)b * 3;
     float Rf[9], tf[3];
