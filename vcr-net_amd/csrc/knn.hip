@@ -108,11 +108,12 @@ struct Selector {
   float* lv; int* li;                                    // log [PEND + 1][COLS]; row PEND swallows the writes of lanes
                                                          // that have nothing to log (branch-free appends)
   int cnt, done;                                         // entries logged / already inserted (same in a query's lanes)
-  float thr;                                             // rank KS-1 value: nothing <= thr can be a neighbour
+  float thr;                                             // max(thr0, rank KS-1 value): nothing <= thr can be a neighbour
+  float thr0;                                            // filter floor taken from a sample of the candidates (see sample_floor)
   int col, sg;
 
-  __device__ __forceinline__ void init(float* lv_, int* li_, int lane) {
-    lv = lv_; li = li_; cnt = 0; done = 0; thr = VCR_NEG_INF; col = G::col(lane); sg = G::seg(lane);
+  __device__ __forceinline__ void init(float* lv_, int* li_, int lane, float floor0 = VCR_NEG_INF) {
+    lv = lv_; li = li_; cnt = 0; done = 0; thr = thr0 = floor0; col = G::col(lane); sg = G::seg(lane);
 #pragma unroll
     for (int t = 0; t < T; ++t) v[t] = VCR_NEG_INF;
   }
@@ -126,7 +127,13 @@ struct Selector {
   }
   __device__ __forceinline__ void refresh_thr() {
     const float mine = v[TS];
-    thr = gf_from_seg<G>(mine, TL);
+    thr = fmaxf(thr0, gf_from_seg<G>(mine, TL));
+  }
+  // The floor came from a sample: it is only valid if at least KS candidates lie above it.  False -> the list is not
+  // full although a floor was used: the caller scans again without one.
+  __device__ __forceinline__ bool floor_held() const {
+    const float last = gf_from_seg<G>(v[TS], TL);
+    return !(thr0 > VCR_NEG_INF) || last > VCR_NEG_INF;
   }
   // value at global rank r (wave-uniform r) in every lane of the column
   __device__ __forceinline__ float rank_value(int r) const {
@@ -190,6 +197,37 @@ struct Selector {
     }
   }
 };
+
+// Filter floor from a SAMPLE of the candidates.  A streaming top-k logs k (1 + ln(n / k)) candidates per query because
+// its threshold starts at -inf; most of those are entries the first few hundred candidates push through a list that
+// later ones empty again.  A values-only pre-pass (R v_med3 per candidate) over a lane's share of the first 256
+// candidates keeps its R best; the smallest of the lanes' R-th values is a floor with at least LPQ * R - 1 sample
+// values strictly above it, and R is chosen so that this is >= KS: the floor is below the final KS-th best value by
+// construction, for ANY ordering of the cloud.  The scan proper then starts with a useful threshold: at N = 1024,
+// k = 20 it logs ~55 candidates per query instead of ~125, and the log rarely needs compacting.  (Exact ties AT the
+// floor value could still leave fewer than KS values strictly above it; that is checked at the end -- floor_held() --
+// and such a wave scans again without a floor.)
+constexpr int SAMPLE = 256;
+template <int R>
+struct SampleNet {
+  float s[R];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int t = 0; t < R; ++t) s[t] = VCR_NEG_INF;
+  }
+  __device__ __forceinline__ void insert(float d) {
+#pragma unroll
+    for (int t = R - 1; t >= 1; --t) s[t] = __builtin_amdgcn_fmed3f(s[t - 1], d, s[t]);
+    s[0] = fmaxf(s[0], d);
+  }
+};
+template <class G> __device__ __forceinline__ float col_min(float x, int sg) {   // min over the lanes of a query
+  float m = x;
+#pragma unroll
+  for (int w = 0; w < G::LPQ; ++w) m = fminf(m, gf_from_seg<G>(x, w));
+  (void)sg;
+  return m;
+}
 
 // Final stage shared by both kernels: the log holds every candidate above the (k+2)-th best value; fold the lists /
 // logs of the S waves of a query group into wave part 0, reduce the log to the k+1 best, drop rank 0, write the set.
@@ -268,7 +306,6 @@ __global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
   const int q0 = (blockIdx.x * (W / S) + qt) * 32;       // this wave's 32 queries (may lie beyond N: clamped, not written)
   float* lv = reinterpret_cast<float*>(smem) + wave * (2 * (PEND + 1) * 32);
   Selector<G, KS> sel;
-  sel.init(lv, reinterpret_cast<int*>(lv + (PEND + 1) * 32), lane);
 
   const float* xb = a.x + (size_t)b * a.N * a.ldx;
   const float* sqb = a.sq + (size_t)b * a.N;
@@ -292,39 +329,49 @@ __global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
   const float sq_q = sqb[q];
 
   const int ntiles = (a.N + TILE - 1) / TILE;
-  float cf[32];
-  float csq = 0.f;
-  if (part < ntiles) {
-    const int c = min(part * TILE + col, a.N - 1);
-    f32x4 raw[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) raw[m] = ld4(xb + (size_t)c * a.ldx + 4 * m);
-    pick(raw, cf);
-    csq = sqb[c];
-  }
   KTL_DECL;
-  for (int tile = part; tile < ntiles; tile += S) {
-    // the next candidate tile is prefetched as raw rows (64 VGPRs) across the MFMA + selection phase
-    constexpr bool PREFETCH = true;
-    f32x4 nraw[PREFETCH ? 16 : 1];
-    float nsq = 0.f;
-    if (PREFETCH && tile + S < ntiles) {
-      const int c = min((tile + S) * TILE + col, a.N - 1);
+  // walk candidate tiles t0, t0 + S, ... < t1: operands prefetched one tile ahead as raw rows (64 VGPRs), the MFMA
+  // chain, then body(tile, acc)
+  auto scan_tiles = [&](int t0, int t1, auto&& body) {
+    float cf[32];
+    float csq = 0.f;
+    if (t0 < t1) {
+      const int c = min(t0 * TILE + col, a.N - 1);
+      f32x4 raw[16];
 #pragma unroll
-      for (int m = 0; m < (PREFETCH ? 16 : 1); ++m) nraw[m] = ld4(xb + (size_t)c * a.ldx + 4 * m);
-      nsq = sqb[c];
+      for (int m = 0; m < 16; ++m) raw[m] = ld4(xb + (size_t)c * a.ldx + 4 * m);
+      pick(raw, cf);
+      csq = sqb[c];
     }
-    f32x16 acc = {0};
+    for (int tile = t0; tile < t1; tile += S) {
+      f32x4 nraw[16];
+      float nsq = 0.f;
+      if (tile + S < t1) {
+        const int c = min((tile + S) * TILE + col, a.N - 1);
 #pragma unroll
-    for (int st = 0; st < 32; ++st) acc = mfma32(cf[st], qf[st], acc);
-    // 33rd k-step: A[cand][k*] = -sq_cand/2 (half 0), B[k*][q] = 1  ->  acc = dot - sq_j/2, rounded once
-    acc = mfma32(half == 0 ? -0.5f * csq : 0.f, half == 0 ? 1.f : 0.f, acc);
-    // hipcc (ROCm 7.2) under-pads the MFMA -> v_accvgpr_read hazard of this 16-pass instruction when the
-    // accumulator lands in AGPRs (seen in the k = 40 build: register 15, the last one written, was read stale).
-    // Tie the wait states to the accumulator itself so they cannot be scheduled away.
-    if (KS > 22) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
-    KTL(0);                                              // prefetch issue + MFMA chain
-
+        for (int m = 0; m < 16; ++m) nraw[m] = ld4(xb + (size_t)c * a.ldx + 4 * m);
+        nsq = sqb[c];
+      }
+      f32x16 acc = {0};
+#pragma unroll
+      for (int st = 0; st < 32; ++st) acc = mfma32(cf[st], qf[st], acc);
+      // 33rd k-step: A[cand][k*] = -sq_cand/2 (half 0), B[k*][q] = 1  ->  acc = dot - sq_j/2, rounded once
+      acc = mfma32(half == 0 ? -0.5f * csq : 0.f, half == 0 ? 1.f : 0.f, acc);
+      // hipcc (ROCm 7.2) under-pads the MFMA -> v_accvgpr_read hazard of this 16-pass instruction when the
+      // accumulator lands in AGPRs (seen in the k = 40 build: register 15, the last one written, was read stale).
+      // Tie the wait states to the accumulator itself so they cannot be scheduled away.
+      if (KS > 22) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
+      KTL(0);                                            // prefetch issue + MFMA chain
+      body(tile, acc);
+      if (tile + S < t1) {
+        pick(nraw, cf);
+        csq = nsq;
+      }
+      KTL(3);                                            // operand pick (waits for the prefetched rows)
+    }
+  };
+  // the selection proper: filter against sel.thr, log, drain
+  auto select_body = [&](int tile, const f32x16& acc) {
     const int jbase = tile * TILE;
     const bool ragged = jbase + TILE > a.N;              // only the last tile can hold rows beyond N
     // two steps of 16 rows per query (8 per lane): the log has room for 16 new entries, never for 32
@@ -344,9 +391,6 @@ __global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
         for (int r = 0; r < 8; ++r) m &= (jbase + acc_row(8 * hs + r, half) < a.N) ? ~0u : ~(1u << r);
       }
       const unsigned om = (unsigned)G::from_seg((int)m, half ^ 1);
-#ifdef VCR_TIMELINE
-      asm volatile("" :: "v"(om));
-#endif
       KTL(1);
       if (__any(m != 0)) {                               // the two lanes of a column append to ONE log: upper half first
         const int base = sel.cnt + (half ? __popc(om) : 0);
@@ -362,25 +406,31 @@ __global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
       if (__any(sel.cnt - sel.done > 16)) sel.drain();   // keep the threshold fresh
       KTL(5);
     }
-    if (tile + S < ntiles) {
-      if (PREFETCH) {
-        pick(nraw, cf);
-        csq = nsq;
-      } else {
-        const int c = min((tile + S) * TILE + col, a.N - 1);
+  };
+  // sample pre-pass over this wave's first SAMPLE candidates (full tiles only), when it has at least twice as many
+  constexpr int T0 = SAMPLE / TILE, R0 = (KS + 1 + G::LPQ - 1) / G::LPQ;   // LPQ * R0 - 1 >= KS
+  const int my_tiles = part < ntiles ? (ntiles - part + S - 1) / S : 0;
+  float floor0 = VCR_NEG_INF;
+  // Measured (profiles/timeline_knn.py, N = 1024, k = 20): the floor cuts make_room 28 -> 13 us and the drains
+  // 12.5 -> 8 us per wave, and the pre-pass -- eight more tiles of loads + 33 MFMAs + pick -- costs the same 17 us back;
+  // at N = 2048 it loses 5 %.  Distances are too expensive here to compute a quarter of them twice: off in this kernel
+  // (the Cartesian kernel, whose distances are three FMAs, keeps it: 75 -> 65 us).
+  constexpr bool SAMPLE_FLOOR = false;
+  if (SAMPLE_FLOOR && my_tiles >= 2 * T0 + 1) {          // (+1: the last, possibly ragged, tile is never sampled)
+    SampleNet<R0> net;
+    net.init();
+    scan_tiles(part, part + S * T0, [&](int, const f32x16& acc) {
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) {                  // four 64-B quarters of the row: 16 temporaries, not 64
-          f32x4 raw[4];
-#pragma unroll
-          for (int mm = 0; mm < 4; ++mm) raw[mm] = ld4(xb + (size_t)c * a.ldx + 16 * m4 + 4 * mm);
-#pragma unroll
-          for (int st = 0; st < 8; ++st)
-            cf[8 * m4 + st] = half ? raw[st >> 1][(st & 1) * 2 + 1] : raw[st >> 1][(st & 1) * 2];
-        }
-        csq = sqb[c];
-      }
-    }
-    KTL(3);                                              // operand pick (waits for the prefetched rows)
+      for (int r = 0; r < 16; ++r) net.insert(2.f * acc[r] - sq_q);
+    });
+    floor0 = col_min<G>(net.s[R0 - 1], half);
+  }
+  sel.init(lv, reinterpret_cast<int*>(lv + (PEND + 1) * 32), lane, floor0);
+  scan_tiles(part, ntiles, select_body);
+  sel.drain();
+  if (__any(!sel.floor_held())) {                        // the sample misjudged some query of this wave: scan without a floor
+    sel.init(lv, reinterpret_cast<int*>(lv + (PEND + 1) * 32), lane);
+    scan_tiles(part, ntiles, select_body);
   }
   KTL_FLUSH;
   finish<G, KS, S>(sel, a, b, q0 + col, wave, part, smem);
@@ -401,33 +451,40 @@ __global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
   const int q0 = (blockIdx.x * (4 / S) + grp) * 16;
   float* lv = reinterpret_cast<float*>(smem) + wave * (2 * (PEND + 1) * 16);
   Selector<G, KS> sel;
-  sel.init(lv, reinterpret_cast<int*>(lv + (PEND + 1) * 16), lane);
   const float* xb = a.x + (size_t)b * a.N * a.ldx;
   const int qi = q0 + qd;
   const f32x4 qv = ld4(xb + (size_t)min(qi, a.N - 1) * a.ldx);
   // 16 candidates per step, 4 per lane: j = j0 + 4u + s (the quad reads 64 contiguous bytes per load); the next
   // step's rows are in flight while this one is filtered
   const int nsteps = (a.N + 15) / 16;
-  f32x4 c[4], cn[4];
-  auto load = [&](f32x4* dst, int st) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) dst[u] = ld4(xb + (size_t)min(st * 16 + 4 * u + s, a.N - 1) * a.ldx);
-  };
-  if (part < nsteps) load(c, part);
   KTL_DECL;
-  int it = 0;
-  for (int st = part; st < nsteps; st += S, ++it) {
+  auto scan_steps = [&](int s0, int s1, auto&& body) {
+    f32x4 c[4], cn[4];
+    auto load = [&](f32x4* dst, int st) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dst[u] = ld4(xb + (size_t)min(st * 16 + 4 * u + s, a.N - 1) * a.ldx);
+    };
+    if (s0 < s1) load(c, s0);
+    int it = 0;
+    for (int st = s0; st < s1; st += S, ++it) {
+      if (st + S < s1) load(cn, st + S);
+      float dd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float dot = fmaf(qv[2], c[u][2], fmaf(qv[1], c[u][1], qv[0] * c[u][0]));
+        dd[u] = (2.f * dot - c[u][3]) - qv[3];
+      }
+      body(st, it, dd);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = cn[u];
+    }
+  };
+  auto select_body = [&](int st, int it, const float (&dd)[4]) {
     const int j0 = st * 16;
-    if (st + S < nsteps) load(cn, st + S);
     sel.make_room();
-    float dd[4];
     unsigned m = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float dot = fmaf(qv[2], c[u][2], fmaf(qv[1], c[u][1], qv[0] * c[u][0]));
-      dd[u] = (2.f * dot - c[u][3]) - qv[3];
-      m |= (dd[u] > sel.thr && j0 + 4 * u + s < a.N) ? (1u << u) : 0u;
-    }
+    for (int u = 0; u < 4; ++u) m |= (dd[u] > sel.thr && j0 + 4 * u + s < a.N) ? (1u << u) : 0u;
     KTL(0);                                              // distances + filter
     // the quad appends to ONE log: exclusive prefix of the lanes' survivor counts
     const int c0 = __popc(m);
@@ -446,10 +503,27 @@ __global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
       }
     }
     sel.cnt += total;
-    if (it < 3 || __any(sel.cnt - sel.done > 12)) sel.drain();   // early steps: settle the threshold quickly
+    if ((it < 3 && !(sel.thr0 > VCR_NEG_INF)) || __any(sel.cnt - sel.done > 12)) sel.drain();   // no floor: settle the threshold quickly
     KTL(1);                                              // log + drains
+  };
+  constexpr int ST0 = SAMPLE / 16, R0 = (KS + 1 + G::LPQ - 1) / G::LPQ;    // LPQ * R0 - 1 >= KS
+  const int my_steps = part < nsteps ? (nsteps - part + S - 1) / S : 0;
+  float floor0 = VCR_NEG_INF;
+  if (my_steps >= 2 * ST0 + 1) {
+    SampleNet<R0> net;
+    net.init();
+    scan_steps(part, part + S * ST0, [&](int, int, const float (&dd)[4]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) c[u] = cn[u];
+      for (int u = 0; u < 4; ++u) net.insert(dd[u]);
+    });
+    floor0 = col_min<G>(net.s[R0 - 1], s);
+  }
+  sel.init(lv, reinterpret_cast<int*>(lv + (PEND + 1) * 16), lane, floor0);
+  scan_steps(part, nsteps, select_body);
+  sel.drain();
+  if (__any(!sel.floor_held())) {
+    sel.init(lv, reinterpret_cast<int*>(lv + (PEND + 1) * 16), lane);
+    scan_steps(part, nsteps, select_body);
   }
   KTL_FLUSH;
   finish<G, KS, S>(sel, a, b, qi, wave, part, smem);
