@@ -43,6 +43,31 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// Workgroups are dealt round-robin over the chip's 8 XCDs, each with its own L2.  xcd_chunk() renumbers a launch so
+// that XCD x works on the x-th CONTIGUOUS eighth of the blocks: neighbouring blocks (the rows and neighbour gathers
+// of one cloud) then share one L2 instead of pulling the same lines into eight.  A pure renumbering of independent
+// blocks -- it changes speed and HBM traffic, never results.
+__device__ __forceinline__ int xcd_chunk(int bid, int nblk) {
+  const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, i = bid / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+// The same for a 2-D launch whose blockIdx.y is the cloud: (x, y) of the renumbered block.
+__device__ __forceinline__ void xcd_chunk2(int& bx, int& by) {
+  const int lin = xcd_chunk((int)(blockIdx.y * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y));
+  bx = lin % (int)gridDim.x; by = lin / (int)gridDim.x;
+}
+// ... and for a grid-stride loop over `n` items: this block takes first, first + stride, ... (count items), all from
+// its XCD's contiguous eighth of the items.
+struct xcd_slice_t { int first, stride, count; };
+__device__ __forceinline__ xcd_slice_t xcd_slice(int n) {
+  const int g = (int)gridDim.x, bid = (int)blockIdx.x;
+  if (g % 8) return xcd_slice_t{bid, g, bid < n ? (n - bid + g - 1) / g : 0};
+  const int xcd = bid % 8, slot = bid / 8, slots = g / 8;
+  const int q = n / 8, r = n % 8;
+  const int lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, len = q + (xcd < r ? 1 : 0);
+  return xcd_slice_t{lo + slot, slots, slot < len ? (len - slot + slots - 1) / slots : 0};
+}
+
 // exchange with the lane 32 away (the other half of the wave)
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 

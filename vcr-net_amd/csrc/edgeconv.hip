@@ -33,15 +33,17 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_kernel(vcr_edgeconv_args p
   for (int g = 0; g < 16; ++g) wf[g] = ld4(p.w2 + (size_t)(32 * w + l31) * 128 + 8 * g + 4 * half);
   const float bias2 = p.b2[32 * w + l31];
 
-  // this block's work items: points blockIdx.x, +gridDim.x, ... ; each point = row_tiles consecutive items
+  // this block's work items: points sl.first, +sl.stride, ... (inside its XCD's run of clouds); each point =
+  // row_tiles consecutive items
   const int row_tiles = (p.k + 31) / 32;
-  if ((int)blockIdx.x >= p.M) return;
-  const int my_pts = (p.M - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const xcd_slice_t sl = xcd_slice(p.M);
+  if (sl.count == 0) return;
+  const int my_pts = sl.count;
   const int n_items = my_pts * row_tiles;
 
   f32x4 hr[4];                                           // staged rows of the item being built
   auto gather = [&](int it) {
-    const int pt = (int)blockIdx.x + (it / row_tiles) * (int)gridDim.x, rt = it % row_tiles;
+    const int pt = sl.first + (it / row_tiles) * sl.stride, rt = it % row_tiles;
     const int base = (pt / p.n_per_cloud) * p.n_per_cloud;
     const f32x4 q = ld4(p.pq + (size_t)pt * p.ldpq + 128 + ch);
 #pragma unroll
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_kernel(vcr_edgeconv_args p
   };
   f32x4 x1m = f32x4{0.f, 0.f, 0.f, 0.f};                 // H >= 0, so 0 is the identity of this max
   auto commit = [&](int it, int buf) {                   // registers -> LDS, and the x1 running max
-    const int pt = (int)blockIdx.x + (it / row_tiles) * (int)gridDim.x, rt = it % row_tiles;
+    const int pt = sl.first + (it / row_tiles) * sl.stride, rt = it % row_tiles;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       st4(&Hs[buf][rs + 8 * i][ch], hr[i]);
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_kernel(vcr_edgeconv_args p
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
     x2m = fmaxf(x2m, m);
-    const int pt = (int)blockIdx.x + (item / row_tiles) * (int)gridDim.x, rt = item % row_tiles;
+    const int pt = sl.first + (item / row_tiles) * sl.stride, rt = item % row_tiles;
     if (rt == row_tiles - 1) {
       const float v = fmaxf(x2m, xhalf(x2m));
       if (half == 0) p.x2[(size_t)pt * p.ldx2 + 32 * w + l31] = fmaxf(v + bias2, 0.f);
@@ -129,8 +131,9 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_kernel(vcr_edgeconv
   const float bias2 = p.b2[32 * w + l31];
 
   const int ngroups = (p.M + G - 1) / G;
-  if ((int)blockIdx.x >= ngroups) return;
-  const int my_groups = (ngroups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  const xcd_slice_t sl = xcd_slice(ngroups);             // this block's groups, all inside its XCD's run of clouds
+  if (sl.count == 0) return;
+  const int my_groups = sl.count;
 
   f32x4 hr[4];
   auto gather = [&](int grp, int t) {
@@ -150,12 +153,12 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_kernel(vcr_edgeconv
     for (int i = 0; i < 4; ++i) st4(&Hs[buf][rs + 8 * i][ch], hr[i]);
   };
 
-  gather((int)blockIdx.x, 0);
+  gather(sl.first, 0);
   commit(0);
   __syncthreads();
   int cur = 0;
   for (int gi = 0; gi < my_groups; ++gi) {
-    const int grp = (int)blockIdx.x + gi * (int)gridDim.x;
+    const int grp = sl.first + gi * sl.stride;
     const bool more = gi + 1 < my_groups;
     float pm[G], cm[G];                                  // per-point maxima: x2 (MFMA rows) and x1 (this thread's channel)
 #pragma unroll
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_kernel(vcr_edgeconv
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       const bool has_next = t < 4 || more;
-      if (has_next) gather(t < 4 ? grp : grp + (int)gridDim.x, t < 4 ? t + 1 : 0);
+      if (has_next) gather(t < 4 ? grp : grp + sl.stride, t < 4 ? t + 1 : 0);
       // x1 = max over a point's H rows: a conflict-free column pass over the staged tile (the row -> point map is
       // static per tile and row half), instead of LDS atomics that collide on (point, channel)
       if (rowh == 0) {
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_kernel(vcr_edgeconv
 
 __global__ __launch_bounds__(256) void gathermax_kernel(vcr_gathermax_args p) {
   const int lane = threadIdx.x & 63;
-  const int pt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int pt = xcd_chunk((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);
   if (pt >= p.M) return;
   const int c = lane * 4;
   if (c >= p.C) return;
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void gathermax_kernel(vcr_gathermax_args p) {
 // only the first conv enjoys the F7 split.  h[(i,j)] = relu(P[nbr_ij] + Q[i]).
 __global__ __launch_bounds__(256) void edge_rows_kernel(vcr_edgerows_args p) {
   const int lane = threadIdx.x & 63;
-  const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long e = (long)xcd_chunk((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);
   if (e >= (long)p.M * p.k) return;
   const int pt = (int)(e / p.k);
   const int base = (pt / p.n_per_cloud) * p.n_per_cloud;
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void edge_rows_kernel(vcr_edgerows_args p) {
 // accumulate into with atomic max (vcr_linear_args.segmax_out)
 __global__ __launch_bounds__(256) void edge_rows64_kernel(vcr_edgerows_args p) {
   const int lane = threadIdx.x & 63;
-  const int pt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int pt = xcd_chunk((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);
   if (pt >= p.M) return;
   const int base = (pt / p.n_per_cloud) * p.n_per_cloud;
   const int c = (lane & 15) * 4, rg = lane >> 4;
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256) void edge_rows64_kernel(vcr_edgerows_args p) {
 // y[i] = max_j x[(i,j)]   (x.max(dim=-1) of vcrnet_model.py:109-118)
 __global__ __launch_bounds__(256) void segmax_kernel(vcr_segmax_args p) {
   const int lane = threadIdx.x & 63;
-  const int pt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int pt = xcd_chunk((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);
   if (pt >= p.M) return;
   for (int c = lane * 4; c < p.C; c += 256) {
     f32x4 m = ld4(p.x + ((size_t)pt * p.k) * p.ldx + c);

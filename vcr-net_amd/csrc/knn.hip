@@ -301,9 +301,10 @@ __global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, col = lane & 31;
-  const int b = blockIdx.y;
+  int bx, b;
+  xcd_chunk2(bx, b);                                     // a cloud's query tiles share one XCD's L2
   const int qt = wave / S, part = wave % S;
-  const int q0 = (blockIdx.x * (W / S) + qt) * 32;       // this wave's 32 queries (may lie beyond N: clamped, not written)
+  const int q0 = (bx * (W / S) + qt) * 32;       // this wave's 32 queries (may lie beyond N: clamped, not written)
   float* lv = reinterpret_cast<float*>(smem) + wave * (2 * (PEND + 1) * 32);
   Selector<G, KS> sel;
 
@@ -446,9 +447,10 @@ __global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = lane & 3, qd = lane >> 2;
-  const int b = blockIdx.y;
+  int bx, b;
+  xcd_chunk2(bx, b);
   const int grp = wave / S, part = wave % S;
-  const int q0 = (blockIdx.x * (4 / S) + grp) * 16;
+  const int q0 = (bx * (4 / S) + grp) * 16;
   float* lv = reinterpret_cast<float*>(smem) + wave * (2 * (PEND + 1) * 16);
   Selector<G, KS> sel;
   const float* xb = a.x + (size_t)b * a.N * a.ldx;

@@ -52,10 +52,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 3)) void linear_kernel(vcr_lin
   // XCD a contiguous run of tiles; tiles that share an X panel (same tm) then share an L2.
   const int nblk = tiles_m * tiles_n;
   int bid = blockIdx.x;
-  {
-    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, i = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-  }
+  bid = xcd_chunk(bid, nblk);
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -223,10 +220,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_kernel(vc
   const int wm = wave >> 1, wn = wave & 1;
   const int nblk = tiles_m * tiles_n;
   int bid = blockIdx.x;
-  {
-    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, i = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-  }
+  bid = xcd_chunk(bid, nblk);
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   TL(0);
@@ -482,8 +476,7 @@ __global__ __launch_bounds__(256, 2) void linear_persist_kernel(vcr_linear_args 
   // virtual block id -> tile, XCD-aware: ids congruent mod 8 run on one XCD (G is a multiple of 8 or == nblk), and
   // every XCD owns a contiguous run of tiles, so tiles sharing an X panel share an L2
   auto tile_of = [&](int vb, int& m0, int& n0) {
-    const int q = nblk / 8, r = nblk % 8, xcd = vb % 8, i = vb / 8;
-    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    const int bid = xcd_chunk(vb, nblk);
     m0 = (bid / tiles_n) * BM; n0 = (bid % tiles_n) * BN;
   };
   const int frow = lane >> 3, fpc = lane & 7;

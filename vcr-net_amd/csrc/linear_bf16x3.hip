@@ -61,10 +61,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16x3_kernel(vcr_linear_args p
   const int wm = wave >> 1, wn = wave & 1;
   const int nblk = tiles_m * tiles_n;
   int bid = blockIdx.x;
-  {
-    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, i = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
-  }
+  bid = xcd_chunk(bid, nblk);
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * TM, n0 = tn * TN;
   const size_t plane = (size_t)p.N * p.K;                 // elements per weight plane

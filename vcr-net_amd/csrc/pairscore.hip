@@ -37,7 +37,9 @@ __global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_ker
   float* mg = Os + NO * QP;                              // [NW waves][NO owners][5]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.y, o0 = blockIdx.x * NO;
+  int bx, b;
+  xcd_chunk2(bx, b);                                     // the owner tiles of one cloud stream the same rows: one XCD's L2
+  const int o0 = bx * NO;
   const int sb = (b + p.str_batch_shift) % p.nbatch;
   const int chunks = p.E / 64;
 
