@@ -53,9 +53,10 @@ def parse(argv=None):
                     help="SURVEY 8d protocol without a budget: every thread count, B = --batch, median of 5")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the timed K-step block for this long")
     ap.add_argument("--stages", action="store_true", help="print the per-launch table to stderr")
-    ap.add_argument("--linear-mode", default="fp32", choices=["fp32", "bf16x3"],
-                    help="fp32: linears on v_mfma_f32_32x32x2_f32 (default).  bf16x3: the same products as exact 3-way "
-                         "bf16 splits on the bf16 matrix pipe (fp32-equivalent accuracy)")
+    ap.add_argument("--linear-mode", default="fp32", choices=["fp32", "bf16x3", "bf16x3+sdpa"],
+                    help="fp32: linears and attention on v_mfma_f32_32x32x2_f32 (default, the headline).  bf16x3: the "
+                         "linears' products as exact 3-way bf16 splits on the bf16 matrix pipe (fp32-equivalent "
+                         "accuracy); bf16x3+sdpa: the attention products too.  Both are labelled in `dtype`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm); gloo only "
                                                       "for exercising the multi-rank control flow on a 1-GPU box")
     return ap.parse_args(argv)
@@ -277,11 +278,12 @@ def run_rank(a):
         if bound == "mfma":
             ach = fam_flops[dom] / (fam_ms[dom] * 1e-3) / 1e12
             peak = workmodel.PEAK_MFMA_F32_TFLOPS
-            if dom == "linear" and a.linear_mode == "bf16x3":
+            split = (dom == "linear" and a.linear_mode != "fp32") or (dom == "sdpa" and a.linear_mode == "bf16x3+sdpa")
+            if split:
                 peak = workmodel.PEAK_MFMA_BF16_TFLOPS / 6.0    # six bf16 MFMA products per fp32-equivalent MAC
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak,
                     "unit": "TFLOP/s", "frac": ach / peak, "traffic": None}
-            if dom == "linear" and a.linear_mode == "bf16x3":
+            if split:
                 roof["note"] = "fp32-equivalent FLOPs; peak = 2500 TFLOP/s dense bf16 / 6 MFMAs per split product"
         else:
             ach = fam_bytes[dom] / (fam_ms[dom] * 1e-3) / 1e9
@@ -338,7 +340,8 @@ def run_rank(a):
             "metric": "point-cloud pairs/sec (N=%d, batch %d per GPU)" % (Nfull, B), "value": pairs / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.linear_mode == "fp32" else "f32 (linears as exact bf16x3 splits, fp32 accumulate)",
+            "dtype": {"fp32": "f32", "bf16x3": "f32 (linears as exact bf16x3 splits, fp32 accumulate)",
+                      "bf16x3+sdpa": "f32 (linears and attention as exact bf16x3 splits, fp32 accumulate)"}[a.linear_mode],
             "data": "synthetic",
             "config": {"workload": workload_label(a, Nfull, N, B, kind),
                        "num_points": N, "batch_per_gpu": B, "global_batch": B * world, "k": a.k, "iters": a.iters,

@@ -193,6 +193,11 @@ typedef struct {
   float* score_out; int ld_score;
 } vcr_sdpa_args;
 int vcr_sdpa_f32(const vcr_sdpa_args*, vcr_stream_t);
+/* The attention-output form of vcr_sdpa_f32 (out != NULL, rowstat == score_out == NULL, scale > 0) with Q, K, V and the
+ * soft-max probabilities split exactly into three bf16 pieces and every product evaluated as six bf16 MFMAs with fp32
+ * accumulation ("bf16x3", see vcr_linear_bf16x3_f32): fp32-GEMM accuracy on the bf16 matrix pipe.  Opt-in (linear_mode 2
+ * of the drivers); VCR_EUNSUPPORTED for the statistics forms, which stay on vcr_sdpa_f32. */
+int vcr_sdpa_bf16x3_f32(const vcr_sdpa_args*, vcr_stream_t);
 
 /* ---- key mass of the partial-mode decoder (transformer.py:40): mass[kb][key] = sum over heads and queries of the
  * soft-max probability that key receives, from the scores and row statistics a statistics-only vcr_sdpa_f32 pass
@@ -332,7 +337,8 @@ typedef struct {
   int head_mode;                                   /* 0 VcpTopK (neg-distance), 1 VcpByDis / DCP (dot/sqrt(E)), 2 VcpAtt */
   /* linear_mode 0: every 1x1 conv / Linear on v_mfma_f32_32x32x2_f32 (vcr_linear_f32).
    * linear_mode 1: the same products as exact 3-way bf16 splits on the bf16 matrix pipe (vcr_linear_bf16x3_f32);
-   * then `split` holds the weights pre-split by vcr_split_bf16x3_f32, in the order of the sites below. */
+   * then `split` holds the weights pre-split by vcr_split_bf16x3_f32, in the order of the sites below.
+   * linear_mode 2: mode 1, and the attention-output launches through vcr_sdpa_bf16x3_f32 as well. */
   int linear_mode;
   struct {
     const void *dg1_pq, *sn1_pq, *c3, *enc_qkv, *enc_wo, *enc_ffn1, *enc_ffn2, *dec_qkv, *dec_self_wo, *dec_cross_q,

@@ -235,18 +235,20 @@ def test_module_on_its_own_device_without_set_device():
     assert native.stream_ptr(s.device) == torch.cuda.current_stream(s.device).cuda_stream
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3+sdpa"])
 @pytest.mark.parametrize("name", ["whole_n256_b2", "whole_n1024_b2"])
-def test_bf16x3_linear_mode_vs_reference_golden(name):
-    """Opt-in linear_mode='bf16x3' (exact 3-way bf16 splits on the bf16 matrix pipe) keeps the BASELINE tolerances."""
+def test_bf16x3_linear_mode_vs_reference_golden(name, mode):
+    """Opt-in linear_mode='bf16x3' (exact 3-way bf16 splits on the bf16 matrix pipe; '+sdpa': the attention products
+    too) keeps the BASELINE tolerances."""
     g = golden(name)
     net, _ = build_net()
-    net.linear_mode = "bf16x3"
+    net.linear_mode = mode
     src, tgt = torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda()
     with torch.no_grad():
         out = net(src, tgt)
     dR = np.abs(out[2].cpu().numpy() - g["it0_R"]).max()
     dt = np.abs(out[3].cpu().numpy() - g["it0_t"]).max()
-    print(f"{name} bf16x3: max|dR|={dR:.2e} max|dt|={dt:.2e}")
+    print(f"{name} {mode}: max|dR|={dR:.2e} max|dt|={dt:.2e}")
     assert dR <= R_TOL and dt <= T_TOL
 
 

@@ -257,8 +257,10 @@ def test_edgeconv_and_gathermax(nat, W, N, k):
     torch.testing.assert_close(gx3.cpu().view(B, N, 256), x3.transpose(1, 2), atol=3e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("N,shift", [(256, 0), (192, 0), (1024, 2), (100, 1)])
-def test_sdpa(nat, N, shift):
+@pytest.mark.parametrize("bf16x3", [False, True])
+@pytest.mark.parametrize("N,shift", [(256, 0), (192, 0), (1024, 2), (100, 1), (300, 0)])
+def test_sdpa(nat, N, shift, bf16x3):
+    """bf16x3 = the opt-in exact-split kernel on the bf16 matrix pipe (vcr_sdpa_bf16x3_f32): same tolerance."""
     g = torch.Generator().manual_seed(N)
     nb, h = 4, 4
     q, k, v = (torch.randn(nb, N, h * 128, generator=g) for _ in range(3))
@@ -266,8 +268,39 @@ def test_sdpa(nat, N, shift):
     split = lambda t: t.view(nb, N, h, 128).transpose(1, 2)
     ref = oracle.attention(split(q) * 2, split(kk) * 2, split(vv)).transpose(1, 2).reshape(nb * N, h * 128)
     qkv = dev(torch.cat((q * 2, k * 2, v), -1).view(nb * N, 3 * h * 128))   # fused-QKV row layout, pitch 1536
-    out = nat.sdpa(qkv[:, :512], qkv[:, 512:1024], qkv[:, 1024:], nb, h, N, N, 1 / math.sqrt(128), kv_batch_shift=shift)
-    torch.testing.assert_close(out.cpu(), ref, atol=5e-6, rtol=1e-5)
+    run = lambda mode: nat.sdpa(qkv[:, :512], qkv[:, 512:1024], qkv[:, 1024:], nb, h, N, N, 1 / math.sqrt(128),
+                                kv_batch_shift=shift, bf16x3=mode).cpu()
+    if not bf16x3:
+        torch.testing.assert_close(run(False), ref, atol=5e-6, rtol=1e-5)
+        return
+    # the split kernel is a different, equally accurate summation: hold it to the same formula in fp64, where its
+    # error must not exceed the fp32-MFMA kernel's (which the fp32 oracle pins above)
+    ref64 = oracle.attention(split(q).double() * 2, split(kk).double() * 2, split(vv).double())
+    ref64 = ref64.transpose(1, 2).reshape(nb * N, h * 128)
+    e32, e3 = (run(False).double() - ref64).abs().max().item(), (run(True).double() - ref64).abs().max().item()
+    print(f"sdpa N={N}: max|err| vs fp64  fp32-MFMA {e32:.2e}  bf16x3 {e3:.2e}")
+    assert e3 <= 1.25 * e32 + 5e-7 and e3 < 2e-5
+
+
+def test_sdpa_bf16x3_masked_ragged_and_error_vs_fp64(nat):
+    """Key mask + ragged nq != nk through the exact-split kernel; its error against an fp64 reference is no larger than
+    the fp32-MFMA kernel's (the six-product split carries fp32-GEMM accuracy); statistics forms are refused."""
+    g = torch.Generator().manual_seed(31)
+    nb, h, NQ, NK = 2, 4, 300, 170
+    q = torch.randn(nb, NQ, h * 128, generator=g) * 1.5
+    k, v = (torch.randn(nb, NK, h * 128, generator=g) for _ in range(2))
+    keep = torch.rand(nb, NK, generator=g) < 0.7
+    sp = lambda t, n: t.view(nb, n, h, 128).transpose(1, 2).double()
+    s = torch.matmul(sp(q, NQ), sp(k, NK).transpose(-2, -1)) / math.sqrt(128)
+    ref = torch.matmul(torch.softmax(s.masked_fill(~keep.view(nb, 1, 1, NK), float("-inf")), -1), sp(v, NK))
+    ref = ref.transpose(1, 2).reshape(nb * NQ, h * 128)
+    args = (dev(q.view(nb * NQ, -1)), dev(k.view(nb * NK, -1)), dev(v.view(nb * NK, -1)), nb, h, NQ, NK, 1 / math.sqrt(128))
+    e32 = (nat.sdpa(*args, key_keep=dev(keep.to(torch.uint8))).cpu().double() - ref).abs().max().item()
+    e3 = (nat.sdpa(*args, key_keep=dev(keep.to(torch.uint8)), bf16x3=True).cpu().double() - ref).abs().max().item()
+    print(f"sdpa masked ragged: max|err| vs fp64  fp32-MFMA {e32:.2e}  bf16x3 {e3:.2e}")
+    assert e3 < 3e-6 and e3 <= 1.5 * e32 + 2e-7
+    with pytest.raises(nat.VcrHipError):
+        nat.sdpa(*args, want_rowstat=True, bf16x3=True)
 
 
 def test_sdpa_masked_and_rowstat(nat):

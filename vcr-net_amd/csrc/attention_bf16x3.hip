@@ -1,0 +1,276 @@
+// Flash-style attention (model/transformer.py:29-34,55) on the bf16 matrix pipe with fp32-equivalent products:
+// the opt-in "bf16x3" companion of attention.hip, same interface (vcr_sdpa_args) and the same orientation.
+//
+//   Every fp32 operand -- Q, K, V and the soft-max probabilities P -- is split EXACTLY into three bf16 pieces,
+//   x = x1 + x2 + x3, and each dot product is evaluated as the six partial products of weight >= 2^-16,
+//       a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a3 b1 + a2 b2),
+//   on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (see linear_bf16x3.hip): fp32-GEMM accuracy at 2.67x the
+//   fp32 matrix rate.  The soft-max itself (max, exp2, sum, rescale) is the fp32 code of attention.hip.
+//
+// Orientation: S^T = K Q^T (keys = MFMA rows, queries = columns), so a lane owns one query column and the
+// probability accumulator is already laid out as the B operand of O^T += V^T P^T.  With the 16-deep bf16 MFMA a
+// lane supplies 8 consecutive k per step; the accumulator hands lane half h the keys 4h + (j&3) + 8(j>>2) (+16 per
+// step), so V^T is stored in LDS with the key bits 2 and 3 swapped -- the same permutation on both operands, which a
+// sum over keys does not see.
+//
+// Block = 8 waves = 256 queries of one (batch, head): one K/V tile of 32 keys is split once and shared by all eight
+// (the VALU cost of the split is what limits this scheme, so it is amortised over as many queries as the register
+// file allows).  Q lives in registers as 3 x 8 packed fragments (96 VGPRs); K planes [32][128] and V^T planes
+// [128][32] are double buffered in LDS (111 KB), one workgroup per CU, two waves per SIMD.
+//
+// Measured (MI355X, 32 x 4 heads, N = 1024): 370 us against 516 us for attention.hip, 186 TFLOP/s fp32-equivalent.
+// The bound is not the nominal 2.5 PFLOP/s: a register-only v_mfma_f32_32x32x16_bf16 loop on all 256 CUs sustains
+// 1.45-1.68 PFLOP/s on random operands (2.29 on zeros, i.e. the chip clocks down under the matrix pipe's power), so
+// six MFMAs per product cap the scheme at ~2x the fp32 matrix pipe (itself at 0.84 of ITS nominal rate); the MFMAs
+// alone take 266 of the 370 us.  Running the two waves of a SIMD half a tile apart (one in the score MFMAs while its
+// partner does soft-max and splits) measured the same 370 us and was dropped for this simpler loop.
+#include "common.h"
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int KPB = 136;   // K plane row pitch in bf16 (272 B): the 16-lane ds_read_b128 groups are conflict-free
+constexpr int VPB = 40;    // V^T plane row pitch in bf16 (80 B): likewise
+constexpr int EP = 68;     // epilogue row pitch in floats
+
+struct Stage3 {
+  short k[3][32][KPB];     // [plane][key][d]
+  short vt[3][128][VPB];   // [plane][d][permuted key]
+};
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: a -> low half, RNE
+  const bf16x2_t v = __builtin_convertvector(f32x2{a, b}, bf16x2_t);
+  return __builtin_bit_cast(unsigned, v);
+}
+// exact 3-way split of two floats, packed pairs out (both subtractions are exact in fp32)
+__device__ __forceinline__ void split3x2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  h = pk_bf16(a, b);
+  const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+  m = pk_bf16(ra, rb);
+  const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+  l = pk_bf16(sa, sb);
+}
+__device__ __forceinline__ void split3x8(const float* x, bf16x8& h, bf16x8& m, bf16x8& l) {
+  u32x4 H, M, L;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned hh, mm, ll;
+    split3x2(x[2 * i], x[2 * i + 1], hh, mm, ll);
+    H[i] = hh; M[i] = mm; L[i] = ll;
+  }
+  h = __builtin_bit_cast(bf16x8, H); m = __builtin_bit_cast(bf16x8, M); l = __builtin_bit_cast(bf16x8, L);
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// c += a . b with a = a0 + a1 + a2, b = b0 + b1 + b2 (plane 0 = leading piece); smallest terms first
+__device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], bf16x8 b0, bf16x8 b1, bf16x8 b2, f32x16 c) {
+  c = mfma_bf16(a[1], b1, c);
+  c = mfma_bf16(a[0], b2, c);
+  c = mfma_bf16(a[2], b0, c);
+  c = mfma_bf16(a[0], b1, c);
+  c = mfma_bf16(a[1], b0, c);
+  c = mfma_bf16(a[0], b0, c);
+  return c;
+}
+
+template <bool HAS_MASK>
+__global__ __launch_bounds__(512, 1) void sdpa_bf16x3_kernel(vcr_sdpa_args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Stage3* st = reinterpret_cast<Stage3*>(smem);          // [2]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  // XCD-aware block order (as attention.hip): all query blocks of a (batch, head) pair stream K/V through one L2
+  const int nqb = (p.nq + 255) / 256, nbh = p.nbatch * p.heads;
+  int qb, bh;
+  if ((nbh & 7) == 0) {
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    qb = i % nqb; bh = (i / nqb) * 8 + xcd;
+  } else {
+    qb = blockIdx.x % nqb; bh = blockIdx.x / nqb;
+  }
+  const int head = bh % p.heads, b = bh / p.heads;
+  const int kvb = (b + p.kv_batch_shift) % p.nbatch;
+  const int q = qb * 256 + w * 32 + l31;
+  const int qc = min(q, p.nq - 1);
+
+  bf16x8 qh[8], qm[8], ql[8];                            // Q[query l31][16 step + 8 half + 0..7], three planes
+  {
+    const float* qp = p.q + ((size_t)b * p.nq + qc) * p.ldq + head * 128 + 8 * half;
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const f32x4 a = ld4(qp + 16 * s8), c = ld4(qp + 16 * s8 + 4);
+      const float x[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+      split3x8(x, qh[s8], qm[s8], ql[s8]);
+    }
+  }
+  const float* kbase = p.k + (size_t)kvb * p.nk * p.ldk + head * 128;
+  const float* vbase = p.v + (size_t)kvb * p.nk * p.ldv + head * 128;
+  const int skey = t >> 4, sc = (t & 15) * 4;            // K staging: key row, floats sc..sc+3 and 64+sc..
+  // V staging: wave w owns keys 4w..4w+3 (adjacent after the permutation), lane owns head dims lane and lane + 64
+  const int vpos = 16 * (w >> 2) + 8 * (w & 1) + 4 * ((w >> 1) & 1);
+  const int ntiles = (p.nk + 31) / 32;
+
+  f32x4 rk[2];
+  float rv[4][2];
+  auto stage_load = [&](int tile) {
+    const int key = min(tile * 32 + skey, p.nk - 1);
+    rk[0] = ld4(kbase + (size_t)key * p.ldk + sc);
+    rk[1] = ld4(kbase + (size_t)key * p.ldk + 64 + sc);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* vr = vbase + (size_t)min(tile * 32 + 4 * w + c, p.nk - 1) * p.ldv + lane;
+      rv[c][0] = vr[0]; rv[c][1] = vr[64];
+    }
+  };
+  auto stage_write = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      split3x2(rk[i][0], rk[i][1], h0, m0, l0);
+      split3x2(rk[i][2], rk[i][3], h1, m1, l1);
+      *reinterpret_cast<u32x2*>(&st[buf].k[0][skey][sc + 64 * i]) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(&st[buf].k[1][skey][sc + 64 * i]) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2*>(&st[buf].k[2][skey][sc + 64 * i]) = u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      split3x2(rv[0][e], rv[1][e], h0, m0, l0);
+      split3x2(rv[2][e], rv[3][e], h1, m1, l1);
+      *reinterpret_cast<u32x2*>(&st[buf].vt[0][lane + 64 * e][vpos]) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(&st[buf].vt[1][lane + 64 * e][vpos]) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2*>(&st[buf].vt[2][lane + 64 * e][vpos]) = u32x2{l0, l1};
+    }
+  };
+
+  f32x16 o[4];                                           // o[dt][r] = O[query l31][d = 32 dt + acc_row(r, half)]
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o[d] = f32x16{0};
+  float m = VCR_NEG_INF, l = 0.f;
+  const float c2 = p.scale * LOG2E;
+
+  stage_load(0);
+  stage_write(0);
+  __syncthreads();
+  int cur = 0;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    if (tile + 1 < ntiles) stage_load(tile + 1);
+    const Stage3& S = st[cur];
+    f32x16 s = {0};
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      bf16x8 kf[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const bf16x8*>(&S.k[pl][l31][16 * s8 + 8 * half]);
+      s = mfma6(kf, qh[s8], qm[s8], ql[s8], s);
+    }
+    // soft-max of attention.hip's fast path: running maximum kept in log2 units, one fma + exp2 per score
+    float mt = VCR_NEG_INF, ls = 0.f;
+    if (!HAS_MASK && tile * 32 + 32 <= p.nk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = tile * 32 + acc_row(r, half);
+        bool ok = key < p.nk;
+        if (HAS_MASK) ok = ok && p.key_keep[(size_t)kvb * p.nk + min(key, p.nk - 1)] != 0;
+        s[r] = ok ? s[r] : VCR_NEG_INF;
+        mt = fmaxf(mt, s[r]);
+      }
+    }
+    mt = fmaxf(mt, xhalf(mt)) * c2;
+    const float m_new = fmaxf(m, mt);
+    const float mref = (m_new == VCR_NEG_INF) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m - mref);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -mref));
+      ls += s[r];
+    }
+    m = m_new;
+    l = l * alpha + ls;
+    if (__any(alpha != 1.f)) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[d] = o[d] * alpha;
+    }
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {                     // two 16-key steps; registers 8 sp .. 8 sp + 7 are this step's keys
+      const float x[8] = {s[8 * sp], s[8 * sp + 1], s[8 * sp + 2], s[8 * sp + 3],
+                          s[8 * sp + 4], s[8 * sp + 5], s[8 * sp + 6], s[8 * sp + 7]};
+      bf16x8 ph, pm, pl3;
+      split3x8(x, ph, pm, pl3);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x8 vf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          vf[pl] = *reinterpret_cast<const bf16x8*>(&S.vt[pl][32 * dt + l31][16 * sp + 8 * half]);
+        o[dt] = mfma6(vf, ph, pm, pl3, o[dt]);
+      }
+    }
+    if (tile + 1 < ntiles) stage_write(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // O^T (d rows in registers, query on the lane) -> [query][d] rows through this wave's LDS slice, 64 head dims per
+  // round, then 256-B contiguous row stores.  The stage buffers are free (all waves passed the last barrier).
+  const float inv = 1.f / (l + xhalf(l));
+  float* ot = reinterpret_cast<float*>(smem) + (size_t)w * 32 * EP;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x16& a = o[2 * round + dd];
+        st4(&ot[l31 * EP + 32 * dd + 8 * g + 4 * half],
+            f32x4{a[4 * g] * inv, a[4 * g + 1] * inv, a[4 * g + 2] * inv, a[4 * g + 3] * inv});
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + (lane >> 4), c4 = (lane & 15) * 4;
+      const int qq = qb * 256 + w * 32 + row;
+      if (qq < p.nq)
+        st4(p.out + ((size_t)b * p.nq + qq) * p.ldo + head * 128 + 64 * round + c4, ld4(&ot[row * EP + c4]));
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace
+
+// Same contract as vcr_sdpa_f32 for the attention-output form (out != NULL, no row statistics / score dump):
+// the statistics-only passes of the partial-overlap path stay on vcr_sdpa_f32.
+extern "C" int vcr_sdpa_bf16x3_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
+  if (!a || !a->q || !a->k || !a->v || !a->out) return VCR_EINVAL;
+  if (a->rowstat || a->score_out || !(a->scale > 0.f)) return VCR_EUNSUPPORTED;
+  if (a->nbatch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return VCR_EINVAL;
+  if ((a->ldq & 3) || (a->ldk & 3) || (a->ldo & 3)) return VCR_EINVAL;
+  if (a->ldq < a->heads * 128 || a->ldk < a->heads * 128 || a->ldv < a->heads * 128) return VCR_EINVAL;
+  if (((uintptr_t)a->q & 15) || ((uintptr_t)a->k & 15) || ((uintptr_t)a->out & 15)) return VCR_EINVAL;
+  dim3 grid(((a->nq + 255) / 256) * a->heads * a->nbatch);
+  const int lds = 2 * sizeof(Stage3);
+  static_assert(2 * sizeof(Stage3) >= 8 * 32 * EP * 4, "epilogue slices fit");
+  hipStream_t s = (hipStream_t)stream;
+  if (a->key_keep) {
+    VCR_DYN_LDS(sdpa_bf16x3_kernel<true>, lds);
+    hipLaunchKernelGGL(sdpa_bf16x3_kernel<true>, grid, dim3(512), lds, s, *a);
+  } else {
+    VCR_DYN_LDS(sdpa_bf16x3_kernel<false>, lds);
+    hipLaunchKernelGGL(sdpa_bf16x3_kernel<false>, grid, dim3(512), lds, s, *a);
+  }
+  return VCR_LAUNCH_RC();
+}

@@ -138,7 +138,8 @@ struct Runner {
     mark(nm);
     vcr_sdpa_args a{q, ldq, k, ldk, v, ldv, out, ldo, nb, heads, nq, nk, 1.0f / sqrtf(128.f), shift, keep, rowstat,
                     score_out, ld_score};
-    return ok(vcr_sdpa_f32(&a, stream));
+    // linear_mode 2: the attention-output launches on the bf16 matrix pipe as exact splits; statistics passes stay fp32
+    return ok((sdpa_split && out && !rowstat && !score_out) ? vcr_sdpa_bf16x3_f32(&a, stream) : vcr_sdpa_f32(&a, stream));
   }
   bool pairscore(const char* nm, const vcr_pairscore_args& a) {
     if (rc) return false;
@@ -168,6 +169,7 @@ struct Runner {
   // forward; with an auxiliary stream the tie replay runs there, and knn_join(which) makes this stream wait for it
   // right before the first consumer of the indices
   const vcr_vcrnet_io* io_ = nullptr;
+  bool sdpa_split = false;                               // linear_mode 2
   void knn(const char* nm, vcr_knn_args a, int which) {
     if (rc) return;
     mark(nm);
@@ -301,7 +303,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
         W->fold_dec_cross_kv.w && W->fold_dec_ffn1.w))
     return VCR_EINVAL;
   if (((uintptr_t)workspace) & 255) return VCR_EINVAL;
-  if (W->head_mode < 0 || W->head_mode > 2) return VCR_EINVAL;
+  if (W->head_mode < 0 || W->head_mode > 2 || W->linear_mode < 0 || W->linear_mode > 2) return VCR_EINVAL;
   if (W->partial) {                                      // key pruning in the decoder (+ hard pairs for the topK head)
     if (W->has_pointer != 1 || (W->cycle && W->head_mode == 0)) return VCR_EUNSUPPORTED;
     if (!(W->overlap2 > 0.0 && W->overlap2 <= 1.0) || (int)((double)N * W->overlap2) < 1) return VCR_EINVAL;
@@ -316,7 +318,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   Runner R{(hipStream_t)stream, tr};
   R.io_ = io;
   R.ok((int)hipMemsetAsync(w.ties, 0, (size_t)(M2 + 2) * sizeof(int32_t), R.stream));   // both tie counters (and the first block)
-#define SP(site) (W->linear_mode == 1 ? W->split.site : nullptr)
+#define SP(site) (W->linear_mode != 0 ? W->split.site : nullptr)
+  R.sdpa_split = W->linear_mode == 2;
 
   const float* stats_for_ln = (W->has_pointer == 1 && W->linear_mode == 0) ? w.st_emb : nullptr;
   if (W->emb_kind == 1) {

@@ -18,6 +18,8 @@ import torch.nn as nn
 from . import native
 from .weights import strip_module_prefix
 
+LINEAR_MODES = {"fp32": 0, "bf16x3": 1, "bf16x3+sdpa": 2}   # vcr_vcrnet_weights.linear_mode
+
 
 # ---- parameter containers with the reference's module tree (names are API) -------------------------------
 
@@ -194,6 +196,7 @@ class VCRNet(nn.Module):
             raise Exception("Not implemented")                             # reference default n_blocks = 1
         # "fp32": every linear on v_mfma_f32_32x32x2_f32 (default).  "bf16x3": the same products as exact 3-way bf16
         # splits on the bf16 matrix pipe (fp32-equivalent accuracy, ~1.5x faster linears); fused whole-forward only.
+        # "bf16x3+sdpa": that, and the attention products (Q K^T, P V) the same way (vcr_sdpa_bf16x3_f32).
         self.linear_mode = os.environ.get("VCRNET_LINEAR_MODE", "fp32")
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
@@ -295,7 +298,7 @@ class VCRNet(nn.Module):
             mha("dec_cross", d + ".src_attn", True)
             ffn("enc_ffn", e + ".feed_forward"); ffn("dec_ffn", d + ".feed_forward")
             cw.has_pointer = 1
-            if self.linear_mode != "bf16x3":
+            if self.linear_mode == "fp32":
                 # fp32 mode: LayerNorm folded into the six linears that consume one (linear.hip LN_IN)
                 for site, wk, bk, nk in (("enc_qkv", "enc_self.wqkv", "enc_self.bqkv", "enc_ln0"),
                                          ("enc_ffn1", "enc_ffn.w_1.weight", "enc_ffn.w_1.bias", "enc_ln1"),
@@ -308,8 +311,10 @@ class VCRNet(nn.Module):
                     setattr(cw, "fold_" + site, native.FoldedW(*(native.ptr(t) for t in f)))
         else:
             cw.has_pointer = 2 if isinstance(self.pointer, _Identity) else 0
-        cw.linear_mode = 1 if self.linear_mode == "bf16x3" else 0
-        if cw.linear_mode == 1 and self._emb_kind == "lpdnet":
+        if self.linear_mode not in LINEAR_MODES:
+            raise ValueError(f"linear_mode {self.linear_mode!r}: one of {sorted(LINEAR_MODES)}")
+        cw.linear_mode = LINEAR_MODES[self.linear_mode]
+        if cw.linear_mode != 0 and self._emb_kind == "lpdnet":
             # weights pre-split into exact bf16 triplets for vcr_linear_bf16x3_f32 (fp32-equivalent products)
             src = {"dg1_pq": "dg1_wpq", "sn1_pq": "sn1_wpq", "c3": "c3_w", "enc_qkv": "enc_self.wqkv",
                    "enc_wo": "enc_self.wo", "enc_ffn1": "enc_ffn.w_1.weight", "enc_ffn2": "enc_ffn.w_2.weight",
@@ -345,7 +350,7 @@ class VCRNet(nn.Module):
         embedding / pointer / head / cycle / partial combination except the corner cases below, which run kernel by
         kernel from composed.py (DGCNN with bf16x3 linears, partial mode without the Transformer, cycle with the
         partial topK head -- the last one is not defined by the reference either)."""
-        if self._emb_kind == "dgcnn" and self.linear_mode == "bf16x3":
+        if self._emb_kind == "dgcnn" and self.linear_mode != "fp32":
             return False
         if self._partial:
             if not isinstance(self.pointer, _TransformerParams):

@@ -188,7 +188,7 @@ class Trace(C.Structure):
 _SIGS = {
     "vcr_pointwise_f32": PointwiseArgs, "vcr_knn_f32": KnnArgs, "vcr_linear_f32": LinearArgs,
     "vcr_layernorm_f32": LayerNormArgs, "vcr_rowside_f32": RowsideArgs, "vcr_edgeconv_f32": EdgeconvArgs,
-    "vcr_gathermax_f32": GathermaxArgs, "vcr_sdpa_f32": SdpaArgs, "vcr_softcorr_f32": SoftcorrArgs,
+    "vcr_gathermax_f32": GathermaxArgs, "vcr_sdpa_f32": SdpaArgs, "vcr_sdpa_bf16x3_f32": SdpaArgs, "vcr_softcorr_f32": SoftcorrArgs,
     "vcr_rigid_svd_f32": RigidSvdArgs, "vcr_pairscore_f32": PairscoreArgs, "vcr_rankselect_f32": RankselectArgs,
     "vcr_gather_rows_f32": GatherArgs, "vcr_scoremass_f32": ScoremassArgs, "vcr_keymass_f32": KeymassArgs, "vcr_make_pairs_f32": MakePairsArgs,
     "vcr_edgerows_f32": EdgerowsArgs, "vcr_segmax_f32": SegmaxArgs,
@@ -479,15 +479,15 @@ def gathermax(pq, Cc, idx, n_per_cloud):
 
 @_guarded
 def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None, want_rowstat=False, pv=True,
-         score_out=None):
+         score_out=None, bf16x3=False):
     """q [nbatch*nq, >=heads*128] (row views allowed), k/v likewise -> out [nbatch*nq, heads*128].
     score_out [nbatch, heads, nq, ld]: also keep the scaled scores (statistics pass of the partial path)."""
     out = _f32(nbatch * nq, heads * 128, device=q.device) if pv else None
     rs = _f32(nbatch, heads, nq, 2, device=q.device) if want_rowstat else None
-    call("vcr_sdpa_f32", SdpaArgs(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v) if pv else None,
-                                  v.stride(0) if pv else 0, ptr(out), heads * 128 if pv else 0, nbatch, heads, nq, nk,
-                                  scale, kv_batch_shift, ptr(key_keep), ptr(rs), ptr(score_out),
-                                  score_out.stride(2) if score_out is not None else 0))
+    call("vcr_sdpa_bf16x3_f32" if bf16x3 else "vcr_sdpa_f32",
+         SdpaArgs(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v) if pv else None, v.stride(0) if pv else 0, ptr(out),
+                  heads * 128 if pv else 0, nbatch, heads, nq, nk, scale, kv_batch_shift, ptr(key_keep), ptr(rs),
+                  ptr(score_out), score_out.stride(2) if score_out is not None else 0))
     return (out, rs) if want_rowstat else out
 
 
