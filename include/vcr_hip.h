@@ -121,7 +121,8 @@ int vcr_fold_layernorm_f32(const float* w, const float* bias, const float* ln_a,
  * into three bf16 pieces and the six leading partial products are accumulated in fp32 (error <= 2^-24
  * relative per product, i.e. fp32-GEMM accuracy at 2.67x the fp32 matrix rate).  `w_planes` = the weight
  * [N,K] pre-split by vcr_split_bf16x3_f32 (3 consecutive bf16 planes of N*K elements); args->w is ignored.
- * Needs N % 4 == 0 and 16-byte aligned x / y / bias / residual. */
+ * Needs N % 4 == 0 and 16-byte aligned x / y / bias / residual.  ln_stats_in / ln_colsum / stats_out as in
+ * vcr_linear_f32 (w_planes then = the split of the FOLDED weight); segmax_out is not offered here. */
 int vcr_split_bf16x3_f32(const float* x, void* planes, size_t n, vcr_stream_t);
 int vcr_linear_bf16x3_f32(const vcr_linear_args*, const void* w_planes, vcr_stream_t);
 
@@ -337,14 +338,16 @@ typedef struct {
   int head_mode;                                   /* 0 VcpTopK (neg-distance), 1 VcpByDis / DCP (dot/sqrt(E)), 2 VcpAtt */
   /* linear_mode 0: every 1x1 conv / Linear on v_mfma_f32_32x32x2_f32 (vcr_linear_f32).
    * linear_mode 1: the same products as exact 3-way bf16 splits on the bf16 matrix pipe (vcr_linear_bf16x3_f32);
-   * then `split` holds the weights pre-split by vcr_split_bf16x3_f32, in the order of the sites below.
+   * then `split` holds the weights pre-split by vcr_split_bf16x3_f32, in the order of the sites below -- for the six
+   * sites that consume a LayerNorm (enc_qkv, enc_ffn1, dec_qkv, dec_cross_q, dec_cross_kv, dec_ffn1) the split of the
+   * FOLDED weight fold_<site>.w.
    * linear_mode 2: mode 1, and the attention-output launches through vcr_sdpa_bf16x3_f32 as well. */
   int linear_mode;
   struct {
     const void *dg1_pq, *sn1_pq, *c3, *enc_qkv, *enc_wo, *enc_ffn1, *enc_ffn2, *dec_qkv, *dec_self_wo, *dec_cross_q,
                *dec_cross_kv, *dec_cross_wo, *dec_ffn1, *dec_ffn2;
   } split;
-  /* linear_mode 0 with has_pointer 1: the six Linears that consume a LayerNorm, folded with it by
+  /* has_pointer 1 (every linear_mode): the six Linears that consume a LayerNorm, folded with it by
    * vcr_fold_layernorm_f32 (w [N,E], colsum [N], bias [N]).  dec_cross_kv is folded with the ENCODER's final norm. */
   struct vcr_folded { const float *w, *colsum, *bias; } fold_enc_qkv, fold_enc_ffn1, fold_dec_qkv, fold_dec_cross_q,
       fold_dec_cross_kv, fold_dec_ffn1;

@@ -461,6 +461,16 @@ def test_linear_with_fused_layernorm(nat):
     assert err <= 5e-5, err
     y_unfused = nat.linear(nat.layernorm(x, dev(a), dev(b)), dev(w1), dev(b1), relu=True)
     assert (y.cpu() - y_unfused.cpu()).abs().max().item() <= 5e-5
+    # the same producer / consumer pair through the exact-split kernel (vcr_linear_bf16x3_f32)
+    x3, stats3 = nat.linear_bf16x3(dev(x0), nat.split_bf16x3(dev(w0)), K, dev(b0), residual=dev(r0), want_stats=True)
+    torch.testing.assert_close(x3.cpu(), xs, atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(stats3.cpu()[..., 0].sum(1), x3.cpu().sum(1), atol=2e-4, rtol=1e-5)
+    torch.testing.assert_close(stats3.cpu()[..., 1].sum(1), (x3.cpu() ** 2).sum(1), atol=2e-3, rtol=1e-5)
+    y3 = nat.linear_bf16x3(x3, nat.split_bf16x3(wf), N, bf, relu=True, ln=(stats3, cs, 1e-6))
+    ref3 = torch.relu(oracle.layer_norm(x3.cpu().double(), a.double(), b.double()) @ w1.double().t() + b1.double())
+    err3 = (y3.cpu().double() - ref3).abs().max().item()
+    print(f"fused LayerNorm + linear: max|err| vs fp64  fp32-MFMA {err:.2e}  bf16x3 {err3:.2e}")
+    assert err3 <= 5e-5, err3
 
 
 @pytest.mark.parametrize("N,k", [(1024, 20), (2048, 20), (512, 40), (4096, 40), (333, 5), (1344, 20), (1343, 20)])

@@ -43,6 +43,16 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// Sum over the 16 lanes of a DPP row with VALU-rate DPP moves (quad_perm xor 1, xor 2, then row_ror 4 and 8);
+// every lane ends with the full sum, in a fixed order.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+  return v;
+}
+
 // Workgroups are dealt round-robin over the chip's 8 XCDs, each with its own L2.  xcd_chunk() renumbers a launch so
 // that XCD x works on the x-th CONTIGUOUS eighth of the blocks: neighbouring blocks (the rows and neighbour gathers
 // of one cloud) then share one L2 instead of pulling the same lines into eight.  A pure renumbering of independent

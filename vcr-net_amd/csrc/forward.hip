@@ -23,7 +23,7 @@ struct Bump {
 struct Ws {
   float *xyz4, *feat64, *sq64, *pq1, *cat, *pq3, *emb;
   int32_t *idx1, *idx3, *ties;                         // ties: 2 x (count + one slot per row) for the kNN tie replay
-  float *ln, *qkv, *att, *e1, *e2, *mem, *hid, *d1, *d2, *d3, *qc, *kvc, *embf, *side4;
+  float *qkv, *att, *e1, *e2, *hid, *d1, *d2, *d3, *qc, *kvc, *embf, *side4;
   float *st_emb, *st_e1, *st_e2, *st_d1, *st_d2;       // [M, E/64, 2] LayerNorm partial sums
   // partial-overlap mode
   float *rowstat, *keymass; uint8_t* keep;             // cross-attention: [2B,H,N,2], [2B,N], [2B,N]
@@ -51,8 +51,8 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   w.idx1 = bp.take<int32_t>(M * k); w.idx3 = bp.take<int32_t>(M * k); w.ties = bp.take<int32_t>(2 * (1 + M));   // a slot for every row
   w.pq1 = bp.take<float>(M * 256);  w.cat = bp.take<float>(M * 512);   w.pq3 = bp.take<float>(M * 512);
   w.emb = bp.take<float>(M * E);
-  w.ln = bp.take<float>(M * E);     w.qkv = bp.take<float>(M * 3 * E); w.att = bp.take<float>(M * E);
-  w.e1 = bp.take<float>(M * E);     w.e2 = bp.take<float>(M * E);      w.mem = bp.take<float>(M * E);
+  w.qkv = bp.take<float>(M * 3 * E); w.att = bp.take<float>(M * E);
+  w.e1 = bp.take<float>(M * E);     w.e2 = bp.take<float>(M * E);
   w.hid = bp.take<float>(M * F);
   w.d1 = bp.take<float>(M * E);     w.d2 = bp.take<float>(M * E);      w.d3 = bp.take<float>(M * E);
   w.qc = bp.take<float>(M * E);     w.kvc = bp.take<float>(M * 2 * E);
@@ -298,7 +298,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   const int B = io->B, N = io->N, E = W->E, F = W->F, k = W->k;
   if (B <= 0 || N <= 0 || E != 512 || W->heads * 128 != E || k <= 0 || k > 40 || k + 1 > N) return VCR_EINVAL;
   if (W->has_pointer == 1 && (F % 128)) return VCR_EINVAL;
-  if (W->has_pointer == 1 && W->linear_mode == 0 &&
+  if (W->has_pointer == 1 &&
       !(W->fold_enc_qkv.w && W->fold_enc_ffn1.w && W->fold_dec_qkv.w && W->fold_dec_cross_q.w &&
         W->fold_dec_cross_kv.w && W->fold_dec_ffn1.w))
     return VCR_EINVAL;
@@ -321,7 +321,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
 #define SP(site) (W->linear_mode != 0 ? W->split.site : nullptr)
   R.sdpa_split = W->linear_mode == 2;
 
-  const float* stats_for_ln = (W->has_pointer == 1 && W->linear_mode == 0) ? w.st_emb : nullptr;
+  const float* stats_for_ln = W->has_pointer == 1 ? w.st_emb : nullptr;
   if (W->emb_kind == 1) {
     // ---- emb_nn = DGCNN on both clouds (vcrnet_model.py:104-123): one Cartesian kNN, conv1 via the neighbour/centre
     // split (per-point P/Q + gather), conv2..conv4 as N*k-row GEMMs, max over the k edges after each, conv5 on the
@@ -389,70 +389,44 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     R.ok(vcr_gathermax_f32(&a, R.stream));
   }
   R.linear("linear:conv3", w.cat, 512, W->c3_w, SP(c3), W->c3_b, w.emb, E, M2, E, 512, 1, nullptr, 0, nullptr, nullptr,
-           (W->has_pointer == 1 && W->linear_mode == 0) ? w.st_emb : nullptr);
+           W->has_pointer == 1 ? w.st_emb : nullptr);
 
   }
 
   // ---- pointer (transformer.py:264-272) + residual (vcrnet_model.py:504-505)
   const float* head_emb = w.embf;
-  if (W->has_pointer == 1 && W->linear_mode == 0) {
-    // fp32 path with LayerNorm folded into the consuming linears: each producer of a
+  if (W->has_pointer == 1) {
+    // LayerNorm folded into the consuming linears: each producer of a
     // residual stream writes per-row (sum, sum^2) partials from its epilogue, each consumer runs the plain GEMM on
     // the folded weight and applies (mean, 1/(std+eps)) in its epilogue -- six LayerNorm launches and their
     // 2 x 67 MB round trips are gone.
     const int H = W->heads;
-    R.linear("linear:enc.qkv", w.emb, E, W->fold_enc_qkv.w, nullptr, W->fold_enc_qkv.bias, w.qkv, 3 * E, M2, 3 * E, E, 0,
+    R.linear("linear:enc.qkv", w.emb, E, W->fold_enc_qkv.w, SP(enc_qkv), W->fold_enc_qkv.bias, w.qkv, 3 * E, M2, 3 * E, E, 0,
              nullptr, 0, w.st_emb, W->fold_enc_qkv.colsum);
     R.sdpa("sdpa:enc.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
-    R.linear("linear:enc.wo", w.att, E, W->enc_self.wo, nullptr, W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E,
+    R.linear("linear:enc.wo", w.att, E, W->enc_self.wo, SP(enc_wo), W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E,
              nullptr, nullptr, w.st_e1);
-    R.linear("linear:enc.ffn1", w.e1, E, W->fold_enc_ffn1.w, nullptr, W->fold_enc_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
+    R.linear("linear:enc.ffn1", w.e1, E, W->fold_enc_ffn1.w, SP(enc_ffn1), W->fold_enc_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
              w.st_e1, W->fold_enc_ffn1.colsum);
-    R.linear("linear:enc.ffn2", w.hid, F, W->enc_ffn.w2, nullptr, W->enc_ffn.b2, w.e2, E, M2, E, F, 0, w.e1, E,
+    R.linear("linear:enc.ffn2", w.hid, F, W->enc_ffn.w2, SP(enc_ffn2), W->enc_ffn.b2, w.e2, E, M2, E, F, 0, w.e1, E,
              nullptr, nullptr, w.st_e2);
     // decoder; batch b attends to the encoder memory (= enc.norm(e2), applied inside the K/V projection) of
     // batch (b + B) mod 2B
-    R.linear("linear:dec.qkv", w.emb, E, W->fold_dec_qkv.w, nullptr, W->fold_dec_qkv.bias, w.qkv, 3 * E, M2, 3 * E, E, 0,
+    R.linear("linear:dec.qkv", w.emb, E, W->fold_dec_qkv.w, SP(dec_qkv), W->fold_dec_qkv.bias, w.qkv, 3 * E, M2, 3 * E, E, 0,
              nullptr, 0, w.st_emb, W->fold_dec_qkv.colsum);
     R.sdpa("sdpa:dec.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
-    R.linear("linear:dec.self.wo", w.att, E, W->dec_self.wo, nullptr, W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E,
+    R.linear("linear:dec.self.wo", w.att, E, W->dec_self.wo, SP(dec_self_wo), W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E,
              nullptr, nullptr, w.st_d1);
-    R.linear("linear:dec.cross.q", w.d1, E, W->fold_dec_cross_q.w, nullptr, W->fold_dec_cross_q.bias, w.qc, E, M2, E, E, 0, nullptr, 0,
+    R.linear("linear:dec.cross.q", w.d1, E, W->fold_dec_cross_q.w, SP(dec_cross_q), W->fold_dec_cross_q.bias, w.qc, E, M2, E, E, 0, nullptr, 0,
              w.st_d1, W->fold_dec_cross_q.colsum);
-    R.linear("linear:dec.cross.kv", w.e2, E, W->fold_dec_cross_kv.w, nullptr, W->fold_dec_cross_kv.bias, w.kvc, 2 * E, M2, 2 * E, E, 0,
+    R.linear("linear:dec.cross.kv", w.e2, E, W->fold_dec_cross_kv.w, SP(dec_cross_kv), W->fold_dec_cross_kv.bias, w.kvc, 2 * E, M2, 2 * E, E, 0,
              nullptr, 0, w.st_e2, W->fold_dec_cross_kv.colsum);
     R.cross_attention(W, io, w, B, N);
-    R.linear("linear:dec.cross.wo", w.att, E, W->dec_cross.wo, nullptr, W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E,
+    R.linear("linear:dec.cross.wo", w.att, E, W->dec_cross.wo, SP(dec_cross_wo), W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E,
              nullptr, nullptr, w.st_d2);
-    R.linear("linear:dec.ffn1", w.d2, E, W->fold_dec_ffn1.w, nullptr, W->fold_dec_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
+    R.linear("linear:dec.ffn1", w.d2, E, W->fold_dec_ffn1.w, SP(dec_ffn1), W->fold_dec_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
              w.st_d2, W->fold_dec_ffn1.colsum);
-    R.linear("linear:dec.ffn2", w.hid, F, W->dec_ffn.w2, nullptr, W->dec_ffn.b2, w.d3, E, M2, E, F, 0, w.d2, E);
-    R.norm("layernorm:dec.norm+res", w.d3, W->dec_norm, w.embf, M2, E, w.emb, w.xyz4, w.side4);
-  } else if (W->has_pointer == 1) {
-    const int H = W->heads;
-    // encoder layer (pre-norm residual sublayers, transformer.py:156-166) on [src; tgt]
-    R.norm("layernorm:enc.sub0", w.emb, W->enc_ln0, w.ln, M2, E);
-    R.linear("linear:enc.qkv", w.ln, E, W->enc_self.wqkv, SP(enc_qkv), W->enc_self.bqkv, w.qkv, 3 * E, M2, 3 * E, E, 0);
-    R.sdpa("sdpa:enc.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
-    R.linear("linear:enc.wo", w.att, E, W->enc_self.wo, SP(enc_wo), W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E);
-    R.norm("layernorm:enc.sub1", w.e1, W->enc_ln1, w.ln, M2, E);
-    R.linear("linear:enc.ffn1", w.ln, E, W->enc_ffn.w1, SP(enc_ffn1), W->enc_ffn.b1, w.hid, F, M2, F, E, 1);
-    R.linear("linear:enc.ffn2", w.hid, F, W->enc_ffn.w2, SP(enc_ffn2), W->enc_ffn.b2, w.e2, E, M2, E, F, 0, w.e1, E);
-    R.norm("layernorm:enc.norm", w.e2, W->enc_norm, w.mem, M2, E);
-    // decoder layer (transformer.py:169-185); batch b attends to memory of batch (b + B) mod 2B
-    R.norm("layernorm:dec.sub0", w.emb, W->dec_ln0, w.ln, M2, E);
-    R.linear("linear:dec.qkv", w.ln, E, W->dec_self.wqkv, SP(dec_qkv), W->dec_self.bqkv, w.qkv, 3 * E, M2, 3 * E, E, 0);
-    R.sdpa("sdpa:dec.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
-    R.linear("linear:dec.self.wo", w.att, E, W->dec_self.wo, SP(dec_self_wo), W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E);
-    R.norm("layernorm:dec.sub1", w.d1, W->dec_ln1, w.ln, M2, E);
-    R.linear("linear:dec.cross.q", w.ln, E, W->dec_cross.wq, SP(dec_cross_q), W->dec_cross.bq, w.qc, E, M2, E, E, 0);
-    R.linear("linear:dec.cross.kv", w.mem, E, W->dec_cross.wkv, SP(dec_cross_kv), W->dec_cross.bkv, w.kvc, 2 * E, M2, 2 * E, E, 0);
-    R.cross_attention(W, io, w, B, N);
-    R.linear("linear:dec.cross.wo", w.att, E, W->dec_cross.wo, SP(dec_cross_wo), W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E);
-    R.norm("layernorm:dec.sub2", w.d2, W->dec_ln2, w.ln, M2, E);
-    R.linear("linear:dec.ffn1", w.ln, E, W->dec_ffn.w1, SP(dec_ffn1), W->dec_ffn.b1, w.hid, F, M2, F, E, 1);
     R.linear("linear:dec.ffn2", w.hid, F, W->dec_ffn.w2, SP(dec_ffn2), W->dec_ffn.b2, w.d3, E, M2, E, F, 0, w.d2, E);
-    // final decoder norm, + embedding residual, + the head's side record in one pass
     R.norm("layernorm:dec.norm+res", w.d3, W->dec_norm, w.embf, M2, E, w.emb, w.xyz4, w.side4);
   } else if (R.rc == 0) {
     R.mark("layernorm:rowside");
@@ -654,7 +628,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 11; }
+extern "C" int vcr_abi_version(void) { return 12; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

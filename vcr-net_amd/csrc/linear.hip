@@ -175,16 +175,6 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 3)) void linear_kernel(vcr_lin
 template <int BK> struct TileGT { float a[BM][BK]; float b[BN][BK]; };
 using TileG = TileGT<32>;
 
-// Sum over the 16 lanes of a DPP row with VALU-rate DPP moves (quad_perm xor 1, xor 2, then row_ror 4 and 8);
-// every lane ends with the full sum, in a fixed order.
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
-  return v;
-}
-
 __device__ __forceinline__ void glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);

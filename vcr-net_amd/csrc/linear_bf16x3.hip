@@ -5,8 +5,10 @@
 //   each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms are
 //   <= 2^-24 relative, i.e. the result carries fp32-GEMM accuracy, while the six MFMAs cost 6 x 32 cycles
 //   for a 32x32x16 block against 8 x 64 cycles of v_mfma_f32_32x32x2_f32: 2.67x the fp32 matrix rate.
-//   Same interface, epilogue and output layout as linear.hip; weights are pre-split once (vcr_split_bf16x3_f32),
-//   activations are split on the fly while they are staged into LDS.
+//   Same interface, epilogue and output layout as linear.hip -- including the folded LayerNorm (ln_stats_in: the
+//   main loop runs on the folded weight, the epilogue applies the per-row mean / 1/(std+eps)) and the statistics
+//   epilogue (stats_out) -- weights are pre-split once (vcr_split_bf16x3_f32), activations are split on the fly
+//   while they are staged into LDS.
 //
 // 256 x 128 x 32 block tile, 8 waves (4 x 2), wave tile 64 x 64, one block per CU (144 KB LDS, double buffered).
 // LDS image per operand: three planes [rows][32 bf16] (64-B rows, no padding) with the 16-B chunk index
@@ -102,6 +104,16 @@ __global__ __launch_bounds__(512, 2) void linear_bf16x3_kernel(vcr_linear_args p
   load_a(0);
   fill_b(0, 0);
   store_a(0);
+  float* rowst = reinterpret_cast<float*>(smem + 2 * sizeof(Stage3));   // [TM][2] (mean, 1/(std+eps)) of this block's rows
+  if (p.ln_stats_in && t < TM) {
+    const float* sp = p.ln_stats_in + (size_t)min(m0 + t, p.M - 1) * p.ln_nseg * 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int sg = 0; sg < p.ln_nseg; ++sg) { s1 += sp[2 * sg]; s2 += sp[2 * sg + 1]; }     // fixed order
+    const float mean = s1 / (float)p.K;
+    const float var = fmaxf((s2 - s1 * mean) / (float)(p.K - 1), 0.f);                      // unbiased, like x.std()
+    rowst[2 * t] = mean;
+    rowst[2 * t + 1] = 1.f / (sqrtf(var) + p.ln_eps);
+  }
   __syncthreads();
 
   f32x16 acc[2][2];
@@ -154,6 +166,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16x3_kernel(vcr_linear_args p
   float* ot = reinterpret_cast<float*>(smem) + wave * 32 * EP;
   const int c4e = (lane & 15) * 4, col = n0 + wn * 64 + c4e;
   const f32x4 bias = (p.bias && col < p.N) ? ld4(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool ln_in = p.ln_stats_in != nullptr;           // block-uniform
+  const f32x4 csum = (ln_in && col < p.N) ? ld4(p.ln_colsum + col) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -168,10 +182,26 @@ __global__ __launch_bounds__(512, 2) void linear_bf16x3_kernel(vcr_linear_args p
         const int rl = ps * 4 + (lane >> 4);
         const int row = m0 + wm * 64 + i * 32 + rl;
         if (row < p.M) {
-          f32x4 v = ld4(&ot[rl * EP + c4e]) + bias;
+          f32x4 v = ld4(&ot[rl * EP + c4e]);
+          if (ln_in) {
+            const float mean = rowst[2 * (wm * 64 + i * 32 + rl)], inv = rowst[2 * (wm * 64 + i * 32 + rl) + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(inv, fmaf(-mean, csum[e], v[e]), bias[e]);
+          } else {
+            v = v + bias;
+          }
           if (p.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
           if (p.residual) v = v + ld4(p.residual + (size_t)row * p.ldr + col);
           st4(p.y + (size_t)row * p.ldy + col, v);
+          if (p.stats_out) {                             // the 16 lanes of a row group hold this wave's 64 columns of the row
+            float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+            float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            s1 = row16_sum(s1); s2 = row16_sum(s2);
+            if ((lane & 15) == 0) {
+              float* so = p.stats_out + ((size_t)row * (p.N / 64) + (n0 + wn * 64) / 64) * 2;
+              so[0] = s1; so[1] = s2;
+            }
+          }
         }
       }
     }
@@ -199,7 +229,9 @@ extern "C" int vcr_split_bf16x3_f32(const float* x, void* planes, size_t n, vcr_
 
 extern "C" int vcr_linear_bf16x3_f32(const vcr_linear_args* a, const void* w_planes, vcr_stream_t stream) {
   if (!a || !a->x || !w_planes || !a->y) return VCR_EINVAL;
-  if (a->ln_stats_in || a->stats_out) return VCR_EUNSUPPORTED;   // LayerNorm fusion lives in vcr_linear_f32
+  if (a->ln_stats_in && (!a->ln_colsum || !a->bias || a->ln_nseg <= 0 || a->K < 2 || ((uintptr_t)a->ln_colsum & 15)))
+    return VCR_EINVAL;
+  if (a->stats_out && (a->N % 64)) return VCR_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % TK) != 0) return VCR_EINVAL;
   if ((a->ldx & 3) || a->ldx < a->K || a->ldy < a->N || (a->residual && a->ldr < a->N)) return VCR_EINVAL;
   if ((a->N % 4) || (a->ldy % 4) || ((uintptr_t)a->y & 15) || ((uintptr_t)a->x & 15) || ((uintptr_t)w_planes & 15))
@@ -207,7 +239,7 @@ extern "C" int vcr_linear_bf16x3_f32(const vcr_linear_args* a, const void* w_pla
   if ((a->bias && ((uintptr_t)a->bias & 15)) || (a->residual && ((a->ldr % 4) || ((uintptr_t)a->residual & 15))))
     return VCR_EINVAL;
   const int tiles_m = (a->M + TM - 1) / TM, tiles_n = (a->N + TN - 1) / TN;
-  const int lds = 2 * sizeof(Stage3);
+  const int lds = 2 * sizeof(Stage3) + TM * 2 * sizeof(float);
   static_assert(2 * sizeof(Stage3) >= 8 * 32 * 68 * 4, "epilogue slices fit");
   VCR_DYN_LDS(linear_bf16x3_kernel, lds);
   hipLaunchKernelGGL(linear_bf16x3_kernel, dim3(tiles_m * tiles_n), dim3(512), lds, (hipStream_t)stream, *a,

@@ -298,17 +298,18 @@ class VCRNet(nn.Module):
             mha("dec_cross", d + ".src_attn", True)
             ffn("enc_ffn", e + ".feed_forward"); ffn("dec_ffn", d + ".feed_forward")
             cw.has_pointer = 1
-            if self.linear_mode == "fp32":
-                # fp32 mode: LayerNorm folded into the six linears that consume one (linear.hip LN_IN)
-                for site, wk, bk, nk in (("enc_qkv", "enc_self.wqkv", "enc_self.bqkv", "enc_ln0"),
-                                         ("enc_ffn1", "enc_ffn.w_1.weight", "enc_ffn.w_1.bias", "enc_ln1"),
-                                         ("dec_qkv", "dec_self.wqkv", "dec_self.bqkv", "dec_ln0"),
-                                         ("dec_cross_q", "dec_cross.wq", "dec_cross.bq", "dec_ln1"),
-                                         ("dec_cross_kv", "dec_cross.wkv", "dec_cross.bkv", "enc_norm"),
-                                         ("dec_ffn1", "dec_ffn.w_1.weight", "dec_ffn.w_1.bias", "dec_ln2")):
-                    f = native.fold_layernorm(P[wk], P[bk], P[nk + ".a"], P[nk + ".b"])
-                    P["fold." + site] = f
-                    setattr(cw, "fold_" + site, native.FoldedW(*(native.ptr(t) for t in f)))
+            # LayerNorm folded into the six linears that consume one (linear.hip LN_IN; the bf16x3 kernel takes the same
+            # folded weight, pre-split below)
+            for site, wk, bk, nk in (("enc_qkv", "enc_self.wqkv", "enc_self.bqkv", "enc_ln0"),
+                                     ("enc_ffn1", "enc_ffn.w_1.weight", "enc_ffn.w_1.bias", "enc_ln1"),
+                                     ("dec_qkv", "dec_self.wqkv", "dec_self.bqkv", "dec_ln0"),
+                                     ("dec_cross_q", "dec_cross.wq", "dec_cross.bq", "dec_ln1"),
+                                     ("dec_cross_kv", "dec_cross.wkv", "dec_cross.bkv", "enc_norm"),
+                                     ("dec_ffn1", "dec_ffn.w_1.weight", "dec_ffn.w_1.bias", "dec_ln2")):
+                f = native.fold_layernorm(P[wk], P[bk], P[nk + ".a"], P[nk + ".b"])
+                P["fold." + site] = f
+                P["fold." + site + ".w"] = f[0]
+                setattr(cw, "fold_" + site, native.FoldedW(*(native.ptr(t) for t in f)))
         else:
             cw.has_pointer = 2 if isinstance(self.pointer, _Identity) else 0
         if self.linear_mode not in LINEAR_MODES:
@@ -316,10 +317,11 @@ class VCRNet(nn.Module):
         cw.linear_mode = LINEAR_MODES[self.linear_mode]
         if cw.linear_mode != 0 and self._emb_kind == "lpdnet":
             # weights pre-split into exact bf16 triplets for vcr_linear_bf16x3_f32 (fp32-equivalent products)
-            src = {"dg1_pq": "dg1_wpq", "sn1_pq": "sn1_wpq", "c3": "c3_w", "enc_qkv": "enc_self.wqkv",
-                   "enc_wo": "enc_self.wo", "enc_ffn1": "enc_ffn.w_1.weight", "enc_ffn2": "enc_ffn.w_2.weight",
-                   "dec_qkv": "dec_self.wqkv", "dec_self_wo": "dec_self.wo", "dec_cross_q": "dec_cross.wq",
-                   "dec_cross_kv": "dec_cross.wkv", "dec_cross_wo": "dec_cross.wo", "dec_ffn1": "dec_ffn.w_1.weight",
+            # (the six LayerNorm consumers: the FOLDED weight is what their main loop multiplies)
+            src = {"dg1_pq": "dg1_wpq", "sn1_pq": "sn1_wpq", "c3": "c3_w", "enc_qkv": "fold.enc_qkv.w",
+                   "enc_wo": "enc_self.wo", "enc_ffn1": "fold.enc_ffn1.w", "enc_ffn2": "enc_ffn.w_2.weight",
+                   "dec_qkv": "fold.dec_qkv.w", "dec_self_wo": "dec_self.wo", "dec_cross_q": "fold.dec_cross_q.w",
+                   "dec_cross_kv": "fold.dec_cross_kv.w", "dec_cross_wo": "dec_cross.wo", "dec_ffn1": "fold.dec_ffn1.w",
                    "dec_ffn2": "dec_ffn.w_2.weight"}
             for site, key in src.items():
                 if key in P:

@@ -197,7 +197,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 11         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 12         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -427,16 +427,21 @@ def split_bf16x3(w):
 
 
 @_guarded
-def linear_bf16x3(x, w_planes, n_out, bias=None, relu=False, residual=None, out=None):
+def linear_bf16x3(x, w_planes, n_out, bias=None, relu=False, residual=None, out=None, ln=None, want_stats=False):
+    """vcr_linear_bf16x3_f32; ln / want_stats as in linear() (w_planes = split_bf16x3 of the folded weight)."""
     L = lib()
     M, K = x.shape
     y = out if out is not None else _f32(M, n_out, device=x.device)
+    stats = _f32(M, n_out // 64, 2, device=x.device) if want_stats else None
     a = LinearArgs(ptr(x), x.stride(0), None, ptr(bias), ptr(residual),
                    residual.stride(0) if residual is not None else 0, ptr(y), y.stride(0), M, n_out, K, int(relu))
+    if ln is not None:
+        a.ln_stats_in, a.ln_nseg, a.ln_colsum, a.ln_eps = ptr(ln[0]), ln[0].shape[1], ptr(ln[1]), ln[2]
+    a.stats_out = ptr(stats)
     L.vcr_linear_bf16x3_f32.argtypes = [C.POINTER(LinearArgs), C.c_void_p, C.c_void_p]
     L.vcr_linear_bf16x3_f32.restype = C.c_int
     check(L.vcr_linear_bf16x3_f32(C.byref(a), ptr(w_planes), C.c_void_p(stream_ptr())), "vcr_linear_bf16x3_f32")
-    return y
+    return (y, stats) if want_stats else y
 
 
 @_guarded
