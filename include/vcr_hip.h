@@ -172,6 +172,15 @@ typedef struct {
   float* ymax; int ldymax; int zero_to;
 } vcr_edgerows_args;
 int vcr_edgerows_f32(const vcr_edgerows_args*, vcr_stream_t);
+/* The whole chain in one kernel (k = 20 or 40, else VCR_EUNSUPPORTED -- use the pieces above): pq = conv1's per-point
+ * (P | Q) rows [M, >= 128]; w2 [64,64], w3 [128,64], w4 [256,128] row-major [out][in] with their biases (BatchNorm
+ * folded); out [M, >= 512] = (x1 | x2 | x3 | x4) of vcrnet_model.py:109-118.  No per-edge tensor is written. */
+typedef struct {
+  const float* pq; int ldpq; const int32_t* idx; int k; int M; int n_per_cloud;
+  const float *w2, *b2, *w3, *b3, *w4, *b4;
+  float* out; int ldo;
+} vcr_edgechain_args;
+int vcr_edgechain_f32(const vcr_edgechain_args*, vcr_stream_t);
 typedef struct {
   const float* x; int ldx; int M, k, C; float* y; int ldy;
 } vcr_segmax_args;

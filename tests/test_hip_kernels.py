@@ -212,6 +212,43 @@ def test_edgerows_with_max_and_zero_base(nat):
     assert torch.equal(h0.cpu(), ref)
 
 
+@pytest.mark.parametrize("B,N,k", [(2, 300, 20), (3, 101, 20), (2, 130, 40), (16, 1024, 20)])
+def test_edgechain_equals_the_separate_kernels(nat, B, N, k):
+    """DGCNN's EdgeConv chain as ONE kernel (no per-edge tensor written) against the same chain run as separate
+    launches (edge rows, three GEMMs with the fused max): same fp32 MFMA products in the same order -> the same
+    bits; ragged point counts (M not a multiple of the 8- or 4-point group), both k of the path; and against fp64."""
+    g = torch.Generator().manual_seed(B * N + k)
+    M = B * N
+    pq = dev(torch.randn(M, 128, generator=g))
+    idx = dev(torch.randint(0, N, (M, k), generator=g).int())
+    W = [dev(torch.randn(o, i, generator=g) / math.sqrt(i)) for o, i in ((64, 64), (128, 64), (256, 128))]
+    bs = [dev(torch.randn(o, generator=g) * 0.3) for o in (64, 128, 256)]
+    cat = torch.full((M, 512), float("nan"), device="cuda")
+    h = nat.edgerows(pq, 64, idx, N, ymax=cat, zero_to=512)
+    col = 64
+    for wt, b in zip(W, bs):
+        last = wt.shape[0] == 256
+        h = nat.linear(h, wt, b, relu=True, segmax=(cat[:, col:col + wt.shape[0]], k), store=not last)
+        col += wt.shape[0]
+    out = torch.full((M, 512), float("nan"), device="cuda")
+    nat.edgechain(pq, idx, N, W[0], bs[0], W[1], bs[1], W[2], bs[2], out=out)
+    assert not torch.isnan(out).any()
+    diff = (out - cat).abs().max().item()
+    print(f"edgechain B={B} N={N} k={k}: max|chain - separate| = {diff:.2e}")
+    assert diff <= 2e-6
+    if M <= 1000:
+        P, Q = pq[:, :64].cpu().double(), pq[:, 64:].cpu().double()
+        nbr = idx.cpu().long() + (torch.arange(M) // N * N).view(-1, 1)
+        x = torch.relu(P[nbr] + Q[:, None, :])
+        ref = [x.max(1)[0]]
+        for wt, b in zip(W, bs):
+            x = torch.relu(x @ wt.cpu().double().t() + b.cpu().double())
+            ref.append(x.max(1)[0])
+        torch.testing.assert_close(out.cpu().double(), torch.cat(ref, 1), atol=2e-5, rtol=1e-5)
+    with pytest.raises(nat.VcrHipError):                   # other k: the caller falls back to the separate kernels
+        nat.edgechain(pq, idx[:, :10].contiguous(), N, W[0], bs[0], W[1], bs[1], W[2], bs[2])
+
+
 def test_layernorm(nat):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1000, 512, generator=g) * 3 + 0.5

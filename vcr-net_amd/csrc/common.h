@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <atomic>
+#include <utility>
 #include "../../include/vcr_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -42,6 +43,20 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// CUs of the current device (cached per device: the attribute query is cheap but not free)
+inline int vcr_cu_count() {
+  static std::atomic<int> cache[16];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const bool ok = dev >= 0 && dev < 16;
+  int n = ok ? cache[dev].load(std::memory_order_relaxed) : 0;
+  if (n <= 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    if (ok) cache[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
 
 // Sum over the 16 lanes of a DPP row with VALU-rate DPP moves (quad_perm xor 1, xor 2, then row_ror 4 and 8);
 // every lane ends with the full sum, in a fixed order.

@@ -75,7 +75,7 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
     w.so_s = bp.take<float>(B1 * K1 * 4); w.to_s = bp.take<float>(B1 * K1 * 4);
     w.peak = bp.take<float>(B1 * K1 * 2);
   }
-  if (emb_kind == 1) {
+  if (emb_kind == 1 && k != 20 && k != 40) {              // (k = 20 / 40 run the chain in one kernel: no per-edge tensor at all)
     const size_t Mk = M * k;
     w.eh1 = bp.take<float>(Mk * 64); w.eh2 = bp.take<float>(Mk * 64);
     w.eh3 = bp.take<float>(Mk * 128);                      // (conv4's [M*k, 256] output is only ever max-reduced: never stored)
@@ -352,14 +352,24 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       R.ok(vcr_linear_f32(&a, R.stream));
     };
     R.knn_join(1);
-    if (R.rc == 0) {
-      R.mark("gathermax:dg_c1");
-      vcr_edgerows_args a{w.pq1, 128, 64, w.idx3, k, M2, N, w.eh1, 64, w.cat, 512, 512};
-      R.ok(vcr_edgerows_f32(&a, R.stream));
+    if (k == 20 || k == 40) {
+      // the path's k: the whole chain in one kernel, the per-edge activations stay in LDS (edgechain.hip)
+      if (R.rc == 0) {
+        R.mark("edgeconv:dg_chain");
+        vcr_edgechain_args a{w.pq1, 128, w.idx3, k, M2, N, W->dgcnn.c2_w, W->dgcnn.c2_b, W->dgcnn.c3_w, W->dgcnn.c3_b,
+                             W->dgcnn.c4_w, W->dgcnn.c4_b, w.cat, 512};
+        R.ok(vcr_edgechain_f32(&a, R.stream));
+      }
+    } else {
+      if (R.rc == 0) {
+        R.mark("gathermax:dg_c1");
+        vcr_edgerows_args a{w.pq1, 128, 64, w.idx3, k, M2, N, w.eh1, 64, w.cat, 512, 512};
+        R.ok(vcr_edgerows_f32(&a, R.stream));
+      }
+      conv_max("linear:dg_c2", w.eh1, 64, W->dgcnn.c2_w, W->dgcnn.c2_b, w.eh2, 64, 64);
+      conv_max("linear:dg_c3", w.eh2, 64, W->dgcnn.c3_w, W->dgcnn.c3_b, w.eh3, 128, 128);
+      conv_max("linear:dg_c4", w.eh3, 128, W->dgcnn.c4_w, W->dgcnn.c4_b, nullptr, 256, 256);
     }
-    conv_max("linear:dg_c2", w.eh1, 64, W->dgcnn.c2_w, W->dgcnn.c2_b, w.eh2, 64, 64);
-    conv_max("linear:dg_c3", w.eh2, 64, W->dgcnn.c3_w, W->dgcnn.c3_b, w.eh3, 128, 128);
-    conv_max("linear:dg_c4", w.eh3, 128, W->dgcnn.c4_w, W->dgcnn.c4_b, nullptr, 256, 256);
     R.linear("linear:conv3", w.cat, 512, W->dgcnn.c5_w, nullptr, W->dgcnn.c5_b, w.emb, E, M2, E, 512, 1, nullptr, 0, nullptr,
              nullptr, const_cast<float*>(stats_for_ln));
   } else {

@@ -687,19 +687,6 @@ __global__ __launch_bounds__(256, 2) void linear_persist_kernel(vcr_linear_args 
 #endif
 }
 
-// CUs of the current device (cached per device: the attribute query is cheap but not free)
-inline int vcr_cu_count() {
-  static std::atomic<int> cache[16];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  const bool ok = dev >= 0 && dev < 16;
-  int n = ok ? cache[dev].load(std::memory_order_relaxed) : 0;
-  if (n <= 0) {
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    if (ok) cache[dev].store(n, std::memory_order_relaxed);
-  }
-  return n;
-}
 
 }  // namespace
 

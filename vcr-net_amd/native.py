@@ -114,6 +114,12 @@ class EdgerowsArgs(C.Structure):
                 ("zero_to", C.c_int)]
 
 
+class EdgechainArgs(C.Structure):
+    _fields_ = [("pq", f32p), ("ldpq", C.c_int), ("idx", f32p), ("k", C.c_int), ("M", C.c_int), ("n_per_cloud", C.c_int),
+                ("w2", f32p), ("b2", f32p), ("w3", f32p), ("b3", f32p), ("w4", f32p), ("b4", f32p),
+                ("out", f32p), ("ldo", C.c_int)]
+
+
 class SegmaxArgs(C.Structure):
     _fields_ = [("x", f32p), ("ldx", C.c_int), ("M", C.c_int), ("k", C.c_int), ("C", C.c_int), ("y", f32p),
                 ("ldy", C.c_int)]
@@ -191,7 +197,7 @@ _SIGS = {
     "vcr_gathermax_f32": GathermaxArgs, "vcr_sdpa_f32": SdpaArgs, "vcr_sdpa_bf16x3_f32": SdpaArgs, "vcr_softcorr_f32": SoftcorrArgs,
     "vcr_rigid_svd_f32": RigidSvdArgs, "vcr_pairscore_f32": PairscoreArgs, "vcr_rankselect_f32": RankselectArgs,
     "vcr_gather_rows_f32": GatherArgs, "vcr_scoremass_f32": ScoremassArgs, "vcr_keymass_f32": KeymassArgs, "vcr_make_pairs_f32": MakePairsArgs,
-    "vcr_edgerows_f32": EdgerowsArgs, "vcr_segmax_f32": SegmaxArgs,
+    "vcr_edgerows_f32": EdgerowsArgs, "vcr_segmax_f32": SegmaxArgs, "vcr_edgechain_f32": EdgechainArgs,
 }
 
 _lib: Optional[C.CDLL] = None
@@ -624,6 +630,17 @@ def edgerows(pq, Cc, idx, n_per_cloud, ymax=None, zero_to=0):
     call("vcr_edgerows_f32", EdgerowsArgs(ptr(pq), pq.stride(0), Cc, ptr(idx), k, M, n_per_cloud, ptr(h), Cc,
                                           ptr(ymax), ymax.stride(0) if ymax is not None else 0, zero_to))
     return h
+
+
+@_guarded
+def edgechain(pq, idx, n_per_cloud, w2, b2, w3, b3, w4, b4, out=None):
+    """vcr_edgechain_f32: DGCNN's conv1-gather -> conv2 -> conv3 -> conv4 with the four maxima, one kernel (k = 20 / 40).
+    pq [M, >= 128] (P | Q), idx [M, k] -> out [M, 512] = (x1 | x2 | x3 | x4)."""
+    M, k = idx.shape
+    out = out if out is not None else _f32(M, 512, device=pq.device)
+    call("vcr_edgechain_f32", EdgechainArgs(ptr(pq), pq.stride(0), ptr(idx), k, M, n_per_cloud, ptr(w2), ptr(b2), ptr(w3),
+                                            ptr(b3), ptr(w4), ptr(b4), ptr(out), out.stride(0)))
+    return out
 
 
 @_guarded

@@ -59,6 +59,9 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
             return 2.0 * M1 * E * E, 4.0 * (2 * M1 * E + E * E)
         n, kk = (r(v) for v in _LINEAR_SHAPES[site])
         return 2.0 * M2 * n * kk, 4.0 * (M2 * kk + n * kk + M2 * n)
+    if fam == "edgeconv" and site == "dg_chain":
+        # DGCNN conv1-gather .. conv4 in one kernel: P|Q rows [M2,128] once, idx, the 512-wide maxima out
+        return 2.0 * M2 * k * (64 * 64 + 128 * 64 + 256 * 128), 4.0 * M2 * (128 + k + 512)
     if fam == "edgeconv":      # convDG2 on the per-edge features (the per-point half of convDG1 is linear:dg1_pq)
         # compulsory: P|Q rows [M2,256] once, idx, x1 and x2 out
         return 2.0 * M2 * k * 128 * 128, 4.0 * M2 * (256 + k + 256)
@@ -117,7 +120,7 @@ def gather_bytes(name: str, B: int, N: int, k: int = 20) -> float:
     fam, site = name.split(":", 1)
     M2 = 2 * B * N
     if fam == "edgeconv":
-        return 4.0 * M2 * k * 128
+        return 4.0 * M2 * k * (64 if site == "dg_chain" else 128)
     if fam == "gathermax" and site == "sn1":
         return 4.0 * M2 * k * 256
     if fam == "gathermax" and site == "dg_c1":
