@@ -52,6 +52,10 @@ int vcr_pointwise_f32(const vcr_pointwise_args*, vcr_stream_t);
 
 /* x_cf [B,3,N] channels-first -> xyz4 [B,N,4] rows (x, y, z, x^2+y^2+z^2): layout change only. */
 int vcr_rows4_f32(const float* x_cf, float* xyz4, int B, int N, vcr_stream_t);
+/* rows4 plus a K = 3 per-point linear in the same pass: pq[i][0:C] = W xyz_i + b, W [C, ldw >= 3] (DGCNN's first EdgeConv
+ * through the neighbour / centre split, vcrnet_model.py:108).  C % 4 == 0, C / 4 divides 256. */
+int vcr_rows4_pq_f32(const float* x_cf, float* xyz4, int B, int N, const float* wpq, int ldw, const float* bpq, int C,
+                     float* pq, int ldpq, vcr_stream_t);
 
 /* ---- kernel 1: fused pairwise-distance + top-k (util/util.py:143-160) ----
  * D_ij = (-sq_j + 2 x_i.x_j) - sq_i ; idx = indices of the k largest D per row after dropping

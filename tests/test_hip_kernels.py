@@ -249,6 +249,26 @@ def test_edgechain_equals_the_separate_kernels(nat, B, N, k):
         nat.edgechain(pq, idx[:, :10].contiguous(), N, W[0], bs[0], W[1], bs[1], W[2], bs[2])
 
 
+def test_rows4_with_first_edgeconv_projection(nat):
+    """DGCNN's conv1 per point (K = 3) in the pass that lays the points out as rows: equal to the K-padded MFMA GEMM it
+    replaced (an fp32 fma chain in k order either way)."""
+    g = torch.Generator().manual_seed(5)
+    B, N = 3, 333
+    x = torch.randn(B, 3, N, generator=g)
+    w = torch.zeros(128, 32)
+    w[:, :3] = torch.randn(128, 3, generator=g)
+    b = torch.randn(128, generator=g)
+    rows, pq = nat.rows4_pq(dev(x), dev(w), dev(b))
+    assert torch.equal(rows, nat.to_rows4(dev(x)))
+    xin = torch.zeros(B * N, 32)
+    xin[:, :3] = x.transpose(1, 2).reshape(B * N, 3)
+    ref = nat.linear(dev(xin), dev(w), dev(b))
+    d = (pq - ref).abs().max().item()
+    print(f"rows4_pq vs padded GEMM: max|diff| = {d:.2e}")
+    assert d <= 1e-6
+    torch.testing.assert_close(pq.cpu().double(), xin.double() @ w.double().t() + b.double(), atol=2e-6, rtol=1e-6)
+
+
 def test_layernorm(nat):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1000, 512, generator=g) * 3 + 0.5

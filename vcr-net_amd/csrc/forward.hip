@@ -87,17 +87,6 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   return w;
 }
 
-// xin[row][0..31] = (x, y, z, 0, ..., 0): the K = 32 operand of DGCNN's first (split) EdgeConv projection
-__global__ __launch_bounds__(256) void xyz_pad32_kernel(const float* __restrict__ xyz4, float* __restrict__ xin, long M) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;    // one 16-B chunk per thread, 8 chunks per row
-  if (i >= M * 8) return;
-  const long row = i >> 3;
-  const int c = (int)(i & 7);
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (c == 0) { v = ld4(xyz4 + row * 4); v[3] = 0.f; }
-  st4(xin + row * 32 + c * 4, v);
-}
-
 struct Runner {
   hipStream_t stream; vcr_trace* tr; int rc = 0;
   void mark(const char* name) {
@@ -327,18 +316,12 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     // split (per-point P/Q + gather), conv2..conv4 as N*k-row GEMMs, max over the k edges after each, conv5 on the
     // 512-wide concatenation.  BatchNorm (eval mode) is folded into the weights by the host.
     if (W->linear_mode != 0) return VCR_EUNSUPPORTED;
-    for (int c = 0; c < 2 && R.rc == 0; ++c) {
+    for (int c = 0; c < 2 && R.rc == 0; ++c) {             // rows (x, y, z, |p|^2) and conv1's per-point (P | Q), one pass
       R.mark(c ? "pointwise:tgt" : "pointwise:src");
-      R.ok(vcr_rows4_f32(c ? io->tgt_cf : io->src_cf, w.xyz4 + (size_t)c * M1 * 4, B, N, R.stream));
+      R.ok(vcr_rows4_pq_f32(c ? io->tgt_cf : io->src_cf, w.xyz4 + (size_t)c * M1 * 4, B, N, W->dgcnn.c1_wpq, 32,
+                            W->dgcnn.c1_bpq, 128, w.pq1 + (size_t)c * M1 * 128, 128, R.stream));
     }
     R.knn("knn:xyz", vcr_knn_args{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2}, 1);
-    if (R.rc == 0) {
-      R.mark("pointwise:pad");
-      hipLaunchKernelGGL(xyz_pad32_kernel, dim3((unsigned)(((long)M2 * 8 + 255) / 256)), dim3(256), 0, R.stream, w.xyz4,
-                         w.feat64, (long)M2);
-      R.ok(VCR_LAUNCH_RC());
-    }
-    R.linear("linear:dg_c1_pq", w.feat64, 32, W->dgcnn.c1_wpq, nullptr, W->dgcnn.c1_bpq, w.pq1, 128, M2, 128, 32, 0);
     const int Mk = M2 * k;
     // Every x.max(dim=-1) of vcrnet_model.py:109-118 rides on the kernel that produces the per-edge rows: the edge-row
     // builder writes x1 (and the zero base of x2..x4), conv2..conv4 fold the max over each point's k rows into their

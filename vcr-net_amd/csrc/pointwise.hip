@@ -105,7 +105,38 @@ __global__ __launch_bounds__(256) void rows4_kernel(const float* x_cf, float* xy
   st4(xyz4 + i * 4, f32x4{x, y, z, (x * x + y * y) + z * z});
 }
 
+// rows4 + DGCNN's first EdgeConv projection per point (model/vcrnet_model.py:108 through the neighbour / centre split):
+// pq[i] = W xyz_i + b with W [C,ldw] (only its first three columns are non-zero: K = 3), C / 4 lanes per point.
+// The fp32 fma chain in k order is what the K-padded MFMA GEMM it replaces computes.
+__global__ __launch_bounds__(256) void rows4_pq_kernel(const float* x_cf, float* xyz4, int B, int N, const float* wpq,
+                                                       int ldw, const float* bpq, int C, float* pq, int ldpq) {
+  const int per = C / 4, cg = threadIdx.x % per;
+  const long i = (long)blockIdx.x * (256 / per) + threadIdx.x / per;
+  if (i >= (long)B * N) return;
+  const int b = (int)(i / N), n = (int)(i % N);
+  const float* xb = x_cf + (size_t)b * 3 * N;
+  const float x = xb[n], y = xb[N + n], z = xb[2 * N + n];
+  if (cg == 0) st4(xyz4 + i * 4, f32x4{x, y, z, (x * x + y * y) + z * z});
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float* wr = wpq + (size_t)(4 * cg + e) * ldw;
+    o[e] = fmaf(wr[2], z, fmaf(wr[1], y, wr[0] * x)) + bpq[4 * cg + e];
+  }
+  st4(pq + i * ldpq + 4 * cg, o);
+}
+
 }  // namespace
+
+extern "C" int vcr_rows4_pq_f32(const float* x_cf, float* xyz4, int B, int N, const float* wpq, int ldw, const float* bpq,
+                                int C, float* pq, int ldpq, vcr_stream_t stream) {
+  if (!x_cf || !xyz4 || !wpq || !bpq || !pq || B <= 0 || N <= 0) return VCR_EINVAL;
+  if (C <= 0 || (C % 4) || 256 % (C / 4) || ldw < 3 || ldpq < C || (ldpq & 3) || ((uintptr_t)pq & 15)) return VCR_EINVAL;
+  const int pts = 256 / (C / 4);
+  hipLaunchKernelGGL(rows4_pq_kernel, dim3((unsigned)(((long)B * N + pts - 1) / pts)), dim3(256), 0, (hipStream_t)stream,
+                     x_cf, xyz4, B, N, wpq, ldw, bpq, C, pq, ldpq);
+  return VCR_LAUNCH_RC();
+}
 
 extern "C" int vcr_rows4_f32(const float* x_cf, float* xyz4, int B, int N, vcr_stream_t stream) {
   if (!x_cf || !xyz4 || B <= 0 || N <= 0) return VCR_EINVAL;

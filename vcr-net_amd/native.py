@@ -600,6 +600,22 @@ def to_rows4(x_cf):
 
 
 @_guarded
+def rows4_pq(x_cf, wpq, bpq):
+    """vcr_rows4_pq_f32: [B,3,N] -> ([B,N,4] rows, [B*N, C] = W xyz + b with W [C, >= 3])."""
+    L = lib()
+    B, _, N = x_cf.shape
+    x = x_cf.contiguous().float()
+    Cc = wpq.shape[0]
+    out, pq = _f32(B, N, 4, device=x.device), _f32(B * N, Cc, device=x.device)
+    L.vcr_rows4_pq_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_int, C.c_void_p]
+    L.vcr_rows4_pq_f32.restype = C.c_int
+    check(L.vcr_rows4_pq_f32(ptr(x), ptr(out), B, N, ptr(wpq), wpq.stride(0), ptr(bpq), Cc, ptr(pq), Cc,
+                             C.c_void_p(stream_ptr())), "vcr_rows4_pq_f32")
+    return out, pq
+
+
+@_guarded
 def icp(src_cf, dst_cf, max_iterations=10, tolerance=0.001):
     """ICP.forward (model/icp_model.py:26-48) on the device: returns (final [B,3,N], R, t, R_ba, t_ba, iters)."""
     L = lib()
