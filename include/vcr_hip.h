@@ -78,8 +78,14 @@ typedef struct {
    * tie_events[1] has completed -- the caller makes its consumer wait for it (vcr_stream_wait_event).
    * tie_zeroed != 0: the caller guarantees tie_scratch[0] == 0 on entry (no memset is enqueued here). */
   vcr_stream_t tie_stream; void* tie_events[2]; int tie_zeroed;
+  /* tie_defer != 0: the tied rows are only listed; idx is final after a later vcr_knn_ties_f32 on these same args. */
+  int tie_defer;
 } vcr_knn_args;
 int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
+/* The tie replay of one (b == NULL) or two earlier vcr_knn_f32 calls made with tie_defer, as ONE launch: the replay is
+ * latency-bound (~25 us whatever the number of tied rows), so two kNN launches whose indices are consumed later -- the
+ * Cartesian and the feature-space kNN of LPDNet -- pay for it once. */
+int vcr_knn_ties_f32(const vcr_knn_args* a, const vcr_knn_args* b, vcr_stream_t);
 
 /* ---- pointwise linear / 1x1 conv: Y = act(X W^T + bias) (+ residual) ----
  * replaces nn.Conv1d/Conv2d(kernel 1) and nn.Linear on the path (lpdnet_model.py:123-135 after the

@@ -530,6 +530,24 @@ def test_linear_with_fused_layernorm(nat):
     assert err3 <= 5e-5, err3
 
 
+def test_knn_deferred_tie_replay_for_two_launches(nat):
+    """vcr_knn_args.tie_defer + vcr_knn_ties_f32: the Cartesian and the feature-space launch list their tied rows, one
+    replay launch serves both -- the same indices as two self-contained calls, on inputs built to tie massively."""
+    rs = np.random.RandomState(77)
+    B, N, k = 2, 1024, 20
+    side = int(np.ceil(N ** (1 / 3))) + 1
+    pts = np.stack([rs.permutation(side ** 3)[:N] for _ in range(B)])
+    xyz = np.stack([pts // (side * side), pts // side % side, pts % side], -1).astype(np.float32)      # [B,N,3]
+    x4 = dev(torch.from_numpy(np.concatenate((xyz, (xyz ** 2).sum(-1, keepdims=True)), -1)))
+    feat = dev(torch.from_numpy(rs.randint(0, 3, (B, N, 64)).astype(np.float32)))
+    sq = (feat ** 2).sum(-1)
+    ref_a, ref_b = nat.knn(x4, None, k), nat.knn(feat, sq, k)
+    a, b = nat.knn_pair_deferred(x4, None, feat, sq, k)
+    assert torch.equal(a, ref_a) and torch.equal(b, ref_b)
+    lazy = nat.knn(feat, sq, k, exact_ties=False)
+    assert not torch.equal(lazy, ref_b)                    # the replay did matter on this input
+
+
 @pytest.mark.parametrize("N,k", [(1024, 20), (2048, 20), (512, 40), (4096, 40), (333, 5), (1344, 20), (1343, 20)])
 def test_knn_exact_ties_follow_torch_topk(nat, N, k):
     """Exact distance ties at the k-th neighbour: Tensor.topk on the CPU is libstdc++'s nth_element (or partial_sort

@@ -159,14 +159,26 @@ struct Runner {
   // right before the first consumer of the indices
   const vcr_vcrnet_io* io_ = nullptr;
   bool sdpa_split = false;                               // linear_mode 2
-  void knn(const char* nm, vcr_knn_args a, int which) {
+  vcr_knn_args deferred[2];                              // kNN launches whose tie replay is still owed (knn_ties)
+  int n_deferred = 0;
+  void knn(const char* nm, vcr_knn_args a, int which, bool defer = false) {
     if (rc) return;
     mark(nm);
     a.tie_zeroed = 1;
     if (io_ && io_->aux_stream && io_->aux_events[2 * which] && io_->aux_events[2 * which + 1]) {
       a.tie_stream = io_->aux_stream; a.tie_events[0] = io_->aux_events[2 * which]; a.tie_events[1] = io_->aux_events[2 * which + 1];
+    } else if (defer && n_deferred < 2) {
+      a.tie_defer = 1;
+      deferred[n_deferred++] = a;
     }
     ok(vcr_knn_f32(&a, stream));
+  }
+  // one replay launch for every kNN deferred so far: to be called before the first consumer of any of their indices
+  void knn_ties() {
+    if (rc || n_deferred == 0) return;
+    mark("knn:ties");
+    ok(vcr_knn_ties_f32(&deferred[0], n_deferred == 2 ? &deferred[1] : nullptr, stream));
+    n_deferred = 0;
   }
   void knn_join(int which) {
     if (rc || !io_ || !io_->aux_stream || !io_->aux_events[2 * which + 1]) return;
@@ -365,9 +377,10 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   }
   // The Cartesian kNN (lpdnet_model.py:129) needs nothing but xyz: it goes first, so that its tie replay -- and, with an
   // auxiliary stream, the feature-space one too -- sits beside the kernels that do not read the indices.
-  R.knn("knn:xyz", vcr_knn_args{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2}, 1);
-  R.knn("knn:feat64", vcr_knn_args{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2}, 0);
+  R.knn("knn:xyz", vcr_knn_args{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2}, 1, true);
+  R.knn("knn:feat64", vcr_knn_args{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2}, 0, true);
   R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
+  R.knn_ties();                                          // both tie replays in one launch (one latency instead of two)
   R.knn_join(0);
   if (R.rc == 0) {
     R.mark("edgeconv:dg1_dg2");
@@ -621,7 +634,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 12; }
+extern "C" int vcr_abi_version(void) { return 13; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

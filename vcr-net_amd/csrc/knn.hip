@@ -777,7 +777,7 @@ __device__ int tb_partition_parallel(PairArr& q, int first, int last, int* A, in
 // One block per tied row: all threads recompute the row's N distances with the SAME arithmetic as the main kernels
 // (C == 64: the k-ascending fma chain the MFMA produces, then the -sq_j/2 step, then 2 acc - sq_i; C == 4: the VALU
 // expression of knn3_kernel), thread 0 replays the selection and rewrites the row's k indices.
-__global__ __launch_bounds__(256) void knn_tiebreak_kernel(vcr_knn_args a) {
+__device__ __forceinline__ void tiebreak_body(const vcr_knn_args& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* val = reinterpret_cast<float*>(smem);
   int* id = reinterpret_cast<int*>(val + a.N);
@@ -848,10 +848,16 @@ __global__ __launch_bounds__(256) void knn_tiebreak_kernel(vcr_knn_args a) {
   }
 }
 
-template <auto Kernel>
-int launch(dim3 grid, dim3 block, size_t lds, hipStream_t s, const vcr_knn_args& a) {
+__global__ __launch_bounds__(256) void knn_tiebreak_kernel(vcr_knn_args a) { tiebreak_body(a); }
+// the replays of two kNN launches in one launch (blockIdx.y picks the launch): one latency instead of two
+__global__ __launch_bounds__(256) void knn_tiebreak2_kernel(vcr_knn_args a, vcr_knn_args b) {
+  if (blockIdx.y == 0) tiebreak_body(a); else tiebreak_body(b);
+}
+
+template <auto Kernel, class... Args>
+int launch(dim3 grid, dim3 block, size_t lds, hipStream_t s, const Args&... a) {
   VCR_DYN_LDS(Kernel, (int)lds);                         // one cache per kernel: Kernel is a template argument
-  hipLaunchKernelGGL(Kernel, grid, block, lds, s, a);
+  hipLaunchKernelGGL(Kernel, grid, block, lds, s, a...);
   return VCR_LAUNCH_RC();
 }
 
@@ -866,6 +872,17 @@ extern "C" int vcr_dbg_timeline_knn(unsigned long long* host_dst, int clear) {
   return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(vcr_tl_knn), sizeof(unsigned long long) * 4096 * 8);
 }
 #endif
+
+static size_t tiebreak_lds(int N) { return (size_t)N * 16 + 256 + (16 + 2 * 256 + 2) * 4; }
+
+extern "C" int vcr_knn_ties_f32(const vcr_knn_args* a, const vcr_knn_args* b, vcr_stream_t stream) {
+  if (!a || !a->x || !a->idx || !a->tie_scratch || a->tie_cap < 1) return VCR_EINVAL;
+  if (b && (!b->x || !b->idx || !b->tie_scratch || b->tie_cap < 1)) return VCR_EINVAL;
+  const size_t lds = b ? (tiebreak_lds(a->N) > tiebreak_lds(b->N) ? tiebreak_lds(a->N) : tiebreak_lds(b->N)) : tiebreak_lds(a->N);
+  if (lds > 160 * 1024) return VCR_EUNSUPPORTED;
+  if (b) return launch<knn_tiebreak2_kernel>(dim3(64, 2), dim3(256), lds, (hipStream_t)stream, *a, *b);
+  return launch<knn_tiebreak_kernel>(dim3(64), dim3(256), lds, (hipStream_t)stream, *a);
+}
 
 extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->idx) return VCR_EINVAL;
@@ -908,8 +925,8 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   }
   if (rc != 0) return rc;
   // rows with an exact tie at the (k+1)-th value: replay libstdc++'s selection on them (see knn_tiebreak_kernel)
-  const size_t tb_lds = (size_t)a->N * 16 + 256 + (16 + 2 * 256 + 2) * 4;
-  if (a->tie_scratch && tb_lds <= 160 * 1024) {
+  const size_t tb_lds = tiebreak_lds(a->N);
+  if (a->tie_scratch && !a->tie_defer && tb_lds <= 160 * 1024) {
     if (a->tie_stream) {                                 // replay beside the caller's next launches (see vcr_hip.h)
       hipStream_t ts = (hipStream_t)a->tie_stream;
       hipError_t e = hipEventRecord((hipEvent_t)a->tie_events[0], s);

@@ -27,7 +27,8 @@ class PointwiseArgs(C.Structure):
 class KnnArgs(C.Structure):
     _fields_ = [("x", f32p), ("ldx", C.c_int), ("sq", f32p), ("B", C.c_int), ("N", C.c_int), ("C", C.c_int),
                 ("k", C.c_int), ("idx", f32p), ("tie_scratch", f32p), ("tie_cap", C.c_int), ("waves", C.c_int),
-                ("tie_stream", C.c_void_p), ("tie_events", C.c_void_p * 2), ("tie_zeroed", C.c_int)]
+                ("tie_stream", C.c_void_p), ("tie_events", C.c_void_p * 2), ("tie_zeroed", C.c_int),
+                ("tie_defer", C.c_int)]
 
 
 class LinearArgs(C.Structure):
@@ -203,7 +204,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 12         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 13         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -381,6 +382,25 @@ def knn(x, sq, k, exact_ties=True, waves=0):
     ties = torch.empty(1 + B * N, dtype=torch.int32, device=x.device) if exact_ties else None   # room for every row
     call("vcr_knn_f32", KnnArgs(ptr(x), x.stride(1), ptr(sq), B, N, Cc, k, ptr(idx), ptr(ties), B * N if exact_ties else 0, waves))
     return idx
+
+
+@_guarded
+def knn_pair_deferred(xa, sqa, xb, sqb, k):
+    """Two kNN launches with tie_defer and ONE vcr_knn_ties_f32 replay for both (the LPDNet pattern) -> (idx_a, idx_b)."""
+    L = lib()
+    args, keep = [], []
+    for x, sq in ((xa, sqa), (xb, sqb)):
+        B, N, Cc = x.shape
+        idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+        ties = torch.zeros(1 + B * N, dtype=torch.int32, device=x.device)
+        a = KnnArgs(ptr(x), x.stride(1), ptr(sq), B, N, Cc, k, ptr(idx), ptr(ties), B * N, 0)
+        a.tie_zeroed, a.tie_defer = 1, 1
+        call("vcr_knn_f32", a)
+        args.append(a); keep.append((idx, ties))
+    L.vcr_knn_ties_f32.argtypes = [C.POINTER(KnnArgs), C.POINTER(KnnArgs), C.c_void_p]
+    L.vcr_knn_ties_f32.restype = C.c_int
+    check(L.vcr_knn_ties_f32(C.byref(args[0]), C.byref(args[1]), C.c_void_p(stream_ptr())), "vcr_knn_ties_f32")
+    return keep[0][0], keep[1][0]
 
 
 @_guarded
