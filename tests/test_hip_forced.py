@@ -77,6 +77,35 @@ def test_fused_forward_teacher_forced_every_iteration(name):
             assert fR <= R_TOL and ft <= T_TOL, (it, fR, ft)
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "bf16x3+sdpa"])
+def test_exact_split_modes_on_the_partial_path(mode):
+    """The opt-in bf16x3 linears / attention (masked attention included: the decoder's pruned keys) with the
+    reference's selections forced: the BASELINE tolerance on every iteration of partial_n768_b2_it3."""
+    g = golden("partial_n768_b2_it3")
+    net, _ = build_net(partial=True, overlap2=float(g["overlap2"]))
+    net.linear_mode = mode
+    assert net.fused_supported()
+    tgt = torch.from_numpy(g["tgt"]).cuda()
+    for it in range(int(g["iters"])):
+        p = f"it{it}_"
+        cur, force = torch.from_numpy(g[p + "in"]).cuda(), golden_selections(g, p)
+        with torch.no_grad():
+            out = net._forward_fused(cur, tgt, force=force)
+            free = net._forward_fused(cur, tgt, want_selections=True)
+        assert np.array_equal(out[0].cpu().numpy(), g[p + "srcK"]) and np.array_equal(out[1].cpu().numpy(), g[p + "corrK"])
+        dR, dt = np.abs(out[2].cpu().numpy() - g[p + "R"]).max(), np.abs(out[3].cpu().numpy() - g[p + "t"]).max()
+        # free-running: the selections come out of the split-arithmetic embeddings -- the same flip bounds as fp32
+        fl = count_flips(free[6], force)
+        fR, ft = np.abs(free[2].cpu().numpy() - g[p + "R"]).max(), np.abs(free[3].cpu().numpy() - g[p + "t"]).max()
+        print(f"partial {mode} it{it}: forced max|dR| {dR:.2e} max|dt| {dt:.2e}; free-running flips {fl}, max|dR| {fR:.2e}")
+        assert dR <= R_TOL and dt <= T_TOL, (it, dR, dt)
+        B, N = cur.shape[0], cur.shape[2]
+        assert fl["keys"] <= max(2, 2 * B * N // 100) and fl["overlap"] <= max(4, B * N // 50)
+        assert fl["pairs"] <= max(2, fl["n_pairs"] // 20), fl
+        if fl["keys"] == fl["overlap"] == fl["pairs"] == 0:
+            assert fR <= R_TOL and ft <= T_TOL, (it, fR, ft)
+
+
 @pytest.mark.parametrize("name", ["partial_n192_b2_it2", "partial_n768_b2_it3"])
 def test_fused_iter_loop_teacher_forced(name):
     """ONE vcr_vcrnet_iter_f32 call (device-side loop, poses composed by pose_step) with the reference's selections of
