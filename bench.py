@@ -12,7 +12,9 @@ virtual-correspondence block -> soft correspondences -> SVD rigid solve) over on
 N=1024 points PER GPU (BASELINE.json configs[1]; weak scaling), inputs already resident in HBM, plus -- for N > 1 --
 the RCCL all-gather of the per-rank (R, t).  The K-step timed block (barrier + synchronize on both sides, MAX over
 ranks) is repeated until >= 2 s of GPU time have been spent so that external samplers see the load; the MEDIAN block
-is reported and every block's time is listed.  Prints ONE JSON line on rank 0.
+is reported and every block's time is listed.  The per-launch HIP events behind `roofline` / `stages` are recorded
+inside those same timed blocks, on every 5th step (--trace-every): ~35 event records cost ~2 % of a step that carries
+them.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -53,6 +55,9 @@ def parse(argv=None):
                     help="SURVEY 8d protocol without a budget: every thread count, B = --batch, median of 5")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the timed K-step block for this long")
     ap.add_argument("--stages", action="store_true", help="print the per-launch table to stderr")
+    ap.add_argument("--trace-every", type=int, default=5,
+                    help="record the per-launch HIP events (roofline / stage table) on every N-th step of each timed "
+                         "block: the ~35 event records cost ~2 %% of a step they are recorded in; 1 = every step")
     ap.add_argument("--linear-mode", default="fp32", choices=["fp32", "bf16x3", "bf16x3+sdpa"],
                     help="fp32: linears and attention on v_mfma_f32_32x32x2_f32 (default, the headline).  bf16x3: the "
                          "linears' products as exact 3-way bf16 splits on the bf16 matrix pipe (fp32-equivalent "
@@ -224,7 +229,9 @@ def run_rank(a):
     torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
-    traces = [native.LaunchTrace() for _ in range(a.steps)]
+    traced_steps = list(range(0, a.steps, max(1, a.trace_every)))      # steps of a block that carry per-launch events
+    traces = {i: native.LaunchTrace() for i in traced_steps}
+    nt = len(traced_steps)
 
     def fence():
         torch.cuda.synchronize()
@@ -242,7 +249,7 @@ def run_rank(a):
         fence()
         t0 = time.perf_counter()
         for i in range(a.steps):
-            step(traces[i].trace)
+            step(traces[i].trace if i in traces else None)
         fence()
         el = time.perf_counter() - t0
         if world > 1:
@@ -260,7 +267,7 @@ def run_rank(a):
 
     # per-launch durations from the HIP events recorded inside the (last) timed block
     fam_ms, fam_flops, fam_bytes, fam_gather, rows = {}, {}, {}, {}, {}
-    for tr in traces:
+    for tr in traces.values():
         for name, ms in tr.launches():
             fam = name.split(":")[0]
             fl, by = workmodel.launch_work(name, B, N, a.k, overlap2=net._overlap2)
@@ -305,11 +312,12 @@ def run_rank(a):
                 roof["traffic"] = sum(e["hbm_bytes_per_launch"] * n for e, n in zip(ents, nd)) / sum(nd)
                 roof["traffic_source"] = os.path.relpath(pmcs[-1], ROOT)
         total_ms = sum(fam_ms.values())
-        roof["launches_per_step"] = sum(r[3] for n, r in rows.items() if n.startswith(dom + ":")) // a.steps
-        roof["avg_launch_ms"] = fam_ms[dom] / max(1, roof["launches_per_step"] * a.steps)
+        roof["launches_per_step"] = sum(r[3] for n, r in rows.items() if n.startswith(dom + ":")) // nt
+        roof["avg_launch_ms"] = fam_ms[dom] / max(1, roof["launches_per_step"] * nt)
+        roof["timed_with"] = f"HIP events on {nt} of the {a.steps} steps of the last timed block"
         # gbs = HBM-compulsory bytes (each distinct row once) over the launch time; l2_gather_gbs = the k-fold
         # neighbour re-reads the EdgeConv kernels pull through L2 (not HBM traffic: never priced against 8 TB/s)
-        stages = {f: {"ms_per_step": fam_ms[f] / a.steps, "share": fam_ms[f] / total_ms,
+        stages = {f: {"ms_per_step": fam_ms[f] / nt, "share": fam_ms[f] / total_ms,
                       "tflops": fam_flops[f] / (fam_ms[f] * 1e-3) / 1e12, "gbs": fam_bytes[f] / (fam_ms[f] * 1e-3) / 1e9,
                       **({"l2_gather_gbs": fam_gather[f] / (fam_ms[f] * 1e-3) / 1e9} if fam_gather[f] else {})}
                   for f in sorted(fam_ms, key=fam_ms.get, reverse=True)}
@@ -318,14 +326,14 @@ def run_rank(a):
         # gathers included), time = its launches inside the timed region (all iterations)
         emb_sites = ("pointwise:", "knn:", "edgeconv:", "gathermax:", "linear:dg1_pq", "linear:sn1_pq", "linear:conv3",
                      "linear:dg_c")
-        emb_ms = sum(r[0] for n, r in rows.items() if n.startswith(emb_sites)) / a.steps
+        emb_ms = sum(r[0] for n, r in rows.items() if n.startswith(emb_sites)) / nt
         emb_bytes = 2.0 * N * (7448 + 784 * a.k) * B * a.iters
         emb_gf = a.iters * sum(workmodel.launch_work(n, B, N, a.k)[0] for n in
                                ("linear:dg1_pq", "edgeconv:dg1_dg2", "linear:sn1_pq", "linear:conv3")) / 1e9
         emb_stage = {"ms_per_step": emb_ms, "algorithmic_bytes_per_pair": emb_bytes / B / a.iters, "iters": a.iters,
                      "achieved_gbs": emb_bytes / (emb_ms * 1e-3) / 1e9,
                      "hbm_frac": emb_bytes / (emb_ms * 1e-3) / 1e9 / workmodel.PEAK_HBM_GBS,
-                     "knn_ms_per_step": sum(r[0] for n, r in rows.items() if n.startswith("knn:")) / a.steps,
+                     "knn_ms_per_step": sum(r[0] for n, r in rows.items() if n.startswith("knn:")) / nt,
                      "note": "fp32 1x1 convs of this stage are MFMA-bound (SURVEY section 7): %.1f GF per step alone "
                              "need %.2f ms at the fp32 matrix peak, i.e. <= %.2f of the HBM roofline"
                              % (emb_gf, emb_gf / workmodel.PEAK_MFMA_F32_TFLOPS,
@@ -347,7 +355,9 @@ def run_rank(a):
                        "num_points": N, "batch_per_gpu": B, "global_batch": B * world, "k": a.k, "iters": a.iters,
                        "parallelism": f"dp{world} (pairs sharded per rank, RCCL all-gather of R,t)"},
             "timed_blocks": {"count": len(blocks), "steps_per_block": a.steps, "reported": "median",
-                             "seconds": [round(b, 6) for b in blocks[:64]]},
+                             "seconds": [round(b, 6) for b in blocks[:64]],
+                             "per_launch_events": f"steps {traced_steps} of every block (a step that carries the ~35 event "
+                                                  "records runs ~2 % longer: the stage times sum to that step, not to ms_per_step)"},
             "roofline": roof,
             "stages": stages,
             "knn_edgeconv_stage": emb_stage,
