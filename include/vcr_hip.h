@@ -86,6 +86,10 @@ int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
  * latency-bound (~25 us whatever the number of tied rows), so two kNN launches whose indices are consumed later -- the
  * Cartesian and the feature-space kNN of LPDNet -- pay for it once. */
 int vcr_knn_ties_f32(const vcr_knn_args* a, const vcr_knn_args* b, vcr_stream_t);
+/* LPDNet's two independent searches (lpdnet_model.py:113,129) -- a64: C == 64 feature space, a3: C == 4 Cartesian -- as ONE
+ * launch when both are in the regime of the path (same k <= 20, >= 1024 query groups each, no tie_stream); otherwise
+ * exactly the two vcr_knn_f32 calls.  Same results either way. */
+int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3, vcr_stream_t);
 
 /* ---- pointwise linear / 1x1 conv: Y = act(X W^T + bias) (+ residual) ----
  * replaces nn.Conv1d/Conv2d(kernel 1) and nn.Linear on the path (lpdnet_model.py:123-135 after the

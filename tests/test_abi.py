@@ -32,7 +32,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.vcr_abi_version() == 13
+    assert lib.vcr_abi_version() == 14
     assert lib.vcr_strerror(0) == b"ok"
     assert b"invalid" in lib.vcr_strerror(-1)
     assert b"workspace" in lib.vcr_strerror(-2)

@@ -530,6 +530,19 @@ def test_linear_with_fused_layernorm(nat):
     assert err3 <= 5e-5, err3
 
 
+@pytest.mark.parametrize("B,N,k", [(32, 1024, 20), (2, 1024, 20), (16, 2048, 20), (4, 777, 9), (4, 1024, 40)])
+def test_knn_pair_equals_the_two_launches(nat, B, N, k):
+    """vcr_knn_pair_f32 (LPDNet's two searches in one launch; falls back to two launches outside the path's regime):
+    the same indices as the self-contained calls, ties included."""
+    rs = np.random.RandomState(B * N + k)
+    feat = dev(torch.from_numpy(rs.randint(0, 4, (B, N, 64)).astype(np.float32) + rs.randn(B, N, 64).astype(np.float32) * (B % 3 == 0)))
+    xyz = rs.randint(0, 12, (B, N, 3)).astype(np.float32) if B == 4 else rs.randn(B, N, 3).astype(np.float32)
+    x4 = dev(torch.from_numpy(np.concatenate((xyz, (xyz ** 2).sum(-1, keepdims=True)), -1)))
+    sq = (feat ** 2).sum(-1)
+    a, b = nat.knn_pair(feat, sq, x4, k)
+    assert torch.equal(a, nat.knn(feat, sq, k)) and torch.equal(b, nat.knn(x4, None, k))
+
+
 def test_knn_deferred_tie_replay_for_two_launches(nat):
     """vcr_knn_args.tie_defer + vcr_knn_ties_f32: the Cartesian and the feature-space launch list their tied rows, one
     replay launch serves both -- the same indices as two self-contained calls, on inputs built to tie massively."""

@@ -173,6 +173,20 @@ struct Runner {
     }
     ok(vcr_knn_f32(&a, stream));
   }
+  // LPDNet's two independent searches as one launch (vcr_knn_pair_f32), their tie replays deferred to knn_ties()
+  void knn_pair(const char* nm, vcr_knn_args a64, vcr_knn_args a3) {
+    if (rc) return;
+    if (io_ && io_->aux_stream) {                        // replays on the auxiliary stream: the self-contained calls
+      knn("knn:xyz", a3, 1);
+      knn("knn:feat64", a64, 0);
+      return;
+    }
+    mark(nm);
+    a64.tie_zeroed = a3.tie_zeroed = 1;
+    a64.tie_defer = a3.tie_defer = 1;
+    deferred[0] = a64; deferred[1] = a3; n_deferred = 2;
+    ok(vcr_knn_pair_f32(&a64, &a3, stream));
+  }
   // one replay launch for every kNN deferred so far: to be called before the first consumer of any of their indices
   void knn_ties() {
     if (rc || n_deferred == 0) return;
@@ -375,10 +389,10 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
                          w.xyz4 + (size_t)c * M1 * 4, w.feat64 + (size_t)c * M1 * 64, w.sq64 + (size_t)c * M1};
     R.ok(vcr_pointwise_f32(&a, R.stream));
   }
-  // The Cartesian kNN (lpdnet_model.py:129) needs nothing but xyz: it goes first, so that its tie replay -- and, with an
-  // auxiliary stream, the feature-space one too -- sits beside the kernels that do not read the indices.
-  R.knn("knn:xyz", vcr_knn_args{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2}, 1, true);
-  R.knn("knn:feat64", vcr_knn_args{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2}, 0, true);
+  // The feature-space and the Cartesian kNN (lpdnet_model.py:113,129) are independent: one launch for both, and one
+  // tie replay for both right before the first consumer of the indices.
+  R.knn_pair("knn:feat64+xyz", vcr_knn_args{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2},
+             vcr_knn_args{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2});
   R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
   R.knn_ties();                                          // both tie replays in one launch (one latency instead of two)
   R.knn_join(0);
@@ -634,7 +648,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 13; }
+extern "C" int vcr_abi_version(void) { return 14; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

@@ -295,14 +295,12 @@ __device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args&
 // Workgroup = W waves = W/S query tiles of 32 queries; wave (qt, part) scans candidate tiles part, part+S, ...
 // (W = 4, or 2 for k > 20 whose longer logs would otherwise leave one workgroup per CU)
 template <int KS, int S, int W>
-__global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
+__device__ __forceinline__ void knn64_body(const vcr_knn_args& a, int bx, int b) {   // block bx of cloud b
   using G = GeomMfma;
   constexpr int PEND = pend_of<KS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, col = lane & 31;
-  int bx, b;
-  xcd_chunk2(bx, b);                                     // a cloud's query tiles share one XCD's L2
   const int qt = wave / S, part = wave % S;
   const int q0 = (bx * (W / S) + qt) * 32;       // this wave's 32 queries (may lie beyond N: clamped, not written)
   float* lv = reinterpret_cast<float*>(smem) + wave * (2 * (PEND + 1) * 32);
@@ -436,19 +434,23 @@ __global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
   KTL_FLUSH;
   finish<G, KS, S>(sel, a, b, q0 + col, wave, part, smem);
 }
+template <int KS, int S, int W>
+__global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
+  int bx, b;
+  xcd_chunk2(bx, b);                                     // a cloud's query tiles share one XCD's L2
+  knn64_body<KS, S, W>(a, bx, b);
+}
 
 // ---------------------------------------------------------------- C == 4 (xyz4, VALU)
 // Wave = 16 queries x 4 lanes (DPP quad = query); lane s of the quad computes the distances of candidates j = 4u + s.
 // S waves of a workgroup may split the candidates of a query group (small grids, k <= 20).
 template <int KS, int S>
-__global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
+__device__ __forceinline__ void knn3_body(const vcr_knn_args& a, int bx, int b) {
   using G = GeomQuad;
   constexpr int PEND = pend_of<KS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = lane & 3, qd = lane >> 2;
-  int bx, b;
-  xcd_chunk2(bx, b);
   const int grp = wave / S, part = wave % S;
   const int q0 = (bx * (4 / S) + grp) * 16;
   float* lv = reinterpret_cast<float*>(smem) + wave * (2 * (PEND + 1) * 16);
@@ -529,6 +531,28 @@ __global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
   }
   KTL_FLUSH;
   finish<G, KS, S>(sel, a, b, qi, wave, part, smem);
+}
+template <int KS, int S>
+__global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
+  int bx, b;
+  xcd_chunk2(bx, b);
+  knn3_body<KS, S>(a, bx, b);
+}
+
+// Both kNN graphs of an LPDNet pass in ONE launch (lpdnet_model.py:113,129 -- the feature-space and the Cartesian search
+// are independent): the first n64 workgroups run the MFMA kernel's body, the rest the Cartesian one.  Either kernel
+// alone is latency-bound at one wave per SIMD (1024 waves on 1024 SIMDs); launched together the second fills the
+// first one's idle issue slots, and the pair costs little more than the longer of the two.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void knn_pair_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
+  const int bid = (int)blockIdx.x;
+  if (bid < n64) {
+    const int lin = xcd_chunk(bid, n64);
+    knn64_body<KS, 1, 4>(a64, lin % gx64, lin / gx64);
+  } else {
+    const int lin = xcd_chunk(bid - n64, (int)gridDim.x - n64);
+    knn3_body<KS, 1>(a3, lin % gx3, lin / gx3);
+  }
 }
 
 // ---------------------------------------------------------------- exact replica of Tensor.topk's tie-breaking
@@ -882,6 +906,38 @@ extern "C" int vcr_knn_ties_f32(const vcr_knn_args* a, const vcr_knn_args* b, vc
   if (lds > 160 * 1024) return VCR_EUNSUPPORTED;
   if (b) return launch<knn_tiebreak2_kernel>(dim3(64, 2), dim3(256), lds, (hipStream_t)stream, *a, *b);
   return launch<knn_tiebreak_kernel>(dim3(64), dim3(256), lds, (hipStream_t)stream, *a);
+}
+
+// Feature-space (a64: C == 64) and Cartesian (a3: C == 4) kNN of the same pass as one launch (see knn_pair_kernel) when
+// both are in the one-list-per-query regime the path runs in (k <= 20, >= 1024 query groups each); any other shape, or
+// a tie_stream, simply makes the two self-contained calls.  Tie handling as in vcr_knn_f32 (tie_defer honoured; a
+// replay that is not deferred serves both launches at once).
+extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3, vcr_stream_t stream) {
+  if (!a64 || !a3 || !a64->x || !a3->x || !a64->idx || !a3->idx || a64->C != 64 || a3->C != 4) return VCR_EINVAL;
+  const bool fusable = a64->k == a3->k && a64->k <= 20 && !a64->tie_stream && !a3->tie_stream && a64->waves == 0 && a3->waves == 0 &&
+                       (long)((a64->N + 31) / 32) * a64->B >= 1024 && (long)((a3->N + 15) / 16) * a3->B >= 1024 &&
+                       (a64->tie_scratch != nullptr) == (a3->tie_scratch != nullptr) && a64->tie_defer == a3->tie_defer;
+  if (!fusable) {
+    const int rc = vcr_knn_f32(a3, stream);
+    return rc ? rc : vcr_knn_f32(a64, stream);
+  }
+  for (const vcr_knn_args* a : {a64, a3}) {
+    if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k + 1 > a->N || a->N > 65535 || a->ldx < a->C || (a->ldx & 3)) return VCR_EINVAL;
+    if (a->tie_scratch && a->tie_cap < 1) return VCR_EINVAL;
+  }
+  if (!a64->sq) return VCR_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  for (const vcr_knn_args* a : {a64, a3})
+    if (a->tie_scratch && !a->tie_zeroed) {
+      const hipError_t e = hipMemsetAsync(a->tie_scratch, 0, sizeof(int32_t), s);
+      if (e != hipSuccess) return (int)e;
+    }
+  const int gx64 = (a64->N + 127) / 128, gx3 = (a3->N + 63) / 64;      // 4 waves x 32 queries / 4 waves x 16 queries
+  const int n64 = gx64 * a64->B, n3 = gx3 * a3->B;
+  const size_t lds64 = (size_t)4 * 2 * (pend_of<22>() + 1) * 32 * 4, lds3 = (size_t)4 * 2 * (pend_of<22>() + 1) * 16 * 4;
+  int rc = launch<knn_pair_kernel<22>>(dim3(n64 + n3), dim3(256), lds64 > lds3 ? lds64 : lds3, s, *a64, *a3, n64, gx64, gx3);
+  if (rc == 0 && a64->tie_scratch && !a64->tie_defer) rc = vcr_knn_ties_f32(a64, a3, stream);
+  return rc;
 }
 
 extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {

@@ -204,7 +204,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 13         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 14         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -382,6 +382,24 @@ def knn(x, sq, k, exact_ties=True, waves=0):
     ties = torch.empty(1 + B * N, dtype=torch.int32, device=x.device) if exact_ties else None   # room for every row
     call("vcr_knn_f32", KnnArgs(ptr(x), x.stride(1), ptr(sq), B, N, Cc, k, ptr(idx), ptr(ties), B * N if exact_ties else 0, waves))
     return idx
+
+
+@_guarded
+def knn_pair(feat, sq, xyz4, k):
+    """vcr_knn_pair_f32: the feature-space (feat [B,N,64], sq [B,N]) and the Cartesian (xyz4 [B,N,4]) kNN in one launch
+    -> (idx_feat, idx_xyz), tie replay included."""
+    L = lib()
+    out, args, keep = [], [], []
+    for x, s_ in ((feat, sq), (xyz4, None)):
+        B, N, Cc = x.shape
+        idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
+        ties = torch.empty(1 + B * N, dtype=torch.int32, device=x.device)
+        args.append(KnnArgs(ptr(x), x.stride(1), ptr(s_), B, N, Cc, k, ptr(idx), ptr(ties), B * N, 0))
+        out.append(idx); keep.append(ties)
+    L.vcr_knn_pair_f32.argtypes = [C.POINTER(KnnArgs), C.POINTER(KnnArgs), C.c_void_p]
+    L.vcr_knn_pair_f32.restype = C.c_int
+    check(L.vcr_knn_pair_f32(C.byref(args[0]), C.byref(args[1]), C.c_void_p(stream_ptr())), "vcr_knn_pair_f32")
+    return out[0], out[1]
 
 
 @_guarded

@@ -47,6 +47,8 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
             return 0.0, 4.0 * M2 * (4 + 32)
         return 2.0 * M1 * (3 * 64 + 64 * 64), 4.0 * M1 * (3 + 4 + 64 + 1)
     if fam == "knn":
+        if site == "feat64+xyz":                           # both searches in one launch
+            return 2.0 * (64 + 3) * N * N * 2 * B, 4.0 * M2 * (64 + 1 + 4 + 2 * k)
         if site == "ties":                                 # the replay of the few rows with a boundary tie: latency only
             return 0.0, 4.0 * M2
         C = 64 if site == "feat64" else 3
