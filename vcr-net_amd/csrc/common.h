@@ -5,6 +5,7 @@
 #include <math.h>
 #include <atomic>
 #include <utility>
+#include <type_traits>
 #include "../../include/vcr_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

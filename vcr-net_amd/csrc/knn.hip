@@ -41,7 +41,14 @@ namespace {
 constexpr int TILE = 32;            // candidates per MFMA tile
 // log entries per query: room for the KS-1 entries a compaction can leave, the <= 16 a step adds, and slack so that
 // compactions stay rare
-template <int KS> constexpr int pend_of() { return KS <= 22 ? 64 : 96; }
+// Log capacity per query.  Measured for the MFMA kernel at k = 20 (MI355X, 32 clouds): 96 / 128 entries make the kernel
+// alone 7 % faster at N = 1024 (fewer compactions) but cost the second workgroup per CU at N = 2048 (+20 %) and the
+// co-residency of the one-launch kNN pair (+20 %): 64 stays.
+#ifndef VCR_KNN_PEND_MFMA
+#define VCR_KNN_PEND_MFMA 64
+#endif
+struct GeomMfma;
+template <class G, int KS> constexpr int pend_of() { return KS > 22 ? 96 : std::is_same<G, GeomMfma>::value ? VCR_KNN_PEND_MFMA : 64; }
 
 #ifdef VCR_TIMELINE
 // Experiment-only (profiles/timeline_knn.py, -DVCR_TIMELINE builds): wave 0 of every workgroup accumulates the 100 MHz
@@ -101,7 +108,7 @@ template <class G> __device__ __forceinline__ float gf_from_seg(float x, int whi
 // ---- per-query selection state of one wave: sorted top-KS values in registers (T per lane), (value, index) log in LDS
 template <class G, int KS>
 struct Selector {
-  static constexpr int PEND = pend_of<KS>();
+  static constexpr int PEND = pend_of<G, KS>();
   static constexpr int T = (KS + G::LPQ - 1) / G::LPQ;   // values per lane; the list holds LPQ*T >= KS values
   static constexpr int TL = (KS - 1) / T, TS = (KS - 1) % T;   // segment / slot of rank KS-1: the filter threshold
   float v[T];
@@ -297,7 +304,7 @@ __device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args&
 template <int KS, int S, int W>
 __device__ __forceinline__ void knn64_body(const vcr_knn_args& a, int bx, int b) {   // block bx of cloud b
   using G = GeomMfma;
-  constexpr int PEND = pend_of<KS>();
+  constexpr int PEND = pend_of<G, KS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, col = lane & 31;
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
 template <int KS, int S>
 __device__ __forceinline__ void knn3_body(const vcr_knn_args& a, int bx, int b) {
   using G = GeomQuad;
-  constexpr int PEND = pend_of<KS>();
+  constexpr int PEND = pend_of<G, KS>();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = lane & 3, qd = lane >> 2;
@@ -934,7 +941,7 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
     }
   const int gx64 = (a64->N + 127) / 128, gx3 = (a3->N + 63) / 64;      // 4 waves x 32 queries / 4 waves x 16 queries
   const int n64 = gx64 * a64->B, n3 = gx3 * a3->B;
-  const size_t lds64 = (size_t)4 * 2 * (pend_of<22>() + 1) * 32 * 4, lds3 = (size_t)4 * 2 * (pend_of<22>() + 1) * 16 * 4;
+  const size_t lds64 = (size_t)4 * 2 * (pend_of<GeomMfma, 22>() + 1) * 32 * 4, lds3 = (size_t)4 * 2 * (pend_of<GeomQuad, 22>() + 1) * 16 * 4;
   int rc = launch<knn_pair_kernel<22>>(dim3(n64 + n3), dim3(256), lds64 > lds3 ? lds64 : lds3, s, *a64, *a3, n64, gx64, gx3);
   if (rc == 0 && a64->tie_scratch && !a64->tie_defer) rc = vcr_knn_ties_f32(a64, a3, stream);
   return rc;
@@ -964,7 +971,7 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
     const int S = pick_s((long)((a->N + 31) / 32) * a->B), W = k20 ? 4 : 2;
     const dim3 grid((a->N + 32 * (W / S) - 1) / (32 * (W / S)), a->B);
-    const size_t lds = (size_t)W * 2 * ((k20 ? pend_of<22>() : pend_of<42>()) + 1) * 32 * 4;
+    const size_t lds = (size_t)W * 2 * ((k20 ? pend_of<GeomMfma, 22>() : pend_of<GeomMfma, 42>()) + 1) * 32 * 4;
     rc = !k20 ? launch<knn64_kernel<42, 1, 2>>(grid, dim3(128), lds, s, *a)
          : S == 1 ? launch<knn64_kernel<22, 1, 4>>(grid, dim3(256), lds, s, *a)
          : S == 2 ? launch<knn64_kernel<22, 2, 4>>(grid, dim3(256), lds, s, *a)
@@ -973,7 +980,7 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
     if (a->ldx < 4 || (a->ldx & 3)) return VCR_EINVAL;
     const int S = pick_s((long)((a->N + 15) / 16) * a->B);
     const dim3 grid((a->N + 16 * (4 / S) - 1) / (16 * (4 / S)), a->B);
-    const size_t lds = (size_t)4 * 2 * ((k20 ? pend_of<22>() : pend_of<42>()) + 1) * 16 * 4;
+    const size_t lds = (size_t)4 * 2 * ((k20 ? pend_of<GeomQuad, 22>() : pend_of<GeomQuad, 42>()) + 1) * 16 * 4;
     rc = !k20 ? launch<knn3_kernel<42, 1>>(grid, dim3(256), lds, s, *a)
          : S == 1 ? launch<knn3_kernel<22, 1>>(grid, dim3(256), lds, s, *a)
          : S == 2 ? launch<knn3_kernel<22, 2>>(grid, dim3(256), lds, s, *a)
