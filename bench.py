@@ -290,6 +290,11 @@ def run_rank(a):
                 peak = workmodel.PEAK_MFMA_BF16_TFLOPS / 6.0    # six bf16 MFMA products per fp32-equivalent MAC
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak,
                     "unit": "TFLOP/s", "frac": ach / peak, "traffic": None}
+            if not split:
+                # register-only MFMA loops on all 256 CUs, random operands (profiles/r2e_mfma_sustained_rates.txt): the
+                # fp32 matrix pipe is power-limited chip-wide below its nominal rate
+                roof["sustained_peak_measured"] = {"four_accumulators": 127.2, "one_accumulator": 135.6, "unit": "TFLOP/s",
+                                                   "frac_of_four_accumulator_rate": ach / 127.2}
             if split:
                 roof["note"] = "fp32-equivalent FLOPs; peak = 2500 TFLOP/s dense bf16 / 6 MFMAs per split product"
         else:
