@@ -48,6 +48,7 @@ def test_ctypes_structs_match_the_c_layout(tmp_path):
              "vcr_linear_args": native.LinearArgs, "vcr_layernorm_args": native.LayerNormArgs,
              "vcr_rowside_args": native.RowsideArgs, "vcr_edgeconv_args": native.EdgeconvArgs,
              "vcr_gathermax_args": native.GathermaxArgs, "vcr_edgerows_args": native.EdgerowsArgs,
+             "vcr_edgechain_args": native.EdgechainArgs,
              "vcr_segmax_args": native.SegmaxArgs, "vcr_sdpa_args": native.SdpaArgs,
              "vcr_keymass_args": native.KeymassArgs, "vcr_softcorr_args": native.SoftcorrArgs,
              "vcr_pairscore_args": native.PairscoreArgs, "vcr_scoremass_args": native.ScoremassArgs,
