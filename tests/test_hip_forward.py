@@ -340,10 +340,11 @@ def test_aux_stream_for_tie_replays_changes_nothing():
 
 def test_forward_captures_into_a_hip_graph():
     """vcr_vcrnet_forward_f32 neither allocates nor synchronises, so a whole forward records into ONE HIP graph
-    (torch.cuda.CUDAGraph) and its replays are bit-identical to the eager call -- repeatedly, with other work in
-    between.  Replays are issued on the capture stream: on this ROCm / torch build a replay on the legacy default stream
-    after unrelated default-stream work hung or faulted (cause not isolated; the graph holds kernel nodes and one memset node).
-    Measured on MI355X: replay and eager run the same 5.17 ms per step at configs[1] -- the path is GPU-bound."""
+    (torch.cuda.CUDAGraph) and its replays are bit-identical to the eager call -- repeatedly, on the capture stream and on
+    the default stream, with unrelated work in between.  (The tie counters are zeroed by a kernel, not hipMemsetAsync: with
+    a memset node in the graph a replay on the default stream after unrelated default-stream work hung or faulted on this
+    ROCm / torch build.)  Measured on MI355X: replay and eager run the same 5.17 ms per step at configs[1] -- the path is
+    GPU-bound."""
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import synth
     net, _ = build_net()
@@ -358,8 +359,10 @@ def test_forward_captures_into_a_hip_graph():
             st.synchronize()
             with torch.cuda.graph(g, stream=st):
                 out = net(s, t)
-            torch.cuda.synchronize()
-            for rep in range(4):
+        torch.cuda.synchronize()
+        for rep in range(6):
+            ctx = torch.cuda.stream(st) if rep % 2 else torch.cuda.stream(torch.cuda.current_stream())
+            with ctx:
                 for x in out[1:]:
                     x.zero_()
                 g.replay()

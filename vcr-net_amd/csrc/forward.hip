@@ -87,6 +87,11 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   return w;
 }
 
+__global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* p, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 struct Runner {
   hipStream_t stream; vcr_trace* tr; int rc = 0;
   void mark(const char* name) {
@@ -332,7 +337,10 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   const int M1 = B * N, M2 = 2 * M1;
   Runner R{(hipStream_t)stream, tr};
   R.io_ = io;
-  R.ok((int)hipMemsetAsync(w.ties, 0, (size_t)(M2 + 2) * sizeof(int32_t), R.stream));   // both tie counters (and the first block)
+  // both tie counters (and the first block).  A kernel, not hipMemsetAsync: the forward then records into a HIP graph of
+  // kernel nodes only
+  hipLaunchKernelGGL(zero_i32_kernel, dim3((unsigned)((M2 + 2 + 255) / 256)), dim3(256), 0, R.stream, w.ties, (long)(M2 + 2));
+  R.ok(VCR_LAUNCH_RC());
 #define SP(site) (W->linear_mode != 0 ? W->split.site : nullptr)
   R.sdpa_split = W->linear_mode == 2;
 
