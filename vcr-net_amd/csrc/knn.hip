@@ -904,6 +904,14 @@ extern "C" int vcr_dbg_timeline_knn(unsigned long long* host_dst, int clear) {
 }
 #endif
 
+// the tie counter is zeroed by a kernel, not hipMemsetAsync: a memset NODE in a captured HIP graph made replays on the
+// default stream hang on this ROCm build (see forward.hip)
+__global__ void zero_count_kernel(int32_t* p) { *p = 0; }
+static int zero_count(int32_t* p, hipStream_t s) {
+  hipLaunchKernelGGL(zero_count_kernel, dim3(1), dim3(1), 0, s, p);
+  return VCR_LAUNCH_RC();
+}
+
 static size_t tiebreak_lds(int N) { return (size_t)N * 16 + 256 + (16 + 2 * 256 + 2) * 4; }
 
 extern "C" int vcr_knn_ties_f32(const vcr_knn_args* a, const vcr_knn_args* b, vcr_stream_t stream) {
@@ -936,8 +944,8 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
   hipStream_t s = (hipStream_t)stream;
   for (const vcr_knn_args* a : {a64, a3})
     if (a->tie_scratch && !a->tie_zeroed) {
-      const hipError_t e = hipMemsetAsync(a->tie_scratch, 0, sizeof(int32_t), s);
-      if (e != hipSuccess) return (int)e;
+      const int e = zero_count(a->tie_scratch, s);
+      if (e != 0) return e;
     }
   const int gx64 = (a64->N + 127) / 128, gx3 = (a3->N + 63) / 64;      // 4 waves x 32 queries / 4 waves x 16 queries
   const int n64 = gx64 * a64->B, n3 = gx3 * a3->B;
@@ -955,8 +963,8 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
     if (a->tie_cap < 1) return VCR_EINVAL;
     if (a->tie_stream && (!a->tie_events[0] || !a->tie_events[1])) return VCR_EINVAL;
     if (!a->tie_zeroed) {
-      const hipError_t e = hipMemsetAsync(a->tie_scratch, 0, sizeof(int32_t), s);
-      if (e != hipSuccess) return (int)e;
+      const int e = zero_count(a->tie_scratch, s);
+      if (e != 0) return e;
     }
   }
   int rc = VCR_EUNSUPPORTED;
