@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 
 
 def main(argv=None):
-    """Returns {"ab": A->B metrics, "ba": B->A metrics, "pairs": n} on rank 0 (None elsewhere)."""
+    """Returns {"ab": A->B metrics, "ba": B->A metrics, "pairs": n, "returns": test_one_epoch's 17-tuple} on rank 0
+    (None elsewhere)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--items", type=int, default=64, help="test-set size (pairs)")
     ap.add_argument("--batch", type=int, default=16)
@@ -35,6 +36,8 @@ def main(argv=None):
     ap.add_argument("--partial", action="store_true")
     ap.add_argument("--cycle", action="store_true", help="args.cycle: second head for (R_ba, t_ba) + the B->A log line")
     ap.add_argument("--first-item", type=int, default=0)
+    ap.add_argument("--loss", default="pose", help="args.loss of the reference: pose | point | anything else = pose + 0.1 point")
+    ap.add_argument("--vcp-nn", default="topK", choices=("topK", "att", "dist"))
     ap.add_argument("--backend", default="nccl")
     a = ap.parse_args(argv)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -49,10 +52,10 @@ def main(argv=None):
     from vcrnet_amd import evalmetrics, shard, synth, weights
     from vcrnet_amd.module import VCRNet, vcrnetIcpNet, vcrnetIter
 
-    args = SimpleNamespace(emb_dims=512, cycle=a.cycle, emb_nn="lpdnet", pointer="transformer", vcp_nn="topK",
+    args = SimpleNamespace(emb_dims=512, cycle=a.cycle, emb_nn="lpdnet", pointer="transformer", vcp_nn=a.vcp_nn,
                            partial=a.partial, overlap2=synth.OVERLAP2_0575 if a.partial else 0.75, t3d=False, tfea=False,
                            n_blocks=1, dropout=0.0, ff_dims=1024, n_heads=4, max_iterations=50)
-    w = weights.generate_weights(1234, lpd=weights.load_lpd_fixture())
+    w = weights.generate_weights(1234, lpd=weights.load_lpd_fixture(), vcp_nn=a.vcp_nn)
     net = VCRNet(args)
     net.load_state_dict(w)
     net.emb_nn.k = a.k
@@ -60,7 +63,7 @@ def main(argv=None):
 
     lo, hi = shard.shard_range(a.items, rank, world)
     lo, hi = lo + a.first_item, hi + a.first_item
-    acc = evalmetrics.EvalAccumulator(cycle=a.cycle)
+    acc = evalmetrics.EvalAccumulator(cycle=a.cycle, loss=a.loss)
     kind = "object" if a.points <= 2048 else "uniform"
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -85,7 +88,7 @@ def main(argv=None):
             print(evalmetrics.EvalAccumulator.format_final_ba(mb))
         print(f"[{merged.num_examples} pairs on {world} GPU(s), {elapsed:.2f} s incl. pair construction and metrics]",
               flush=True)
-        result = {"ab": m, "ba": mb, "pairs": merged.num_examples}
+        result = {"ab": m, "ba": mb, "pairs": merged.num_examples, "returns": merged.returns()}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

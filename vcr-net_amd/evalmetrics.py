@@ -23,8 +23,10 @@ def transform_point_cloud(p: torch.Tensor, R: torch.Tensor, t: torch.Tensor) -> 
 
 @dataclass
 class EvalAccumulator:
-    """Running sums of test_one_epoch.  ``loss='pose'`` (util/initPara.py default)."""
+    """Running sums of test_one_epoch.  ``loss`` is args.loss: 'pose' (util/initPara.py default), 'point', anything
+    else = pose + 0.1 * point loss on the full clouds (vcrnet_model.py:597-605)."""
     cycle: bool = False
+    loss: str = "pose"
     num_examples: int = 0
     sums: Dict[str, float] = field(default_factory=lambda: dict(loss=0.0, loss_vcr=0.0, cycle=0.0, mse_ab=0.0,
                                                                  mae_ab=0.0, mse_ba=0.0, mae_ba=0.0))
@@ -44,7 +46,14 @@ class EvalAccumulator:
         eye = torch.eye(3, device=Rp.device).unsqueeze(0).repeat(B, 1, 1)
         mse = torch.nn.functional.mse_loss
         loss_pose = mse(torch.matmul(Rp.transpose(2, 1), R_ab), eye) + mse(tp, t_ab)      # :606-607
-        self.sums["loss_vcr"] += loss_pose.item() * B                                       # args.loss == 'pose'
+        tsrcK = transform_point_cloud(srcK, R_ab, t_ab)                                     # :585
+        if self.loss == "pose":                                                             # :597-605
+            loss_vcr = loss_pose
+        elif self.loss == "point":
+            loss_vcr = mse(tsrcK, corrK)
+        else:
+            loss_vcr = loss_pose + 0.1 * mse(transform_point_cloud(src, Rp, tp), tgt)
+        self.sums["loss_vcr"] += loss_vcr.item() * B                                        # :609
         if self.cycle:                                                                      # :611-620
             rot = mse(torch.matmul(Rbp, Rp), eye)
             tr = torch.mean((torch.matmul(Rbp.transpose(2, 1), tp.view(B, 3, 1)).view(B, 3) + tbp) ** 2, dim=[0, 1])
@@ -52,7 +61,6 @@ class EvalAccumulator:
             loss_pose = loss_pose + cyc * 0.1
             self.sums["cycle"] += cyc.item() * 0.1 * B
         self.sums["loss"] += loss_pose.item() * B
-        tsrcK = transform_point_cloud(srcK, R_ab, t_ab)                                     # :585
         ttgt = transform_point_cloud(tgt, Rbp, tbp)                                         # :583
         self.sums["mse_ab"] += torch.mean((tsrcK - corrK) ** 2).item() * B                 # :626-627
         self.sums["mae_ab"] += torch.mean(torch.abs(tsrcK - corrK)).item() * B
@@ -63,6 +71,19 @@ class EvalAccumulator:
         self.euler_gt.append(np.asarray(euler_ab.cpu() if torch.is_tensor(euler_ab) else euler_ab))
         self.Rba_pred.append(Rbp.detach().cpu().numpy()); self.tba_pred.append(tbp.detach().cpu().numpy())   # :577-580
 
+    def returns(self):
+        """The 17-tuple test_one_epoch returns (vcrnet_model.py:645-649), in its order: mean pose loss (with the cycle
+        term when args.cycle), mean cycle loss, mse_ab, mae_ab, mse_ba, mae_ba, the stacked labels / predictions of
+        both directions, the Euler labels, mean args.loss."""
+        n = self.num_examples
+        Rg, tg, eg = np.concatenate(self.R_gt, 0), np.concatenate(self.t_gt, 0), np.concatenate(self.euler_gt, 0)
+        R_ba = np.swapaxes(Rg, 1, 2)
+        t_ba = -np.einsum("bij,bj->bi", R_ba, tg)
+        s = self.sums
+        return (s["loss"] / n, s["cycle"] / n, s["mse_ab"] / n, s["mae_ab"] / n, s["mse_ba"] / n, s["mae_ba"] / n,
+                Rg, tg, np.concatenate(self.R_pred, 0), np.concatenate(self.t_pred, 0), R_ba, t_ba,
+                np.concatenate(self.Rba_pred, 0), np.concatenate(self.tba_pred, 0), eg, -eg[:, ::-1], s["loss_vcr"] / n)
+
     def final_ba(self) -> Dict[str, float]:
         """testVCRNet's B -> A figures, :775,781-790: the predicted inverse pose against the loader's B -> A labels
         (R_ba = R_ab^T, t_ba = -R_ba t_ab, euler_ba = -euler_ab[::-1]; util/data.py:278,286,295), Euler angles of the
@@ -72,12 +93,12 @@ class EvalAccumulator:
         Rb, tb = np.concatenate(self.Rba_pred, 0), np.concatenate(self.tba_pred, 0)
         t_ba = -np.einsum("bji,bj->bi", Rg, tg)                             # -R_ab^T t_ab
         d = npmat2euler(Rb, "xyz") - np.degrees(-eg[:, ::-1])
-        r_mse = float(np.mean(d ** 2))
-        t_mse = float(np.mean((t_ba - tb) ** 2))
+        r_mse = np.mean(d ** 2)                 # np.float32 scalars, like the reference's: sqrt is taken in fp32
+        t_mse = np.mean((t_ba - tb) ** 2)
         mse_ba = self.sums["mse_ba"] / n
         return {"loss": self.sums["loss_vcr"] / n, "loss_pose": self.sums["loss"] / n, "mse": mse_ba,
-                "rmse": float(np.sqrt(mse_ba)), "mae": self.sums["mae_ba"] / n, "rot_mse": r_mse,
-                "rot_rmse": float(np.sqrt(r_mse)), "rot_mae": float(np.mean(np.abs(d))), "trans_mse": t_mse,
+                "rmse": float(np.sqrt(mse_ba)), "mae": self.sums["mae_ba"] / n, "rot_mse": float(r_mse),
+                "rot_rmse": float(np.sqrt(r_mse)), "rot_mae": float(np.mean(np.abs(d))), "trans_mse": float(t_mse),
                 "trans_rmse": float(np.sqrt(t_mse)), "trans_mae": float(np.mean(np.abs(t_ba - tb)))}
 
     def final(self) -> Dict[str, float]:
@@ -87,13 +108,13 @@ class EvalAccumulator:
         tg, eg = np.concatenate(self.t_gt, 0), np.concatenate(self.euler_gt, 0)
         e = npmat2euler(Rp)
         d = e - np.degrees(eg)
-        r_mse = float(np.mean(d ** 2))
-        t_mse = float(np.mean((tg - tp) ** 2))
+        r_mse = np.mean(d ** 2)                 # np.float32 scalars, like the reference's: sqrt is taken in fp32
+        t_mse = np.mean((tg - tp) ** 2)
         mse_ab = self.sums["mse_ab"] / n
         return {"loss": self.sums["loss_vcr"] / n, "loss_pose": self.sums["loss"] / n,
                 "cycle_loss": self.sums["cycle"] / n, "mse": mse_ab, "rmse": float(np.sqrt(mse_ab)),
-                "mae": self.sums["mae_ab"] / n, "rot_mse": r_mse, "rot_rmse": float(np.sqrt(r_mse)),
-                "rot_mae": float(np.mean(np.abs(d))), "trans_mse": t_mse, "trans_rmse": float(np.sqrt(t_mse)),
+                "mae": self.sums["mae_ab"] / n, "rot_mse": float(r_mse), "rot_rmse": float(np.sqrt(r_mse)),
+                "rot_mae": float(np.mean(np.abs(d))), "trans_mse": float(t_mse), "trans_rmse": float(np.sqrt(t_mse)),
                 "trans_mae": float(np.mean(np.abs(tg - tp)))}
 
     def merge(self, world: int, device="cpu") -> "EvalAccumulator":
@@ -120,7 +141,7 @@ class EvalAccumulator:
         pad[: rec.shape[0]] = torch.from_numpy(rec).to(device)
         g = shard.all_gather_poses(pad, world).view(world, per, -1).cpu().numpy()
         allrec = np.concatenate([g[r, : int(counts[r].item())] for r in range(world)], 0)
-        out = EvalAccumulator(cycle=self.cycle, num_examples=int(round(vec[-1].item())))
+        out = EvalAccumulator(cycle=self.cycle, loss=self.loss, num_examples=int(round(vec[-1].item())))
         out.sums = {k: float(vec[i].item()) for i, k in enumerate(keys)}
         out.R_gt, out.t_gt = [allrec[:, 0:9].reshape(-1, 3, 3)], [allrec[:, 9:12]]
         out.R_pred, out.t_pred = [allrec[:, 12:21].reshape(-1, 3, 3)], [allrec[:, 21:24]]

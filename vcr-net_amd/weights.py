@@ -93,6 +93,9 @@ def generate_weights(seed: int = 1234, lpd: Optional[Dict[str, torch.Tensor]] = 
       * ``bn.weight``             : 1 + 0.2 * U(-1,1); ``bn.bias``/``running_mean``: 0.1 * U(-1,1);
         ``running_var``           : 1 + 0.5 * U(0,1)
       * ``svd.reflect``           : diag(1, 1, -1)                         (vcrnet_model.py:353-354)
+      * ``head.linears_emb|linears_3d`` (VcpAtt): identity + 1e-3 * U(-1,1), bias 1e-3 * U(-1,1) -- the reference
+        initialises them to the identity with zero bias (util/initPara.py:57-65); the small perturbation keeps the
+        weight and bias paths observable without making the fixture ill-conditioned
     Keys present in ``lpd`` (the pretrained feature extractor) override the generated values
     AFTER generation, so the random stream does not depend on whether the fixture is used.
     """
@@ -105,6 +108,10 @@ def generate_weights(seed: int = 1234, lpd: Optional[Dict[str, torch.Tensor]] = 
         leaf = key.rsplit(".", 1)[-1]
         if key == "svd.reflect":
             t = torch.eye(3); t[2, 2] = -1
+        elif key.startswith("head.linears_"):
+            t = 1e-3 * u(shape)
+            if leaf == "weight":
+                t = t + torch.eye(shape[0])
         elif leaf == "a_2":
             t = 1 + 0.1 * u(shape)
         elif leaf == "b_2":
