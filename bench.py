@@ -5,13 +5,17 @@
 
 N > 1: one process per GPU over RCCL.  Either launched by torch.distributed.run (RANK / WORLD_SIZE in the
 environment) or plainly as above, in which case this process only spawns the N rank processes (fresh children started
-BEFORE anything here touches the GPU), waits for them and exits with their worst code; rank 0 prints the line.
+BEFORE anything here touches the GPU), waits for them and exits with their worst code; rank 0 prints the line.  A rank
+that dies or a run that passes --deadline-s takes every other rank down with it: the parent prints one JSON line with
+an "error" field, leaves each rank's stderr in gpurun_out/rank<r>.err and exits non-zero -- it never hangs.
+--strong: --batch is the GLOBAL batch, split evenly over the ranks (BASELINE configs[3]: --gpus 8 --points 2048
+--batch 128 --strong = 16 pairs per GPU); the default is weak scaling (--batch pairs per GPU).
 
 One "step" = one pass of the whole hot path (VCRNet.forward: LPDNet kNN-graph embedding -> Transformer
 virtual-correspondence block -> soft correspondences -> SVD rigid solve) over one batch of 16 synthetic pairs of
 N=1024 points PER GPU (BASELINE.json configs[1]; weak scaling), inputs already resident in HBM, plus -- for N > 1 --
 the RCCL all-gather of the per-rank (R, t).  The K-step timed block (barrier + synchronize on both sides, MAX over
-ranks) is repeated until >= 2 s of GPU time have been spent so that external samplers see the load; the MEDIAN block
+ranks) is repeated until >= 12 s of GPU time have been spent so that external samplers see the load; the MEDIAN block
 is reported and every block's time is listed.  The per-launch HIP events behind `roofline` / `stages` are recorded
 inside those same timed blocks, on every 5th step (--trace-every): ~35 event records cost ~2 % of a step that carries
 them.  Prints ONE JSON line on rank 0.
@@ -38,7 +42,13 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="pairs per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="pairs per GPU (with --strong: pairs in total)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --batch is the global batch, sharded evenly over the ranks")
+    ap.add_argument("--deadline-s", type=float, default=1200.0,
+                    help="N > 1: overall wall-clock limit; when it passes every rank is killed, their stacks are in "
+                         "gpurun_out/rank<r>.err and one JSON line with an \"error\" field is printed")
+    ap.add_argument("--init-timeout-s", type=float, default=120.0, help="torch.distributed rendezvous / collective timeout")
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--partial", action="store_true",
@@ -48,12 +58,12 @@ def parse(argv=None):
     ap.add_argument("--emb-nn", default="lpdnet", choices=["lpdnet", "dgcnn"],
                     help="feature extractor (--emb_nn of the reference; dgcnn uses seeded weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=75.0,
+    ap.add_argument("--cpu-budget-s", type=float, default=100.0,
                     help="wall-clock budget of the CPU-baseline thread sweep (each thread count: one warm-up, then up "
                          "to 5 timed runs while the budget lasts)")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="SURVEY 8d protocol without a budget: every thread count, B = --batch, median of 5")
-    ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the timed K-step block for this long")
+    ap.add_argument("--min-seconds", type=float, default=12.0, help="repeat the timed K-step block for this long")
     ap.add_argument("--stages", action="store_true", help="print the per-launch table to stderr")
     ap.add_argument("--trace-every", type=int, default=5,
                     help="record the per-launch HIP events (roofline / stage table) on every N-th step of each timed "
@@ -76,35 +86,84 @@ def model_args(partial=False, emb_nn="lpdnet"):
 
 # ---- N > 1 without torchrun: spawn the ranks ourselves -------------------------------------------------------------
 
+def _error_line(a, msg, logs=()):
+    """The one JSON line of a failed multi-rank run (same keys the driver parses, value null, plus `error`)."""
+    tails = {}
+    for r, path in enumerate(logs):
+        try:
+            with open(path, errors="replace") as f:
+                tails[str(r)] = f.read()[-600:]
+        except OSError:
+            pass
+    return json.dumps({"metric": "point-cloud pairs/sec (N=%d, batch %d%s)" % (a.points, a.batch, "" if a.strong else " per GPU"),
+                       "value": None, "unit": "pairs/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+                       "error": msg, "rank_stderr_tail": tails})
+
+
 def spawn_ranks(a) -> int:
-    """Start a.gpus fresh rank processes of this script (one per GPU, LOCAL_RANK = rank) and wait for them.  The parent
-    never initialises the GPU: torch.cuda.device_count() does not, and nothing else here touches HIP."""
+    """Start a.gpus fresh rank processes of this script (one per GPU, LOCAL_RANK = rank) and watch them.  The parent
+    never initialises the GPU (torch.cuda.device_count() does not, and nothing else here touches HIP) and never
+    re-executes itself.  Fail fast: the first rank that exits non-zero, or the deadline, ends the run -- the other ranks
+    (blocked in a collective by then) are killed by PID, stderr of every rank stays in gpurun_out/rank<r>.err."""
     ndev = torch.cuda.device_count()
     if a.backend == "nccl" and a.gpus > ndev:
         print(f"bench.py: --gpus {a.gpus} but {ndev} GPU(s) visible: one process per GPU", file=sys.stderr)
+        print(_error_line(a, f"--gpus {a.gpus} but {ndev} GPU(s) visible"), flush=True)
         return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    logdir = os.environ.get("VCR_BENCH_LOGDIR", os.path.join(ROOT, "gpurun_out"))
+    os.makedirs(logdir, exist_ok=True)
+    procs, logs, files = [], [], []
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+        logs.append(os.path.join(logdir, f"rank{r}.err"))
+        files.append(open(logs[-1], "w"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stderr=files[-1]))
+    deadline = time.monotonic() + a.deadline_s
+    failure = None
+    while failure is None:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failure = "rank %d exited with code %d" % bad[0]
+        elif all(c == 0 for c in codes):
+            break
+        elif time.monotonic() > deadline:
+            failure = "deadline of %.0f s passed (ranks still running: %s)" % (
+                a.deadline_s, [r for r, c in enumerate(codes) if c is None])
+        else:
+            time.sleep(0.1)
+    if failure is not None:
+        for p in procs:                        # exact PIDs of our own children
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    for f in files:
+        f.close()
+    if failure is not None:
+        print(f"bench.py: {failure}; see {logdir}/rank*.err", file=sys.stderr)
+        print(_error_line(a, failure, logs), flush=True)
+        return 1
+    for r, path in enumerate(logs):            # a clean run still forwards what the ranks said
+        with open(path, errors="replace") as f:
+            txt = f.read()
+        if txt.strip():
+            sys.stderr.write(f"--- rank {r} stderr ---\n{txt}")
+    return 0
 
 
 # ---- CPU baseline ----------------------------------------------------------------------------------------------------
 
-def cpu_baseline(w, B, N, k, partial=False, iters=1, budget_s=75.0, full=False):
+def cpu_baseline(w, B, N, k, partial=False, iters=1, budget_s=100.0, full=False, one_thread_full_s=30.0):
     """The CPU oracle (a port of the reference's PyTorch CPU path) timed on this box's host cores: the
     bench workload's own batch size, thread counts {1, 8, 16, 32, 64, nproc}, one warm-up then the median of up to 5
-    runs each.  The default run is bounded by `budget_s` (the 1-thread leg uses a 2-pair sample); `full` lifts the
-    bound.  `value` = the best thread count's pairs/s; the whole table is kept."""
+    runs each.  The default run is bounded by `budget_s` (the 1-thread leg starts on a 2-pair sample and adds ONE run at
+    the full batch size when that sample predicts it takes <= `one_thread_full_s`); `full` lifts the bound.  `value` = the best thread count's pairs/s; the whole table is kept."""
     import oracle
     from vcrnet_amd import synth
     ncpu = os.cpu_count() or 1
@@ -139,6 +198,12 @@ def cpu_baseline(w, B, N, k, partial=False, iters=1, budget_s=75.0, full=False):
                 oracle.vcrnet_iter(w, s, t, cfg, iters=iters)
                 ts.append(time.perf_counter() - t0)
             table[th] = {"pairs_per_s": nb / float(np.median(ts)), "sample_pairs": nb, "runs": len(ts)}
+            if nb < full_B and float(np.median(ts)) * full_B / nb <= one_thread_full_s:
+                # the 1-thread leg at the workload's own batch size when the sample says one run fits (warmed up above)
+                s, t = sample(full_B)
+                t0 = time.perf_counter()
+                oracle.vcrnet_iter(w, s, t, cfg, iters=iters)
+                table[th] = {"pairs_per_s": full_B / (time.perf_counter() - t0), "sample_pairs": full_B, "runs": 1}
     finally:
         torch.set_num_threads(prev)
     best = max(table, key=lambda th: table[th]["pairs_per_s"])
@@ -151,12 +216,14 @@ def cpu_baseline(w, B, N, k, partial=False, iters=1, budget_s=75.0, full=False):
                       f"best = {best} threads of os.cpu_count()={ncpu}"}
 
 
-def workload_label(a, Nfull, N, B, kind):
+def workload_label(a, Nfull, N, B, kind, world=1):
     if a.partial:
         base = ("BASELINE configs[2]" if (Nfull, B, a.iters) == (1024, 24, 3) else "partial-overlap (configs[2] recipe)") + \
             ": partial-to-partial overlap 0.575 (clouds cropped %d -> %d points), " % (Nfull, N)
     elif kind == "uniform":
         base = ("BASELINE configs[4]: kNN/EdgeConv stress, " if (N, a.k) == (4096, 40) else
+                "BASELINE configs[3] (global batch 128 sharded over 8 GPUs): " if (N == 2048 and a.strong and
+                                                                                    (a.batch, world) == (128, 8)) else
                 "BASELINE configs[3] (one GPU's share): " if N == 2048 else "") + "synthetic random clouds U(-0.5,0.5)^3, "
     else:
         base = ("BASELINE configs[1]: " if (N, B) == (1024, 16) else "configs[1] recipe: ") + \
@@ -180,23 +247,35 @@ def run_rank(a):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("VCR_BENCH_HANG_RANK") in (str(rank), "all"):     # fault injection for the deadline tests
+        time.sleep(1e6)
     ndev = torch.cuda.device_count()
     if a.backend == "nccl" and world > ndev:
         raise SystemExit(f"{world} ranks but {ndev} GPUs: one process per GPU")
     local = local % max(1, ndev)
+    if world > 1:
+        # a hung collective must not hang the run: past the deadline every thread's stack goes to stderr
+        # (gpurun_out/rank<r>.err when bench.py spawned the ranks) and the process exits non-zero
+        import faulthandler
+        faulthandler.dump_traceback_later(a.deadline_s, exit=True)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        tmo = datetime.timedelta(seconds=a.init_timeout_s)
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(a.backend)
+            dist.init_process_group(a.backend, timeout=tmo)
+    if os.environ.get("VCR_BENCH_FAIL_RANK") == str(rank):     # fault injection for tests/test_hip_multi.py
+        print(f"rank {rank}: injected failure", file=sys.stderr, flush=True)
+        os._exit(3)
 
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import native, shard, synth, weights, workmodel
-    from vcrnet_amd.module import VCRNet
+    from vcrnet_amd.module import VCRNet, vcrnetIter
 
     w = (weights.generate_weights(1234, lpd=weights.load_lpd_fixture()) if a.emb_nn == "lpdnet"
          else weights.generate_weights(1234, emb_nn="dgcnn"))
@@ -207,7 +286,12 @@ def run_rank(a):
     net = net.to(dev).eval()
 
     B, N = a.batch, a.points
-    # each rank owns B consecutive items of the global batch (weak scaling); inputs live in HBM
+    if a.strong:
+        if a.batch % world:
+            raise SystemExit(f"--strong: --batch {a.batch} does not divide over {world} ranks")
+        B = a.batch // world
+    # each rank owns B consecutive items of the global batch (weak scaling: B = --batch; strong: --batch / ranks);
+    # inputs live in HBM
     # object-like clouds have 2048 points (the ModelNet40 convention); larger N (configs 3/4) use uniform clouds
     # built on the device from base clouds + host-drawn permutations / poses (vcr_make_pairs_f32; untimed)
     kind = "object" if N < 2048 else "uniform"
@@ -216,8 +300,9 @@ def run_rank(a):
     assert src.shape == (B, 3, N) and src.is_cuda, src.shape
 
     def step(trace=None):
+        net.launch_trace = trace                # profiling hook of the module: per-launch HIP events on traced steps
         with torch.no_grad():
-            out = net._forward_fused(src, tgt, trace=trace, iters=a.iters)
+            out = vcrnetIter(net, src, tgt, iter=a.iters)      # the public entry point SURVEY 8d names (one C call)
         pose = torch.cat((out[2].view(B, 9), out[3]), 1)
         if world > 1:
             pose = shard.all_gather_poses(pose, world)
@@ -350,15 +435,17 @@ def run_rank(a):
                       + (f"  (+{r[4] / ms / 1e6:8.1f} GB/s L2 gathers)" if r[4] else ""), file=sys.stderr)
         pairs = B * world * a.steps
         line = {
-            "metric": "point-cloud pairs/sec (N=%d, batch %d per GPU)" % (Nfull, B), "value": pairs / elapsed, "unit": "pairs/s",
+            "metric": "point-cloud pairs/sec (N=%d, batch %d per GPU)" % (Nfull, B) if not a.strong else
+            "point-cloud pairs/sec (N=%d, global batch %d over %d GPU(s))" % (Nfull, a.batch, world), "value": pairs / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "f32 (linears as exact bf16x3 splits, fp32 accumulate)",
                       "bf16x3+sdpa": "f32 (linears and attention as exact bf16x3 splits, fp32 accumulate)"}[a.linear_mode],
             "data": "synthetic",
-            "config": {"workload": workload_label(a, Nfull, N, B, kind),
+            "config": {"workload": workload_label(a, Nfull, N, B, kind, world),
                        "num_points": N, "batch_per_gpu": B, "global_batch": B * world, "k": a.k, "iters": a.iters,
-                       "parallelism": f"dp{world} (pairs sharded per rank, RCCL all-gather of R,t)"},
+                       "parallelism": f"dp{world} (pairs sharded per rank, RCCL all-gather of R,t)",
+                       "entry_point": "vcrnet_amd.module.vcrnetIter(net, src, tgt, iter) -> vcr_vcrnet_iter_f32"},
             "timed_blocks": {"count": len(blocks), "steps_per_block": a.steps, "reported": "median",
                              "seconds": [round(b, 6) for b in blocks[:64]],
                              "per_launch_events": f"steps {traced_steps} of every block (a step that carries the ~35 event "

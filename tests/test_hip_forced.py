@@ -172,7 +172,8 @@ def test_config3_single_call_vs_oracle():
     ok = int(((fR <= R_TOL) & (ft <= T_TOL)).sum())
     print(f"config 3 free-running: {ok}/{B} pairs within tolerance, median|dR| {np.median(fR):.2e}, max|dR| {fR.max():.2e}")
     assert free[0].shape == (B, 3, 196) and torch.allclose(torch.det(free[2]).cpu(), torch.ones(B), atol=1e-5)
-    assert np.median(fR) < 1e-2 and fR.max() < 0.5
+    # the free-running bound lives in tests/test_selfdiv.py: against the RECORDED reference run of this very batch, inside
+    # the envelope of the reference's own float64 twin (tests/golden/selfdiv.npz)
 
 
 def test_forced_selections_are_rejected_in_whole_mode():

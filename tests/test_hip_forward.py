@@ -180,7 +180,8 @@ def test_iter_wrapper_with_cycle_returns_the_inverse_pose(vcp, iters):
     np.testing.assert_allclose(out[4].cpu().numpy(), R.transpose(1, 2).numpy(), atol=1e-6)
     np.testing.assert_allclose(out[5].cpu().numpy(), -torch.matmul(R.transpose(1, 2), tt.unsqueeze(2)).squeeze(2).numpy(),
                                atol=1e-6)
-    tol = 10 if vcp == "att" else 2           # VcpAtt's seeded-random projections amplify fp32 noise (see test_hip_variants)
+    tol = 2           # two composed passes / the cycle pair: the per-pass tolerance adds up (selfdiv.npz it2_n256: the
+                      # reference's own four runs spread by 8.8e-6 on the composed t)
     np.testing.assert_allclose(R.numpy(), ref[2].numpy(), atol=R_TOL)
     np.testing.assert_allclose(tt.numpy(), ref[3].numpy(), atol=tol * T_TOL)
     np.testing.assert_allclose(out[4].cpu().numpy(), ref[4].numpy(), atol=R_TOL)

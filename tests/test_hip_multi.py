@@ -81,6 +81,38 @@ def test_bench_spawns_its_own_ranks():
     assert j["timed_blocks"]["count"] >= 1 and j["timed_blocks"]["steps_per_block"] == 3
 
 
+def test_bench_kills_the_run_when_a_rank_dies_after_rendezvous():
+    """Rank 1 exits right after init_process_group (injected); rank 0 is by then blocked in its first collective.  The
+    parent notices the dead rank, kills rank 0 by PID and reports: rc != 0 within seconds, one JSON line with `error`."""
+    import tempfile
+    import time
+    env = dict(os.environ, VCR_BENCH_FAIL_RANK="1", VCR_BENCH_LOGDIR=tempfile.mkdtemp(prefix="vcr_bench_logs_"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3",
+                        "--warmup", "1", "--batch", "4", "--points", "256", "--min-seconds", "0.2", "--deadline-s", "300"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 240, (r.returncode, time.time() - t0)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["value"] is None and "rank 1 exited with code 3" in j["error"]
+    assert "injected failure" in j["rank_stderr_tail"]["1"]
+
+
+def test_bench_strong_scaling_shards_the_global_batch():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--batch", "8", "--strong", "--points", "256", "--min-seconds", "0.1"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["scaling"] == "strong" and j["config"]["global_batch"] == 8 and j["config"]["batch_per_gpu"] == 4
+
+
 def test_bench_under_torchrun_still_works():
     port = _free_port()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",

@@ -63,15 +63,7 @@ def test_cycle_consistency(name, kw):
     g, out = run(name, cycle=True, **kw)
     print(name, "max|dt|", np.abs(out[3].cpu().numpy() - g["it0_t"]).max(), "max|dt_ba|",
           np.abs(out[5].cpu().numpy() - g["it0_t_ba"]).max(), "max|dR_ba|", np.abs(out[4].cpu().numpy() - g["it0_R_ba"]).max())
-    if kw.get("vcp_nn") == "att":
-        # VcpAtt's seeded-random 512x512 projections amplify fp32 noise in the 512-d scores (see below): t gets 1e-4
-        assert_mostly_close(out[1].cpu().numpy(), g["it0_corrK"], atol=5e-4)
-        np.testing.assert_allclose(out[2].cpu().numpy(), g["it0_R"], atol=R_TOL)
-        np.testing.assert_allclose(out[4].cpu().numpy(), g["it0_R_ba"], atol=R_TOL)
-        np.testing.assert_allclose(out[3].cpu().numpy(), g["it0_t"], atol=1e-4)
-        np.testing.assert_allclose(out[5].cpu().numpy(), g["it0_t_ba"], atol=1e-4)
-    else:
-        check(g, out)
+    check(g, out)            # VcpAtt included: its projections carry the reference's identity init (util/initPara.py:57-62)
     # and the second pose is NOT merely the inverse of the first
     assert np.abs(out[4].cpu().numpy() - np.transpose(out[2].cpu().numpy(), (0, 2, 1))).max() > 1e-4
 
@@ -129,8 +121,8 @@ def test_fused_driver_covers_the_variant_and_matches_kernel_by_kernel(kw):
         f = net(s, t)
         c = composed.forward_composed(net, s, t)
     # the fused driver folds LayerNorm into the linears, the composition runs it as a kernel: fp32-noise apart
-    # (VcpAtt's seeded-random 512x512 projections amplify that noise in the scores: 1e-4 on t for that head)
-    t_tol = 1e-4 if kw.get("vcp_nn") == "att" else 3 * T_TOL
+    # (two HIP paths against each other, each within T_TOL of the reference: up to the sum; derived t_ba inherits |dR| |t|)
+    t_tol = 3 * T_TOL
     for i, tol in ((2, R_TOL), (3, t_tol), (4, R_TOL), (5, t_tol)):
         np.testing.assert_allclose(f[i].cpu().numpy(), c[i].cpu().numpy(), atol=tol)
     assert_mostly_close(f[1].cpu().numpy(), c[1].cpu().numpy(), atol=5e-4)

@@ -129,3 +129,44 @@ def test_eval_accumulator_merge_equals_single_process():
     for rank in (0, 1):
         for k, v in ref.items():
             assert abs(res[rank][k] - v) <= 1e-6 * max(1.0, abs(v)), (rank, k, res[rank][k], v)
+
+
+def _bench(args, env_extra, timeout=120):
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    logdir = tempfile.mkdtemp(prefix="vcr_bench_logs_")
+    env["VCR_BENCH_LOGDIR"] = logdir
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[0]) if lines else None), logdir, time.time() - t0
+
+
+def test_bench_multi_rank_run_fails_fast_when_a_rank_dies():
+    """`python bench.py --gpus 2`: a rank that exits non-zero ends the run at once (here, without a GPU, every rank
+    dies at torch.cuda.set_device): rc != 0, exactly one JSON line carrying `error`, per-rank stderr kept."""
+    r, j, logdir, el = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--deadline-s", "60"], {})
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: the ranks do not die here (covered by tests/test_hip_multi.py)")
+    assert r.returncode != 0 and el < 60
+    assert j is not None and j["value"] is None and "exited with code" in j["error"] and j["n_gpus"] == 2
+    assert sorted(os.listdir(logdir)) == ["rank0.err", "rank1.err"]
+    assert any(os.path.getsize(os.path.join(logdir, f)) > 0 for f in os.listdir(logdir))
+
+
+def test_bench_multi_rank_run_honours_its_deadline():
+    """Every rank hangs (injected before anything touches the GPU): the parent kills them at --deadline-s and says so."""
+    r, j, logdir, el = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--deadline-s", "4"],
+                              {"VCR_BENCH_HANG_RANK": "all"})
+    assert r.returncode != 0 and el < 60
+    assert j is not None and "deadline" in j["error"] and j["value"] is None

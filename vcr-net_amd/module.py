@@ -205,6 +205,9 @@ class VCRNet(nn.Module):
         # optional second stream for the kNN tie replays (native.AuxStream, VCRNET_AUX_STREAM=1).  Off by default:
         # measured on MI355X the two cross-stream joins cost what the overlap hides (3006 vs 3030 pairs/s at configs[1])
         self.use_aux_stream = os.environ.get("VCRNET_AUX_STREAM", "0") == "1"
+        # profiling hook: a native.Trace that the next forward() / vcrnetIter() call records its per-launch HIP events
+        # into (bench.py sets it on the steps it traces; None = no events)
+        self.launch_trace: Optional[native.Trace] = None
         self._aux: Dict[torch.device, native.AuxStream] = {}
 
     # -- checkpoints saved through nn.DataParallel carry a "module." prefix --
@@ -383,7 +386,7 @@ class VCRNet(nn.Module):
             if not self.fused_supported():
                 from .composed import forward_composed
                 return forward_composed(self, src, tgt)
-            return self._forward_fused(src, tgt)
+            return self._forward_fused(src, tgt, trace=self.launch_trace)
 
     def selection_sizes(self, N: int) -> Dict[str, int]:
         """Per-sample lengths of the partial-mode selections (transformer.py:41, vcrnet_model.py:208,284)."""
@@ -471,7 +474,7 @@ class VCRNet(nn.Module):
         self._check_call(src, tgt)
         if not self.fused_supported():
             return None
-        return self._forward_fused(src, tgt, iters=int(iters), iter_api=True)
+        return self._forward_fused(src, tgt, trace=self.launch_trace, iters=int(iters), iter_api=True)
 
 
 class DCP(VCRNet):
@@ -538,6 +541,10 @@ def vcrnetIter(net, src, tgt, iter=1):
     # scatter; with several device ids the wrapper must do its scatter / replicate, and the Python loop below drives it.
     inner = net.module if isinstance(net, nn.DataParallel) else net
     single = inner is net or len(getattr(net, "device_ids", ())) <= 1
+    if inner is not net and single and getattr(net, "device_ids", None):
+        # what DataParallel.forward's scatter does with one device id: inputs are moved to that device
+        dev = torch.device("cuda", net.device_ids[0]) if isinstance(net.device_ids[0], int) else torch.device(net.device_ids[0])
+        src, tgt = src.to(dev), tgt.to(dev)
     if isinstance(inner, VCRNet) and single and iter >= 1:
         out = inner.forward_iter(src, tgt, iter)
         if out is not None:
