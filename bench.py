@@ -72,6 +72,9 @@ def parse(argv=None):
                     help="fp32: linears and attention on v_mfma_f32_32x32x2_f32 (default, the headline).  bf16x3: the "
                          "linears' products as exact 3-way bf16 splits on the bf16 matrix pipe (fp32-equivalent "
                          "accuracy); bf16x3+sdpa: the attention products too.  Both are labelled in `dtype`")
+    ap.add_argument("--linear-mfma", type=int, default=0, choices=[0, 16, 32],
+                    help="MFMA shape of the fp32 linears: 0 = the library's choice, 16 = v_mfma_f32_16x16x4_f32, 32 = 32x32x2")
+    ap.add_argument("--sdpa-mfma", type=int, default=0, choices=[0, 16, 32], help="the same for the attention kernel")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm); gloo only "
                                                       "for exercising the multi-rank control flow on a 1-GPU box")
     return ap.parse_args(argv)
@@ -283,6 +286,7 @@ def run_rank(a):
     net.load_state_dict(w)
     net.emb_nn.k = a.k
     net.linear_mode = a.linear_mode
+    net.linear_mfma, net.sdpa_mfma = a.linear_mfma, a.sdpa_mfma
     net = net.to(dev).eval()
 
     B, N = a.batch, a.points

@@ -60,16 +60,19 @@ int vcr_rows4_pq_f32(const float* x_cf, float* xyz4, int B, int N, const float* 
 /* ---- kernel 1: fused pairwise-distance + top-k (util/util.py:143-160) ----
  * D_ij = (-sq_j + 2 x_i.x_j) - sq_i ; idx = indices of the k largest D per row after dropping
  * rank 0 ("topk(k+1)[:, :, 1:]").  C == 64 (feature space, fp32 MFMA) or C == 4 (xyz4 rows; Cartesian, VALU).
- * k <= 40, N <= 65535.  Exact ties at the (k+1)-th value: with tie_scratch the kept SET equals what Tensor.topk
- * (libstdc++ nth_element / partial_sort on the CPU) keeps; without it one of the tied candidates is kept
- * (deterministically, but not by a documented rule). */
+ * Limits of this library (the reference's knn has none): k <= 40 and N <= 65535, VCR_EUNSUPPORTED beyond.
+ * Exact ties at the (k+1)-th value: with tie_scratch the kept SET equals what Tensor.topk (libstdc++ nth_element /
+ * partial_sort on the CPU) keeps; without it one of the tied candidates is kept (deterministically, but not by a
+ * documented rule).  The replay holds a row's N distances in LDS up to N = 10 196; longer rows need tie_work
+ * (vcr_knn_tie_work_bytes(N) bytes of 16-B aligned device scratch) -- with tie_scratch set and tie_work missing such a
+ * call returns VCR_EUNSUPPORTED: the replay is never skipped silently. */
 typedef struct {
   const float* x; int ldx;            /* [B,N,C] rows                                  */
   const float* sq;                    /* [B,N] squared norms (C==64); ignored for C==4 */
   int B, N, C, k;
   int32_t* idx;                       /* [B,N,k], neighbour index within the cloud     */
   int32_t* tie_scratch; int tie_cap;  /* optional: [1 + tie_cap] ints of scratch (count, then the rows with a boundary
-                                         tie; 256 entries are plenty: ~1 row in 10^4 ties), N <= 20000 */
+                                         tie; 256 entries are plenty: ~1 row in 10^4 ties) */
   int waves;                          /* tuning / tests: waves of a workgroup that share one group of queries and split its
                                          candidates (1, 2 or 4); 0 = chosen from the grid size.  Never changes a result. */
   /* Optional overlap of the tie replay (a latency-bound kernel that keeps ~4 CUs busy for ~25 us) with whatever the
@@ -80,8 +83,10 @@ typedef struct {
   vcr_stream_t tie_stream; void* tie_events[2]; int tie_zeroed;
   /* tie_defer != 0: the tied rows are only listed; idx is final after a later vcr_knn_ties_f32 on these same args. */
   int tie_defer;
+  void* tie_work; size_t tie_work_bytes;   /* see above: NULL / 0 unless vcr_knn_tie_work_bytes(N) > 0 */
 } vcr_knn_args;
 int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
+size_t vcr_knn_tie_work_bytes(int N);
 /* The tie replay of one (b == NULL) or two earlier vcr_knn_f32 calls made with tie_defer, as ONE launch: the replay is
  * latency-bound (~25 us whatever the number of tied rows), so two kNN launches whose indices are consumed later -- the
  * Cartesian and the feature-space kNN of LPDNet -- pay for it once. */
@@ -104,8 +109,9 @@ typedef struct {
   int M, N, K;
   int relu;
   /* Optional LayerNorm fusion (transformer.py:141-144; all NULL/0 = plain linear; vcr_linear_f32 only):
-   * stats_out   [M, N/64, 2]: the epilogue also writes (sum y, sum y^2) per row and 64-column segment (N % 64 == 0);
-   * ln_stats_in [M, ln_nseg, 2]: such partial sums over the K columns of x.  The operation becomes
+   * stats_out   [M, N/64, 2]: the epilogue also writes, per row and 64-column segment (N % 64 == 0), (sum y, sum of
+   *             (y - segment mean)^2): moments that combine without cancellation (Chan et al.);
+   * ln_stats_in [M, ln_nseg, 2]: such partials over the K columns of x, K / ln_nseg columns per segment.  The operation becomes
    *             Y = act(LayerNorm(X) W0^T + bias0) for the Linear (W0, bias0) and LayerNorm (a, b) that were folded by
    *             vcr_fold_layernorm_f32 into w, bias and ln_colsum [N]:
    *             y = inv_m * (sum_k x[m,k] w[n,k] - mean_m * ln_colsum[n]) + bias[n],  inv = 1 / (std_unbiased + ln_eps). */
@@ -118,11 +124,11 @@ typedef struct {
   float* segmax_out; int ld_segmax; int seg_k;
   int variant;                        /* tuning / tests, 0 = automatic (LDS-DMA staging, one 128x128 tile per workgroup:
                                          BK 16 and four workgroups per CU without a residual, BK 32 with one).
-                                         bit3 (8) force BK 32, bit6 (64) force BK 16; bit2 (4) register staging instead of
-                                         LDS-DMA, bit0 (1) register-staged BK 16; bit5 (32) persistent workgroups with the
-                                         epilogue deferred under the next tile's MFMAs (measured slower; no alignment
-                                         requirement on y / bias / residual).  Same GEMM results in every variant; bit5
-                                         sums the row statistics of stats_out in a different fixed order. */
+                                         bit3 (8) force BK 32, bit6 (64) force BK 16; bit4 (16) force the 16x16x4 MFMA
+                                         shape, bit10 (1024) force 32x32x2; bit2 (4) the register-staged kernel without
+                                         alignment requirements on y / bias / residual (taken automatically when they
+                                         are not 16-B aligned).  BK and staging do not change results; the two MFMA shapes
+                                         sum k in different orders (fp32-rounding apart).  Any other bit: VCR_EINVAL. */
 } vcr_linear_args;
 int vcr_linear_f32(const vcr_linear_args*, vcr_stream_t);
 
@@ -215,6 +221,8 @@ typedef struct {
   int nbatch, heads, nq, nk; float scale; int kv_batch_shift;
   const uint8_t* key_keep; float* rowstat;
   float* score_out; int ld_score;
+  int variant;                        /* tuning / tests, 0 = automatic: bit4 (16) force the v_mfma_f32_16x16x4_f32 kernel,
+                                         bit10 (1024) force 32x32x2 (fp32-rounding apart); vcr_sdpa_f32 only */
 } vcr_sdpa_args;
 int vcr_sdpa_f32(const vcr_sdpa_args*, vcr_stream_t);
 /* The attention-output form of vcr_sdpa_f32 (out != NULL, rowstat == score_out == NULL, scale > 0) with Q, K, V and the
@@ -393,6 +401,13 @@ typedef struct {
   /* args.cycle (vcrnet_model.py:511-513): (R_ba, t_ba) from a second head + solve with the clouds swapped
    * (soft heads only) instead of the inverse of (R_ab, t_ab) */
   int cycle;
+  /* MFMA shape of the fp32 linears / attention launches of the forward: 0 = the library's choice, 16 =
+   * v_mfma_f32_16x16x4_f32, 32 = v_mfma_f32_32x32x2_f32 (benchmarks / tests; results agree to fp32 rounding) */
+  int linear_mfma, sdpa_mfma;
+  /* partial mode: the decoder's cross-attention scores ([2B,H,N,N] fp32) are kept between the statistics pass and the
+   * key-mass pass when they fit this many MiB of workspace (0 = 4096), and recomputed per head otherwise (< 0: never
+   * kept).  Same kept-key set either way up to summation order. */
+  int xscore_limit_mb;
 } vcr_vcrnet_weights;
 
 typedef struct {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-shape timing of vcr_linear_f32 for the 14 linear launches of one forward at BASELINE configs[1]
-(M = 2*16*1024 rows): the opt-in persistent kernel (variant 32, deferred epilogue) vs the default
-one-tile-per-workgroup kernels (variant 0) and BK 16 forced also with a residual (variant 64).  Run on the GPU box:  python profiles/bench_linear_shapes.py"""
+(M = 2*16*1024 rows, or --rows M): the 32x32x2 MFMA kernels (variant 1024) vs the 16x16x4 ones (variant 16), each with
+the automatic BK and with the other BK forced.  Run on the GPU box:  python profiles/bench_linear_shapes.py [--rows M]"""
 import os
 import sys
 
@@ -31,8 +31,12 @@ def bench(fn, reps=30):
 
 
 def main():
+    global M
+    if "--rows" in sys.argv:
+        M = int(sys.argv[sys.argv.index("--rows") + 1])
     dev = "cuda"
-    print(f"{'site':10s} {'N':>5s} {'K':>5s}  {'persist us':>10s} {'TF/s':>7s}   {'default us':>10s} {'TF/s':>7s}")
+    print(f"M = {M} rows; us per launch (TFLOP/s)")
+    print(f"{'site':10s} {'N':>5s} {'K':>5s}  {'32x32x2 auto':>18s} {'32x32x2 other BK':>18s} {'16x16x4 auto':>18s} {'16x16x4 other BK':>18s}")
     for name, N, K, res, ln, st in SHAPES:
         x = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) / K ** 0.5
@@ -44,12 +48,12 @@ def main():
             stats = torch.rand(M, K // 64, 2, device=dev) + 1.0
             lnarg = (stats, torch.randn(N, device=dev), 1e-6)
         out = []
-        for variant in (32, 0, 64):
+        other = 64 if res else 8                          # automatic: BK 32 with a residual, BK 16 without
+        for variant in (1024, 1024 | other, 16, 16 | other):
             fn = lambda: native.linear(x, w, b, residual=r, out=y, ln=lnarg, want_stats=bool(st), variant=variant)
             ms = bench(fn)
             out.append((ms * 1e3, 2.0 * M * N * K / (ms * 1e-3) / 1e12))
-        print(f"{name:10s} {N:5d} {K:5d}  {out[0][0]:10.1f} {out[0][1]:7.1f}   {out[1][0]:10.1f} {out[1][1]:7.1f}   "
-              f"bk16+res {out[2][0]:10.1f} {out[2][1]:7.1f}")
+        print(f"{name:10s} {N:5d} {K:5d}  " + " ".join(f"{u:9.1f} ({tf:6.1f})" for u, tf in out))
 
 
 if __name__ == "__main__":

@@ -87,7 +87,7 @@ def test_evaluate_main_vs_the_reference_harness(name):
     dR = np.abs(ret["rotations_ab_pred"] - c["ret/rotations_ab_pred"]).reshape(len(ret["rotations_ab_pred"]), -1).max(1)
     dt = np.abs(ret["translations_ab_pred"] - c["ret/translations_ab_pred"]).max(1)
     print(f"{name}: max|dR| {dR.max():.2e} max|dt| {dt.max():.2e} vs the reference's test_one_epoch")
-    mine = _floats(evaluate.evalmetrics.EvalAccumulator.format_final(res["ab"]))
+    mine = _floats(evalmetrics.EvalAccumulator.format_final(res["ab"]))
     ref = _floats(str(c["lines"][2]))
     assert mine.shape == ref.shape == (12,)
     if c["partial"] or c["iters"] == 0:
@@ -95,6 +95,15 @@ def test_evaluate_main_vs_the_reference_harness(name):
         assert ok.sum() >= len(ok) - 1, (dR, dt)
         np.testing.assert_allclose(mine, ref, rtol=2e-2, atol=2e-6)
     else:
-        tol_t = 1e-5 * max(1, c["iters"])             # composed over `iters` passes: the per-pass tolerance adds up
-        assert dR.max() <= 1e-4 and dt.max() <= tol_t, (dR, dt)
-        np.testing.assert_allclose(mine, ref, rtol=1e-3, atol=2e-6)
+        tol_R, tol_t = np.full(len(dR), 1e-4), np.full(len(dt), 1e-5 * max(1, c["iters"]))   # per pass; composed passes add up
+        rtol = 1e-3
+        if name == "whole_it2":
+            # passes after the first start from inputs that differ at 1e-7, so a kNN near-tie can resolve differently: the
+            # reference's own float64 twin moves pair 811 by 5.6e-3 (tests/golden/selfdiv.npz, it2_eval).  Tolerance per
+            # pair = BASELINE + what the reference's own runs differ by on that pair
+            sd = golden("selfdiv")
+            assert int(sd["it2_eval/first"]) == c["first"] and int(sd["it2_eval/B"]) == len(dR)
+            tol_R, tol_t = tol_R + sd["it2_eval/spread_R_pair"], tol_t + sd["it2_eval/spread_t_pair"]
+            rtol = 2e-2
+        assert (dR <= tol_R).all() and (dt <= tol_t).all(), (dR, dt, tol_R, tol_t)
+        np.testing.assert_allclose(mine, ref, rtol=rtol, atol=2e-6)

@@ -142,37 +142,87 @@ def test_linear(nat, M, N, K, relu, res):
     assert err <= 4e-6 * math.sqrt(K) + 1e-6, err            # fp32 fma-chain error ~ eps * sqrt(K) * |a.b|
 
 
-@pytest.mark.parametrize("M,N,K,relu,res,ln", [(33000, 512, 512, False, True, False),   # 1032 tiles on 512 persistent workgroups
-                                                 (20000, 1536, 512, True, False, True),    # LayerNorm-in, 6 tiles per workgroup
-                                                 (66000, 256, 64, False, False, False),    # K = 64: two k-steps, slices flushed
-                                                 (70001, 128, 32, True, True, False),      # K = 32: one k-step; ragged M
-                                                 (513, 200, 96, False, True, False)])      # ragged N, odd row pitches
-def test_linear_persistent_equals_one_tile_per_workgroup(nat, M, N, K, relu, res, ln, pv=32):
-    """The opt-in persistent kernel (variant 32: workgroups walk over their tiles, the epilogue of tile i is issued
-    under the MFMAs of tile i+1 straight from the accumulator registers) against the default one-tile-per-workgroup
-    kernels: the same k order and the same epilogue arithmetic, so y is BIT-identical; the row statistics are summed
-    in a different fixed order."""
+@pytest.mark.parametrize("M,N,K,relu,res,ln", [(33000, 512, 512, False, True, False),   # residual: BK 32 kernels
+                                                 (20000, 1536, 512, True, False, True),    # LayerNorm-in, BK 16 kernels
+                                                 (6600, 256, 64, False, False, False),     # K = 64
+                                                 (7001, 128, 32, True, True, False),       # K = 32: one k-step; ragged M
+                                                 (513, 200, 96, False, True, False)])      # ragged N
+def test_linear_mfma_shapes_and_staging_variants(nat, M, N, K, relu, res, ln):
+    """vcr_linear_args.variant: the 16x16x4 MFMA kernels (bit 4) against the 32x32x2 ones (bit 10) -- two fixed k orders,
+    so fp32 rounding apart, both held to fp64 -- and the selectors that must NOT change results: BK 16 / 32 (bits 6 / 3)
+    and the register-staged alignment-free kernel (bit 2) are bit-identical to the 32x32x2 default."""
     g = torch.Generator().manual_seed(M + N + K)
     x = dev(torch.randn(M, K, generator=g))
     w = dev(torch.randn(N, K, generator=g) / math.sqrt(K))
     b = dev(torch.randn(N, generator=g))
-    r = dev(torch.randn(M, N + 3, generator=g))[:, :N] if res else None       # ldr = N + 3: unaligned residual rows
+    r = dev(torch.randn(M, N, generator=g)) if res else None
     lnarg = None
+    xr = x
     if ln:
         a_, b_ = dev(torch.rand(K, generator=g) + 0.5), dev(torch.randn(K, generator=g))
         _, st = nat.linear(x, dev(torch.eye(K)), None, want_stats=True)   # row statistics of x itself
-        w, cs, b = nat.fold_layernorm(w, b, a_, b_)
+        std = x.double().std(-1, keepdim=True)
+        xr = (a_.double() * (x.double() - x.double().mean(-1, keepdim=True)) / (std + 1e-6) + b_.double())
+        w0 = w
+        w, cs, b0 = nat.fold_layernorm(w, b, a_, b_)
         lnarg = (st, cs, 1e-6)
-    stats_ok = N % 64 == 0
-    vec_ok = N % 4 == 0 and not res                         # the default kernels need 16-B aligned rows (else they fall
-    if ln or stats_ok and vec_ok:                           # back to the register-staged sibling by themselves)
-        y0, s0 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg, want_stats=True)
-        y1, s1 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg, want_stats=True, variant=pv)
-        torch.testing.assert_close(s1, s0, rtol=2e-5, atol=2e-4)
+        ref = xr @ w0.double().t() + b.double()
+        b = b0
     else:
-        y0 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg)
-        y1 = nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg, variant=pv)
-    assert torch.equal(y0, y1), (y0 - y1).abs().max().item()
+        ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    if res:
+        ref = ref + r.double()
+    stats_ok = N % 64 == 0
+    run = lambda v: nat.linear(x, w, b, relu=relu, residual=r, ln=lnarg, want_stats=stats_ok, variant=v)
+    y32, y16 = run(1024), run(16)
+    if stats_ok:
+        (y32, s32), (y16, s16) = y32, y16
+        torch.testing.assert_close(s16, s32, rtol=2e-5, atol=2e-4)
+        # the statistics are (sum, sum of squared deviations from the 64-column segment's mean) of the stored outputs
+        seg = y32.double().view(M, N // 64, 64)
+        torch.testing.assert_close(s32[..., 0].double(), seg.sum(-1), rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(s32[..., 1].double(), ((seg - seg.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-4)
+    tol = (4e-6 * math.sqrt(K) + 1e-6) * (6 if ln else 1)
+    e32, e16 = (y32.double() - ref).abs().max().item(), (y16.double() - ref).abs().max().item()
+    assert e32 <= tol and e16 <= tol, (e32, e16)
+    assert not torch.equal(y32, y16) or K <= 32            # different k orders (K = 32 on one 16-wide group pair can coincide)
+    unpack = lambda o: o[0] if stats_ok else o
+    for v in (8 | 1024, 64 | 1024):                        # the BK choice does not change a shape's result
+        assert torch.equal(unpack(run(v)), y32), v
+    assert torch.equal(unpack(run(8 | 16)), y16) and torch.equal(unpack(run(64 | 16)), y16)
+    if not ln and not stats_ok:
+        assert torch.equal(nat.linear(x, w, b, relu=relu, residual=r, variant=4), y32)      # register-staged fallback
+    for bad in (1, 32, 128, 512):                          # retired selectors are refused
+        with pytest.raises(nat.VcrHipError):
+            nat.linear(x, w, b, variant=bad)
+
+
+def test_folded_layernorm_survives_a_large_row_offset(nat):
+    """Rows with |mean| >> std (mean ~ 1e3, std ~ 1): the per-segment moments are taken about the segment mean and
+    combined exactly (Chan et al.), so the folded LayerNorm still matches torch's x.std() -- the one-pass
+    sum(x^2) - sum(x)^2 / n form loses every digit of the variance here."""
+    g = torch.Generator().manual_seed(77)
+    M, K, N = 1000, 512, 256
+    x = torch.randn(M, K, generator=g) + 1000.0 * (torch.rand(M, 1, generator=g) + 0.5)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    a_, b_ = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    xd = dev(x)
+    _, st = nat.linear(xd, dev(torch.eye(K)), None, want_stats=True)
+    var = st[..., 1].double().sum(-1).cpu()
+    mean_seg = st[..., 0].double().cpu() / 64
+    mean = mean_seg.mean(-1)
+    m2 = var + 64 * ((mean_seg - mean[:, None]) ** 2).sum(-1)
+    torch.testing.assert_close((m2 / (K - 1)).sqrt(), x.double().std(-1), rtol=1e-4, atol=0)
+    wf, cs, bf = nat.fold_layernorm(dev(w), dev(b), dev(a_), dev(b_))
+    y = nat.linear(xd, wf, bf, ln=(st, cs, 1e-6)).cpu().double()
+    xn = a_.double() * (x.double() - x.double().mean(-1, keepdim=True)) / (x.double().std(-1, keepdim=True) + 1e-6) + b_.double()
+    ref = xn @ w.double().t() + b.double()
+    # the GEMM itself runs on un-centred fp32 rows of magnitude 1e3: its rounding (eps * |x| * |w| * sqrt(K)) remains
+    assert (y - ref).abs().max().item() < 5e-2, (y - ref).abs().max().item()
+    assert (y - ref).abs().mean().item() < 5e-3
 
 
 @pytest.mark.parametrize("M,k,K,N,store", [(700, 20, 64, 128, True), (300, 40, 128, 256, False), (129, 7, 64, 64, True)])
@@ -329,6 +379,13 @@ def test_sdpa(nat, N, shift, bf16x3):
                                 kv_batch_shift=shift, bf16x3=mode).cpu()
     if not bf16x3:
         torch.testing.assert_close(run(False), ref, atol=5e-6, rtol=1e-5)
+        # both MFMA shapes of the fp32 kernel, forced: two fixed summation orders, each held to fp64
+        ref64 = oracle.attention(split(q).double() * 2, split(kk).double() * 2, split(vv).double())
+        ref64 = ref64.transpose(1, 2).reshape(nb * N, h * 128)
+        errs = [(nat.sdpa(qkv[:, :512], qkv[:, 512:1024], qkv[:, 1024:], nb, h, N, N, 1 / math.sqrt(128),
+                          kv_batch_shift=shift, variant=variant).cpu().double() - ref64).abs().max().item()
+                for variant in (1024, 16)]
+        assert errs[1] <= 1.5 * errs[0] + 5e-7 and max(errs) < 6e-6, errs
         return
     # the split kernel is a different, equally accurate summation: hold it to the same formula in fp64, where its
     # error must not exceed the fp32-MFMA kernel's (which the fp32 oracle pins above)
@@ -369,17 +426,21 @@ def test_sdpa_masked_and_rowstat(nat):
     s = torch.matmul(split(q), split(k).transpose(-2, -1)) / math.sqrt(128)
     p = torch.softmax(s.masked_fill(~keep.view(nb, 1, 1, N), -1e9), -1)
     ref = torch.matmul(p, split(v)).transpose(1, 2).reshape(nb * N, h * 128)
-    out, rs = nat.sdpa(dev(q.view(nb * N, -1)), dev(k.view(nb * N, -1)), dev(v.view(nb * N, -1)), nb, h, N, N,
-                       1 / math.sqrt(128), key_keep=dev(keep.to(torch.uint8)), want_rowstat=True)
-    torch.testing.assert_close(out.cpu(), ref, atol=5e-6, rtol=1e-5)
     sm = s.masked_fill(~keep.view(nb, 1, 1, N), float("-inf"))
-    torch.testing.assert_close(rs.cpu()[..., 0], sm.max(-1)[0], atol=1e-5, rtol=1e-5)
-    torch.testing.assert_close(rs.cpu()[..., 1], torch.exp(sm - sm.max(-1, keepdim=True)[0]).sum(-1), atol=1e-4, rtol=1e-5)
-    # statistics-only launch (no V, no output)
-    _, rs2 = nat.sdpa(dev(q.view(nb * N, -1)), dev(k.view(nb * N, -1)), None, nb, h, N, N, 1 / math.sqrt(128),
-                      want_rowstat=True, pv=False)
-    s0 = s
-    torch.testing.assert_close(rs2.cpu()[..., 0], s0.max(-1)[0], atol=1e-5, rtol=1e-5)
+    for variant in (1024, 16):                           # both MFMA shapes
+        out, rs = nat.sdpa(dev(q.view(nb * N, -1)), dev(k.view(nb * N, -1)), dev(v.view(nb * N, -1)), nb, h, N, N,
+                           1 / math.sqrt(128), key_keep=dev(keep.to(torch.uint8)), want_rowstat=True, variant=variant)
+        torch.testing.assert_close(out.cpu(), ref, atol=5e-6, rtol=1e-5)
+        torch.testing.assert_close(rs.cpu()[..., 0], sm.max(-1)[0], atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(rs.cpu()[..., 1], torch.exp(sm - sm.max(-1, keepdim=True)[0]).sum(-1), atol=1e-4, rtol=1e-5)
+        # statistics-only launch (no V, no output) that also keeps the scaled scores
+        ld = (N + 31) // 32 * 32
+        sc = torch.full((nb, h, N, ld), float("nan"), device="cuda")
+        _, rs2 = nat.sdpa(dev(q.view(nb * N, -1)), dev(k.view(nb * N, -1)), None, nb, h, N, N, 1 / math.sqrt(128),
+                          want_rowstat=True, pv=False, score_out=sc, variant=variant)
+        torch.testing.assert_close(rs2.cpu()[..., 0], s.max(-1)[0], atol=1e-5, rtol=1e-5)
+        torch.testing.assert_close(sc.cpu()[..., :N], s, atol=1e-5, rtol=1e-5)
+        assert torch.isinf(sc.cpu()[..., N:]).all()
 
 
 @pytest.mark.parametrize("N,mode", [(256, 0), (200, 0), (1024, 0), (256, 1)])
@@ -492,7 +553,8 @@ def test_linear_bf16x3(nat, M, N, K, relu, res):
 
 
 def test_linear_with_fused_layernorm(nat):
-    """the producer's epilogue emits per-row (sum, sum^2) partials; the consumer runs the GEMM
+    """the producer's epilogue emits per-row, per-64-column (sum, sum of squared deviations from the
+    segment mean) partials; the consumer runs the GEMM
     on the weight folded with the LayerNorm affine and applies (mean, 1/(std_unbiased+eps)) in its epilogue --
     equal to LayerNorm followed by Linear."""
     g = torch.Generator().manual_seed(11)
@@ -506,8 +568,9 @@ def test_linear_with_fused_layernorm(nat):
     b1 = torch.randn(N, generator=g)
     x, stats = nat.linear(dev(x0), dev(w0), dev(b0), residual=dev(r0), want_stats=True)     # producer
     xs = x.cpu()
+    seg_m2 = lambda t: ((t.view(M, K // 64, 64) - t.view(M, K // 64, 64).mean(-1, keepdim=True)) ** 2).sum(-1)
     torch.testing.assert_close(stats.cpu()[..., 0].sum(1), xs.sum(1), atol=2e-4, rtol=1e-5)
-    torch.testing.assert_close(stats.cpu()[..., 1].sum(1), (xs ** 2).sum(1), atol=2e-3, rtol=1e-5)
+    torch.testing.assert_close(stats.cpu()[..., 1], seg_m2(xs), atol=2e-4, rtol=1e-5)
     wf, cs, bf = nat.fold_layernorm(dev(w1), dev(b1), dev(a), dev(b))
     torch.testing.assert_close(wf.cpu(), w1 * a, atol=0, rtol=0)
     torch.testing.assert_close(cs.cpu().double(), (w1 * a).double().sum(1), atol=1e-6, rtol=1e-6)
@@ -522,7 +585,7 @@ def test_linear_with_fused_layernorm(nat):
     x3, stats3 = nat.linear_bf16x3(dev(x0), nat.split_bf16x3(dev(w0)), K, dev(b0), residual=dev(r0), want_stats=True)
     torch.testing.assert_close(x3.cpu(), xs, atol=2e-5, rtol=1e-5)
     torch.testing.assert_close(stats3.cpu()[..., 0].sum(1), x3.cpu().sum(1), atol=2e-4, rtol=1e-5)
-    torch.testing.assert_close(stats3.cpu()[..., 1].sum(1), (x3.cpu() ** 2).sum(1), atol=2e-3, rtol=1e-5)
+    torch.testing.assert_close(stats3.cpu()[..., 1], seg_m2(x3.cpu()), atol=2e-4, rtol=1e-5)
     y3 = nat.linear_bf16x3(x3, nat.split_bf16x3(wf), N, bf, relu=True, ln=(stats3, cs, 1e-6))
     ref3 = torch.relu(oracle.layer_norm(x3.cpu().double(), a.double(), b.double()) @ w1.double().t() + b1.double())
     err3 = (y3.cpu().double() - ref3).abs().max().item()
@@ -589,3 +652,25 @@ def test_knn_exact_ties_follow_torch_topk(nat, N, k):
     top2 = torch.topk(D, 2, dim=-1).values
     ok = (top2[..., 0] != top2[..., 1]).numpy()
     assert (got == ref)[ok].all(), f"{int((got != ref).any(-1)[ok].sum())} rows differ (features)"
+
+
+def test_knn_long_rows_replay_ties_through_global_scratch(nat):
+    """N = 12 000 (> 10 196: a row's distances no longer fit the replay's LDS image): with tie_work the replay runs out
+    of global scratch and the neighbour sets still equal Tensor.topk's on every row of a tie-heavy cloud; WITHOUT
+    tie_work the call is refused (VCR_EUNSUPPORTED) instead of silently skipping the replay.  k > 40 is refused too."""
+    N, k = 12000, 20
+    rs = np.random.RandomState(5)
+    side = int(np.ceil(N ** (1 / 3))) + 1
+    pts = rs.permutation(side ** 3)[:N][None]
+    xyz = np.stack([pts // (side * side), (pts // side) % side, pts % side], 1).astype(np.float32)   # [1,3,N]
+    src = torch.from_numpy(xyz)
+    xyz4 = dev(torch.cat((src.transpose(1, 2), (src ** 2).sum(1).unsqueeze(-1)), -1))
+    got = np.sort(nat.knn(xyz4, None, k).cpu().numpy(), -1)
+    ref = np.sort(oracle.knn_indices(src, k).numpy(), -1)
+    assert (got == ref).all(), f"{int((got != ref).any(-1).sum())} rows differ"
+    plain = np.sort(nat.knn(xyz4, None, k, exact_ties=False).cpu().numpy(), -1)
+    assert (plain != ref).any()
+    with pytest.raises(nat.VcrHipError, match="unsupported"):
+        nat.knn(xyz4, None, k, tie_work=False)
+    with pytest.raises(nat.VcrHipError, match="unsupported"):
+        nat.knn(xyz4, None, 41)

@@ -44,6 +44,28 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; accumulator register r of
+// lane l is D[row = 4*(l>>4) + r][col = l&15].  Like the 32x32x2 form the result is bitwise a k-ordered fmaf chain.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Row moments for the folded LayerNorm from per-segment partials [nseg][2] = (sum of the segment's K/nseg values, sum of
+// their squared deviations from the SEGMENT mean): combined as in Chan et al. -- M2 = sum_s (M2_s + n_s (mean_s - mean)^2)
+// -- so a row with |mean| >> std loses nothing to cancellation (the one-pass sum(x^2) - sum(x)^2 / n form does).
+// var is the unbiased one of Tensor.std() (transformer.py:142).
+__device__ __forceinline__ void ln_row_moments(const float* sp, int nseg, int K, float& mean, float& var) {
+  float s1 = 0.f;
+  for (int sg = 0; sg < nseg; ++sg) s1 += sp[2 * sg];                  // fixed order
+  mean = s1 / (float)K;
+  const float nsg = (float)(K / nseg), rn = 1.f / nsg;
+  float m2 = 0.f;
+  for (int sg = 0; sg < nseg; ++sg) {
+    const float d = sp[2 * sg] * rn - mean;
+    m2 += sp[2 * sg + 1] + nsg * (d * d);
+  }
+  var = m2 / (float)(K - 1);
+}
 
 // CUs of the current device (cached per device: the attribute query is cheap but not free)
 inline int vcr_cu_count() {
@@ -110,3 +132,26 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// Device-to-device copies on the path (the driver's selections, the soft heads' srcK, emb_out; ICP's start cloud) are
+// KERNELS, like the tie-counter zeroing:
+// the forward then captures into a HIP graph of kernel nodes only (a memset node made replays hang on this ROCm build;
+// memcpy nodes are the same kind of node).  16-B words when both pointers and the size allow, 4-B words otherwise.
+static __global__ __launch_bounds__(256) void vcr_copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, long n4,
+                                                         int vec) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (vec) {
+    if (i < n4 / 4) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  } else if (i < n4) {
+    dst[i] = src[i];
+  }
+}
+static inline int vcr_copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t s) {     // bytes % 4 == 0
+  if (bytes == 0) return 0;
+  const long n4 = (long)(bytes / 4);
+  const int vec = ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0 && (n4 & 3) == 0) ? 1 : 0;
+  const long items = vec ? n4 / 4 : n4;
+  hipLaunchKernelGGL(vcr_copy_words_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const uint32_t*>(src), reinterpret_cast<uint32_t*>(dst), n4, vec);
+  return VCR_LAUNCH_RC();
+}

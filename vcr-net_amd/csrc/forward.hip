@@ -23,6 +23,7 @@ struct Bump {
 struct Ws {
   float *xyz4, *feat64, *sq64, *pq1, *cat, *pq3, *emb;
   int32_t *idx1, *idx3, *ties;                         // ties: 2 x (count + one slot per row) for the kNN tie replay
+  unsigned char* tie_work; size_t tie_work_each;       // 2 x vcr_knn_tie_work_bytes(N): replay scratch of long rows (else NULL)
   float *qkv, *att, *e1, *e2, *hid, *d1, *d2, *d3, *qc, *kvc, *embf, *side4;
   float *st_emb, *st_e1, *st_e2, *st_d1, *st_d2;       // [M, E/64, 2] LayerNorm partial sums
   // partial-overlap mode
@@ -43,12 +44,14 @@ struct Ws {
 inline int overlap_k1(int N, double o2) { return (int)((double)N * 0.84 * o2); }
 inline int overlap_k2(int N, double o2) { return (int)((double)overlap_k1(N, o2) * 0.52 * o2); }
 
-Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, double o2, int emb_kind) {
+Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, double o2, int emb_kind, int xscore_limit_mb) {
   Bump bp{reinterpret_cast<unsigned char*>(base), 0, 0};
   const size_t M = (size_t)2 * B * N;
   Ws w{};
   w.xyz4 = bp.take<float>(M * 4);   w.feat64 = bp.take<float>(M * 64); w.sq64 = bp.take<float>(M);
   w.idx1 = bp.take<int32_t>(M * k); w.idx3 = bp.take<int32_t>(M * k); w.ties = bp.take<int32_t>(2 * (1 + M));   // a slot for every row
+  w.tie_work_each = vcr_knn_tie_work_bytes(N);
+  w.tie_work = w.tie_work_each ? bp.take<unsigned char>(2 * w.tie_work_each) : nullptr;
   w.pq1 = bp.take<float>(M * 256);  w.cat = bp.take<float>(M * 512);   w.pq3 = bp.take<float>(M * 512);
   w.emb = bp.take<float>(M * E);
   w.qkv = bp.take<float>(M * 3 * E); w.att = bp.take<float>(M * E);
@@ -64,7 +67,8 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
     const size_t K1 = (size_t)overlap_k1(N, o2), K2 = (size_t)overlap_k2(N, o2), B1 = (size_t)B;
     w.rowstat = bp.take<float>(M * heads * 2); w.keymass = bp.take<float>(M); w.keep = bp.take<uint8_t>(M);
     const size_t xs = M * heads * ((N + 31) & ~31);       // keep the cross-attention scores if they fit 4 GB
-    w.xscore = xs * 4 <= ((size_t)4 << 30) ? bp.take<float>(xs) : nullptr;
+    const size_t xlimit = xscore_limit_mb > 0 ? (size_t)xscore_limit_mb << 20 : xscore_limit_mb < 0 ? 0 : (size_t)4 << 30;
+    w.xscore = xs * 4 <= xlimit ? bp.take<float>(xs) : nullptr;
     w.xorder = bp.take<int32_t>(M);
     w.rstat = bp.take<float>(B1 * N * 2); w.cstat = bp.take<float>(B1 * N * 2);
     w.colsum = bp.take<float>(B1 * N);    w.rowsum = bp.take<float>(B1 * N);
@@ -91,7 +95,6 @@ __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* p, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = 0;
 }
-
 struct Runner {
   hipStream_t stream; vcr_trace* tr; int rc = 0;
   void mark(const char* name) {
@@ -116,6 +119,7 @@ struct Runner {
     vcr_linear_args a{x, ldx, w, b, res, ldr, y, ldy, M, N, K, relu};
     if (ln_stats) { a.ln_stats_in = ln_stats; a.ln_nseg = K / 64; a.ln_colsum = ln_colsum; a.ln_eps = 1e-6f; }
     a.stats_out = stats_out;
+    a.variant = linear_variant;
     return ok(wsplit ? vcr_linear_bf16x3_f32(&a, wsplit, stream) : vcr_linear_f32(&a, stream));
   }
   bool norm(const char* nm, const float* x, const vcr_norm_w& n, float* y, int M, int E,
@@ -131,7 +135,7 @@ struct Runner {
     if (rc) return false;
     mark(nm);
     vcr_sdpa_args a{q, ldq, k, ldk, v, ldv, out, ldo, nb, heads, nq, nk, 1.0f / sqrtf(128.f), shift, keep, rowstat,
-                    score_out, ld_score};
+                    score_out, ld_score, sdpa_variant};
     // linear_mode 2: the attention-output launches on the bf16 matrix pipe as exact splits; statistics passes stay fp32
     return ok((sdpa_split && out && !rowstat && !score_out) ? vcr_sdpa_bf16x3_f32(&a, stream) : vcr_sdpa_f32(&a, stream));
   }
@@ -164,6 +168,7 @@ struct Runner {
   // right before the first consumer of the indices
   const vcr_vcrnet_io* io_ = nullptr;
   bool sdpa_split = false;                               // linear_mode 2
+  int linear_variant = 0, sdpa_variant = 0;              // MFMA shape forced by vcr_vcrnet_weights.linear_mfma / sdpa_mfma
   vcr_knn_args deferred[2];                              // kNN launches whose tie replay is still owed (knn_ties)
   int n_deferred = 0;
   void knn(const char* nm, vcr_knn_args a, int which, bool defer = false) {
@@ -208,7 +213,7 @@ struct Runner {
   void copy_idx(const char* nm, int32_t* dst, const int32_t* src, size_t n) {
     if (rc) return;
     mark(nm);
-    ok((int)hipMemcpyAsync(dst, src, n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+    ok(vcr_copy_d2d(dst, src, n * sizeof(int32_t), stream));
   }
 
   void cross_attention(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, const Ws& w, int B, int N) {
@@ -316,7 +321,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (!W || !io || !workspace || !io->src_cf || !io->tgt_cf || !io->corr4 || !io->src4 || !io->R_ab || !io->t_ab)
     return VCR_EINVAL;
   const int B = io->B, N = io->N, E = W->E, F = W->F, k = W->k;
-  if (B <= 0 || N <= 0 || E != 512 || W->heads * 128 != E || k <= 0 || k > 40 || k + 1 > N) return VCR_EINVAL;
+  if (B <= 0 || N <= 0 || E != 512 || W->heads * 128 != E || k <= 0 || k + 1 > N) return VCR_EINVAL;
+  if (k > 40 || N > 65535) return VCR_EUNSUPPORTED;     // library limits (vcr_knn_f32)
   if (W->has_pointer == 1 && (F % 128)) return VCR_EINVAL;
   if (W->has_pointer == 1 &&
       !(W->fold_enc_qkv.w && W->fold_enc_ffn1.w && W->fold_dec_qkv.w && W->fold_dec_cross_q.w &&
@@ -324,6 +330,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     return VCR_EINVAL;
   if (((uintptr_t)workspace) & 255) return VCR_EINVAL;
   if (W->head_mode < 0 || W->head_mode > 2 || W->linear_mode < 0 || W->linear_mode > 2) return VCR_EINVAL;
+  for (int ms : {W->linear_mfma, W->sdpa_mfma})
+    if (ms != 0 && ms != 16 && ms != 32) return VCR_EINVAL;
   if (W->partial) {                                      // key pruning in the decoder (+ hard pairs for the topK head)
     if (W->has_pointer != 1 || (W->cycle && W->head_mode == 0)) return VCR_EUNSUPPORTED;
     if (!(W->overlap2 > 0.0 && W->overlap2 <= 1.0) || (int)((double)N * W->overlap2) < 1) return VCR_EINVAL;
@@ -332,7 +340,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (!W->partial && (io->force_keys || io->force_sel_src || io->force_sel_tgt || io->force_argmax || io->force_pairs))
     return VCR_EINVAL;                                   // there is nothing discrete to force in whole mode
   if ((io->force_sel_src != nullptr) != (io->force_sel_tgt != nullptr)) return VCR_EINVAL;
-  Ws w = carve(workspace, B, N, k, E, F, W->heads, W->partial, W->overlap2, W->emb_kind);
+  Ws w = carve(workspace, B, N, k, E, F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb);
   if (ws_bytes < w.bytes) return VCR_EWORKSPACE;
   const int M1 = B * N, M2 = 2 * M1;
   Runner R{(hipStream_t)stream, tr};
@@ -343,6 +351,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   R.ok(VCR_LAUNCH_RC());
 #define SP(site) (W->linear_mode != 0 ? W->split.site : nullptr)
   R.sdpa_split = W->linear_mode == 2;
+  R.linear_variant = W->linear_mfma == 16 ? 16 : W->linear_mfma == 32 ? 1024 : 0;
+  R.sdpa_variant = W->sdpa_mfma == 16 ? 16 : W->sdpa_mfma == 32 ? 1024 : 0;
 
   const float* stats_for_ln = W->has_pointer == 1 ? w.st_emb : nullptr;
   if (W->emb_kind == 1) {
@@ -355,7 +365,11 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       R.ok(vcr_rows4_pq_f32(c ? io->tgt_cf : io->src_cf, w.xyz4 + (size_t)c * M1 * 4, B, N, W->dgcnn.c1_wpq, 32,
                             W->dgcnn.c1_bpq, 128, w.pq1 + (size_t)c * M1 * 128, 128, R.stream));
     }
-    R.knn("knn:xyz", vcr_knn_args{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2}, 1);
+    {
+      vcr_knn_args a3{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
+      a3.tie_work = w.tie_work; a3.tie_work_bytes = w.tie_work_each;
+      R.knn("knn:xyz", a3, 1);
+    }
     const int Mk = M2 * k;
     // Every x.max(dim=-1) of vcrnet_model.py:109-118 rides on the kernel that produces the per-edge rows: the edge-row
     // builder writes x1 (and the zero base of x2..x4), conv2..conv4 fold the max over each point's k rows into their
@@ -399,8 +413,13 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   }
   // The feature-space and the Cartesian kNN (lpdnet_model.py:113,129) are independent: one launch for both, and one
   // tie replay for both right before the first consumer of the indices.
-  R.knn_pair("knn:feat64+xyz", vcr_knn_args{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2},
-             vcr_knn_args{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2});
+  {
+    vcr_knn_args a64{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2};
+    vcr_knn_args a3{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
+    a64.tie_work = w.tie_work; a3.tie_work = w.tie_work ? w.tie_work + w.tie_work_each : nullptr;
+    a64.tie_work_bytes = a3.tie_work_bytes = w.tie_work_each;
+    R.knn_pair("knn:feat64+xyz", a64, a3);
+  }
   R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
   R.knn_ties();                                          // both tie replays in one launch (one latency instead of two)
   R.knn_join(0);
@@ -492,7 +511,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     soft_head("softcorr:head", 0, (size_t)M1, io->corr4);
     if (R.rc == 0) {
       R.mark("rigid_svd:ab");
-      (void)hipMemcpyAsync(io->src4, w.xyz4, (size_t)M1 * 4 * sizeof(float), hipMemcpyDeviceToDevice, R.stream);
+      R.ok(vcr_copy_d2d(io->src4, w.xyz4, (size_t)M1 * 4 * sizeof(float), R.stream));
       vcr_rigid_svd_args a{w.xyz4, 4, io->corr4, 4, B, N, io->R_ab, io->t_ab, io->R_ba, io->t_ba, nullptr};
       R.ok(vcr_rigid_svd_f32(&a, R.stream));
     }
@@ -522,8 +541,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       }
     }
   }
-  if (R.rc == 0 && io->emb_out)
-    (void)hipMemcpyAsync(io->emb_out, w.embf, (size_t)M2 * E * sizeof(float), hipMemcpyDeviceToDevice, R.stream);
+  if (R.rc == 0 && io->emb_out) R.ok(vcr_copy_d2d(io->emb_out, w.embf, (size_t)M2 * E * sizeof(float), R.stream));
   if (last) R.finish();
 #undef SP
   return R.rc;
@@ -576,7 +594,7 @@ __global__ __launch_bounds__(256) void pose_step_kernel(const float* __restrict_
 
 extern "C" size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights* W, int B, int N) {
   if (!W || B <= 0 || N <= 0) return 0;
-  return carve(nullptr, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind).bytes;
+  return carve(nullptr, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb).bytes;
 }
 
 extern "C" int vcr_vcrnet_pairs(const vcr_vcrnet_weights* W, int N) {
@@ -614,7 +632,7 @@ extern "C" int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet
     R.finish();
     return lrc;
   }
-  const Ws w = carve(ws, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind);
+  const Ws w = carve(ws, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb);
   if (bytes < w.bytes) return VCR_EWORKSPACE;
   const size_t nkeys = W->partial ? (size_t)2 * B * (int)((double)N * W->overlap2) : 0;
   const size_t nsel = W->partial ? (size_t)B * overlap_k1(N, W->overlap2) : 0;
@@ -656,7 +674,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 14; }
+extern "C" int vcr_abi_version(void) { return 15; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

@@ -98,7 +98,7 @@ extern "C" int vcr_icp_f32(const vcr_icp_args* a, void* workspace, size_t worksp
   float* Rt = reinterpret_cast<float*>(w);                    w += up((size_t)a->B * 12 * 4);
   IcpState* st = reinterpret_cast<IcpState*>(w);
   float* cur4 = a->final4;                                    // iterate in place in the caller's output buffer
-  (void)hipMemcpyAsync(cur4, a->src4, (size_t)a->B * a->N * 16, hipMemcpyDeviceToDevice, s);
+  { const int rc0 = vcr_copy_d2d(cur4, a->src4, (size_t)a->B * a->N * 16, s); if (rc0) return rc0; }
   hipLaunchKernelGGL(icp_init_kernel, dim3(1), dim3(1), 0, s, st);
   const size_t lds = (size_t)((a->M < 2048 ? a->M : 2048)) * 16;
   for (int it = 0; it < a->max_iterations; ++it) {

@@ -805,17 +805,34 @@ __device__ int tb_partition_parallel(PairArr& q, int first, int last, int* A, in
   return cut;
 }
 
+__host__ __device__ constexpr size_t tiebreak_lds(int N) { return (size_t)N * 16 + 256 + (16 + 2 * 256 + 2) * 4; }
+constexpr size_t TB_LDS_MAX = 160 * 1024;
+constexpr int TB_BLOCKS = 64;
+
 // One block per tied row: all threads recompute the row's N distances with the SAME arithmetic as the main kernels
 // (C == 64: the k-ascending fma chain the MFMA produces, then the -sq_j/2 step, then 2 acc - sq_i; C == 4: the VALU
 // expression of knn3_kernel), thread 0 replays the selection and rewrites the row's k indices.
 __device__ __forceinline__ void tiebreak_body(const vcr_knn_args& a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* val = reinterpret_cast<float*>(smem);
-  int* id = reinterpret_cast<int*>(val + a.N);
-  float* qrow = reinterpret_cast<float*>(id + a.N);      // [64]
-  int* A = reinterpret_cast<int*>(qrow + 64);            // [N] left stoppers, [N] right stoppers, block scratch
-  int* Bd = A + a.N;
-  int* red = Bd + a.N;                                   // [16 + 2*256 + 2]
+  float *val, *qrow;
+  int *id, *A, *Bd, *red;
+  if (tiebreak_lds(a.N) <= TB_LDS_MAX) {
+    val = reinterpret_cast<float*>(smem);
+    id = reinterpret_cast<int*>(val + a.N);
+    qrow = reinterpret_cast<float*>(id + a.N);           // [64]
+    A = reinterpret_cast<int*>(qrow + 64);               // [N] left stoppers, [N] right stoppers, block scratch
+    Bd = A + a.N;
+    red = Bd + a.N;                                      // [16 + 2*256 + 2]
+  } else {
+    // rows too long for an LDS image (N > ~10 100): the four row-sized arrays live in the caller's tie_work, one 16 N-byte
+    // slice per block (the host checked that it is there); __syncthreads() orders a block's global accesses as well
+    val = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(a.tie_work) + (size_t)blockIdx.x * 16 * a.N);
+    id = reinterpret_cast<int*>(val + a.N);
+    A = id + a.N;
+    Bd = A + a.N;
+    qrow = reinterpret_cast<float*>(smem);
+    red = reinterpret_cast<int*>(qrow + 64);
+  }
   const int count = min(a.tie_scratch[0], a.tie_cap);
   for (int t = blockIdx.x; t < count; t += gridDim.x) {
     const int row = a.tie_scratch[1 + t];
@@ -912,15 +929,24 @@ static int zero_count(int32_t* p, hipStream_t s) {
   return VCR_LAUNCH_RC();
 }
 
-static size_t tiebreak_lds(int N) { return (size_t)N * 16 + 256 + (16 + 2 * 256 + 2) * 4; }
+// LDS of a replay launch: the row image when it fits, else only the query row + block scratch (the image is in tie_work)
+static size_t tiebreak_launch_lds(int N) { return tiebreak_lds(N) <= TB_LDS_MAX ? tiebreak_lds(N) : tiebreak_lds(0); }
+extern "C" size_t vcr_knn_tie_work_bytes(int N) {
+  return (N > 0 && tiebreak_lds(N) > TB_LDS_MAX) ? (size_t)TB_BLOCKS * 16 * (size_t)N : 0;
+}
+// a replay is owed (tie_scratch) but the rows need global scratch that the caller did not provide
+static bool tie_work_missing(const vcr_knn_args* a) {
+  const size_t need = vcr_knn_tie_work_bytes(a->N);
+  return a->tie_scratch && need && (!a->tie_work || a->tie_work_bytes < need || ((uintptr_t)a->tie_work & 15));
+}
 
 extern "C" int vcr_knn_ties_f32(const vcr_knn_args* a, const vcr_knn_args* b, vcr_stream_t stream) {
   if (!a || !a->x || !a->idx || !a->tie_scratch || a->tie_cap < 1) return VCR_EINVAL;
   if (b && (!b->x || !b->idx || !b->tie_scratch || b->tie_cap < 1)) return VCR_EINVAL;
-  const size_t lds = b ? (tiebreak_lds(a->N) > tiebreak_lds(b->N) ? tiebreak_lds(a->N) : tiebreak_lds(b->N)) : tiebreak_lds(a->N);
-  if (lds > 160 * 1024) return VCR_OK;                   // rows too long for the replay's LDS image: as vcr_knn_f32, no replay
-  if (b) return launch<knn_tiebreak2_kernel>(dim3(64, 2), dim3(256), lds, (hipStream_t)stream, *a, *b);
-  return launch<knn_tiebreak_kernel>(dim3(64), dim3(256), lds, (hipStream_t)stream, *a);
+  if (tie_work_missing(a) || (b && tie_work_missing(b))) return VCR_EUNSUPPORTED;
+  const size_t la = tiebreak_launch_lds(a->N), lb = b ? tiebreak_launch_lds(b->N) : 0, lds = la > lb ? la : lb;
+  if (b) return launch<knn_tiebreak2_kernel>(dim3(TB_BLOCKS, 2), dim3(256), lds, (hipStream_t)stream, *a, *b);
+  return launch<knn_tiebreak_kernel>(dim3(TB_BLOCKS), dim3(256), lds, (hipStream_t)stream, *a);
 }
 
 // Feature-space (a64: C == 64) and Cartesian (a3: C == 4) kNN of the same pass as one launch (see knn_pair_kernel) when
@@ -937,8 +963,10 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
     return rc ? rc : vcr_knn_f32(a64, stream);
   }
   for (const vcr_knn_args* a : {a64, a3}) {
-    if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k + 1 > a->N || a->N > 65535 || a->ldx < a->C || (a->ldx & 3)) return VCR_EINVAL;
+    if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k + 1 > a->N || a->ldx < a->C || (a->ldx & 3)) return VCR_EINVAL;
+    if (a->N > 65535) return VCR_EUNSUPPORTED;
     if (a->tie_scratch && a->tie_cap < 1) return VCR_EINVAL;
+    if (tie_work_missing(a)) return VCR_EUNSUPPORTED;
   }
   if (!a64->sq) return VCR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -957,10 +985,12 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
 
 extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->idx) return VCR_EINVAL;
-  if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k > 40 || a->k + 1 > a->N || a->N > 65535) return VCR_EINVAL;
+  if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k + 1 > a->N) return VCR_EINVAL;
+  if (a->k > 40 || a->N > 65535) return VCR_EUNSUPPORTED;   // limits of this library, not of the operation (see vcr_hip.h)
   hipStream_t s = (hipStream_t)stream;
   if (a->tie_scratch) {
     if (a->tie_cap < 1) return VCR_EINVAL;
+    if (tie_work_missing(a)) return VCR_EUNSUPPORTED;     // refuse loudly rather than skip the replay silently
     if (a->tie_stream && (!a->tie_events[0] || !a->tie_events[1])) return VCR_EINVAL;
     if (!a->tie_zeroed) {
       const int e = zero_count(a->tie_scratch, s);
@@ -996,17 +1026,17 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   }
   if (rc != 0) return rc;
   // rows with an exact tie at the (k+1)-th value: replay libstdc++'s selection on them (see knn_tiebreak_kernel)
-  const size_t tb_lds = tiebreak_lds(a->N);
-  if (a->tie_scratch && !a->tie_defer && tb_lds <= 160 * 1024) {
+  const size_t tb_lds = tiebreak_launch_lds(a->N);
+  if (a->tie_scratch && !a->tie_defer) {
     if (a->tie_stream) {                                 // replay beside the caller's next launches (see vcr_hip.h)
       hipStream_t ts = (hipStream_t)a->tie_stream;
       hipError_t e = hipEventRecord((hipEvent_t)a->tie_events[0], s);
       if (e == hipSuccess) e = hipStreamWaitEvent(ts, (hipEvent_t)a->tie_events[0], 0);
       if (e != hipSuccess) return (int)e;
-      rc = launch<knn_tiebreak_kernel>(dim3(64), dim3(256), tb_lds, ts, *a);
+      rc = launch<knn_tiebreak_kernel>(dim3(TB_BLOCKS), dim3(256), tb_lds, ts, *a);
       if (rc == 0) rc = (int)hipEventRecord((hipEvent_t)a->tie_events[1], ts);
     } else {
-      rc = launch<knn_tiebreak_kernel>(dim3(64), dim3(256), tb_lds, s, *a);
+      rc = launch<knn_tiebreak_kernel>(dim3(TB_BLOCKS), dim3(256), tb_lds, s, *a);
     }
   }
   return rc;

@@ -106,11 +106,8 @@ __global__ __launch_bounds__(512, 2) void linear_bf16x3_kernel(vcr_linear_args p
   store_a(0);
   float* rowst = reinterpret_cast<float*>(smem + 2 * sizeof(Stage3));   // [TM][2] (mean, 1/(std+eps)) of this block's rows
   if (p.ln_stats_in && t < TM) {
-    const float* sp = p.ln_stats_in + (size_t)min(m0 + t, p.M - 1) * p.ln_nseg * 2;
-    float s1 = 0.f, s2 = 0.f;
-    for (int sg = 0; sg < p.ln_nseg; ++sg) { s1 += sp[2 * sg]; s2 += sp[2 * sg + 1]; }     // fixed order
-    const float mean = s1 / (float)p.K;
-    const float var = fmaxf((s2 - s1 * mean) / (float)(p.K - 1), 0.f);                      // unbiased, like x.std()
+    float mean, var;
+    ln_row_moments(p.ln_stats_in + (size_t)min(m0 + t, p.M - 1) * p.ln_nseg * 2, p.ln_nseg, p.K, mean, var);
     rowst[2 * t] = mean;
     rowst[2 * t + 1] = 1.f / (sqrtf(var) + p.ln_eps);
   }
@@ -195,8 +192,11 @@ __global__ __launch_bounds__(512, 2) void linear_bf16x3_kernel(vcr_linear_args p
           st4(p.y + (size_t)row * p.ldy + col, v);
           if (p.stats_out) {                             // the 16 lanes of a row group hold this wave's 64 columns of the row
             float s1 = (v[0] + v[1]) + (v[2] + v[3]);
-            float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-            s1 = row16_sum(s1); s2 = row16_sum(s2);
+            s1 = row16_sum(s1);
+            const float ms = s1 * (1.f / 64.f);          // (sum, second moment about the segment mean): linear.hip
+            const float d0 = v[0] - ms, d1 = v[1] - ms, d2 = v[2] - ms, d3 = v[3] - ms;
+            float s2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            s2 = row16_sum(s2);
             if ((lane & 15) == 0) {
               float* so = p.stats_out + ((size_t)row * (p.N / 64) + (n0 + wn * 64) / 64) * 2;
               so[0] = s1; so[1] = s2;

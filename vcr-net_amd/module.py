@@ -198,6 +198,9 @@ class VCRNet(nn.Module):
         # splits on the bf16 matrix pipe (fp32-equivalent accuracy, ~1.5x faster linears); fused whole-forward only.
         # "bf16x3+sdpa": that, and the attention products (Q K^T, P V) the same way (vcr_sdpa_bf16x3_f32).
         self.linear_mode = os.environ.get("VCRNET_LINEAR_MODE", "fp32")
+        # MFMA shape of the fp32 linears / attention: 0 = the library's choice, 16 = 16x16x4, 32 = 32x32x2 (benchmarks)
+        self.linear_mfma, self.sdpa_mfma = 0, 0
+        self.xscore_limit_mb = 0            # partial mode: keep the cross-attention scores up to this many MiB (0 = 4096)
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
         self._cw: Optional[native.VcrnetWeights] = None
@@ -218,7 +221,7 @@ class VCRNet(nn.Module):
     def _fingerprint(self):
         ps = list(self.parameters()) + list(self.buffers())
         return (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]), self.emb_nn.k,
-                self.linear_mode)
+                self.linear_mode, self.linear_mfma, self.sdpa_mfma, self.xscore_limit_mb)
 
     def _pack(self):
         key = self._fingerprint()
@@ -337,12 +340,14 @@ class VCRNet(nn.Module):
                 P[f"att.w{i}"], P[f"att.b{i}"] = g(f"head.linears_emb.{i}.weight"), g(f"head.linears_emb.{i}.bias")
                 setattr(cw, f"att_w{i}", native.ptr(P[f"att.w{i}"])); setattr(cw, f"att_b{i}", native.ptr(P[f"att.b{i}"]))
         cw.cycle = int(bool(self.cycle))
+        cw.linear_mfma, cw.sdpa_mfma = int(self.linear_mfma), int(self.sdpa_mfma)
+        cw.xscore_limit_mb = int(self.xscore_limit_mb)
         cw.partial, cw.overlap2 = int(self._partial), self._overlap2
         self._packed, self._packed_key = P, key
         self._cw = cw
 
     def _buffers_for(self, B: int, N: int, device) -> Dict[str, torch.Tensor]:
-        key = (B, N, device, int(self.emb_nn.k))
+        key = (B, N, device, int(self.emb_nn.k), int(self.xscore_limit_mb))
         bufs = self._bufs.get(key)
         if bufs is None:
             nbytes = native.lib().vcr_vcrnet_workspace_bytes(C.byref(self._cw), B, N)

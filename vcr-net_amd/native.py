@@ -28,7 +28,7 @@ class KnnArgs(C.Structure):
     _fields_ = [("x", f32p), ("ldx", C.c_int), ("sq", f32p), ("B", C.c_int), ("N", C.c_int), ("C", C.c_int),
                 ("k", C.c_int), ("idx", f32p), ("tie_scratch", f32p), ("tie_cap", C.c_int), ("waves", C.c_int),
                 ("tie_stream", C.c_void_p), ("tie_events", C.c_void_p * 2), ("tie_zeroed", C.c_int),
-                ("tie_defer", C.c_int)]
+                ("tie_defer", C.c_int), ("tie_work", C.c_void_p), ("tie_work_bytes", C.c_size_t)]
 
 
 class LinearArgs(C.Structure):
@@ -65,7 +65,7 @@ class SdpaArgs(C.Structure):
     _fields_ = [("q", f32p), ("ldq", C.c_int), ("k", f32p), ("ldk", C.c_int), ("v", f32p), ("ldv", C.c_int),
                 ("out", f32p), ("ldo", C.c_int), ("nbatch", C.c_int), ("heads", C.c_int), ("nq", C.c_int),
                 ("nk", C.c_int), ("scale", C.c_float), ("kv_batch_shift", C.c_int), ("key_keep", f32p),
-                ("rowstat", f32p), ("score_out", f32p), ("ld_score", C.c_int)]
+                ("rowstat", f32p), ("score_out", f32p), ("ld_score", C.c_int), ("variant", C.c_int)]
 
 
 class KeymassArgs(C.Structure):
@@ -173,7 +173,8 @@ class VcrnetWeights(C.Structure):
                 ("fold_enc_qkv", FoldedW), ("fold_enc_ffn1", FoldedW), ("fold_dec_qkv", FoldedW),
                 ("fold_dec_cross_q", FoldedW), ("fold_dec_cross_kv", FoldedW), ("fold_dec_ffn1", FoldedW),
                 ("partial", C.c_int), ("overlap2", C.c_double), ("emb_kind", C.c_int), ("dgcnn", DgcnnW),
-                ("att_w0", f32p), ("att_b0", f32p), ("att_w1", f32p), ("att_b1", f32p), ("cycle", C.c_int)]
+                ("att_w0", f32p), ("att_b0", f32p), ("att_w1", f32p), ("att_b1", f32p), ("cycle", C.c_int),
+                ("linear_mfma", C.c_int), ("sdpa_mfma", C.c_int), ("xscore_limit_mb", C.c_int)]
 
 
 class VcrnetIo(C.Structure):
@@ -204,7 +205,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 14         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 15         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -374,13 +375,19 @@ def pointwise(x_cf, w1, b1, w2, b2):
 
 
 @_guarded
-def knn(x, sq, k, exact_ties=True, waves=0):
+def knn(x, sq, k, exact_ties=True, waves=0, tie_work=True):
     """x [B,N,C] rows (C = 64 with sq [B,N], or C = 4 xyz4 rows) -> int32 idx [B,N,k].  exact_ties: rows whose
     (k+1)-th and (k+2)-th distances are equal get Tensor.topk's (libstdc++'s) pick instead of the lower index."""
     B, N, Cc = x.shape
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
     ties = torch.empty(1 + B * N, dtype=torch.int32, device=x.device) if exact_ties else None   # room for every row
-    call("vcr_knn_f32", KnnArgs(ptr(x), x.stride(1), ptr(sq), B, N, Cc, k, ptr(idx), ptr(ties), B * N if exact_ties else 0, waves))
+    a = KnnArgs(ptr(x), x.stride(1), ptr(sq), B, N, Cc, k, ptr(idx), ptr(ties), B * N if exact_ties else 0, waves)
+    L = lib()
+    L.vcr_knn_tie_work_bytes.restype, L.vcr_knn_tie_work_bytes.argtypes = C.c_size_t, [C.c_int]
+    need = L.vcr_knn_tie_work_bytes(N) if (exact_ties and tie_work) else 0
+    work = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None            # long rows: replay scratch
+    a.tie_work, a.tie_work_bytes = ptr(work), need
+    call("vcr_knn_f32", a)
     return idx
 
 
@@ -528,7 +535,7 @@ def gathermax(pq, Cc, idx, n_per_cloud):
 
 @_guarded
 def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None, want_rowstat=False, pv=True,
-         score_out=None, bf16x3=False):
+         score_out=None, bf16x3=False, variant=0):
     """q [nbatch*nq, >=heads*128] (row views allowed), k/v likewise -> out [nbatch*nq, heads*128].
     score_out [nbatch, heads, nq, ld]: also keep the scaled scores (statistics pass of the partial path)."""
     out = _f32(nbatch * nq, heads * 128, device=q.device) if pv else None
@@ -536,7 +543,7 @@ def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None,
     call("vcr_sdpa_bf16x3_f32" if bf16x3 else "vcr_sdpa_f32",
          SdpaArgs(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v) if pv else None, v.stride(0) if pv else 0, ptr(out),
                   heads * 128 if pv else 0, nbatch, heads, nq, nk, scale, kv_batch_shift, ptr(key_keep), ptr(rs),
-                  ptr(score_out), score_out.stride(2) if score_out is not None else 0))
+                  ptr(score_out), score_out.stride(2) if score_out is not None else 0, variant))
     return (out, rs) if want_rowstat else out
 
 
