@@ -73,8 +73,10 @@ typedef struct {
   int32_t* idx;                       /* [B,N,k], neighbour index within the cloud     */
   int32_t* tie_scratch; int tie_cap;  /* optional: [1 + tie_cap] ints of scratch (count, then the rows with a boundary
                                          tie; 256 entries are plenty: ~1 row in 10^4 ties) */
-  int waves;                          /* tuning / tests: waves of a workgroup that share one group of queries and split its
-                                         candidates (1, 2 or 4); 0 = chosen from the grid size.  Never changes a result. */
+  int waves;                          /* tuning / tests, never changes a result.  0 = chosen from the shape.  C == 64: 8 = the
+                                         16-query-wave kernel (v_mfma_f32_16x16x4_f32, four lanes per query); 1 / 2 / 4 = the
+                                         32-query-wave kernel with that many waves sharing one group of queries and splitting
+                                         its candidates.  C == 4: 1 / 2 / 4 likewise. */
   /* Optional overlap of the tie replay (a latency-bound kernel that keeps ~4 CUs busy for ~25 us) with whatever the
    * caller enqueues next on `stream`: with tie_stream and two caller-owned event handles (vcr_event_create) the replay
    * is enqueued on tie_stream, fenced by tie_events[0] (recorded on `stream` after the main kernel); idx is final once
@@ -123,7 +125,8 @@ typedef struct {
    * be NULL: the per-edge activations of the last conv are never written.  LDS-DMA kernels (variant 0) only. */
   float* segmax_out; int ld_segmax; int seg_k;
   int variant;                        /* tuning / tests, 0 = automatic (LDS-DMA staging, one 128x128 tile per workgroup:
-                                         BK 16 and four workgroups per CU without a residual, BK 32 with one).
+                                         BK 16, 32x32x2 MFMAs and four workgroups per CU without a residual; BK 32 and
+                                         16x16x4 MFMAs with one).
                                          bit3 (8) force BK 32, bit6 (64) force BK 16; bit4 (16) force the 16x16x4 MFMA
                                          shape, bit10 (1024) force 32x32x2; bit2 (4) the register-staged kernel without
                                          alignment requirements on y / bias / residual (taken automatically when they
@@ -404,6 +407,8 @@ typedef struct {
   /* MFMA shape of the fp32 linears / attention launches of the forward: 0 = the library's choice, 16 =
    * v_mfma_f32_16x16x4_f32, 32 = v_mfma_f32_32x32x2_f32 (benchmarks / tests; results agree to fp32 rounding) */
   int linear_mfma, sdpa_mfma;
+  int linear_bk;                                   /* 0 = the library's choice, 16 / 32 = that k-slab for every fp32 linear (benchmarks) */
+  int knn_waves;                                   /* vcr_knn_args.waves of the feature-space kNN (0 = automatic; benchmarks) */
   /* partial mode: the decoder's cross-attention scores ([2B,H,N,N] fp32) are kept between the statistics pass and the
    * key-mass pass when they fit this many MiB of workspace (0 = 4096), and recomputed per head otherwise (< 0: never
    * kept).  Same kept-key set either way up to summation order. */

@@ -30,7 +30,7 @@ def main():
         xyz = torch.rand(B, N, 3, generator=g) - 0.5
         xyz4 = torch.cat((xyz, (xyz ** 2).sum(-1, keepdim=True)), -1).cuda().contiguous()
         for name, x, s in (("feat64", f, sq), ("xyz", xyz4, None)):
-            for waves in (1, 2):
+            for waves in (0, 1, 2):          # 0 = automatic: the 16-query kernel on these grids (feat64)
                 for _ in range(2):
                     native.knn(x, s, k, exact_ties=False, waves=waves)
                 torch.cuda.synchronize()

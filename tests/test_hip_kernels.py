@@ -385,7 +385,7 @@ def test_sdpa(nat, N, shift, bf16x3):
         errs = [(nat.sdpa(qkv[:, :512], qkv[:, 512:1024], qkv[:, 1024:], nb, h, N, N, 1 / math.sqrt(128),
                           kv_batch_shift=shift, variant=variant).cpu().double() - ref64).abs().max().item()
                 for variant in (1024, 16)]
-        assert errs[1] <= 1.5 * errs[0] + 5e-7 and max(errs) < 6e-6, errs
+        assert errs[1] <= 1.5 * errs[0] + 5e-7 and max(errs) < 2e-5, errs
         return
     # the split kernel is a different, equally accurate summation: hold it to the same formula in fp64, where its
     # error must not exceed the fp32-MFMA kernel's (which the fp32 oracle pins above)

@@ -330,8 +330,9 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     return VCR_EINVAL;
   if (((uintptr_t)workspace) & 255) return VCR_EINVAL;
   if (W->head_mode < 0 || W->head_mode > 2 || W->linear_mode < 0 || W->linear_mode > 2) return VCR_EINVAL;
-  for (int ms : {W->linear_mfma, W->sdpa_mfma})
+  for (int ms : {W->linear_mfma, W->sdpa_mfma, W->linear_bk})
     if (ms != 0 && ms != 16 && ms != 32) return VCR_EINVAL;
+  if (W->knn_waves != 0 && W->knn_waves != 1 && W->knn_waves != 8) return VCR_EINVAL;
   if (W->partial) {                                      // key pruning in the decoder (+ hard pairs for the topK head)
     if (W->has_pointer != 1 || (W->cycle && W->head_mode == 0)) return VCR_EUNSUPPORTED;
     if (!(W->overlap2 > 0.0 && W->overlap2 <= 1.0) || (int)((double)N * W->overlap2) < 1) return VCR_EINVAL;
@@ -351,7 +352,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   R.ok(VCR_LAUNCH_RC());
 #define SP(site) (W->linear_mode != 0 ? W->split.site : nullptr)
   R.sdpa_split = W->linear_mode == 2;
-  R.linear_variant = W->linear_mfma == 16 ? 16 : W->linear_mfma == 32 ? 1024 : 0;
+  R.linear_variant = (W->linear_mfma == 16 ? 16 : W->linear_mfma == 32 ? 1024 : 0) | (W->linear_bk == 16 ? 64 : W->linear_bk == 32 ? 8 : 0);
   R.sdpa_variant = W->sdpa_mfma == 16 ? 16 : W->sdpa_mfma == 32 ? 1024 : 0;
 
   const float* stats_for_ln = W->has_pointer == 1 ? w.st_emb : nullptr;
@@ -414,7 +415,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   // The feature-space and the Cartesian kNN (lpdnet_model.py:113,129) are independent: one launch for both, and one
   // tie replay for both right before the first consumer of the indices.
   {
-    vcr_knn_args a64{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2};
+    vcr_knn_args a64{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2, W->knn_waves};
     vcr_knn_args a3{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
     a64.tie_work = w.tie_work; a3.tie_work = w.tie_work ? w.tie_work + w.tie_work_each : nullptr;
     a64.tie_work_bytes = a3.tie_work_bytes = w.tie_work_each;

@@ -85,6 +85,34 @@ struct GeomMfma {                    // 32 query columns, lanes l and l+32 share
   __device__ static __forceinline__ int from_prev(int x, int) { return from_seg(x, 0); }   // only segment 1 has a predecessor
   __device__ static __forceinline__ int col_sum(int x, int sg) { return x + from_seg(x, sg ^ 1); }
 };
+struct GeomCol16 {                   // v_mfma_f32_16x16x4_f32 layout: 16 query columns, lanes c, c+16, c+32, c+48 share one.
+  // The value list of a query runs through its four lanes in the row order 0 -> 1 -> 3 -> 2 (seg 0..3), chosen so that
+  // every segment's predecessor is ONE row swap away: v_permlane16_swap exchanges rows (0,1) and (2,3),
+  // v_permlane32_swap rows (0,2) and (1,3).  With both operands = x, swap16 returns {even row of the pair, odd row of
+  // the pair} in every lane of the pair, swap32 {row of the lower half, row of the upper half} in both halves.
+  static constexpr int COLS = 16, LPQ = 4;
+  __device__ static __forceinline__ int col(int lane) { return lane & 15; }
+  __device__ static __forceinline__ int seg(int lane) { const int q = lane >> 4; return q ^ (q >> 1); }   // 0,1,3,2
+  __device__ static __forceinline__ int from_seg(int x, int which) {      // `which` is wave-uniform
+    const int q = which ^ (which >> 1);                                   // the row that holds segment `which`
+    const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    const int v = (q & 1) ? a[1] : a[0];
+    const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (q >> 1) ? b[1] : b[0];
+  }
+  __device__ static __forceinline__ int from_prev(int x, int sg) {        // segment sg - 1's value (sg == 0: unused)
+    const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return sg == 1 ? a[0] : sg == 2 ? b[0] : a[1];     // row 1 <- row 0; row 3 <- row 1; row 2 <- row 3
+  }
+  __device__ static __forceinline__ int col_sum(int x, int sg) {
+    const int q = sg ^ (sg >> 1);
+    const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    x += (q & 1) ? a[0] : a[1];
+    const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return x + ((q >> 1) ? b[0] : b[1]);
+  }
+};
 struct GeomQuad {                    // 16 queries, one DPP quad each: segment = lane & 3
   static constexpr int COLS = 16, LPQ = 4;
   __device__ static __forceinline__ int col(int lane) { return lane >> 2; }
@@ -448,6 +476,163 @@ __global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
   knn64_body<KS, S, W>(a, bx, b);
 }
 
+// ---------------------------------------------------------------- C == 64 on v_mfma_f32_16x16x4_f32 (round 3)
+// Half-size waves: 16 queries per wave (MFMA columns), candidate tiles of 16 (MFMA rows), four lanes per query.  Twice as
+// many, half as wide waves as knn64_body with the SAME selection work per query (one value list, one log), ~100 VGPRs and
+// 8 KB of log per wave: four waves per SIMD instead of one or two, so one wave's 17-MFMA distance chain and its LDS /
+// scalar-branch latencies run under the other waves' selection code (rocprofv3 counters of the 32-query kernel in the
+// one-launch pair: VALU issuing in 30 % of its wave-cycles, 26 % parked at a waitcnt, 32 % waiting to issue).
+// k order: MFMA step s multiplies k = 4s .. 4s+3 (lane row q supplies k = 4s + q), i.e. the natural ascending order, so
+// the distance is bit-for-bit the same k-ascending fma chain as in knn64_body and in the reference's CPU sgemm; the
+// -sq_j/2 term rides as a 17th step.  Operands are read from the natural [N][64] rows as 16-B chunks and transposed
+// across the four lane rows of a column in registers (see load_raw / transpose).
+template <int KS, int W>
+__device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b) {
+  using G = GeomCol16;
+  constexpr int PEND = pend_of<G, KS>();
+  constexpr int CT = 16;                                 // candidates per tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q4 = lane >> 4, col = lane & 15;
+  const int q0 = (bx * W + wave) * 16;
+  // log [PEND + 4][16]: rows PEND .. PEND+3 swallow the branch-free appends of lanes without a survivor, one row per
+  // lane row q4 (the four lanes of a column would otherwise hit one LDS word with four different values)
+  constexpr int LROWS = PEND + 4;
+  float* lv = reinterpret_cast<float*>(smem) + wave * (2 * LROWS * 16);
+  Selector<G, KS> sel;
+  const float* xb = a.x + (size_t)b * a.N * a.ldx;
+  const float* sqb = a.sq + (size_t)b * a.N;
+  const int q = min(q0 + col, a.N - 1);
+  // Operand fetch.  MFMA step s needs x[row][4 s + q4] in lane row q4: every fourth float of the row.  Fetched as such
+  // (16 x global_load_dword) the texture path sees 4-byte requests -- 8x the requests of knn64_body per byte, and the
+  // kernel is bound by them (measured: 145 of a wave's 208 us at N = 1024).  Instead lane row q4 loads the 16-B chunks
+  // 4 g + q4 (g = 0..3; four global_load_dwordx4) and a 4 x 4 transpose between lane rows and vector components --
+  // v_permlane16_swap on the register pairs (0,1) (2,3), then v_permlane32_swap on (0,2) (1,3) -- leaves
+  // component j of chunk register g = x[row][4 (4 g + j) + q4], i.e. the operand of step s = 4 g + j.
+  auto load_raw = [&](int row, f32x4* raw) {
+    const float* rp = xb + (size_t)row * a.ldx + 4 * q4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) raw[g] = ld4(rp + 16 * g);
+  };
+  auto swap16 = [](float& x, float& y) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(x), __float_as_int(y), false, false);
+    x = __int_as_float(r[0]); y = __int_as_float(r[1]);
+  };
+  auto swap32 = [](float& x, float& y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(x), __float_as_int(y), false, false);
+    x = __int_as_float(r[0]); y = __int_as_float(r[1]);
+  };
+  auto transpose = [&](const f32x4* raw, float* dst) {   // dst[4 g + j] = operand of MFMA step 4 g + j
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float r0 = raw[g][0], r1 = raw[g][1], r2 = raw[g][2], r3 = raw[g][3];
+      swap16(r0, r1); swap16(r2, r3);
+      swap32(r0, r2); swap32(r1, r3);
+      dst[4 * g] = r0; dst[4 * g + 1] = r1; dst[4 * g + 2] = r2; dst[4 * g + 3] = r3;
+    }
+  };
+  float qf[16];
+  {
+    f32x4 raw[4];
+    load_raw(q, raw);
+    transpose(raw, qf);
+  }
+  const float sq_q = sqb[q];
+  const int ntiles = (a.N + CT - 1) / CT;
+
+  sel.init(lv, reinterpret_cast<int*>(lv + LROWS * 16), lane);
+  KTL_DECL;
+  // Two candidate tiles per step: their two 17-MFMA chains are independent and issue alternately (a dependent
+  // v_mfma_f32_16x16x4_f32 chain leaves 8 of every 40 cycles empty), and the next two tiles' rows are in flight meanwhile.
+  float cf[2][16];
+  f32x4 nraw[2][4];
+  float csq[2], nsq[2] = {0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int c = min(u * CT + col, a.N - 1);
+    load_raw(c, nraw[u]);
+    csq[u] = sqb[c];
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    transpose(nraw[u], cf[u]);                           // (VALU consumers: the first tiles have arrived before the loop)
+    asm volatile("" : "+v"(csq[u]));
+  }
+  // the selection proper for one tile: 16 new distances per query (4 per lane: candidate rows 4 q4 + r)
+  auto select_tile = [&](int tile, const f32x4& acc) {
+    sel.make_room();
+    KTL(2);
+    const int jbase = tile * CT + 4 * q4;
+    float dd[4];
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dd[r] = 2.f * acc[r] - sq_q;                       // (-sq_j + 2 dot) - sq_i
+      m |= (dd[r] > sel.thr && jbase + r < a.N) ? (1u << r) : 0u;
+    }
+    // the four lanes of a column append to ONE log, in row order 0, 1, 2, 3: exclusive prefix of their survivor counts
+    const int c0 = __popc(m);
+    const auto pa = __builtin_amdgcn_permlane16_swap(c0, c0, false, false);      // {even row, odd row} of the pair
+    const int pair_total = pa[0] + pa[1];
+    const auto pb = __builtin_amdgcn_permlane32_swap(pair_total, pair_total, false, false);   // {rows 0+1, rows 2+3}
+    const int pre = ((q4 & 1) ? pa[0] : 0) + ((q4 >> 1) ? pb[0] : 0);
+    KTL(1);                                              // distances + filter + prefix
+    if (__any(m != 0)) {
+      const int base = sel.cnt + pre;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                      // branch-free: a lane without a survivor in row r writes its trash row
+        const int pos = (m & (1u << r)) ? base + __popc(m & ((1u << r) - 1u)) : PEND + q4;
+        sel.lv[pos * 16 + col] = dd[r];
+        sel.li[pos * 16 + col] = jbase + r;
+      }
+    }
+    sel.cnt += pb[0] + pb[1];
+    KTL(4);                                              // log push
+    if (__any(sel.cnt - sel.done > 16)) sel.drain();     // keep the threshold fresh
+    KTL(5);
+  };
+  for (int tile = 0; tile < ntiles; tile += 2) {
+    const bool more = tile + 2 < ntiles;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {                      // (a tile beyond the last one re-reads the last row: masked in select_tile)
+        const int c = min((tile + 2 + u) * CT + col, a.N - 1);
+        load_raw(c, nraw[u]);
+        nsq[u] = sqb[c];
+      }
+    }
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      acc[0] = mfma16(cf[0][st], qf[st], acc[0]);
+      acc[1] = mfma16(cf[1][st], qf[st], acc[1]);
+    }
+    // 17th k-step: A[cand][k*] = -sq_cand/2 (row 0 of the lanes), B[k*][q] = 1  ->  acc = dot - sq_j/2, rounded once
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[u] = mfma16(q4 == 0 ? -0.5f * csq[u] : 0.f, q4 == 0 ? 1.f : 0.f, acc[u]);
+    KTL(0);                                              // prefetch issue + MFMA chains
+    select_tile(tile, acc[0]);
+    if (tile + 1 < ntiles) select_tile(tile + 1, acc[1]);
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        transpose(nraw[u], cf[u]);                       // the wait for the prefetch sits HERE
+        csq[u] = nsq[u];
+        asm volatile("" : "+v"(csq[u]));
+      }
+    }
+    KTL(3);                                              // wait for the prefetched rows + transpose
+  }
+  KTL_FLUSH;
+  finish<G, KS, 1>(sel, a, b, q0 + col, wave, 0, smem);
+}
+template <int KS, int W>
+__global__ __launch_bounds__(64 * W, 4) void knn64c_kernel(vcr_knn_args a) {
+  int bx, b;
+  xcd_chunk2(bx, b);
+  knn64c_body<KS, W>(a, bx, b);
+}
+
 // ---------------------------------------------------------------- C == 4 (xyz4, VALU)
 // Wave = 16 queries x 4 lanes (DPP quad = query); lane s of the quad computes the distances of candidates j = 4u + s.
 // S waves of a workgroup may split the candidates of a query group (small grids, k <= 20).
@@ -550,12 +735,13 @@ __global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
 // are independent): the first n64 workgroups run the MFMA kernel's body, the rest the Cartesian one.  Either kernel
 // alone is latency-bound at one wave per SIMD (1024 waves on 1024 SIMDs); launched together the second fills the
 // first one's idle issue slots, and the pair costs little more than the longer of the two.
-template <int KS>
-__global__ __launch_bounds__(256, 2) void knn_pair_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
+template <int KS, bool COL16>
+__global__ __launch_bounds__(256, (COL16 ? 4 : 2)) void knn_pair_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
   const int bid = (int)blockIdx.x;
   if (bid < n64) {
     const int lin = xcd_chunk(bid, n64);
-    knn64_body<KS, 1, 4>(a64, lin % gx64, lin / gx64);
+    if constexpr (COL16) knn64c_body<KS, 4>(a64, lin % gx64, lin / gx64);
+    else knn64_body<KS, 1, 4>(a64, lin % gx64, lin / gx64);
   } else {
     const int lin = xcd_chunk(bid - n64, (int)gridDim.x - n64);
     knn3_body<KS, 1>(a3, lin % gx3, lin / gx3);
@@ -949,14 +1135,29 @@ extern "C" int vcr_knn_ties_f32(const vcr_knn_args* a, const vcr_knn_args* b, vc
   return launch<knn_tiebreak_kernel>(dim3(TB_BLOCKS), dim3(256), lds, (hipStream_t)stream, *a);
 }
 
+// Which feature-space kernel: 16-query waves on 16x16x4 MFMAs (knn64c_body) or 32-query waves on 32x32x2 (knn64_body).
+// vcr_knn_args.waves: 8 forces the former; 1 / 2 / 4 the latter with that candidate split; 0 = the half-size waves as soon
+// as there are 1024 groups of 16 queries (a wave for every SIMD), by measurement on MI355X (profiles/r3i_bench_knn.txt;
+// 16- vs 32-query waves): one-launch pair 32 clouds x 1024: 148 vs 176 us inside the forward; pair 32 x 2048: 452 vs 477;
+// 64 x 4096, k = 40: 2.39 vs 2.92 ms; alone they are level at k = 20 (32 x 1024: 112 vs 123 us, 32 x 2048: 315 vs 303).
+// Smaller grids keep the 32-query kernels, whose S = 2 / 4 waves split the candidates of a query group.  Results are
+// identical either way (same k-ascending fma chain, same selection).
+static bool use_col16(const vcr_knn_args* a) {
+  if (a->waves == 8) return true;
+  if (a->waves != 0) return false;
+  return (long)((a->N + 15) / 16) * a->B >= 1024;
+}
+
 // Feature-space (a64: C == 64) and Cartesian (a3: C == 4) kNN of the same pass as one launch (see knn_pair_kernel) when
 // both are in the one-list-per-query regime the path runs in (k <= 20, >= 1024 query groups each); any other shape, or
 // a tie_stream, simply makes the two self-contained calls.  Tie handling as in vcr_knn_f32 (tie_defer honoured; a
 // replay that is not deferred serves both launches at once).
 extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3, vcr_stream_t stream) {
   if (!a64 || !a3 || !a64->x || !a3->x || !a64->idx || !a3->idx || a64->C != 64 || a3->C != 4) return VCR_EINVAL;
-  const bool fusable = a64->k == a3->k && a64->k <= 20 && !a64->tie_stream && !a3->tie_stream && a64->waves == 0 && a3->waves == 0 &&
-                       (long)((a64->N + 31) / 32) * a64->B >= 1024 && (long)((a3->N + 15) / 16) * a3->B >= 1024 &&
+  const bool col16 = use_col16(a64);
+  const bool fusable = a64->k == a3->k && a64->k <= 20 && !a64->tie_stream && !a3->tie_stream &&
+                       (a64->waves == 0 || a64->waves == 1 || a64->waves == 8) && a3->waves == 0 &&
+                       (long)((a64->N + (col16 ? 15 : 31)) / (col16 ? 16 : 32)) * a64->B >= 1024 && (long)((a3->N + 15) / 16) * a3->B >= 1024 &&
                        (a64->tie_scratch != nullptr) == (a3->tie_scratch != nullptr) && a64->tie_defer == a3->tie_defer;
   if (!fusable) {
     const int rc = vcr_knn_f32(a3, stream);
@@ -975,10 +1176,12 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
       const int e = zero_count(a->tie_scratch, s);
       if (e != 0) return e;
     }
-  const int gx64 = (a64->N + 127) / 128, gx3 = (a3->N + 63) / 64;      // 4 waves x 32 queries / 4 waves x 16 queries
+  const int gx64 = col16 ? (a64->N + 63) / 64 : (a64->N + 127) / 128, gx3 = (a3->N + 63) / 64;   // 4 waves x 16 (or 32) queries
   const int n64 = gx64 * a64->B, n3 = gx3 * a3->B;
-  const size_t lds64 = (size_t)4 * 2 * (pend_of<GeomMfma, 22>() + 1) * 32 * 4, lds3 = (size_t)4 * 2 * (pend_of<GeomQuad, 22>() + 1) * 16 * 4;
-  int rc = launch<knn_pair_kernel<22>>(dim3(n64 + n3), dim3(256), lds64 > lds3 ? lds64 : lds3, s, *a64, *a3, n64, gx64, gx3);
+  const size_t lds64 = col16 ? (size_t)4 * 2 * (pend_of<GeomCol16, 22>() + 4) * 16 * 4 : (size_t)4 * 2 * (pend_of<GeomMfma, 22>() + 1) * 32 * 4;
+  const size_t lds3 = (size_t)4 * 2 * (pend_of<GeomQuad, 22>() + 1) * 16 * 4, lds = lds64 > lds3 ? lds64 : lds3;
+  int rc = col16 ? launch<knn_pair_kernel<22, true>>(dim3(n64 + n3), dim3(256), lds, s, *a64, *a3, n64, gx64, gx3)
+                 : launch<knn_pair_kernel<22, false>>(dim3(n64 + n3), dim3(256), lds, s, *a64, *a3, n64, gx64, gx3);
   if (rc == 0 && a64->tie_scratch && !a64->tie_defer) rc = vcr_knn_ties_f32(a64, a3, stream);
   return rc;
 }
@@ -1003,9 +1206,16 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   // number of lists (S per query), and measured on MI355X a second wave per SIMD bought with S = 2 only breaks even, so
   // S stays 1 as soon as that gives every SIMD (1024 of them) one wave; smaller grids split to fill the chip.
   // (the fold of S > 1 waves parks the value lists behind the logs: there is room for that with k <= 20 only)
+  if (a->waves != 0 && a->waves != 1 && a->waves != 2 && a->waves != 4 && a->waves != 8) return VCR_EINVAL;
   auto pick_s = [&](long groups) { return !k20 ? 1 : a->waves == 1 || a->waves == 2 || a->waves == 4 ? a->waves
                                           : groups >= 1024 ? 1 : groups >= 512 ? 2 : 4; };
-  if (a->C == 64) {
+  if (a->C == 64 && use_col16(a)) {
+    // the half-size-wave kernel (see use_col16)
+    if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
+    const dim3 grid((a->N + 63) / 64, a->B);
+    const size_t lds = (size_t)4 * 2 * ((k20 ? pend_of<GeomCol16, 22>() : pend_of<GeomCol16, 42>()) + 4) * 16 * 4;
+    rc = k20 ? launch<knn64c_kernel<22, 4>>(grid, dim3(256), lds, s, *a) : launch<knn64c_kernel<42, 4>>(grid, dim3(256), lds, s, *a);
+  } else if (a->C == 64) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
     const int S = pick_s((long)((a->N + 31) / 32) * a->B), W = k20 ? 4 : 2;
     const dim3 grid((a->N + 32 * (W / S) - 1) / (32 * (W / S)), a->B);

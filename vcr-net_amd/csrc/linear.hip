@@ -18,7 +18,7 @@ namespace {
 constexpr int BM = 128, BN = 128;
 // MFMA shape of the LDS-DMA kernels when the call does not force one (vcr_linear_args.variant bits 4 / 10)
 #ifndef VCR_LINEAR_MS_DEFAULT
-#define VCR_LINEAR_MS_DEFAULT 32
+#define VCR_LINEAR_MS_DEFAULT 0      /* 0 = per launch (see vcr_linear_f32), 16 / 32 = that shape everywhere */
 #endif
 
 #ifdef VCR_TIMELINE
@@ -490,9 +490,11 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
   } while (0)
     // Without a residual: BK = 16, four workgroups per CU (measured +2-3 % on the qkv / ffn1 / kv projections).
     // With one: BK = 32 and the residual tile prefetched across the GEMM loop (bit 3 forces BK 32, bit 6 BK 16).
-    // MFMA shape: bit 4 (16) forces 16x16x4, bit 10 (1024) forces 32x32x2; automatic = VCR_LINEAR_MS_DEFAULT.
+    // MFMA shape: bit 4 (16) forces 16x16x4, bit 10 (1024) forces 32x32x2.  Automatic: 16x16x4 for the launches with a
+    // residual (the BK 32 kernels: measured in the pipeline at BASELINE configs[1], wo 155 -> 151 us, ffn2 276 -> 266 us),
+    // 32x32x2 for the BK 16 kernels (qkv / ffn1 / kv / q / conv3: equal within 1 %); DESIGN.md 5.1.
     const bool bk16 = (!a->residual || (variant & 64)) && !(variant & 8);
-    const bool ms16 = (variant & 16) ? true : (variant & 1024) ? false : VCR_LINEAR_MS_DEFAULT == 16;
+    const bool ms16 = (variant & 16) ? true : (variant & 1024) ? false : (VCR_LINEAR_MS_DEFAULT == 16 || (VCR_LINEAR_MS_DEFAULT == 0 && !bk16));
     if (bk16) { if (ms16) VCR_LIN_PICK(16, 16); else VCR_LIN_PICK(16, 32); }
     else { if (ms16) VCR_LIN_PICK(32, 16); else VCR_LIN_PICK(32, 32); }
 #undef VCR_LIN_PICK

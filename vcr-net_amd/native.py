@@ -174,7 +174,7 @@ class VcrnetWeights(C.Structure):
                 ("fold_dec_cross_q", FoldedW), ("fold_dec_cross_kv", FoldedW), ("fold_dec_ffn1", FoldedW),
                 ("partial", C.c_int), ("overlap2", C.c_double), ("emb_kind", C.c_int), ("dgcnn", DgcnnW),
                 ("att_w0", f32p), ("att_b0", f32p), ("att_w1", f32p), ("att_b1", f32p), ("cycle", C.c_int),
-                ("linear_mfma", C.c_int), ("sdpa_mfma", C.c_int), ("xscore_limit_mb", C.c_int)]
+                ("linear_mfma", C.c_int), ("sdpa_mfma", C.c_int), ("linear_bk", C.c_int), ("knn_waves", C.c_int), ("xscore_limit_mb", C.c_int)]
 
 
 class VcrnetIo(C.Structure):
