@@ -77,6 +77,8 @@ def parse(argv=None):
     ap.add_argument("--sdpa-mfma", type=int, default=0, choices=[0, 16, 32], help="the same for the attention kernel")
     ap.add_argument("--knn-waves", type=int, default=0, choices=[0, 1, 8],
                     help="feature-space kNN kernel: 8 = 16-query waves (16x16x4 MFMA), 1 = 32-query waves, 0 = the library's choice")
+    ap.add_argument("--no-merge-encdec", action="store_true",
+                    help="enc.qkv / dec.qkv and the two self-attentions as separate launches (default: one GEMM + one grouped launch)")
     ap.add_argument("--linear-bk", type=int, default=0, choices=[0, 16, 32], help="k-slab of the fp32 linears (0 = the library's choice)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm); gloo only "
                                                       "for exercising the multi-rank control flow on a 1-GPU box")
@@ -289,6 +291,7 @@ def run_rank(a):
     net.load_state_dict(w)
     net.emb_nn.k = a.k
     net.linear_mode = a.linear_mode
+    net.merge_encdec = not a.no_merge_encdec
     net.linear_mfma, net.sdpa_mfma, net.linear_bk, net.knn_waves = a.linear_mfma, a.sdpa_mfma, a.linear_bk, a.knn_waves
     net = net.to(dev).eval()
 

@@ -226,6 +226,11 @@ typedef struct {
   float* score_out; int ld_score;
   int variant;                        /* tuning / tests, 0 = automatic: bit4 (16) force the v_mfma_f32_16x16x4_f32 kernel,
                                          bit10 (1024) force 32x32x2 (fp32-rounding apart); vcr_sdpa_f32 only */
+  /* Optional: ngroups > 1 runs that many independent attention problems of identical shape as ONE launch (the
+   * encoder's and the decoder's self-attention of the forward: fewer, fuller rounds of workgroups).  Group g reads
+   * q / k / v at q + g * q_group_stride ... (element offsets) and writes out + g * out_group_stride; kv_batch_shift acts
+   * inside a group.  Attention-output form only (no key_keep / rowstat / score_out); 0 or 1 = one group; vcr_sdpa_f32 only. */
+  int ngroups; long q_group_stride, k_group_stride, v_group_stride, out_group_stride;
 } vcr_sdpa_args;
 int vcr_sdpa_f32(const vcr_sdpa_args*, vcr_stream_t);
 /* The attention-output form of vcr_sdpa_f32 (out != NULL, rowstat == score_out == NULL, scale > 0) with Q, K, V and the
@@ -385,6 +390,10 @@ typedef struct {
    * vcr_fold_layernorm_f32 (w [N,E], colsum [N], bias [N]).  dec_cross_kv is folded with the ENCODER's final norm. */
   struct vcr_folded { const float *w, *colsum, *bias; } fold_enc_qkv, fold_enc_ffn1, fold_dec_qkv, fold_dec_cross_q,
       fold_dec_cross_kv, fold_dec_ffn1;
+  /* optional (linear_mode 0): fold_enc_qkv and fold_dec_qkv stacked, w [6E,E], colsum [6E], bias [6E] -- both consume the
+   * embedding rows with the same row statistics, so the two projections run as ONE GEMM and the encoder's and the
+   * decoder's self-attention as ONE grouped launch (fewer, fuller rounds of workgroups).  w == NULL: two launches each. */
+  struct vcr_folded fold_encdec_qkv;
   /* partial-overlap mode (args.partial, vcrnet_model.py:178-187 + transformer.py:35-53): the decoder's
    * cross-attention keeps the int(N*overlap2) keys with the largest soft-max mass; with head_mode 0 the head is
    * selectCom + getCopair and the outputs hold vcr_vcrnet_pairs() hard pairs per sample instead of N soft ones.

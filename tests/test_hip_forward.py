@@ -372,3 +372,40 @@ def test_forward_captures_into_a_hip_graph():
                 for a, b in zip(out[1:], ref[1:]):
                     assert torch.equal(a, b), rep
                 _ = torch.randn(1 << 16, device="cuda").sum().item()       # unrelated allocation + kernels + sync
+
+
+@pytest.mark.parametrize("partial", [False, True])
+def test_merged_encoder_decoder_launches_change_nothing(partial):
+    """enc.qkv + dec.qkv as ONE stacked GEMM and the encoder's / decoder's self-attention as ONE grouped launch
+    (vcr_vcrnet_weights.fold_encdec_qkv, vcr_sdpa_args.ngroups) against the four separate launches: the same tiles with
+    the same arithmetic, so every output is bit-identical."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    kw = dict(partial=True, overlap2=synth.OVERLAP2_0575) if partial else {}
+    net, _ = build_net(**kw)
+    src, tgt, _, _, _ = synth.make_batch(7100, 3, 320, partial=partial)
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    outs = []
+    for merge in (True, False):
+        net.merge_encdec = merge
+        with torch.no_grad():
+            outs.append(net._forward_fused(s, t, want_emb=True))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_grouped_sdpa_equals_separate_launches():
+    import math
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native
+    g = torch.Generator().manual_seed(3)
+    nb, h, N = 4, 4, 200
+    qkv2 = torch.randn(nb * N, 6 * 512, generator=g).cuda()
+    for variant in (0, 16):
+        grouped = native.sdpa(qkv2[:, :512], qkv2[:, 512:1024], qkv2[:, 1024:1536], nb, h, N, N, 1 / math.sqrt(128),
+                              kv_batch_shift=1, groups=(2, 1536, 1536, 1536), variant=variant)
+        for gi in range(2):
+            o = 1536 * gi
+            one = native.sdpa(qkv2[:, o:o + 512], qkv2[:, o + 512:o + 1024], qkv2[:, o + 1024:o + 1536], nb, h, N, N,
+                              1 / math.sqrt(128), kv_batch_shift=1, variant=variant)
+            assert torch.equal(grouped[gi], one)

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
   // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD whole
   // (batch, head) pairs -- all query blocks of a pair then stream the same K/V through ONE L2 instead of
   // eight (measured before: 1.14 GB fetched per launch = 8 x the K/V bytes).  Speed only, never correctness.
-  const int nqb = (p.nq + 127) / 128, nbh = p.nbatch * p.heads;
+  const int nqb = (p.nq + 127) / 128, nbh = p.nbatch * p.heads * (p.ngroups > 1 ? p.ngroups : 1);
   int qb, bh;
   if ((nbh & 7) == 0) {
     const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
@@ -42,7 +42,10 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
   } else {
     qb = blockIdx.x % nqb; bh = blockIdx.x / nqb;
   }
-  const int head = bh % p.heads, b = bh / p.heads;
+  const int head = bh % p.heads;
+  const int grp = (bh / p.heads) / p.nbatch, b = (bh / p.heads) % p.nbatch;   // (grp == 0 unless p.ngroups > 1; grid covers them)
+  p.q += (size_t)grp * p.q_group_stride; p.k += (size_t)grp * p.k_group_stride;
+  if (DO_PV) { p.v += (size_t)grp * p.v_group_stride; p.out += (size_t)grp * p.out_group_stride; }
   const int kvb = (b + p.kv_batch_shift) % p.nbatch;
   const int q = qb * 128 + w * 32 + l31;
   const int qc = min(q, p.nq - 1);
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void sdpa16_kernel(vcr_sdpa_args p) {
   Stage* st = reinterpret_cast<Stage*>(smem);
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int half = lane >> 5, l31 = lane & 31, qt = lane >> 4, l15 = lane & 15;
-  const int nqb = (p.nq + 127) / 128, nbh = p.nbatch * p.heads;
+  const int nqb = (p.nq + 127) / 128, nbh = p.nbatch * p.heads * (p.ngroups > 1 ? p.ngroups : 1);
   int qb, bh;
   if ((nbh & 7) == 0) {
     const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
@@ -228,7 +231,10 @@ __global__ __launch_bounds__(256, 2) void sdpa16_kernel(vcr_sdpa_args p) {
   } else {
     qb = blockIdx.x % nqb; bh = blockIdx.x / nqb;
   }
-  const int head = bh % p.heads, b = bh / p.heads;
+  const int head = bh % p.heads;
+  const int grp = (bh / p.heads) / p.nbatch, b = (bh / p.heads) % p.nbatch;
+  p.q += (size_t)grp * p.q_group_stride; p.k += (size_t)grp * p.k_group_stride;
+  if (DO_PV) { p.v += (size_t)grp * p.v_group_stride; p.out += (size_t)grp * p.out_group_stride; }
   const int kvb = (b + p.kv_batch_shift) % p.nbatch;
   int q[2];
   f32x4 qf[2][8];                                        // [jq][g]: dims 16 g + 4 qt .. + 3 of query 16 jq + l15
@@ -476,7 +482,9 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   if (a->nbatch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return VCR_EINVAL;
   if ((a->ldq & 3) || (a->ldk & 3) || (pv && ((a->ldv & 3) || (a->ldo & 3)))) return VCR_EINVAL;
   if (a->ldq < a->heads * 128 || a->ldk < a->heads * 128) return VCR_EINVAL;
-  dim3 grid(((a->nq + 127) / 128) * a->heads * a->nbatch);
+  const int ng = a->ngroups > 1 ? a->ngroups : 1;
+  if (ng > 1 && (!pv || a->key_keep || a->rowstat || a->score_out)) return VCR_EINVAL;
+  dim3 grid(((a->nq + 127) / 128) * a->heads * a->nbatch * ng);
   const int lds = 2 * sizeof(Stage);
   hipStream_t s = (hipStream_t)stream;
   // MFMA shape: variant bit 4 (16) forces 16x16x4, bit 10 (1024) forces 32x32x2, 0 = VCR_SDPA_MS_DEFAULT

@@ -44,7 +44,8 @@ struct Ws {
 inline int overlap_k1(int N, double o2) { return (int)((double)N * 0.84 * o2); }
 inline int overlap_k2(int N, double o2) { return (int)((double)overlap_k1(N, o2) * 0.52 * o2); }
 
-Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, double o2, int emb_kind, int xscore_limit_mb) {
+Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, double o2, int emb_kind, int xscore_limit_mb,
+         int merged) {
   Bump bp{reinterpret_cast<unsigned char*>(base), 0, 0};
   const size_t M = (size_t)2 * B * N;
   Ws w{};
@@ -54,7 +55,8 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   w.tie_work = w.tie_work_each ? bp.take<unsigned char>(2 * w.tie_work_each) : nullptr;
   w.pq1 = bp.take<float>(M * 256);  w.cat = bp.take<float>(M * 512);   w.pq3 = bp.take<float>(M * 512);
   w.emb = bp.take<float>(M * E);
-  w.qkv = bp.take<float>(M * 3 * E); w.att = bp.take<float>(M * E);
+  // merged: the encoder's and the decoder's Q|K|V side by side ([M, 6E]) and their attention outputs one after the other
+  w.qkv = bp.take<float>(M * 3 * E * (merged ? 2 : 1)); w.att = bp.take<float>(M * E * (merged ? 2 : 1));
   w.e1 = bp.take<float>(M * E);     w.e2 = bp.take<float>(M * E);
   w.hid = bp.take<float>(M * F);
   w.d1 = bp.take<float>(M * E);     w.d2 = bp.take<float>(M * E);      w.d3 = bp.take<float>(M * E);
@@ -89,6 +91,11 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   w.Rb = bp.take<float>((size_t)B * 9); w.tb = bp.take<float>((size_t)B * 3);
   w.bytes = bp.off + 256;
   return w;
+}
+
+// enc.qkv + dec.qkv as one GEMM, the two self-attentions as one grouped launch: needs the stacked folded weight (fp32 mode)
+inline int merged_encdec(const vcr_vcrnet_weights* W) {
+  return W->has_pointer == 1 && W->linear_mode == 0 && W->fold_encdec_qkv.w && W->fold_encdec_qkv.colsum && W->fold_encdec_qkv.bias;
 }
 
 __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* p, long n) {
@@ -131,11 +138,16 @@ struct Runner {
   }
   bool sdpa(const char* nm, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
             int ldo, int nb, int heads, int nq, int nk, int shift, const uint8_t* keep = nullptr,
-            float* rowstat = nullptr, float* score_out = nullptr, int ld_score = 0) {
+            float* rowstat = nullptr, float* score_out = nullptr, int ld_score = 0, int ngroups = 1, long in_group_stride = 0,
+            long out_group_stride = 0) {
     if (rc) return false;
     mark(nm);
     vcr_sdpa_args a{q, ldq, k, ldk, v, ldv, out, ldo, nb, heads, nq, nk, 1.0f / sqrtf(128.f), shift, keep, rowstat,
                     score_out, ld_score, sdpa_variant};
+    if (ngroups > 1) {
+      a.ngroups = ngroups; a.q_group_stride = a.k_group_stride = a.v_group_stride = in_group_stride;
+      a.out_group_stride = out_group_stride;
+    }
     // linear_mode 2: the attention-output launches on the bf16 matrix pipe as exact splits; statistics passes stay fp32
     return ok((sdpa_split && out && !rowstat && !score_out) ? vcr_sdpa_bf16x3_f32(&a, stream) : vcr_sdpa_f32(&a, stream));
   }
@@ -341,7 +353,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (!W->partial && (io->force_keys || io->force_sel_src || io->force_sel_tgt || io->force_argmax || io->force_pairs))
     return VCR_EINVAL;                                   // there is nothing discrete to force in whole mode
   if ((io->force_sel_src != nullptr) != (io->force_sel_tgt != nullptr)) return VCR_EINVAL;
-  Ws w = carve(workspace, B, N, k, E, F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb);
+  Ws w = carve(workspace, B, N, k, E, F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W));
   if (ws_bytes < w.bytes) return VCR_EWORKSPACE;
   const int M1 = B * N, M2 = 2 * M1;
   Runner R{(hipStream_t)stream, tr};
@@ -449,9 +461,21 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     // the folded weight and applies (mean, 1/(std+eps)) in its epilogue -- six LayerNorm launches and their
     // 2 x 67 MB round trips are gone.
     const int H = W->heads;
+    const bool merged = merged_encdec(W) != 0;
+    const float* att_dec = w.att;                        // the decoder's self-attention output
+    if (merged) {
+      // both first sublayers read the embedding rows with the same row statistics: one [M, 6E] projection, and the two
+      // independent self-attentions as one grouped launch (group 0 = encoder, 1 = decoder)
+      R.linear("linear:encdec.qkv", w.emb, E, W->fold_encdec_qkv.w, nullptr, W->fold_encdec_qkv.bias, w.qkv, 6 * E, M2, 6 * E, E, 0,
+               nullptr, 0, w.st_emb, W->fold_encdec_qkv.colsum);
+      R.sdpa("sdpa:encdec.self", w.qkv, 6 * E, w.qkv + E, 6 * E, w.qkv + 2 * E, 6 * E, w.att, E, 2 * B, H, N, N, 0, nullptr, nullptr,
+             nullptr, 0, 2, 3 * E, (long)M2 * E);
+      att_dec = w.att + (size_t)M2 * E;
+    } else {
     R.linear("linear:enc.qkv", w.emb, E, W->fold_enc_qkv.w, SP(enc_qkv), W->fold_enc_qkv.bias, w.qkv, 3 * E, M2, 3 * E, E, 0,
              nullptr, 0, w.st_emb, W->fold_enc_qkv.colsum);
     R.sdpa("sdpa:enc.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
+    }
     R.linear("linear:enc.wo", w.att, E, W->enc_self.wo, SP(enc_wo), W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E,
              nullptr, nullptr, w.st_e1);
     R.linear("linear:enc.ffn1", w.e1, E, W->fold_enc_ffn1.w, SP(enc_ffn1), W->fold_enc_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
@@ -460,10 +484,12 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
              nullptr, nullptr, w.st_e2);
     // decoder; batch b attends to the encoder memory (= enc.norm(e2), applied inside the K/V projection) of
     // batch (b + B) mod 2B
+    if (!merged) {
     R.linear("linear:dec.qkv", w.emb, E, W->fold_dec_qkv.w, SP(dec_qkv), W->fold_dec_qkv.bias, w.qkv, 3 * E, M2, 3 * E, E, 0,
              nullptr, 0, w.st_emb, W->fold_dec_qkv.colsum);
     R.sdpa("sdpa:dec.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
-    R.linear("linear:dec.self.wo", w.att, E, W->dec_self.wo, SP(dec_self_wo), W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E,
+    }
+    R.linear("linear:dec.self.wo", att_dec, E, W->dec_self.wo, SP(dec_self_wo), W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E,
              nullptr, nullptr, w.st_d1);
     R.linear("linear:dec.cross.q", w.d1, E, W->fold_dec_cross_q.w, SP(dec_cross_q), W->fold_dec_cross_q.bias, w.qc, E, M2, E, E, 0, nullptr, 0,
              w.st_d1, W->fold_dec_cross_q.colsum);
@@ -595,7 +621,7 @@ __global__ __launch_bounds__(256) void pose_step_kernel(const float* __restrict_
 
 extern "C" size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights* W, int B, int N) {
   if (!W || B <= 0 || N <= 0) return 0;
-  return carve(nullptr, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb).bytes;
+  return carve(nullptr, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W)).bytes;
 }
 
 extern "C" int vcr_vcrnet_pairs(const vcr_vcrnet_weights* W, int N) {
@@ -633,7 +659,7 @@ extern "C" int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet
     R.finish();
     return lrc;
   }
-  const Ws w = carve(ws, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb);
+  const Ws w = carve(ws, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W));
   if (bytes < w.bytes) return VCR_EWORKSPACE;
   const size_t nkeys = W->partial ? (size_t)2 * B * (int)((double)N * W->overlap2) : 0;
   const size_t nsel = W->partial ? (size_t)B * overlap_k1(N, W->overlap2) : 0;

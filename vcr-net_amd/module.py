@@ -200,6 +200,8 @@ class VCRNet(nn.Module):
         self.linear_mode = os.environ.get("VCRNET_LINEAR_MODE", "fp32")
         # MFMA shape of the fp32 linears / attention: 0 = the library's choice, 16 = 16x16x4, 32 = 32x32x2 (benchmarks)
         self.linear_mfma, self.sdpa_mfma, self.linear_bk, self.knn_waves = 0, 0, 0, 0
+        # enc.qkv + dec.qkv as one GEMM and the two self-attentions as one grouped launch (fp32 mode; same arithmetic)
+        self.merge_encdec = os.environ.get("VCRNET_MERGE_ENCDEC", "1") == "1"
         self.xscore_limit_mb = 0            # partial mode: keep the cross-attention scores up to this many MiB (0 = 4096)
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
@@ -221,7 +223,8 @@ class VCRNet(nn.Module):
     def _fingerprint(self):
         ps = list(self.parameters()) + list(self.buffers())
         return (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]), self.emb_nn.k,
-                self.linear_mode, self.linear_mfma, self.sdpa_mfma, self.linear_bk, self.knn_waves, self.xscore_limit_mb)
+                self.linear_mode, self.linear_mfma, self.sdpa_mfma, self.linear_bk, self.knn_waves, self.xscore_limit_mb,
+                self.merge_encdec)
 
     def _pack(self):
         key = self._fingerprint()
@@ -316,6 +319,11 @@ class VCRNet(nn.Module):
                 P["fold." + site] = f
                 P["fold." + site + ".w"] = f[0]
                 setattr(cw, "fold_" + site, native.FoldedW(*(native.ptr(t) for t in f)))
+            if self.merge_encdec:
+                # the encoder's and the decoder's first sublayers both read the embedding rows: one stacked projection
+                f = tuple(torch.cat((a_, b_), 0).contiguous() for a_, b_ in zip(P["fold.enc_qkv"], P["fold.dec_qkv"]))
+                P["fold.encdec_qkv"] = f
+                cw.fold_encdec_qkv = native.FoldedW(*(native.ptr(t) for t in f))
         else:
             cw.has_pointer = 2 if isinstance(self.pointer, _Identity) else 0
         if self.linear_mode not in LINEAR_MODES:
@@ -348,7 +356,7 @@ class VCRNet(nn.Module):
         self._cw = cw
 
     def _buffers_for(self, B: int, N: int, device) -> Dict[str, torch.Tensor]:
-        key = (B, N, device, int(self.emb_nn.k), int(self.xscore_limit_mb))
+        key = (B, N, device, int(self.emb_nn.k), int(self.xscore_limit_mb), bool(self.merge_encdec), self.linear_mode)
         bufs = self._bufs.get(key)
         if bufs is None:
             nbytes = native.lib().vcr_vcrnet_workspace_bytes(C.byref(self._cw), B, N)

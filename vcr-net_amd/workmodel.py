@@ -24,7 +24,7 @@ FAMILY_BOUND = {"pointwise": "hbm", "knn": "mfma", "linear": "mfma", "edgeconv":
 _LINEAR_SHAPES = {  # site -> (N_out, K) as multiples resolved below
     "dg1_pq": (256, 64), "sn1_pq": (512, 128), "conv3": ("E", 512),
     "enc.qkv": ("3E", "E"), "enc.wo": ("E", "E"), "enc.ffn1": ("F", "E"), "enc.ffn2": ("E", "F"),
-    "dec.qkv": ("3E", "E"), "dec.self.wo": ("E", "E"), "dec.cross.q": ("E", "E"), "dec.cross.kv": ("2E", "E"),
+    "dec.qkv": ("3E", "E"), "encdec.qkv": ("6E", "E"), "dec.self.wo": ("E", "E"), "dec.cross.q": ("E", "E"), "dec.cross.kv": ("2E", "E"),
     "dec.cross.wo": ("E", "E"), "dec.ffn1": ("F", "E"), "dec.ffn2": ("E", "F"),
 }
 
@@ -40,7 +40,7 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
     """(flops, bytes) of one launch called `name` ("family:site") for B pairs of N points."""
     fam, site = name.split(":", 1)
     M1, M2 = B * N, 2 * B * N
-    sym = {"E": E, "2E": 2 * E, "3E": 3 * E, "F": F}
+    sym = {"E": E, "2E": 2 * E, "3E": 3 * E, "6E": 6 * E, "F": F}
     r = lambda v: sym[v] if isinstance(v, str) else v
     if fam == "pointwise":
         if site == "pad":
@@ -85,7 +85,8 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
     if fam == "sdpa":
         if site == "dec.cross.stats":                      # QK^T + row statistics only
             return 2.0 * 2 * B * N * N * E, 4.0 * M2 * E * 2
-        return 4.0 * 2 * B * N * N * E, 4.0 * M2 * E * 4
+        g = 2 if site == "encdec.self" else 1               # encoder's and decoder's self-attention as one grouped launch
+        return g * 4.0 * 2 * B * N * N * E, g * 4.0 * M2 * E * 4
     if fam == "pairscore":
         if site == "dec.cross.keymass":                    # one head: 128-d scores of every (key, query) pair
             return 2.0 * 2 * B * N * N * (E // 4), 4.0 * M2 * (E // 4) * 2
