@@ -134,6 +134,10 @@ typedef struct {
                                          sum k in different orders (fp32-rounding apart).  Any other bit: VCR_EINVAL. */
 } vcr_linear_args;
 int vcr_linear_f32(const vcr_linear_args*, vcr_stream_t);
+/* Two independent linears as ONE launch when both resolve to the same kernel configuration (k-slab, MFMA shape,
+ * LayerNorm-in, statistics-out; no fused max), else exactly the two calls: fewer, fuller rounds of workgroups for e.g. the
+ * encoder's and the decoder's output projections.  Every tile is computed as in its own launch: identical results. */
+int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_args* b, vcr_stream_t);
 
 /* Fold LayerNorm(a, b) into the Linear (w [N,K], bias [N] or NULL) that consumes it, once per weight:
  * w_out[n,k] = w[n,k] a[k];  colsum[n] = sum_k w_out[n,k];  bias_out[n] = bias[n] + sum_k w[n,k] b[k]. */

@@ -674,3 +674,29 @@ def test_knn_long_rows_replay_ties_through_global_scratch(nat):
         nat.knn(xyz4, None, k, tie_work=False)
     with pytest.raises(nat.VcrHipError, match="unsupported"):
         nat.knn(xyz4, None, 41)
+
+
+def test_linear_pair_equals_two_launches(nat):
+    """vcr_linear_pair_f32: two independent linears of one kernel configuration in ONE launch (and the fallback to two
+    launches when the configurations differ) -- bit-identical to the separate calls, statistics included."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(5)
+    M, K = 3000, 512
+    L = nat.lib()
+    L.vcr_linear_pair_f32.argtypes = [C.POINTER(nat.LinearArgs), C.POINTER(nat.LinearArgs), C.c_void_p]
+    L.vcr_linear_pair_f32.restype = C.c_int
+    for (Na, Nb, res_b) in ((512, 512, True), (1024, 512, False), (512, 256, True)):
+        xa, xb = dev(torch.randn(M, K, generator=g)), dev(torch.randn(M + 77, K, generator=g))
+        wa, wb = dev(torch.randn(Na, K, generator=g) / 22), dev(torch.randn(Nb, K, generator=g) / 22)
+        ba, bb = dev(torch.randn(Na, generator=g)), dev(torch.randn(Nb, generator=g))
+        ra = dev(torch.randn(M, Na, generator=g))
+        rb = dev(torch.randn(M + 77, Nb, generator=g)) if res_b else None
+        ya, sa = nat.linear(xa, wa, ba, residual=ra, want_stats=True)
+        yb, sb = nat.linear(xb, wb, bb, residual=rb, want_stats=True)
+        ya2, yb2 = torch.empty_like(ya), torch.empty_like(yb)
+        sa2, sb2 = torch.empty_like(sa), torch.empty_like(sb)
+        A = nat.LinearArgs(nat.ptr(xa), K, nat.ptr(wa), nat.ptr(ba), nat.ptr(ra), Na, nat.ptr(ya2), Na, M, Na, K, 0)
+        Bq = nat.LinearArgs(nat.ptr(xb), K, nat.ptr(wb), nat.ptr(bb), nat.ptr(rb), Nb if res_b else 0, nat.ptr(yb2), Nb, M + 77, Nb, K, 0)
+        A.stats_out, Bq.stats_out = nat.ptr(sa2), nat.ptr(sb2)
+        nat.check(L.vcr_linear_pair_f32(C.byref(A), C.byref(Bq), C.c_void_p(nat.stream_ptr())), "vcr_linear_pair_f32")
+        assert torch.equal(ya, ya2) and torch.equal(yb, yb2) and torch.equal(sa, sa2) and torch.equal(sb, sb2), (Na, Nb, res_b)

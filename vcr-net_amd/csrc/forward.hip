@@ -129,6 +129,21 @@ struct Runner {
     a.variant = linear_variant;
     return ok(wsplit ? vcr_linear_bf16x3_f32(&a, wsplit, stream) : vcr_linear_f32(&a, stream));
   }
+  // the argument block of linear() without launching it, and two such blocks as one launch (vcr_linear_pair_f32)
+  vcr_linear_args linear_args(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int N, int K,
+                              int relu, const float* res = nullptr, int ldr = 0, const float* ln_stats = nullptr,
+                              const float* ln_colsum = nullptr, float* stats_out = nullptr) {
+    vcr_linear_args a{x, ldx, w, b, res, ldr, y, ldy, M, N, K, relu};
+    if (ln_stats) { a.ln_stats_in = ln_stats; a.ln_nseg = K / 64; a.ln_colsum = ln_colsum; a.ln_eps = 1e-6f; }
+    a.stats_out = stats_out;
+    a.variant = linear_variant;
+    return a;
+  }
+  bool linear2(const char* nm, const vcr_linear_args& a, const vcr_linear_args& b) {
+    if (rc) return false;
+    mark(nm);
+    return ok(vcr_linear_pair_f32(&a, &b, stream));
+  }
   bool norm(const char* nm, const float* x, const vcr_norm_w& n, float* y, int M, int E,
             const float* res = nullptr, const float* xyz4 = nullptr, float* side4 = nullptr) {
     if (rc) return false;
@@ -476,6 +491,20 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
              nullptr, 0, w.st_emb, W->fold_enc_qkv.colsum);
     R.sdpa("sdpa:enc.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
     }
+    if (merged) {
+      // independent launches of one kernel configuration run as pairs: the two output projections (inputs = the two
+      // attention outputs, residual = the embedding), then the encoder's FFN-in beside the decoder's cross-attention query
+      R.linear2("linear:enc.wo+dec.self.wo",
+                R.linear_args(w.att, E, W->enc_self.wo, W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E, nullptr, nullptr, w.st_e1),
+                R.linear_args(att_dec, E, W->dec_self.wo, W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E, nullptr, nullptr, w.st_d1));
+      R.linear2("linear:enc.ffn1+dec.cross.q",
+                R.linear_args(w.e1, E, W->fold_enc_ffn1.w, W->fold_enc_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0, w.st_e1,
+                              W->fold_enc_ffn1.colsum),
+                R.linear_args(w.d1, E, W->fold_dec_cross_q.w, W->fold_dec_cross_q.bias, w.qc, E, M2, E, E, 0, nullptr, 0, w.st_d1,
+                              W->fold_dec_cross_q.colsum));
+      R.linear("linear:enc.ffn2", w.hid, F, W->enc_ffn.w2, nullptr, W->enc_ffn.b2, w.e2, E, M2, E, F, 0, w.e1, E,
+               nullptr, nullptr, w.st_e2);
+    } else {
     R.linear("linear:enc.wo", w.att, E, W->enc_self.wo, SP(enc_wo), W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E,
              nullptr, nullptr, w.st_e1);
     R.linear("linear:enc.ffn1", w.e1, E, W->fold_enc_ffn1.w, SP(enc_ffn1), W->fold_enc_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
@@ -484,15 +513,15 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
              nullptr, nullptr, w.st_e2);
     // decoder; batch b attends to the encoder memory (= enc.norm(e2), applied inside the K/V projection) of
     // batch (b + B) mod 2B
-    if (!merged) {
     R.linear("linear:dec.qkv", w.emb, E, W->fold_dec_qkv.w, SP(dec_qkv), W->fold_dec_qkv.bias, w.qkv, 3 * E, M2, 3 * E, E, 0,
              nullptr, 0, w.st_emb, W->fold_dec_qkv.colsum);
     R.sdpa("sdpa:dec.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
-    }
     R.linear("linear:dec.self.wo", att_dec, E, W->dec_self.wo, SP(dec_self_wo), W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E,
              nullptr, nullptr, w.st_d1);
     R.linear("linear:dec.cross.q", w.d1, E, W->fold_dec_cross_q.w, SP(dec_cross_q), W->fold_dec_cross_q.bias, w.qc, E, M2, E, E, 0, nullptr, 0,
              w.st_d1, W->fold_dec_cross_q.colsum);
+    }
+    // batch b attends to the encoder memory (= enc.norm(e2), applied inside the K/V projection) of batch (b + B) mod 2B
     R.linear("linear:dec.cross.kv", w.e2, E, W->fold_dec_cross_kv.w, SP(dec_cross_kv), W->fold_dec_cross_kv.bias, w.kvc, 2 * E, M2, 2 * E, E, 0,
              nullptr, 0, w.st_e2, W->fold_dec_cross_kv.colsum);
     R.cross_attention(W, io, w, B, N);

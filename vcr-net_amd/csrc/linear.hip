@@ -201,7 +201,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 //         the matrix pipe's power limit (profiles/r2e_mfma_sustained_rates.txt: 132-140 vs 127-136 TFLOP/s).  The two
 //         shapes sum k in different orders: results agree to fp32 rounding, not bitwise.
 template <int BK, bool LN_IN, bool STATS_OUT, int MS>
-__global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_kernel(vcr_linear_args p, int tiles_m, int tiles_n) {
+__device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int tiles_m, int tiles_n, int blk) {
   using Tile = TileGT<BK>;
   constexpr int CPR = BK / 4;                            // 16-B chunks per LDS row
   constexpr int RPK = 64 / CPR;                          // rows per 1-KiB LDS-DMA wave instruction
@@ -216,8 +216,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_kernel(vc
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
   const int nblk = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  bid = xcd_chunk(bid, nblk);
+  const int bid = xcd_chunk(blk, nblk);
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   TL(0);
@@ -436,6 +435,21 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_kernel(vc
 #endif
 }
 
+template <int BK, bool LN_IN, bool STATS_OUT, int MS>
+__global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_kernel(vcr_linear_args p, int tiles_m, int tiles_n) {
+  linear_glds_body<BK, LN_IN, STATS_OUT, MS>(p, tiles_m, tiles_n, (int)blockIdx.x);
+}
+// Two independent linears of the same kernel configuration as ONE launch (the first n0 workgroups work on p0, the rest
+// on p1): the encoder's and the decoder's output projections, or enc.ffn1 beside dec.cross.q -- fewer, fuller rounds of
+// workgroups; each tile is computed exactly as in its own launch.
+template <int BK, bool LN_IN, bool STATS_OUT, int MS>
+__global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_pair_kernel(vcr_linear_args p0, vcr_linear_args p1, int tm0,
+                                                                                 int tn0, int tm1, int tn1) {
+  const int n0 = tm0 * tn0;
+  if ((int)blockIdx.x < n0) linear_glds_body<BK, LN_IN, STATS_OUT, MS>(p0, tm0, tn0, (int)blockIdx.x);
+  else linear_glds_body<BK, LN_IN, STATS_OUT, MS>(p1, tm1, tn1, (int)blockIdx.x - n0);
+}
+
 }  // namespace
 
 #ifdef VCR_TIMELINE
@@ -448,7 +462,11 @@ extern "C" int vcr_dbg_timeline(unsigned long long* host_dst, int clear) {
 }
 #endif
 
-extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
+namespace {
+struct LinearPlan { bool glds, bk16, ms16, ln_in, st_out; int tiles_m, tiles_n, vec, lds; };
+
+// validation + kernel choice of one linear (shared by vcr_linear_f32 and vcr_linear_pair_f32)
+int linear_plan(const vcr_linear_args* a, LinearPlan* pl) {
   if (!a || !a->x || !a->w || (!a->y && !a->segmax_out)) return VCR_EINVAL;
   if (a->segmax_out && (a->seg_k <= 0 || !a->relu || a->residual || a->ln_stats_in || a->stats_out || (a->ld_segmax & 3) ||
                         a->ld_segmax < a->N || ((uintptr_t)a->segmax_out & 15) || (a->variant & 4)))
@@ -458,52 +476,89 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
   if (variant & ~(4 | 8 | 16 | 64 | 1024)) return VCR_EINVAL;     // retired selectors (1, 32, 128, 256, 512) are refused, not ignored
   if ((a->ldx & 3) || a->ldx < a->K || (a->y && a->ldy < a->N) || (a->residual && a->ldr < a->N)) return VCR_EINVAL;
   if (((uintptr_t)a->x | (uintptr_t)a->w) & 15) return VCR_EINVAL;
-  const int tiles_m = (a->M + BM - 1) / BM, tiles_n = (a->N + BN - 1) / BN;
-  const int lds32 = 2 * sizeof(TileT<32>);
-  const int vec = (a->N % 4 == 0) && (!a->y || ((a->ldy % 4 == 0) && (((uintptr_t)a->y & 15) == 0))) &&
-                  (!a->bias || ((uintptr_t)a->bias & 15) == 0) &&
-                  (!a->residual || ((a->ldr % 4 == 0) && ((uintptr_t)a->residual & 15) == 0));
+  pl->tiles_m = (a->M + BM - 1) / BM; pl->tiles_n = (a->N + BN - 1) / BN;
+  pl->vec = (a->N % 4 == 0) && (!a->y || ((a->ldy % 4 == 0) && (((uintptr_t)a->y & 15) == 0))) &&
+            (!a->bias || ((uintptr_t)a->bias & 15) == 0) &&
+            (!a->residual || ((a->ldr % 4 == 0) && ((uintptr_t)a->residual & 15) == 0));
   if (a->ln_stats_in || a->stats_out) {                  // fused LayerNorm prologue / statistics epilogue
     if (a->ln_stats_in && (!a->ln_colsum || !a->bias || a->ln_nseg <= 0 || a->K < 2 || (a->K % a->ln_nseg))) return VCR_EINVAL;
     if (a->stats_out && (a->N % 64)) return VCR_EINVAL;
-    if (!vec || (variant & 4)) return VCR_EUNSUPPORTED;  // the LDS-DMA kernels move 16 B per lane
+    if (!pl->vec || (variant & 4)) return VCR_EUNSUPPORTED;   // the LDS-DMA kernels move 16 B per lane
     if (a->ln_stats_in && ((uintptr_t)a->ln_colsum & 15)) return VCR_EINVAL;
   }
-  if (a->segmax_out && !vec) return VCR_EUNSUPPORTED;
-  if (!(variant & 4) && vec) {   // LDS-DMA staging, one tile per workgroup
-    const bool ln_in = a->ln_stats_in != nullptr, st_out = a->stats_out != nullptr;
-    hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(tiles_m * tiles_n);
-#define VCR_LIN_LAUNCH(BKV, LI, SO, MSV)                                                                                \
-  do {                                                                                                                   \
-    const int stage = 2 * (int)sizeof(TileGT<BKV>) > 4 * 32 * 68 * 4 ? 2 * (int)sizeof(TileGT<BKV>) : 4 * 32 * 68 * 4;    \
-    const int lds = stage + (LI ? BM * 2 * 4 : 0);                                                                       \
-    VCR_DYN_LDS((linear_glds_kernel<BKV, LI, SO, MSV>), lds);                                                            \
-    hipLaunchKernelGGL((linear_glds_kernel<BKV, LI, SO, MSV>), grid, dim3(256), lds, s, *a, tiles_m, tiles_n);          \
-  } while (0)
-#define VCR_LIN_PICK(BKV, MSV)                                                                                          \
-  do {                                                                                                                   \
-    if (ln_in && st_out) VCR_LIN_LAUNCH(BKV, true, true, MSV);                                                           \
-    else if (ln_in) VCR_LIN_LAUNCH(BKV, true, false, MSV);                                                               \
-    else if (st_out) VCR_LIN_LAUNCH(BKV, false, true, MSV);                                                              \
-    else VCR_LIN_LAUNCH(BKV, false, false, MSV);                                                                         \
-  } while (0)
-    // Without a residual: BK = 16, four workgroups per CU (measured +2-3 % on the qkv / ffn1 / kv projections).
-    // With one: BK = 32 and the residual tile prefetched across the GEMM loop (bit 3 forces BK 32, bit 6 BK 16).
-    // MFMA shape: bit 4 (16) forces 16x16x4, bit 10 (1024) forces 32x32x2.  Automatic: 16x16x4 for the launches with a
-    // residual (the BK 32 kernels: measured in the pipeline at BASELINE configs[1], wo 155 -> 151 us, ffn2 276 -> 266 us),
-    // 32x32x2 for the BK 16 kernels (qkv / ffn1 / kv / q / conv3: equal within 1 %); DESIGN.md 5.1.
-    const bool bk16 = (!a->residual || (variant & 64)) && !(variant & 8);
-    const bool ms16 = (variant & 16) ? true : (variant & 1024) ? false : (VCR_LINEAR_MS_DEFAULT == 16 || (VCR_LINEAR_MS_DEFAULT == 0 && !bk16));
-    if (bk16) { if (ms16) VCR_LIN_PICK(16, 16); else VCR_LIN_PICK(16, 32); }
-    else { if (ms16) VCR_LIN_PICK(32, 16); else VCR_LIN_PICK(32, 32); }
-#undef VCR_LIN_PICK
-#undef VCR_LIN_LAUNCH
+  if (a->segmax_out && !pl->vec) return VCR_EUNSUPPORTED;
+  pl->glds = !(variant & 4) && pl->vec;                  // LDS-DMA staging, one tile per workgroup
+  pl->ln_in = a->ln_stats_in != nullptr; pl->st_out = a->stats_out != nullptr;
+  // Without a residual: BK = 16, four workgroups per CU (measured +2-3 % on the qkv / ffn1 / kv projections).
+  // With one: BK = 32 and the residual tile prefetched across the GEMM loop (bit 3 forces BK 32, bit 6 BK 16).
+  // MFMA shape: bit 4 (16) forces 16x16x4, bit 10 (1024) forces 32x32x2.  Automatic: 16x16x4 for the launches with a
+  // residual (the BK 32 kernels: measured in the pipeline at BASELINE configs[1], wo 155 -> 151 us, ffn2 276 -> 266 us),
+  // 32x32x2 for the BK 16 kernels (qkv / ffn1 / kv / q / conv3: equal within 1 %); DESIGN.md 5.1.
+  pl->bk16 = (!a->residual || (variant & 64)) && !(variant & 8);
+  pl->ms16 = (variant & 16) ? true : (variant & 1024) ? false : (VCR_LINEAR_MS_DEFAULT == 16 || (VCR_LINEAR_MS_DEFAULT == 0 && !pl->bk16));
+  const int bkv = pl->bk16 ? 16 : 32;
+  const int stage = 2 * BM * bkv * 4 * 2 > 4 * 32 * 68 * 4 ? 2 * BM * bkv * 4 * 2 : 4 * 32 * 68 * 4;   // 2 x TileGT<BK> or the epilogue slices
+  pl->lds = stage + (pl->ln_in ? BM * 2 * 4 : 0);
+  return VCR_OK;
+}
+
+// dispatch over the template grid (BK, LN_IN, STATS_OUT, MS): F is a generic lambda taking four integral_constants
+template <class F>
+void linear_dispatch(const LinearPlan& pl, F&& f) {
+  auto d3 = [&](auto bk, auto ms) {
+    if (pl.ln_in && pl.st_out) f(bk, std::true_type{}, std::true_type{}, ms);
+    else if (pl.ln_in) f(bk, std::true_type{}, std::false_type{}, ms);
+    else if (pl.st_out) f(bk, std::false_type{}, std::true_type{}, ms);
+    else f(bk, std::false_type{}, std::false_type{}, ms);
+  };
+  using I16 = std::integral_constant<int, 16>;
+  using I32 = std::integral_constant<int, 32>;
+  if (pl.bk16) { if (pl.ms16) d3(I16{}, I16{}); else d3(I16{}, I32{}); }
+  else { if (pl.ms16) d3(I32{}, I16{}); else d3(I32{}, I32{}); }
+}
+}  // namespace
+
+extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
+  LinearPlan pl{};
+  const int rc = linear_plan(a, &pl);
+  if (rc != VCR_OK) return rc;
+  if (pl.glds) {
+    linear_dispatch(pl, [&](auto bk, auto li, auto so, auto ms) {
+      constexpr int BKV = decltype(bk)::value, MSV = decltype(ms)::value;
+      constexpr bool LI = decltype(li)::value, SO = decltype(so)::value;
+      VCR_DYN_LDS((linear_glds_kernel<BKV, LI, SO, MSV>), pl.lds);
+      hipLaunchKernelGGL((linear_glds_kernel<BKV, LI, SO, MSV>), dim3(pl.tiles_m * pl.tiles_n), dim3(256), pl.lds, (hipStream_t)stream,
+                         *a, pl.tiles_m, pl.tiles_n);
+    });
   } else {
     // alignment-free fallback (odd N, unaligned y / bias / residual; bit 2 forces it): register staging, scalar epilogue
+    const int lds32 = 2 * sizeof(TileT<32>);
     VCR_DYN_LDS(linear_kernel<32>, lds32);
-    hipLaunchKernelGGL(linear_kernel<32>, dim3(tiles_m * tiles_n), dim3(256), lds32, (hipStream_t)stream, *a, tiles_m,
-                       tiles_n, vec);
+    hipLaunchKernelGGL(linear_kernel<32>, dim3(pl.tiles_m * pl.tiles_n), dim3(256), lds32, (hipStream_t)stream, *a, pl.tiles_m,
+                       pl.tiles_n, pl.vec);
   }
+  return VCR_LAUNCH_RC();
+}
+
+// Two independent linears as one launch when they resolve to the same LDS-DMA kernel configuration (k-slab, MFMA shape,
+// LayerNorm-in, statistics-out; neither with a fused max); otherwise exactly the two vcr_linear_f32 calls.  Same results.
+extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_args* b, vcr_stream_t stream) {
+  LinearPlan pa{}, pb{};
+  int rc = linear_plan(a, &pa);
+  if (rc == VCR_OK) rc = linear_plan(b, &pb);
+  if (rc != VCR_OK) return rc;
+  const bool same = pa.glds && pb.glds && pa.bk16 == pb.bk16 && pa.ms16 == pb.ms16 && pa.ln_in == pb.ln_in && pa.st_out == pb.st_out &&
+                    !a->segmax_out && !b->segmax_out;
+  if (!same) {
+    rc = vcr_linear_f32(a, stream);
+    return rc ? rc : vcr_linear_f32(b, stream);
+  }
+  linear_dispatch(pa, [&](auto bk, auto li, auto so, auto ms) {
+    constexpr int BKV = decltype(bk)::value, MSV = decltype(ms)::value;
+    constexpr bool LI = decltype(li)::value, SO = decltype(so)::value;
+    VCR_DYN_LDS((linear_glds_pair_kernel<BKV, LI, SO, MSV>), pa.lds);
+    hipLaunchKernelGGL((linear_glds_pair_kernel<BKV, LI, SO, MSV>), dim3(pa.tiles_m * pa.tiles_n + pb.tiles_m * pb.tiles_n), dim3(256),
+                       pa.lds, (hipStream_t)stream, *a, *b, pa.tiles_m, pa.tiles_n, pb.tiles_m, pb.tiles_n);
+  });
   return VCR_LAUNCH_RC();
 }

@@ -61,6 +61,9 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
             return 2.0 * rows * n * kk, 4.0 * (rows * kk + n * kk + out_rows * n)
         if site.startswith("head.att"):                    # VcpAtt's two Linear(E,E), one cloud each
             return 2.0 * M1 * E * E, 4.0 * (2 * M1 * E + E * E)
+        if "+" in site:                                    # two independent linears as one launch (vcr_linear_pair_f32)
+            parts = [launch_work("linear:" + p, B, N, k, E, F, overlap2) for p in site.split("+")]
+            return sum(p[0] for p in parts), sum(p[1] for p in parts)
         n, kk = (r(v) for v in _LINEAR_SHAPES[site])
         return 2.0 * M2 * n * kk, 4.0 * (M2 * kk + n * kk + M2 * n)
     if fam == "edgeconv" and site == "dg_chain":
