@@ -47,6 +47,8 @@ typedef struct {
   const float* w1; const float* b1;   /* [64,3], [64]  */
   const float* w2; const float* b2;   /* [64,64], [64] */
   float* xyz4; float* feat64; float* sq64;
+  const float* x_cf2; int B2;         /* optional second block of B2 clouds (same N) processed by the same launch; its rows
+                                         follow the first block's in xyz4 / feat64 / sq64 (the forward: src, then tgt) */
 } vcr_pointwise_args;
 int vcr_pointwise_f32(const vcr_pointwise_args*, vcr_stream_t);
 
@@ -86,9 +88,14 @@ typedef struct {
   /* tie_defer != 0: the tied rows are only listed; idx is final after a later vcr_knn_ties_f32 on these same args. */
   int tie_defer;
   void* tie_work; size_t tie_work_bytes;   /* see above: NULL / 0 unless vcr_knn_tie_work_bytes(N) > 0 */
+  int tie_inline;                     /* the library's own (set on its copy of the struct; callers' value is ignored) */
 } vcr_knn_args;
 int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
 size_t vcr_knn_tie_work_bytes(int N);
+/* 1 when vcr_knn_f32 / vcr_knn_pair_f32 with these args replays the tied rows INSIDE the kNN launch (workgroups of 4 x 16
+ * queries whose LDS holds a row's replay image: N <= ~2400): idx is then final when the launch ends, whatever tie_defer
+ * says, and a later vcr_knn_ties_f32 on these args has nothing to do. */
+int vcr_knn_ties_inline(const vcr_knn_args*);
 /* The tie replay of one (b == NULL) or two earlier vcr_knn_f32 calls made with tie_defer, as ONE launch: the replay is
  * latency-bound (~25 us whatever the number of tied rows), so two kNN launches whose indices are consumed later -- the
  * Cartesian and the feature-space kNN of LPDNet -- pay for it once. */

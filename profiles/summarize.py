@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def short(name):
-    for key in ("linear_kernel", "sdpa_kernel", "edgeconv_dg_kernel", "softcorr_kernel", "layernorm512_kernel",
+    for key in ("linear_glds_pair_kernel", "linear_kernel", "sdpa_kernel", "edgeconv_dg_kernel", "softcorr_kernel", "layernorm512_kernel",
                 "knn3_kernel", "knn64_kernel", "gathermax_kernel", "pointwise12_kernel", "rigid_svd_kernel",
                 "rowside_kernel", "linear_glds16_kernel", "linear_glds_kernel", "linear_persist_kernel",
                 "edgeconv_dg_packed_kernel", "pairscore_kernel", "rankselect_kernel", "knn_tiebreak_kernel",

@@ -204,7 +204,7 @@ struct Runner {
     a.tie_zeroed = 1;
     if (io_ && io_->aux_stream && io_->aux_events[2 * which] && io_->aux_events[2 * which + 1]) {
       a.tie_stream = io_->aux_stream; a.tie_events[0] = io_->aux_events[2 * which]; a.tie_events[1] = io_->aux_events[2 * which + 1];
-    } else if (defer && n_deferred < 2) {
+    } else if (defer && n_deferred < 2 && !vcr_knn_ties_inline(&a)) {   // (inline: the launch replays its own ties)
       a.tie_defer = 1;
       deferred[n_deferred++] = a;
     }
@@ -221,7 +221,9 @@ struct Runner {
     mark(nm);
     a64.tie_zeroed = a3.tie_zeroed = 1;
     a64.tie_defer = a3.tie_defer = 1;
-    deferred[0] = a64; deferred[1] = a3; n_deferred = 2;
+    n_deferred = 0;                                      // (a launch that replays its ties itself owes nothing)
+    if (!vcr_knn_ties_inline(&a64)) deferred[n_deferred++] = a64;
+    if (!vcr_knn_ties_inline(&a3)) deferred[n_deferred++] = a3;
     ok(vcr_knn_pair_f32(&a64, &a3, stream));
   }
   // one replay launch for every kNN deferred so far: to be called before the first consumer of any of their indices
@@ -433,10 +435,9 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
              nullptr, const_cast<float*>(stats_for_ln));
   } else {
   // ---- emb_nn = LPDNet on both clouds (lpdnet_model.py:103-137)
-  for (int c = 0; c < 2 && R.rc == 0; ++c) {
-    R.mark(c ? "pointwise:tgt" : "pointwise:src");
-    vcr_pointwise_args a{c ? io->tgt_cf : io->src_cf, B, N, W->c1_w, W->c1_b, W->c2_w, W->c2_b,
-                         w.xyz4 + (size_t)c * M1 * 4, w.feat64 + (size_t)c * M1 * 64, w.sq64 + (size_t)c * M1};
+  if (R.rc == 0) {                                       // both clouds in one launch: rows 0..M1-1 = src, then tgt
+    R.mark("pointwise:src+tgt");
+    vcr_pointwise_args a{io->src_cf, B, N, W->c1_w, W->c1_b, W->c2_w, W->c2_b, w.xyz4, w.feat64, w.sq64, io->tgt_cf, B};
     R.ok(vcr_pointwise_f32(&a, R.stream));
   }
   // The feature-space and the Cartesian kNN (lpdnet_model.py:113,129) are independent: one launch for both, and one

@@ -63,6 +63,31 @@ __device__ unsigned long long vcr_tl_knn[4096 * 8];
 #define KTL_FLUSH ((void)0)
 #endif
 
+// In-kernel tie replay (vcr_knn_args.tie_inline, set by the host when a row's replay image fits the workgroup's LDS): the
+// rows of a workgroup whose (k+1)-th and (k+2)-th values tie are listed in LDS and replayed by that workgroup itself
+// once its four waves have written their results -- the separate, latency-bound replay launch (36 us at BASELINE
+// configs[1] for a handful of rows) disappears; only the few workgroups that own a tied row run ~20 us longer.
+constexpr int BLK_TIES = 64;                             // a 64-query workgroup cannot list more
+__host__ __device__ constexpr size_t tiebreak_lds(int N) { return (size_t)N * 16 + 256 + (16 + 2 * 256 + 2) * 4; }
+// the list sits behind whichever is larger, the waves' logs or the replay's LDS image of a row
+__host__ __device__ constexpr size_t inline_tie_offset(size_t log_bytes, int N) {
+  return ((log_bytes > tiebreak_lds(N) ? log_bytes : tiebreak_lds(N)) + 15) & ~(size_t)15;
+}
+constexpr size_t INLINE_TIE_MAX_LDS = 40 * 1024;         // four workgroups per CU must still fit
+__device__ void tiebreak_row(const vcr_knn_args& a, int row, unsigned char* smem, unsigned char* gwork);
+__device__ __forceinline__ void replay_block_ties(const vcr_knn_args& a, int* blk_ties, unsigned char* smem) {
+  __syncthreads();                                       // every wave is done with its log: the LDS is free
+  const int n = min(blk_ties[0], BLK_TIES);
+  int rows[4];                                           // (the list itself lies behind the replay's LDS image)
+  for (int t0 = 0; t0 < n; t0 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rows[u] = t0 + u < n ? blk_ties[1 + t0 + u] : -1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (rows[u] >= 0) tiebreak_row(a, rows[u], smem, nullptr);
+  }
+}
+
 // Row whose (k+1)-th and (k+2)-th best values are equal: hand it to knn_tiebreak_kernel (ties[0] = count).
 __device__ __forceinline__ void report_tie(int32_t* ties, int cap, int row) {
   if (!ties) return;
@@ -268,7 +293,7 @@ template <class G> __device__ __forceinline__ float col_min(float x, int sg) {  
 // logs of the S waves of a query group into wave part 0, reduce the log to the k+1 best, drop rank 0, write the set.
 template <class G, int KS, int S>
 __device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args& a, int b, int q, int wave, int part,
-                                       unsigned char* smem) {
+                                       unsigned char* smem, int* blk_ties = nullptr) {
   constexpr int T = Selector<G, KS>::T;
   constexpr int PEND = Selector<G, KS>::PEND;
   constexpr int AREA = 2 * (PEND + 1) * G::COLS;         // floats per wave
@@ -322,7 +347,14 @@ __device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args&
     int32_t* o = a.idx + ((size_t)b * a.N + q) * a.k;
     for (int i = sel.sg; i < sel.cnt && i <= a.k; i += G::LPQ)
       if (i != imax) o[i - (i > imax ? 1 : 0)] = sel.li[i * G::COLS + sel.col];
-    if (sel.sg == 0 && vk1 == vk && vk1 > VCR_NEG_INF) report_tie(a.tie_scratch, a.tie_cap, b * a.N + q);
+    if (sel.sg == 0 && vk1 == vk && vk1 > VCR_NEG_INF) {
+      if (blk_ties) {                                    // replayed by this very workgroup (replay_block_ties)
+        const int pos = atomicAdd(&blk_ties[0], 1);
+        if (pos < BLK_TIES) blk_ties[1 + pos] = b * a.N + q;
+      } else {
+        report_tie(a.tie_scratch, a.tie_cap, b * a.N + q);
+      }
+    }
   }
 }
 
@@ -541,6 +573,11 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   const int ntiles = (a.N + CT - 1) / CT;
 
   sel.init(lv, reinterpret_cast<int*>(lv + LROWS * 16), lane);
+  int* blk_ties = a.tie_inline ? reinterpret_cast<int*>(smem + inline_tie_offset((size_t)W * 2 * LROWS * 16 * 4, a.N)) : nullptr;
+  if (blk_ties) {
+    if (threadIdx.x == 0) blk_ties[0] = 0;
+    __syncthreads();
+  }
   KTL_DECL;
   // Two candidate tiles per step: their two 17-MFMA chains are independent and issue alternately (a dependent
   // v_mfma_f32_16x16x4_f32 chain leaves 8 of every 40 cycles empty), and the next two tiles' rows are in flight meanwhile.
@@ -624,7 +661,8 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
     KTL(3);                                              // wait for the prefetched rows + transpose
   }
   KTL_FLUSH;
-  finish<G, KS, 1>(sel, a, b, q0 + col, wave, 0, smem);
+  finish<G, KS, 1>(sel, a, b, q0 + col, wave, 0, smem, blk_ties);
+  if (blk_ties) replay_block_ties(a, blk_ties, smem);
 }
 template <int KS, int W>
 __global__ __launch_bounds__(64 * W, 4) void knn64c_kernel(vcr_knn_args a) {
@@ -714,6 +752,11 @@ __device__ __forceinline__ void knn3_body(const vcr_knn_args& a, int bx, int b) 
     });
     floor0 = col_min<G>(net.s[R0 - 1], s);
   }
+  int* blk_ties = (S == 1 && a.tie_inline) ? reinterpret_cast<int*>(smem + inline_tie_offset((size_t)4 * 2 * (PEND + 1) * 16 * 4, a.N)) : nullptr;
+  if (blk_ties) {
+    if (threadIdx.x == 0) blk_ties[0] = 0;
+    __syncthreads();
+  }
   sel.init(lv, reinterpret_cast<int*>(lv + (PEND + 1) * 16), lane, floor0);
   scan_steps(part, nsteps, select_body);
   sel.drain();
@@ -722,7 +765,8 @@ __device__ __forceinline__ void knn3_body(const vcr_knn_args& a, int bx, int b) 
     scan_steps(part, nsteps, select_body);
   }
   KTL_FLUSH;
-  finish<G, KS, S>(sel, a, b, qi, wave, part, smem);
+  finish<G, KS, S>(sel, a, b, qi, wave, part, smem, blk_ties);
+  if (blk_ties) replay_block_ties(a, blk_ties, smem);
 }
 template <int KS, int S>
 __global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
@@ -991,18 +1035,16 @@ __device__ int tb_partition_parallel(PairArr& q, int first, int last, int* A, in
   return cut;
 }
 
-__host__ __device__ constexpr size_t tiebreak_lds(int N) { return (size_t)N * 16 + 256 + (16 + 2 * 256 + 2) * 4; }
 constexpr size_t TB_LDS_MAX = 160 * 1024;
 constexpr int TB_BLOCKS = 64;
 
 // One block per tied row: all threads recompute the row's N distances with the SAME arithmetic as the main kernels
 // (C == 64: the k-ascending fma chain the MFMA produces, then the -sq_j/2 step, then 2 acc - sq_i; C == 4: the VALU
 // expression of knn3_kernel), thread 0 replays the selection and rewrites the row's k indices.
-__device__ __forceinline__ void tiebreak_body(const vcr_knn_args& a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ void tiebreak_row(const vcr_knn_args& a, int row, unsigned char* smem, unsigned char* gwork) {
   float *val, *qrow;
   int *id, *A, *Bd, *red;
-  if (tiebreak_lds(a.N) <= TB_LDS_MAX) {
+  if (!gwork) {
     val = reinterpret_cast<float*>(smem);
     id = reinterpret_cast<int*>(val + a.N);
     qrow = reinterpret_cast<float*>(id + a.N);           // [64]
@@ -1012,16 +1054,14 @@ __device__ __forceinline__ void tiebreak_body(const vcr_knn_args& a) {
   } else {
     // rows too long for an LDS image (N > ~10 100): the four row-sized arrays live in the caller's tie_work, one 16 N-byte
     // slice per block (the host checked that it is there); __syncthreads() orders a block's global accesses as well
-    val = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(a.tie_work) + (size_t)blockIdx.x * 16 * a.N);
+    val = reinterpret_cast<float*>(gwork);
     id = reinterpret_cast<int*>(val + a.N);
     A = id + a.N;
     Bd = A + a.N;
     qrow = reinterpret_cast<float*>(smem);
     red = reinterpret_cast<int*>(qrow + 64);
   }
-  const int count = min(a.tie_scratch[0], a.tie_cap);
-  for (int t = blockIdx.x; t < count; t += gridDim.x) {
-    const int row = a.tie_scratch[1 + t];
+  {
     const int b = row / a.N, qi = row - b * a.N;
     const float* xb = a.x + (size_t)b * a.N * a.ldx;
     __syncthreads();
@@ -1080,6 +1120,16 @@ __device__ __forceinline__ void tiebreak_body(const vcr_knn_args& a) {
         if (i != best) o[w++] = id[i];
     }
   }
+}
+
+__device__ __forceinline__ void tiebreak_body(const vcr_knn_args& a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // rows too long for an LDS image (N > ~10 100): the four row-sized arrays live in the caller's tie_work, one 16 N-byte
+  // slice per block (the host checked that it is there); __syncthreads() orders a block's global accesses as well
+  unsigned char* gwork = tiebreak_lds(a.N) <= TB_LDS_MAX ? nullptr
+                                                         : reinterpret_cast<unsigned char*>(a.tie_work) + (size_t)blockIdx.x * 16 * a.N;
+  const int count = min(a.tie_scratch[0], a.tie_cap);
+  for (int t = blockIdx.x; t < count; t += gridDim.x) tiebreak_row(a, a.tie_scratch[1 + t], smem, gwork);
 }
 
 __global__ __launch_bounds__(256) void knn_tiebreak_kernel(vcr_knn_args a) { tiebreak_body(a); }
@@ -1148,6 +1198,31 @@ static bool use_col16(const vcr_knn_args* a) {
   return (long)((a->N + 15) / 16) * a->B >= 1024;
 }
 
+// In-kernel tie replay: the launch's workgroups are 4 waves of 16 queries (knn64c_body / knn3_body with S = 1) and a row's
+// replay image fits beside nothing else in <= 40 KB of LDS (N <= ~2400): see replay_block_ties.
+static size_t knn_log_bytes(const vcr_knn_args* a) {       // LDS of the four logs of such a workgroup
+  const bool k20 = a->k <= 20;
+  return a->C == 64 ? (size_t)4 * 2 * ((k20 ? pend_of<GeomCol16, 22>() : pend_of<GeomCol16, 42>()) + 4) * 16 * 4
+                    : (size_t)4 * 2 * ((k20 ? pend_of<GeomQuad, 22>() : pend_of<GeomQuad, 42>()) + 1) * 16 * 4;
+}
+static int knn_s(const vcr_knn_args* a) {                  // candidate split of the 32-query / Cartesian kernels (vcr_knn_f32)
+  if (a->k > 20) return 1;
+  if (a->waves == 1 || a->waves == 2 || a->waves == 4) return a->waves;
+  const long groups = (long)((a->N + (a->C == 64 ? 31 : 15)) / (a->C == 64 ? 32 : 16)) * a->B;
+  return groups >= 1024 ? 1 : groups >= 512 ? 2 : 4;
+}
+static bool ties_inline(const vcr_knn_args* a) {
+  if (!a->tie_scratch || a->tie_stream) return false;
+  if (a->C == 64 ? !use_col16(a) : knn_s(a) != 1) return false;
+  return inline_tie_offset(knn_log_bytes(a), a->N) + (1 + BLK_TIES) * 4 <= INLINE_TIE_MAX_LDS;
+}
+static size_t knn_lds_bytes(const vcr_knn_args* a, bool inl) {
+  return inl ? inline_tie_offset(knn_log_bytes(a), a->N) + (1 + BLK_TIES) * 4 : knn_log_bytes(a);
+}
+extern "C" int vcr_knn_ties_inline(const vcr_knn_args* a) {
+  return (a && a->x && a->idx && a->B > 0 && a->N > 0 && a->k > 0 && a->k <= 40 && (a->C == 64 || a->C == 4) && ties_inline(a)) ? 1 : 0;
+}
+
 // Feature-space (a64: C == 64) and Cartesian (a3: C == 4) kNN of the same pass as one launch (see knn_pair_kernel) when
 // both are in the one-list-per-query regime the path runs in (k <= 20, >= 1024 query groups each); any other shape, or
 // a tie_stream, simply makes the two self-contained calls.  Tie handling as in vcr_knn_f32 (tie_defer honoured; a
@@ -1178,11 +1253,18 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
     }
   const int gx64 = col16 ? (a64->N + 63) / 64 : (a64->N + 127) / 128, gx3 = (a3->N + 63) / 64;   // 4 waves x 16 (or 32) queries
   const int n64 = gx64 * a64->B, n3 = gx3 * a3->B;
-  const size_t lds64 = col16 ? (size_t)4 * 2 * (pend_of<GeomCol16, 22>() + 4) * 16 * 4 : (size_t)4 * 2 * (pend_of<GeomMfma, 22>() + 1) * 32 * 4;
-  const size_t lds3 = (size_t)4 * 2 * (pend_of<GeomQuad, 22>() + 1) * 16 * 4, lds = lds64 > lds3 ? lds64 : lds3;
-  int rc = col16 ? launch<knn_pair_kernel<22, true>>(dim3(n64 + n3), dim3(256), lds, s, *a64, *a3, n64, gx64, gx3)
-                 : launch<knn_pair_kernel<22, false>>(dim3(n64 + n3), dim3(256), lds, s, *a64, *a3, n64, gx64, gx3);
-  if (rc == 0 && a64->tie_scratch && !a64->tie_defer) rc = vcr_knn_ties_f32(a64, a3, stream);
+  vcr_knn_args k64 = *a64, k3 = *a3;                     // (tie_inline is the library's own field)
+  k64.tie_inline = ties_inline(a64) ? 1 : 0; k3.tie_inline = ties_inline(a3) ? 1 : 0;
+  const size_t lds64 = col16 ? knn_lds_bytes(a64, k64.tie_inline != 0) : (size_t)4 * 2 * (pend_of<GeomMfma, 22>() + 1) * 32 * 4;
+  const size_t lds3 = knn_lds_bytes(a3, k3.tie_inline != 0), lds = lds64 > lds3 ? lds64 : lds3;
+  int rc = col16 ? launch<knn_pair_kernel<22, true>>(dim3(n64 + n3), dim3(256), lds, s, k64, k3, n64, gx64, gx3)
+                 : launch<knn_pair_kernel<22, false>>(dim3(n64 + n3), dim3(256), lds, s, k64, k3, n64, gx64, gx3);
+  // whatever was not replayed inside the launch: one replay launch, now or (tie_defer) when the caller asks for it
+  if (rc == 0 && a64->tie_scratch && !a64->tie_defer) {
+    if (!k64.tie_inline && !k3.tie_inline) rc = vcr_knn_ties_f32(a64, a3, stream);
+    else if (!k64.tie_inline) rc = vcr_knn_ties_f32(a64, nullptr, stream);
+    else if (!k3.tie_inline) rc = vcr_knn_ties_f32(a3, nullptr, stream);
+  }
   return rc;
 }
 
@@ -1207,14 +1289,16 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   // S stays 1 as soon as that gives every SIMD (1024 of them) one wave; smaller grids split to fill the chip.
   // (the fold of S > 1 waves parks the value lists behind the logs: there is room for that with k <= 20 only)
   if (a->waves != 0 && a->waves != 1 && a->waves != 2 && a->waves != 4 && a->waves != 8) return VCR_EINVAL;
-  auto pick_s = [&](long groups) { return !k20 ? 1 : a->waves == 1 || a->waves == 2 || a->waves == 4 ? a->waves
-                                          : groups >= 1024 ? 1 : groups >= 512 ? 2 : 4; };
+  auto pick_s = [&](long) { return knn_s(a); };
+  vcr_knn_args ka = *a;                                  // (tie_inline is the library's own field)
+  const bool inl = ties_inline(a);
+  ka.tie_inline = inl ? 1 : 0;
   if (a->C == 64 && use_col16(a)) {
     // the half-size-wave kernel (see use_col16)
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
     const dim3 grid((a->N + 63) / 64, a->B);
-    const size_t lds = (size_t)4 * 2 * ((k20 ? pend_of<GeomCol16, 22>() : pend_of<GeomCol16, 42>()) + 4) * 16 * 4;
-    rc = k20 ? launch<knn64c_kernel<22, 4>>(grid, dim3(256), lds, s, *a) : launch<knn64c_kernel<42, 4>>(grid, dim3(256), lds, s, *a);
+    const size_t lds = knn_lds_bytes(a, inl);
+    rc = k20 ? launch<knn64c_kernel<22, 4>>(grid, dim3(256), lds, s, ka) : launch<knn64c_kernel<42, 4>>(grid, dim3(256), lds, s, ka);
   } else if (a->C == 64) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
     const int S = pick_s((long)((a->N + 31) / 32) * a->B), W = k20 ? 4 : 2;
@@ -1228,16 +1312,16 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
     if (a->ldx < 4 || (a->ldx & 3)) return VCR_EINVAL;
     const int S = pick_s((long)((a->N + 15) / 16) * a->B);
     const dim3 grid((a->N + 16 * (4 / S) - 1) / (16 * (4 / S)), a->B);
-    const size_t lds = (size_t)4 * 2 * ((k20 ? pend_of<GeomQuad, 22>() : pend_of<GeomQuad, 42>()) + 1) * 16 * 4;
-    rc = !k20 ? launch<knn3_kernel<42, 1>>(grid, dim3(256), lds, s, *a)
-         : S == 1 ? launch<knn3_kernel<22, 1>>(grid, dim3(256), lds, s, *a)
+    const size_t lds = knn_lds_bytes(a, inl);
+    rc = !k20 ? launch<knn3_kernel<42, 1>>(grid, dim3(256), lds, s, ka)
+         : S == 1 ? launch<knn3_kernel<22, 1>>(grid, dim3(256), lds, s, ka)
          : S == 2 ? launch<knn3_kernel<22, 2>>(grid, dim3(256), lds, s, *a)
                   : launch<knn3_kernel<22, 4>>(grid, dim3(256), lds, s, *a);
   }
   if (rc != 0) return rc;
   // rows with an exact tie at the (k+1)-th value: replay libstdc++'s selection on them (see knn_tiebreak_kernel)
   const size_t tb_lds = tiebreak_launch_lds(a->N);
-  if (a->tie_scratch && !a->tie_defer) {
+  if (a->tie_scratch && !a->tie_defer && !inl) {         // (inl: the launch replayed its ties itself)
     if (a->tie_stream) {                                 // replay beside the caller's next launches (see vcr_hip.h)
       hipStream_t ts = (hipStream_t)a->tie_stream;
       hipError_t e = hipEventRecord((hipEvent_t)a->tie_events[0], s);

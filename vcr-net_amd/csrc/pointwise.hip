@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void pointwise12_kernel(vcr_pointwise_args a) 
   const int n = blockIdx.x * PTS + p;
   const bool live = n < a.N;
   const int nc = live ? n : a.N - 1;
-  const float* xb = a.x_cf + (size_t)b * 3 * a.N;
+  const float* xb = b < a.B ? a.x_cf + (size_t)b * 3 * a.N : a.x_cf2 + (size_t)(b - a.B) * 3 * a.N;   // (second block of clouds)
   const float x = xb[nc], y = xb[a.N + nc], z = xb[2 * a.N + nc];
   __syncthreads();
 #pragma unroll
@@ -147,8 +147,8 @@ extern "C" int vcr_rows4_f32(const float* x_cf, float* xyz4, int B, int N, vcr_s
 
 extern "C" int vcr_pointwise_f32(const vcr_pointwise_args* a, vcr_stream_t stream) {
   if (!a || !a->x_cf || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->xyz4 || !a->feat64 || !a->sq64) return VCR_EINVAL;
-  if (a->B <= 0 || a->N <= 0) return VCR_EINVAL;
-  dim3 grid((a->N + PTS - 1) / PTS, a->B);
+  if (a->B <= 0 || a->N <= 0 || a->B2 < 0 || (a->B2 > 0 && !a->x_cf2)) return VCR_EINVAL;
+  dim3 grid((a->N + PTS - 1) / PTS, a->B + a->B2);
   hipLaunchKernelGGL(pointwise12_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
   return VCR_LAUNCH_RC();
 }

@@ -21,14 +21,14 @@ f32p = C.c_void_p  # device pointers travel as integers
 
 class PointwiseArgs(C.Structure):
     _fields_ = [("x_cf", f32p), ("B", C.c_int), ("N", C.c_int), ("w1", f32p), ("b1", f32p), ("w2", f32p),
-                ("b2", f32p), ("xyz4", f32p), ("feat64", f32p), ("sq64", f32p)]
+                ("b2", f32p), ("xyz4", f32p), ("feat64", f32p), ("sq64", f32p), ("x_cf2", f32p), ("B2", C.c_int)]
 
 
 class KnnArgs(C.Structure):
     _fields_ = [("x", f32p), ("ldx", C.c_int), ("sq", f32p), ("B", C.c_int), ("N", C.c_int), ("C", C.c_int),
                 ("k", C.c_int), ("idx", f32p), ("tie_scratch", f32p), ("tie_cap", C.c_int), ("waves", C.c_int),
                 ("tie_stream", C.c_void_p), ("tie_events", C.c_void_p * 2), ("tie_zeroed", C.c_int),
-                ("tie_defer", C.c_int), ("tie_work", C.c_void_p), ("tie_work_bytes", C.c_size_t)]
+                ("tie_defer", C.c_int), ("tie_work", C.c_void_p), ("tie_work_bytes", C.c_size_t), ("tie_inline", C.c_int)]
 
 
 class LinearArgs(C.Structure):

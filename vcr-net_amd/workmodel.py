@@ -45,7 +45,8 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
     if fam == "pointwise":
         if site == "pad":
             return 0.0, 4.0 * M2 * (4 + 32)
-        return 2.0 * M1 * (3 * 64 + 64 * 64), 4.0 * M1 * (3 + 4 + 64 + 1)
+        g = 2 if site == "src+tgt" else 1                  # both clouds in one launch
+        return g * 2.0 * M1 * (3 * 64 + 64 * 64), g * 4.0 * M1 * (3 + 4 + 64 + 1)
     if fam == "knn":
         if site == "feat64+xyz":                           # both searches in one launch
             return 2.0 * (64 + 3) * N * N * 2 * B, 4.0 * M2 * (64 + 1 + 4 + 2 * k)
