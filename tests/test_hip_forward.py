@@ -147,17 +147,42 @@ def test_cpu_input_fails_loudly():
         net(torch.zeros(1, 3, 64), torch.zeros(1, 3, 64))
 
 
+def check_iter_against_oracle(net, w, cfg, src, tgt, iters, out):
+    """vcrnetIter(iter >= 2) against the CPU oracle WITHOUT comparing two free-running refinement loops: a pass after the
+    first starts from a source moved by a pose that differs at 1e-7, where a kNN near-tie can resolve differently (the
+    reference's own float64 twin moves one of four poses by 5.6e-3 that way, tests/golden/selfdiv.npz it2_eval), and the
+    oracle's fp32 rounding itself changes with the host's thread count -- such a comparison is a coin toss per box.
+    Instead (a) every pass is teacher-forced: the HIP forward on the ORACLE's moved source of that pass against the
+    oracle's pass, at the BASELINE tolerance; (b) the device-side loop equals the composition of HIP forwards on its own
+    moved sources (the plumbing of vcr_vcrnet_iter_f32: pose_step, composition, inverse)."""
+    per = []
+    oracle.vcrnet_iter(w, src, tgt, cfg, iters=iters, per_iter=per)
+    t_d = tgt.cuda()
+    with torch.no_grad():
+        for it, (R_ref, t_ref, cur_ref, _) in enumerate(per):                 # (a)
+            o = net(cur_ref.cuda(), t_d)
+            np.testing.assert_allclose(o[2].cpu().numpy(), R_ref.numpy(), atol=R_TOL, err_msg=f"pass {it}")
+            np.testing.assert_allclose(o[3].cpu().numpy(), t_ref.numpy(), atol=T_TOL, err_msg=f"pass {it}")
+        cur, R_f, t_f = src.cuda(), None, None                                # (b)
+        for _ in range(iters):
+            o = net(cur, t_d)
+            R, t = o[2], o[3]
+            cur = torch.matmul(R, cur) + t.unsqueeze(2)
+            R_f, t_f = (R, t) if R_f is None else (torch.matmul(R, R_f), torch.matmul(R, t_f.unsqueeze(2)).squeeze(2) + t)
+    np.testing.assert_allclose(out[2].cpu().numpy(), R_f.cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(out[3].cpu().numpy(), t_f.cpu().numpy(), atol=2e-6)
+
+
 def test_iter_wrapper_whole():
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import synth
     from vcrnet_amd.module import vcrnetIter
     net, w = build_net()
     src, tgt, _, _, _ = synth.make_batch(400, 2, 256)
-    ref = oracle.vcrnet_iter(w, torch.from_numpy(src), torch.from_numpy(tgt), oracle.OracleConfig(), iters=2)
+    s, t = torch.from_numpy(src), torch.from_numpy(tgt)
     with torch.no_grad():
-        out = vcrnetIter(net, torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda(), iter=2)
-    np.testing.assert_allclose(out[2].cpu().numpy(), ref[2].numpy(), atol=R_TOL)
-    np.testing.assert_allclose(out[3].cpu().numpy(), ref[3].numpy(), atol=2 * T_TOL)
+        out = vcrnetIter(net, s.cuda(), t.cuda(), iter=2)
+    check_iter_against_oracle(net, w, oracle.OracleConfig(), s, t, 2, out)
 
 
 @pytest.mark.parametrize("iters", [1, 2])
@@ -180,11 +205,12 @@ def test_iter_wrapper_with_cycle_returns_the_inverse_pose(vcp, iters):
     np.testing.assert_allclose(out[4].cpu().numpy(), R.transpose(1, 2).numpy(), atol=1e-6)
     np.testing.assert_allclose(out[5].cpu().numpy(), -torch.matmul(R.transpose(1, 2), tt.unsqueeze(2)).squeeze(2).numpy(),
                                atol=1e-6)
-    tol = 2           # two composed passes / the cycle pair: the per-pass tolerance adds up (selfdiv.npz it2_n256: the
-                      # reference's own four runs spread by 8.8e-6 on the composed t)
-    np.testing.assert_allclose(R.numpy(), ref[2].numpy(), atol=R_TOL)
-    np.testing.assert_allclose(tt.numpy(), ref[3].numpy(), atol=tol * T_TOL)
-    np.testing.assert_allclose(out[4].cpu().numpy(), ref[4].numpy(), atol=R_TOL)
+    if iters == 1:
+        np.testing.assert_allclose(R.numpy(), ref[2].numpy(), atol=R_TOL)
+        np.testing.assert_allclose(tt.numpy(), ref[3].numpy(), atol=T_TOL)
+        np.testing.assert_allclose(out[4].cpu().numpy(), ref[4].numpy(), atol=R_TOL)
+    else:             # two free-running loops are not comparable pass by pass (see check_iter_against_oracle)
+        check_iter_against_oracle(net, w, oracle.OracleConfig(cycle=True, vcp_nn=vcp), s, t, iters, out)
     # the plain forward DOES return the cycle head's pose, which is not the inverse
     assert np.abs(fwd[4].cpu().numpy() - fwd[2].cpu().transpose(1, 2).numpy()).max() > 1e-4
 

@@ -180,10 +180,11 @@ struct Selector {
   // one value into the query's list, all segments at once (inserting -inf or anything <= the last value is a no-op)
   __device__ __forceinline__ void insert(float d) {
     const float pb = __int_as_float(G::from_prev(__float_as_int(v[T - 1]), sg));
-    d = sg ? fminf(d, pb) : d;
+    // (v_med3_f32 with an infinite third operand: min / max without the NaN-quieting v_max x,x pairs fminf / fmaxf cost)
+    d = sg ? __builtin_amdgcn_fmed3f(d, pb, VCR_NEG_INF) : d;
 #pragma unroll
     for (int t = T - 1; t >= 1; --t) v[t] = __builtin_amdgcn_fmed3f(v[t - 1], d, v[t]);
-    v[0] = fmaxf(v[0], d);
+    v[0] = __builtin_amdgcn_fmed3f(v[0], d, __builtin_huge_valf());
   }
   __device__ __forceinline__ void refresh_thr() {
     const float mine = v[TS];
@@ -604,7 +605,7 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
     unsigned m = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      dd[r] = 2.f * acc[r] - sq_q;                       // (-sq_j + 2 dot) - sq_i
+      dd[r] = fmaf(2.f, acc[r], -sq_q);                  // (-sq_j + 2 dot) - sq_i: 2 x is exact, so one fma rounds like mul + sub
       m |= (dd[r] > sel.thr && jbase + r < a.N) ? (1u << r) : 0u;
     }
     // the four lanes of a column append to ONE log, in row order 0, 1, 2, 3: exclusive prefix of their survivor counts

@@ -217,7 +217,13 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
   const int wm = wave >> 1, wn = wave & 1;
   const int nblk = tiles_m * tiles_n;
   const int bid = xcd_chunk(blk, nblk);
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  // Tile order: M-major inside column GROUPS of <= 12 tiles (a 3 MB slice of W for K = 512), so that the weight slice an
+  // XCD works on stays in its 4 MB L2 while the X panels stream past it.  Up to N = 1536 that is the plain M-major
+  // order; for the stacked [6E, E] projection (24 column tiles, W = 6 MB) the plain order fetched 1.2 GB per launch
+  // (rocprofv3 FETCH_SIZE, profiles/r3f_pmc_summary.json) against 70 MB of operands.  A renumbering: same results.
+  constexpr int GW = 12;
+  const int grp = bid / (GW * tiles_m), wg = min(GW, tiles_n - grp * GW), loc = bid - grp * GW * tiles_m;
+  const int tm = loc / wg, tn = grp * GW + loc % wg;
   const int m0 = tm * BM, n0 = tn * BN;
   TL(0);
 
