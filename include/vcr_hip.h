@@ -79,12 +79,8 @@ typedef struct {
                                          16-query-wave kernel (v_mfma_f32_16x16x4_f32, four lanes per query); 1 / 2 / 4 = the
                                          32-query-wave kernel with that many waves sharing one group of queries and splitting
                                          its candidates.  C == 4: 1 / 2 / 4 likewise. */
-  /* Optional overlap of the tie replay (a latency-bound kernel that keeps ~4 CUs busy for ~25 us) with whatever the
-   * caller enqueues next on `stream`: with tie_stream and two caller-owned event handles (vcr_event_create) the replay
-   * is enqueued on tie_stream, fenced by tie_events[0] (recorded on `stream` after the main kernel); idx is final once
-   * tie_events[1] has completed -- the caller makes its consumer wait for it (vcr_stream_wait_event).
-   * tie_zeroed != 0: the caller guarantees tie_scratch[0] == 0 on entry (no memset is enqueued here). */
-  vcr_stream_t tie_stream; void* tie_events[2]; int tie_zeroed;
+  /* tie_zeroed != 0: the caller guarantees tie_scratch[0] == 0 on entry (no zeroing kernel is enqueued here). */
+  int tie_zeroed;
   /* tie_defer != 0: the tied rows are only listed; idx is final after a later vcr_knn_ties_f32 on these same args. */
   int tie_defer;
   void* tie_work; size_t tie_work_bytes;   /* see above: NULL / 0 unless vcr_knn_tie_work_bytes(N) > 0 */
@@ -101,7 +97,7 @@ int vcr_knn_ties_inline(const vcr_knn_args*);
  * Cartesian and the feature-space kNN of LPDNet -- pay for it once. */
 int vcr_knn_ties_f32(const vcr_knn_args* a, const vcr_knn_args* b, vcr_stream_t);
 /* LPDNet's two independent searches (lpdnet_model.py:113,129) -- a64: C == 64 feature space, a3: C == 4 Cartesian -- as ONE
- * launch when both are in the regime of the path (same k <= 20, >= 1024 query groups each, no tie_stream); otherwise
+ * launch when both are in the regime of the path (same k <= 20, >= 1024 query groups each); otherwise
  * exactly the two vcr_knn_f32 calls.  Same results either way. */
 int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3, vcr_stream_t);
 
@@ -454,12 +450,6 @@ typedef struct {
    *   pairs   [B, K2]      positions in sel_src of the kept sources, K2 = vcr_vcrnet_pairs() (vcrnet_model.py:312) */
   const int32_t *force_keys, *force_sel_src, *force_sel_tgt, *force_argmax, *force_pairs;
   int32_t *out_keys, *out_sel_src, *out_sel_tgt, *out_argmax, *out_pairs;
-  /* Optional second stream + four caller-owned events (vcr_event_create): the two kNN tie replays then run beside the
-   * GEMMs that follow them instead of in front of them (measured on MI355X: the two cross-stream joins cost as much
-   * as the ~50 us they hide, so the host module leaves this off by default).  Everything is joined
-   * back into `stream` before the call returns control of the outputs: the caller only ever synchronises `stream`.
-   * NULL = everything on `stream`. */
-  vcr_stream_t aux_stream; void* aux_events[4];
 } vcr_vcrnet_io;
 
 size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights*, int B, int N);
@@ -494,7 +484,6 @@ int vcr_event_create(void** ev);
 int vcr_event_destroy(void* ev);
 int vcr_event_record(void* ev, vcr_stream_t stream);
 int vcr_event_elapsed_ms(void* start, void* stop, float* ms);
-int vcr_stream_wait_event(vcr_stream_t stream, void* ev);   /* work enqueued on stream after this call waits for ev */
 
 #ifdef __cplusplus
 }

@@ -337,34 +337,6 @@ def test_runs_on_the_callers_stream():
         assert torch.equal(a, b)
 
 
-def test_aux_stream_for_tie_replays_changes_nothing():
-    """With VcrnetIo.aux_stream the two kNN tie replays run on a second stream beside the GEMMs that follow them; the
-    driver joins them back before the first consumer of the indices.  Same bits as the single-stream order, also when
-    the caller is on a side stream and also for the device-side iteration loop."""
-    import vcrnet_amd  # noqa: F401
-    from vcrnet_amd import synth
-    from vcrnet_amd.module import vcrnetIter
-    net, _ = build_net()
-    net.use_aux_stream = True                                 # (off by default: no measured gain, see module.py)
-    src, tgt, _, _, _ = synth.make_batch(2000, 16, 1024)      # this batch holds rows with exact boundary ties
-    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
-    with torch.no_grad():
-        a = net(s, t)
-        ai = vcrnetIter(net, s, t, iter=2)
-        side = torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            a2 = net(s, t)
-        side.synchronize()
-        net.use_aux_stream = False
-        b = net(s, t)
-        bi = vcrnetIter(net, s, t, iter=2)
-    torch.cuda.synchronize()
-    for x, y, z in zip(a[1:], b[1:], a2[1:]):
-        assert torch.equal(x, y) and torch.equal(x, z)
-    for x, y in zip(ai[1:], bi[1:]):
-        assert torch.equal(x, y)
-
-
 def test_forward_captures_into_a_hip_graph():
     """vcr_vcrnet_forward_f32 neither allocates nor synchronises, so a whole forward records into ONE HIP graph
     (torch.cuda.CUDAGraph) and its replays are bit-identical to the eager call -- repeatedly, on the capture stream and on

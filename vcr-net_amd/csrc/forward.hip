@@ -190,9 +190,8 @@ struct Runner {
   // KEY receives over heads and queries, keep the int(nk*overlap2) heaviest keys, soft-max again over those.
   // The first soft-max is never written: a statistics pass leaves (max, sum) per query row, the mass pass
   // streams the queries past each key block (owner = keys of batch b, streamed = queries of batch (b+B) % 2B).
-  // kNN launch `which` (0 = feature space, 1 = Cartesian): the tie counters were zeroed together at the start of the
-  // forward; with an auxiliary stream the tie replay runs there, and knn_join(which) makes this stream wait for it
-  // right before the first consumer of the indices
+  // kNN launches: the tie counters were zeroed together at the start of the forward; a launch that does not replay its
+  // tied rows itself (long rows) is listed in `deferred` and replayed by knn_ties() before the first consumer of the indices
   const vcr_vcrnet_io* io_ = nullptr;
   bool sdpa_split = false;                               // linear_mode 2
   int linear_variant = 0, sdpa_variant = 0;              // MFMA shape forced by vcr_vcrnet_weights.linear_mfma / sdpa_mfma
@@ -202,9 +201,7 @@ struct Runner {
     if (rc) return;
     mark(nm);
     a.tie_zeroed = 1;
-    if (io_ && io_->aux_stream && io_->aux_events[2 * which] && io_->aux_events[2 * which + 1]) {
-      a.tie_stream = io_->aux_stream; a.tie_events[0] = io_->aux_events[2 * which]; a.tie_events[1] = io_->aux_events[2 * which + 1];
-    } else if (defer && n_deferred < 2 && !vcr_knn_ties_inline(&a)) {   // (inline: the launch replays its own ties)
+    if (defer && n_deferred < 2 && !vcr_knn_ties_inline(&a)) {          // (inline: the launch replays its own ties)
       a.tie_defer = 1;
       deferred[n_deferred++] = a;
     }
@@ -213,11 +210,6 @@ struct Runner {
   // LPDNet's two independent searches as one launch (vcr_knn_pair_f32), their tie replays deferred to knn_ties()
   void knn_pair(const char* nm, vcr_knn_args a64, vcr_knn_args a3) {
     if (rc) return;
-    if (io_ && io_->aux_stream) {                        // replays on the auxiliary stream: the self-contained calls
-      knn("knn:xyz", a3, 1);
-      knn("knn:feat64", a64, 0);
-      return;
-    }
     mark(nm);
     a64.tie_zeroed = a3.tie_zeroed = 1;
     a64.tie_defer = a3.tie_defer = 1;
@@ -233,11 +225,6 @@ struct Runner {
     ok(vcr_knn_ties_f32(&deferred[0], n_deferred == 2 ? &deferred[1] : nullptr, stream));
     n_deferred = 0;
   }
-  void knn_join(int which) {
-    if (rc || !io_ || !io_->aux_stream || !io_->aux_events[2 * which + 1]) return;
-    ok((int)hipStreamWaitEvent(stream, (hipEvent_t)io_->aux_events[2 * which + 1], 0));
-  }
-
   // device-to-device copy of a forced / reported selection (tiny; stays on the stream)
   void copy_idx(const char* nm, int32_t* dst, const int32_t* src, size_t n) {
     if (rc) return;
@@ -412,7 +399,6 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       a.segmax_out = w.cat + col; a.ld_segmax = 512; a.seg_k = k;
       R.ok(vcr_linear_f32(&a, R.stream));
     };
-    R.knn_join(1);
     if (k == 20 || k == 40) {
       // the path's k: the whole chain in one kernel, the per-edge activations stay in LDS (edgechain.hip)
       if (R.rc == 0) {
@@ -451,14 +437,12 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   }
   R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
   R.knn_ties();                                          // both tie replays in one launch (one latency instead of two)
-  R.knn_join(0);
   if (R.rc == 0) {
     R.mark("edgeconv:dg1_dg2");
     vcr_edgeconv_args a{w.pq1, 256, w.idx1, k, M2, N, W->dg2_w, W->dg2_b, w.cat, 512, w.cat + 128, 512};
     R.ok(vcr_edgeconv_f32(&a, R.stream));
   }
   R.linear("linear:sn1_pq", w.cat + 128, 512, W->sn1_wpq, SP(sn1_pq), W->sn1_bpq, w.pq3, 512, M2, 512, 128, 0);
-  R.knn_join(1);
   if (R.rc == 0) {
     R.mark("gathermax:sn1");
     vcr_gathermax_args a{w.pq3, 512, 256, w.idx3, k, M2, N, w.cat + 256, 512};
@@ -745,9 +729,6 @@ extern "C" int vcr_event_create(void** ev) {
 extern "C" int vcr_event_destroy(void* ev) { return ev ? (int)hipEventDestroy((hipEvent_t)ev) : VCR_EINVAL; }
 extern "C" int vcr_event_record(void* ev, vcr_stream_t stream) {
   return ev ? (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) : VCR_EINVAL;
-}
-extern "C" int vcr_stream_wait_event(vcr_stream_t stream, void* ev) {
-  return ev ? (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0) : VCR_EINVAL;
 }
 extern "C" int vcr_event_elapsed_ms(void* start, void* stop, float* ms) {
   if (!start || !stop || !ms) return VCR_EINVAL;

@@ -1213,7 +1213,7 @@ static int knn_s(const vcr_knn_args* a) {                  // candidate split of
   return groups >= 1024 ? 1 : groups >= 512 ? 2 : 4;
 }
 static bool ties_inline(const vcr_knn_args* a) {
-  if (!a->tie_scratch || a->tie_stream) return false;
+  if (!a->tie_scratch) return false;
   if (a->C == 64 ? !use_col16(a) : knn_s(a) != 1) return false;
   return inline_tie_offset(knn_log_bytes(a), a->N) + (1 + BLK_TIES) * 4 <= INLINE_TIE_MAX_LDS;
 }
@@ -1225,13 +1225,13 @@ extern "C" int vcr_knn_ties_inline(const vcr_knn_args* a) {
 }
 
 // Feature-space (a64: C == 64) and Cartesian (a3: C == 4) kNN of the same pass as one launch (see knn_pair_kernel) when
-// both are in the one-list-per-query regime the path runs in (k <= 20, >= 1024 query groups each); any other shape, or
-// a tie_stream, simply makes the two self-contained calls.  Tie handling as in vcr_knn_f32 (tie_defer honoured; a
+// both are in the one-list-per-query regime the path runs in (k <= 20, >= 1024 query groups each); any other shape
+// simply makes the two self-contained calls.  Tie handling as in vcr_knn_f32 (tie_defer honoured; a
 // replay that is not deferred serves both launches at once).
 extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3, vcr_stream_t stream) {
   if (!a64 || !a3 || !a64->x || !a3->x || !a64->idx || !a3->idx || a64->C != 64 || a3->C != 4) return VCR_EINVAL;
   const bool col16 = use_col16(a64);
-  const bool fusable = a64->k == a3->k && a64->k <= 20 && !a64->tie_stream && !a3->tie_stream &&
+  const bool fusable = a64->k == a3->k && a64->k <= 20 &&
                        (a64->waves == 0 || a64->waves == 1 || a64->waves == 8) && a3->waves == 0 &&
                        (long)((a64->N + (col16 ? 15 : 31)) / (col16 ? 16 : 32)) * a64->B >= 1024 && (long)((a3->N + 15) / 16) * a3->B >= 1024 &&
                        (a64->tie_scratch != nullptr) == (a3->tie_scratch != nullptr) && a64->tie_defer == a3->tie_defer;
@@ -1277,7 +1277,6 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   if (a->tie_scratch) {
     if (a->tie_cap < 1) return VCR_EINVAL;
     if (tie_work_missing(a)) return VCR_EUNSUPPORTED;     // refuse loudly rather than skip the replay silently
-    if (a->tie_stream && (!a->tie_events[0] || !a->tie_events[1])) return VCR_EINVAL;
     if (!a->tie_zeroed) {
       const int e = zero_count(a->tie_scratch, s);
       if (e != 0) return e;
@@ -1323,16 +1322,7 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   // rows with an exact tie at the (k+1)-th value: replay libstdc++'s selection on them (see knn_tiebreak_kernel)
   const size_t tb_lds = tiebreak_launch_lds(a->N);
   if (a->tie_scratch && !a->tie_defer && !inl) {         // (inl: the launch replayed its ties itself)
-    if (a->tie_stream) {                                 // replay beside the caller's next launches (see vcr_hip.h)
-      hipStream_t ts = (hipStream_t)a->tie_stream;
-      hipError_t e = hipEventRecord((hipEvent_t)a->tie_events[0], s);
-      if (e == hipSuccess) e = hipStreamWaitEvent(ts, (hipEvent_t)a->tie_events[0], 0);
-      if (e != hipSuccess) return (int)e;
-      rc = launch<knn_tiebreak_kernel>(dim3(TB_BLOCKS), dim3(256), tb_lds, ts, *a);
-      if (rc == 0) rc = (int)hipEventRecord((hipEvent_t)a->tie_events[1], ts);
-    } else {
-      rc = launch<knn_tiebreak_kernel>(dim3(TB_BLOCKS), dim3(256), tb_lds, s, *a);
-    }
+    rc = launch<knn_tiebreak_kernel>(dim3(TB_BLOCKS), dim3(256), tb_lds, s, *a);
   }
   return rc;
 }

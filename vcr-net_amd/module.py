@@ -207,9 +207,6 @@ class VCRNet(nn.Module):
         self._packed_key = None
         self._cw: Optional[native.VcrnetWeights] = None
         self._bufs: Dict[Tuple, Dict[str, torch.Tensor]] = {}
-        # optional second stream for the kNN tie replays (native.AuxStream, VCRNET_AUX_STREAM=1).  Off by default:
-        # measured on MI355X the two cross-stream joins cost what the overlap hides (3006 vs 3030 pairs/s at configs[1])
-        self.use_aux_stream = os.environ.get("VCRNET_AUX_STREAM", "0") == "1"
         # profiling hook: a native.Trace that the next forward() / vcrnetIter() call records its per-launch HIP events
         # into (bench.py sets it on the steps it traces; None = no events)
         self.launch_trace: Optional[native.Trace] = None
@@ -458,11 +455,6 @@ class VCRNet(nn.Module):
                 if want_selections and (self._vcp == "topK" or name == "keys"):
                     sel[name] = torch.empty(iters, rows, sizes[name], dtype=torch.int32, device=dev)
                     setattr(io, "out_" + name, native.ptr(sel[name]))
-        if self.use_aux_stream:
-            aux = self._aux.get(dev)
-            if aux is None:
-                aux = self._aux[dev] = native.AuxStream(dev)
-            aux.attach(io)
         stream = C.c_void_p(native.stream_ptr(dev))
         wsp = C.c_void_p(ws.data_ptr() + off)
         if iters != 1 or iter_api:

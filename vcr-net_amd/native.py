@@ -27,7 +27,7 @@ class PointwiseArgs(C.Structure):
 class KnnArgs(C.Structure):
     _fields_ = [("x", f32p), ("ldx", C.c_int), ("sq", f32p), ("B", C.c_int), ("N", C.c_int), ("C", C.c_int),
                 ("k", C.c_int), ("idx", f32p), ("tie_scratch", f32p), ("tie_cap", C.c_int), ("waves", C.c_int),
-                ("tie_stream", C.c_void_p), ("tie_events", C.c_void_p * 2), ("tie_zeroed", C.c_int),
+                ("tie_zeroed", C.c_int),
                 ("tie_defer", C.c_int), ("tie_work", C.c_void_p), ("tie_work_bytes", C.c_size_t), ("tie_inline", C.c_int)]
 
 
@@ -185,7 +185,7 @@ class VcrnetIo(C.Structure):
                 ("R_ab", f32p), ("t_ab", f32p), ("R_ba", f32p), ("t_ba", f32p), ("emb_out", f32p),
                 ("force_keys", f32p), ("force_sel_src", f32p), ("force_sel_tgt", f32p), ("force_argmax", f32p),
                 ("force_pairs", f32p), ("out_keys", f32p), ("out_sel_src", f32p), ("out_sel_tgt", f32p),
-                ("out_argmax", f32p), ("out_pairs", f32p), ("aux_stream", C.c_void_p), ("aux_events", C.c_void_p * 4)]
+                ("out_argmax", f32p), ("out_pairs", f32p)]
 
 
 SELECTION_FIELDS = ("keys", "sel_src", "sel_tgt", "argmax", "pairs")
@@ -249,30 +249,8 @@ def lib() -> C.CDLL:
         L.vcr_event_record.argtypes = [C.c_void_p, C.c_void_p]; L.vcr_event_record.restype = C.c_int
         L.vcr_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
         L.vcr_event_elapsed_ms.restype = C.c_int
-        L.vcr_stream_wait_event.argtypes = [C.c_void_p, C.c_void_p]; L.vcr_stream_wait_event.restype = C.c_int
         _lib = L
     return _lib
-
-
-class AuxStream:
-    """A second HIP stream + four events for VcrnetIo.aux_stream / aux_events: the kNN tie replays then run beside the
-    GEMMs that follow them (include/vcr_hip.h).  One per (module, device); the driver joins everything back into the
-    caller's stream, so callers never synchronise this stream themselves."""
-
-    def __init__(self, device):
-        L = lib()
-        self.stream = torch.cuda.Stream(device=device)
-        self.events = (C.c_void_p * 4)()
-        with torch.cuda.device(device):
-            for i in range(4):
-                e = C.c_void_p()
-                check(L.vcr_event_create(C.byref(e)), "vcr_event_create")
-                self.events[i] = e.value
-
-    def attach(self, io: "VcrnetIo") -> None:
-        io.aux_stream = self.stream.cuda_stream
-        for i in range(4):
-            io.aux_events[i] = self.events[i]
 
 
 class LaunchTrace:
