@@ -74,7 +74,6 @@ def parse(argv=None):
                          "accuracy); bf16x3+sdpa: the attention products too.  Both are labelled in `dtype`")
     ap.add_argument("--linear-mfma", type=int, default=0, choices=[0, 16, 32],
                     help="MFMA shape of the fp32 linears: 0 = the library's choice, 16 = v_mfma_f32_16x16x4_f32, 32 = 32x32x2")
-    ap.add_argument("--sdpa-mfma", type=int, default=0, choices=[0, 16, 32], help="the same for the attention kernel")
     ap.add_argument("--knn-waves", type=int, default=0, choices=[0, 1, 8],
                     help="feature-space kNN kernel: 8 = 16-query waves (16x16x4 MFMA), 1 = 32-query waves, 0 = the library's choice")
     ap.add_argument("--no-merge-encdec", action="store_true",
@@ -292,7 +291,7 @@ def run_rank(a):
     net.emb_nn.k = a.k
     net.linear_mode = a.linear_mode
     net.merge_encdec = not a.no_merge_encdec
-    net.linear_mfma, net.sdpa_mfma, net.linear_bk, net.knn_waves = a.linear_mfma, a.sdpa_mfma, a.linear_bk, a.knn_waves
+    net.linear_mfma, net.linear_bk, net.knn_waves = a.linear_mfma, a.linear_bk, a.knn_waves
     net = net.to(dev).eval()
 
     B, N = a.batch, a.points

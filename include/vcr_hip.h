@@ -231,8 +231,6 @@ typedef struct {
   int nbatch, heads, nq, nk; float scale; int kv_batch_shift;
   const uint8_t* key_keep; float* rowstat;
   float* score_out; int ld_score;
-  int variant;                        /* tuning / tests, 0 = automatic: bit4 (16) force the v_mfma_f32_16x16x4_f32 kernel,
-                                         bit10 (1024) force 32x32x2 (fp32-rounding apart); vcr_sdpa_f32 only */
   /* Optional: ngroups > 1 runs that many independent attention problems of identical shape as ONE launch (the
    * encoder's and the decoder's self-attention of the forward: fewer, fuller rounds of workgroups).  Group g reads
    * q / k / v at q + g * q_group_stride ... (element offsets) and writes out + g * out_group_stride; kv_batch_shift acts
@@ -420,9 +418,9 @@ typedef struct {
   /* args.cycle (vcrnet_model.py:511-513): (R_ba, t_ba) from a second head + solve with the clouds swapped
    * (soft heads only) instead of the inverse of (R_ab, t_ab) */
   int cycle;
-  /* MFMA shape of the fp32 linears / attention launches of the forward: 0 = the library's choice, 16 =
-   * v_mfma_f32_16x16x4_f32, 32 = v_mfma_f32_32x32x2_f32 (benchmarks / tests; results agree to fp32 rounding) */
-  int linear_mfma, sdpa_mfma;
+  /* MFMA shape of the fp32 linears of the forward: 0 = the library's choice per launch, 16 = v_mfma_f32_16x16x4_f32,
+   * 32 = v_mfma_f32_32x32x2_f32 (benchmarks / tests; results agree to fp32 rounding) */
+  int linear_mfma;
   int linear_bk;                                   /* 0 = the library's choice, 16 / 32 = that k-slab for every fp32 linear (benchmarks) */
   int knn_waves;                                   /* vcr_knn_args.waves of the feature-space kNN (0 = automatic; benchmarks) */
   /* partial mode: the decoder's cross-attention scores ([2B,H,N,N] fp32) are kept between the statistics pass and the

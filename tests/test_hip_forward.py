@@ -399,11 +399,10 @@ def test_grouped_sdpa_equals_separate_launches():
     g = torch.Generator().manual_seed(3)
     nb, h, N = 4, 4, 200
     qkv2 = torch.randn(nb * N, 6 * 512, generator=g).cuda()
-    for variant in (0, 16):
-        grouped = native.sdpa(qkv2[:, :512], qkv2[:, 512:1024], qkv2[:, 1024:1536], nb, h, N, N, 1 / math.sqrt(128),
-                              kv_batch_shift=1, groups=(2, 1536, 1536, 1536), variant=variant)
-        for gi in range(2):
-            o = 1536 * gi
-            one = native.sdpa(qkv2[:, o:o + 512], qkv2[:, o + 512:o + 1024], qkv2[:, o + 1024:o + 1536], nb, h, N, N,
-                              1 / math.sqrt(128), kv_batch_shift=1, variant=variant)
-            assert torch.equal(grouped[gi], one)
+    grouped = native.sdpa(qkv2[:, :512], qkv2[:, 512:1024], qkv2[:, 1024:1536], nb, h, N, N, 1 / math.sqrt(128),
+                          kv_batch_shift=1, groups=(2, 1536, 1536, 1536))
+    for gi in range(2):
+        o = 1536 * gi
+        one = native.sdpa(qkv2[:, o:o + 512], qkv2[:, o + 512:o + 1024], qkv2[:, o + 1024:o + 1536], nb, h, N, N,
+                          1 / math.sqrt(128), kv_batch_shift=1)
+        assert torch.equal(grouped[gi], one)

@@ -158,7 +158,7 @@ struct Runner {
     if (rc) return false;
     mark(nm);
     vcr_sdpa_args a{q, ldq, k, ldk, v, ldv, out, ldo, nb, heads, nq, nk, 1.0f / sqrtf(128.f), shift, keep, rowstat,
-                    score_out, ld_score, sdpa_variant};
+                    score_out, ld_score};
     if (ngroups > 1) {
       a.ngroups = ngroups; a.q_group_stride = a.k_group_stride = a.v_group_stride = in_group_stride;
       a.out_group_stride = out_group_stride;
@@ -194,7 +194,7 @@ struct Runner {
   // tied rows itself (long rows) is listed in `deferred` and replayed by knn_ties() before the first consumer of the indices
   const vcr_vcrnet_io* io_ = nullptr;
   bool sdpa_split = false;                               // linear_mode 2
-  int linear_variant = 0, sdpa_variant = 0;              // MFMA shape forced by vcr_vcrnet_weights.linear_mfma / sdpa_mfma
+  int linear_variant = 0;                                // MFMA shape / k-slab forced by vcr_vcrnet_weights.linear_mfma / linear_bk
   vcr_knn_args deferred[2];                              // kNN launches whose tie replay is still owed (knn_ties)
   int n_deferred = 0;
   void knn(const char* nm, vcr_knn_args a, int which, bool defer = false) {
@@ -346,7 +346,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     return VCR_EINVAL;
   if (((uintptr_t)workspace) & 255) return VCR_EINVAL;
   if (W->head_mode < 0 || W->head_mode > 2 || W->linear_mode < 0 || W->linear_mode > 2) return VCR_EINVAL;
-  for (int ms : {W->linear_mfma, W->sdpa_mfma, W->linear_bk})
+  for (int ms : {W->linear_mfma, W->linear_bk})
     if (ms != 0 && ms != 16 && ms != 32) return VCR_EINVAL;
   if (W->knn_waves != 0 && W->knn_waves != 1 && W->knn_waves != 8) return VCR_EINVAL;
   if (W->partial) {                                      // key pruning in the decoder (+ hard pairs for the topK head)
@@ -369,7 +369,6 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
 #define SP(site) (W->linear_mode != 0 ? W->split.site : nullptr)
   R.sdpa_split = W->linear_mode == 2;
   R.linear_variant = (W->linear_mfma == 16 ? 16 : W->linear_mfma == 32 ? 1024 : 0) | (W->linear_bk == 16 ? 64 : W->linear_bk == 32 ? 8 : 0);
-  R.sdpa_variant = W->sdpa_mfma == 16 ? 16 : W->sdpa_mfma == 32 ? 1024 : 0;
 
   const float* stats_for_ln = W->has_pointer == 1 ? w.st_emb : nullptr;
   if (W->emb_kind == 1) {

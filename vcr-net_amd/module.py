@@ -198,8 +198,8 @@ class VCRNet(nn.Module):
         # splits on the bf16 matrix pipe (fp32-equivalent accuracy, ~1.5x faster linears); fused whole-forward only.
         # "bf16x3+sdpa": that, and the attention products (Q K^T, P V) the same way (vcr_sdpa_bf16x3_f32).
         self.linear_mode = os.environ.get("VCRNET_LINEAR_MODE", "fp32")
-        # MFMA shape of the fp32 linears / attention: 0 = the library's choice, 16 = 16x16x4, 32 = 32x32x2 (benchmarks)
-        self.linear_mfma, self.sdpa_mfma, self.linear_bk, self.knn_waves = 0, 0, 0, 0
+        # MFMA shape / k-slab of the fp32 linears, feature-space kNN kernel: 0 = the library's choice (benchmarks)
+        self.linear_mfma, self.linear_bk, self.knn_waves = 0, 0, 0
         # enc.qkv + dec.qkv as one GEMM and the two self-attentions as one grouped launch (fp32 mode; same arithmetic)
         self.merge_encdec = os.environ.get("VCRNET_MERGE_ENCDEC", "1") == "1"
         self.xscore_limit_mb = 0            # partial mode: keep the cross-attention scores up to this many MiB (0 = 4096)
@@ -220,7 +220,7 @@ class VCRNet(nn.Module):
     def _fingerprint(self):
         ps = list(self.parameters()) + list(self.buffers())
         return (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]), self.emb_nn.k,
-                self.linear_mode, self.linear_mfma, self.sdpa_mfma, self.linear_bk, self.knn_waves, self.xscore_limit_mb,
+                self.linear_mode, self.linear_mfma, self.linear_bk, self.knn_waves, self.xscore_limit_mb,
                 self.merge_encdec)
 
     def _pack(self):
@@ -345,7 +345,7 @@ class VCRNet(nn.Module):
                 P[f"att.w{i}"], P[f"att.b{i}"] = g(f"head.linears_emb.{i}.weight"), g(f"head.linears_emb.{i}.bias")
                 setattr(cw, f"att_w{i}", native.ptr(P[f"att.w{i}"])); setattr(cw, f"att_b{i}", native.ptr(P[f"att.b{i}"]))
         cw.cycle = int(bool(self.cycle))
-        cw.linear_mfma, cw.sdpa_mfma, cw.linear_bk = int(self.linear_mfma), int(self.sdpa_mfma), int(self.linear_bk)
+        cw.linear_mfma, cw.linear_bk = int(self.linear_mfma), int(self.linear_bk)
         cw.knn_waves = int(self.knn_waves)
         cw.xscore_limit_mb = int(self.xscore_limit_mb)
         cw.partial, cw.overlap2 = int(self._partial), self._overlap2

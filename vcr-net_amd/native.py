@@ -65,7 +65,7 @@ class SdpaArgs(C.Structure):
     _fields_ = [("q", f32p), ("ldq", C.c_int), ("k", f32p), ("ldk", C.c_int), ("v", f32p), ("ldv", C.c_int),
                 ("out", f32p), ("ldo", C.c_int), ("nbatch", C.c_int), ("heads", C.c_int), ("nq", C.c_int),
                 ("nk", C.c_int), ("scale", C.c_float), ("kv_batch_shift", C.c_int), ("key_keep", f32p),
-                ("rowstat", f32p), ("score_out", f32p), ("ld_score", C.c_int), ("variant", C.c_int),
+                ("rowstat", f32p), ("score_out", f32p), ("ld_score", C.c_int),
                 ("ngroups", C.c_int), ("q_group_stride", C.c_long), ("k_group_stride", C.c_long), ("v_group_stride", C.c_long),
                 ("out_group_stride", C.c_long)]
 
@@ -177,7 +177,7 @@ class VcrnetWeights(C.Structure):
                 ("fold_encdec_qkv", FoldedW),
                 ("partial", C.c_int), ("overlap2", C.c_double), ("emb_kind", C.c_int), ("dgcnn", DgcnnW),
                 ("att_w0", f32p), ("att_b0", f32p), ("att_w1", f32p), ("att_b1", f32p), ("cycle", C.c_int),
-                ("linear_mfma", C.c_int), ("sdpa_mfma", C.c_int), ("linear_bk", C.c_int), ("knn_waves", C.c_int), ("xscore_limit_mb", C.c_int)]
+                ("linear_mfma", C.c_int), ("linear_bk", C.c_int), ("knn_waves", C.c_int), ("xscore_limit_mb", C.c_int)]
 
 
 class VcrnetIo(C.Structure):
@@ -516,7 +516,7 @@ def gathermax(pq, Cc, idx, n_per_cloud):
 
 @_guarded
 def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None, want_rowstat=False, pv=True,
-         score_out=None, bf16x3=False, variant=0, groups=None):
+         score_out=None, bf16x3=False, groups=None):
     """q [nbatch*nq, >=heads*128] (row views allowed), k/v likewise -> out [nbatch*nq, heads*128].
     score_out [nbatch, heads, nq, ld]: also keep the scaled scores (statistics pass of the partial path).
     groups = (ngroups, q_stride, k_stride, v_stride): that many problems in one launch, group g at element offset
@@ -526,7 +526,7 @@ def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None,
     rs = _f32(nbatch, heads, nq, 2, device=q.device) if want_rowstat else None
     a = SdpaArgs(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(v) if pv else None, v.stride(0) if pv else 0, ptr(out),
                  heads * 128 if pv else 0, nbatch, heads, nq, nk, scale, kv_batch_shift, ptr(key_keep), ptr(rs),
-                 ptr(score_out), score_out.stride(2) if score_out is not None else 0, variant)
+                 ptr(score_out), score_out.stride(2) if score_out is not None else 0)
     if groups:
         a.ngroups, a.q_group_stride, a.k_group_stride, a.v_group_stride = groups
         a.out_group_stride = nbatch * nq * heads * 128
