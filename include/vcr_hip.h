@@ -236,6 +236,10 @@ typedef struct {
    * q / k / v at q + g * q_group_stride ... (element offsets) and writes out + g * out_group_stride; kv_batch_shift acts
    * inside a group.  Attention-output form only (no key_keep / rowstat / score_out); 0 or 1 = one group; vcr_sdpa_f32 only. */
   int ngroups; long q_group_stride, k_group_stride, v_group_stride, out_group_stride;
+  /* Optional: key_index int32 [nbatch, nk] -- the keys of KEY batch kb are the rows key_index[kb][0..nk-1] of its nk_src
+   * rows of k / v (duplicates allowed; vcr_sdpa_f32 only, not with key_keep / score_out / ngroups).  The same set of
+   * keys as a key_keep mask, with no masked scores computed and no dense copy of the kept rows. */
+  const int32_t* key_index; int nk_src;
 } vcr_sdpa_args;
 int vcr_sdpa_f32(const vcr_sdpa_args*, vcr_stream_t);
 /* The attention-output form of vcr_sdpa_f32 (out != NULL, rowstat == score_out == NULL, scale > 0) with Q, K, V and the

@@ -693,3 +693,17 @@ def test_linear_pair_equals_two_launches(nat):
         A.stats_out, Bq.stats_out = nat.ptr(sa2), nat.ptr(sb2)
         nat.check(L.vcr_linear_pair_f32(C.byref(A), C.byref(Bq), C.c_void_p(nat.stream_ptr())), "vcr_linear_pair_f32")
         assert torch.equal(ya, ya2) and torch.equal(yb, yb2) and torch.equal(sa, sa2) and torch.equal(sb, sb2), (Na, Nb, res_b)
+
+
+def test_sdpa_indexed_keys_equal_the_gathered_rows(nat):
+    """vcr_sdpa_args.key_index: attention over the rows key_index[kb][0..nk-1] of each key batch (the decoder's kept keys of
+    partial-overlap mode), read in place -- bit-identical to attention over a dense copy of those rows in that order."""
+    g = torch.Generator().manual_seed(21)
+    nb, h, NQ, NS, NK = 4, 4, 200, 260, 150
+    q = dev(torch.randn(nb * NQ, h * 128, generator=g))
+    kv = dev(torch.randn(nb * NS, 2 * h * 128, generator=g))
+    idx = torch.stack([torch.randperm(NS, generator=g)[:NK] for _ in range(nb)]).to(torch.int32)
+    dense = kv.view(nb, NS, -1)[torch.arange(nb).view(-1, 1), idx.long()].reshape(nb * NK, -1).contiguous()
+    ref = nat.sdpa(q, dense[:, :512], dense[:, 512:], nb, h, NQ, NK, 1 / math.sqrt(128), kv_batch_shift=1)
+    out = nat.sdpa(q, kv[:, :512], kv[:, 512:], nb, h, NQ, NK, 1 / math.sqrt(128), kv_batch_shift=1, key_index=dev(idx), nk_src=NS)
+    assert torch.equal(out, ref)

@@ -270,8 +270,10 @@ def test_cross_attention_fallback_branches_of_the_driver():
     (a) the score matrix is NOT kept between the statistics pass and the key-mass pass (the driver's > 4 GB fallback,
         forced here through vcr_vcrnet_weights.xscore_limit_mb < 0): the key mass is recomputed per head by the
         pair-score kernel -- same kept keys, same poses;
-    (b) ff_dims < 2 E: the FFN hidden buffer cannot hold the gathered K|V rows, so the second soft-max runs MASKED over
-        all keys instead of dense over the kept ones -- against the CPU oracle with the same ff_dims."""
+    (b) ff_dims < 2 E: the FFN hidden buffer could not hold a dense copy of the kept K|V rows -- irrelevant in fp32, where
+        the attention kernel reads the kept rows through the index list (vcr_sdpa_args.key_index), so forcing keys works
+        too; the exact-split mode falls back to the MASKED second soft-max there and refuses forced keys.  Against the CPU
+        oracle with the same ff_dims."""
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import native, synth, weights
     from vcrnet_amd.module import VCRNet
@@ -301,9 +303,15 @@ def test_cross_attention_fallback_branches_of_the_driver():
                                 oracle.OracleConfig(partial=True, overlap2=o2, record=rec))
     with torch.no_grad():
         out = net2._forward_fused(s, t, want_selections=True)
-        # forcing the kept keys needs the dense-gather path: refused here, loudly
+        forced = net2._forward_fused(s, t, force={"keys": out[6]["keys"]})          # its own keys forced: the same result
+        for a_, b_ in zip(out[:6], forced[:6]):
+            assert torch.equal(a_, b_)
+        net2.linear_mode = "bf16x3+sdpa"                                           # exact-split attention: masked form,
+        split = net2._forward_fused(s, t, want_selections=True)                    # forced keys refused, loudly
         with pytest.raises(native.VcrHipError):
             net2._forward_fused(s, t, force={"keys": out[6]["keys"]})
+        net2.linear_mode = "fp32"
+    np.testing.assert_allclose(split[2].cpu().numpy(), out[2].cpu().numpy(), atol=1e-2)   # (selections may flip between modes)
     same_keys = all(set(a.tolist()) == set(b.tolist()) for a, b in
                     zip(out[6]["keys"][0].cpu(), torch.cat((rec["key_keep_src"], rec["key_keep_tgt"]), 0)))
     same_pairs = torch.equal(out[0].cpu(), ref[0]) and torch.equal(out[1].cpu(), ref[1])

@@ -53,16 +53,25 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) qf[g] = ld4(qp + 8 * g);
   }
-  const float* kbase = p.k + (size_t)kvb * p.nk * p.ldk + head * 128;
-  const float* vbase = p.v + (size_t)kvb * p.nk * p.ldv + head * 128;
+  // keys: rows 0..nk-1 of the key batch, or -- key_index -- the rows key_index[kvb][0..nk-1] of its nk_src rows (the
+  // decoder's kept keys in partial-overlap mode: no dense copy of the kept K|V rows); the list sits in LDS behind the stages
+  const int krows = p.key_index ? p.nk_src : p.nk;
+  const float* kbase = p.k + (size_t)kvb * krows * p.ldk + head * 128;
+  const float* vbase = p.v + (size_t)kvb * krows * p.ldv + head * 128;
   const int srow = t >> 5, sc4 = (t & 31) * 4;           // staging: rows srow + 8i, one 16-B chunk
   const int ntiles = (p.nk + 31) / 32;
+  int* kidx = reinterpret_cast<int*>(smem + 2 * sizeof(Stage));
+  if (p.key_index) {
+    for (int i = t; i < p.nk; i += 256) kidx[i] = p.key_index[(size_t)kvb * p.nk + i];
+    __syncthreads();
+  }
 
   f32x4 rk[4], rv[4];
   auto stage_load = [&](int tile) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int key = min(tile * 32 + srow + 8 * i, p.nk - 1);
+      int key = min(tile * 32 + srow + 8 * i, p.nk - 1);
+      if (p.key_index) key = kidx[key];
       rk[i] = ld4(kbase + (size_t)key * p.ldk + sc4);
       if (DO_PV) rv[i] = ld4(vbase + (size_t)key * p.ldv + sc4);
     }
@@ -251,8 +260,9 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   if (a->ldq < a->heads * 128 || a->ldk < a->heads * 128) return VCR_EINVAL;
   const int ng = a->ngroups > 1 ? a->ngroups : 1;
   if (ng > 1 && (!pv || a->key_keep || a->rowstat || a->score_out)) return VCR_EINVAL;
+  if (a->key_index && (a->nk_src < 1 || a->key_keep || a->score_out || ng > 1 || a->nk > 16384)) return VCR_EINVAL;
   dim3 grid(((a->nq + 127) / 128) * a->heads * a->nbatch * ng);
-  const int lds = 2 * sizeof(Stage);
+  const int lds = 2 * sizeof(Stage) + (a->key_index ? ((a->nk * 4 + 15) & ~15) : 0);
   hipStream_t s = (hipStream_t)stream;
 #define VCR_SDPA_LAUNCH(M, P)                                                                                         \
   do {                                                                                                                 \

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(512, 1) void sdpa_bf16x3_kernel(vcr_sdpa_args p) {
 // the statistics-only passes of the partial-overlap path stay on vcr_sdpa_f32.
 extern "C" int vcr_sdpa_bf16x3_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->out) return VCR_EINVAL;
-  if (a->ngroups > 1) return VCR_EUNSUPPORTED;             // grouped launches: vcr_sdpa_f32 only
+  if (a->ngroups > 1 || a->key_index) return VCR_EUNSUPPORTED;   // grouped / indexed-key launches: vcr_sdpa_f32 only
   if (a->rowstat || a->score_out || !(a->scale > 0.f)) return VCR_EUNSUPPORTED;
   if (a->nbatch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return VCR_EINVAL;
   if ((a->ldq & 3) || (a->ldk & 3) || (a->ldo & 3)) return VCR_EINVAL;

@@ -239,7 +239,7 @@ struct Runner {
       const int nkeep = (int)((double)N * W->overlap2);
       if (io->force_keys) {
         // teacher forcing: the caller's kept keys replace the mass ranking (both passes that only feed it are skipped)
-        if (W->F < 2 * E) { ok(VCR_EUNSUPPORTED); return; }
+        if (sdpa_split && W->F < 2 * E) { ok(VCR_EUNSUPPORTED); return; }   // (the exact-split kernel needs the dense copy)
         copy_idx("select:dec.cross.keys.forced", w.xorder, io->force_keys, (size_t)nb * nkeep);
       } else if (w.xscore) {
         // statistics pass that also keeps the scaled scores; the key mass is then one HBM-bound pass over them
@@ -262,12 +262,22 @@ struct Runner {
           pairscore("pairscore:dec.cross.keymass", a);
         }
       }
-      // the kept keys' K|V rows are gathered into a dense [2B, nkeep, 2E] buffer (hid is free until the FFN) and the
-      // second soft-max runs unmasked over nkeep keys: the same set as masked_fill(-1e9) + softmax, 23 % fewer
-      // score / PV MFMAs at overlap2 = 0.766 and no per-score mask lookups
+      // the second soft-max runs unmasked over the nkeep kept keys only: the same set as masked_fill(-1e9) + softmax, 23 %
+      // fewer score / PV MFMAs at overlap2 = 0.766 and no per-score mask lookups.  fp32: the attention kernel reads the
+      // kept K|V rows THROUGH the list (vcr_sdpa_args.key_index; round 2 gathered them into a dense buffer first: 0.039 ms
+      // and 230 MB per pass at configs[2]); the exact-split attention kernel still takes the dense copy (hid [2B*N, F] is
+      // free until the FFN and holds it when F >= 2E), else the masked form
       if (!io->force_keys) rank("select:dec.cross.keys", w.keymass, 1, nb, N, nkeep, w.xorder, w.keep, 1);
       if (io->out_keys) copy_idx("select:dec.cross.keys.out", io->out_keys, w.xorder, (size_t)nb * nkeep);
-      if (W->F >= 2 * E) {                               // hid [2B*N, F] can hold the gathered rows
+      if (!sdpa_split) {
+        if (rc) return;
+        mark("sdpa:dec.cross");
+        vcr_sdpa_args a{w.qc, E, w.kvc, 2 * E, w.kvc + E, 2 * E, w.att, E, nb, H, N, nkeep, 1.0f / sqrtf(128.f), B};
+        a.key_index = w.xorder; a.nk_src = N;
+        ok(vcr_sdpa_f32(&a, stream));
+        return;
+      }
+      if (W->F >= 2 * E) {
         gather("select:gather.kv", w.kvc, 2 * E, N, w.xorder, nb, nkeep, 2 * E, w.hid);
         sdpa("sdpa:dec.cross", w.qc, E, w.hid, 2 * E, w.hid + E, 2 * E, w.att, E, nb, H, N, nkeep, B);
         return;
