@@ -1,0 +1,45 @@
+"""kNN kernels against each other on random and tie-heavy shapes: 16-query waves (waves=8) vs 32-query waves (waves=1), the
+Cartesian kernel with and without a candidate split, the one-launch pair vs the single launches.  python profiles/fuzz_knn.py <seed> <trials>"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import vcrnet_amd
+from vcrnet_amd import native as nat
+rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+bad = 0
+t0 = time.time()
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
+    k = int(rs.choice([3, 5, 20, 20, 20, 40]))
+    N = int(rs.randint(k + 1, 2600)) if rs.rand() < 0.8 else int(rs.choice([k + 1, k + 2, 1024, 1025, 2047, 2400, 2401, 3000]))
+    B = int(rs.randint(1, 70))
+    while B * N * N > 3.5e8:
+        B = max(1, B // 2)
+    tie = rs.rand() < 0.5
+    if tie:
+        f = torch.from_numpy(rs.randint(0, 3, size=(B, N, 64)).astype(np.float32))
+        xyz = torch.from_numpy(rs.randint(0, 9, size=(B, N, 3)).astype(np.float32))
+    else:
+        f = torch.from_numpy(rs.randn(B, N, 64).astype(np.float32))
+        xyz = torch.from_numpy(rs.rand(B, N, 3).astype(np.float32))
+    f, xyz = f.cuda(), xyz.cuda()
+    sq = (f ** 2).sum(-1).contiguous()
+    x4 = torch.cat((xyz, (xyz ** 2).sum(-1, keepdim=True)), -1).contiguous()
+    a = np.sort(nat.knn(f, sq, k, waves=8).cpu().numpy(), -1)
+    b = np.sort(nat.knn(f, sq, k, waves=1).cpu().numpy(), -1)
+    # duplicate feature rows make rank 0 ambiguous: compare rows whose two best values differ
+    ok = np.ones(a.shape[:2], bool)
+    if tie:
+        D = -((f[:, :, None, :] - f[:, None, :, :]) ** 2).sum(-1) if B * N * N * 64 < 2e8 else None
+        if D is not None:
+            top2 = torch.topk(D, 2, dim=-1).values
+            ok = (top2[..., 0] != top2[..., 1]).cpu().numpy()
+    d64 = int(((a != b).any(-1) & ok).sum())
+    c = np.sort(nat.knn(x4, None, k).cpu().numpy(), -1)
+    e = np.sort(nat.knn(x4, None, k, waves=1 if k > 20 else 2).cpu().numpy(), -1)
+    d3 = int((c != e).any(-1).sum()) if not tie else 0          # (duplicate points: rank 0 ambiguous)
+    p64, p3 = nat.knn_pair(f, sq, x4, k)
+    dp = int(((np.sort(p64.cpu().numpy(), -1) != a).any(-1) & ok).sum()) + (int((np.sort(p3.cpu().numpy(), -1) != c).any(-1).sum()) if not tie else 0)
+    flag = "" if d64 == 0 and d3 == 0 and dp == 0 else "   <<<<<< MISMATCH"
+    bad += bool(flag)
+    print(f"B={B:3d} N={N:5d} k={k:2d} tie={int(tie)}: feat64 16q-vs-32q rows differing {d64}, xyz {d3}, pair-vs-single {dp}{flag}", flush=True)
+print("mismatching trials:", bad, "elapsed", round(time.time() - t0, 1))

@@ -1,0 +1,36 @@
+"""Random-shape parity sweep of the whole forward (HIP path vs the CPU oracle; run on the GPU box: python profiles/fuzz_whole.py <seed> <trials>)."""
+import torch, numpy as np, sys, time
+sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import vcrnet_amd
+from vcrnet_amd import native, synth, composed
+from test_hip_forward import build_net
+import oracle
+rs=np.random.RandomState(int(sys.argv[1]) if len(sys.argv)>1 else 0)
+nets={}
+worst=(0,0)
+t0=time.time()
+for trial in range(int(sys.argv[2]) if len(sys.argv)>2 else 12):
+    k=int(rs.choice([5,20,20,40])); B=int(rs.randint(2,9)); N=int(rs.randint(k+1,900)) if rs.rand()<0.8 else int(rs.choice([k+1,k+2,1024,1025,1279]))
+    kind=str(rs.choice(["whole","dist","identity"]))
+    kw={"whole":{},"dist":dict(vcp_nn="dist"),"identity":dict(pointer="identity")}[kind]
+    key=(kind,)
+    if key not in nets: nets[key]=build_net(**kw)
+    net,w=nets[key]; net.emb_nn.k=k; net.knn_waves=8 if trial%2 else 0
+    src,tgt,_,_,_=synth.make_batch(int(rs.randint(0,1000)),B,N)
+    s,t=torch.from_numpy(src),torch.from_numpy(tgt)
+    rec={}
+    cfg=oracle.OracleConfig(k=k,record=rec, **({"vcp_nn":"dist"} if kind=="dist" else {}), **({"pointer":"identity"} if kind=="identity" else {}))
+    ref=oracle.vcrnet_forward(w,s,t,cfg)
+    with torch.no_grad(): out=net(s.cuda(),t.cuda())
+    amb=torch.zeros(B,dtype=torch.bool)
+    if N>k+1:
+        for side,xyz in (("emb_src",s),("emb_tgt",t)):
+            for feat in (rec[side]["x64"],xyz):
+                top=torch.topk(oracle.neg_sqdist_knn(feat),k+2,dim=-1).values
+                amb|=(top[...,k]==top[...,k+1]).any(1)
+    keep=torch.ones_like(amb)
+    dR=float((out[2].cpu()-ref[2])[keep].abs().max()) if keep.any() else 0
+    dt=float((out[3].cpu()-ref[3])[keep].abs().max()) if keep.any() else 0
+    flag="" if (dR<=1e-4 and dt<=(3e-5 if N<=128 else 1e-5)) else "  <<<<<< FAIL"
+    print(f"{kind:8s} B={B} N={N:5d} k={k:2d} amb={int(amb.sum())} dR={dR:.2e} dt={dt:.2e}{flag}", flush=True)
+print("elapsed",time.time()-t0)
