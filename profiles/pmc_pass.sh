@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: profiles/pmc_pass.sh <tag> <counter> [<counter> ...]  -- one rocprofv3 --pmc pass (kernel-trace only) per counter
+# usage: [BENCH_ARGS='--linear-mfma 16'] profiles/pmc_pass.sh <tag> <counter> [<counter> ...]  -- one rocprofv3 --pmc pass (kernel-trace only) per counter
 # GROUP over a short bench.py run; writes gpurun_out/pmc_<tag>_<group index>/ and a per-kernel mean table to
 # gpurun_out/<tag>_pmc_<group index>.txt.  Counter groups are separated by commas: "A B,C D" = two passes.
 TAG=$1; shift
@@ -12,7 +12,7 @@ IFS=',' read -ra GROUPS_ <<< "$*"
 i=0
 for g in "${GROUPS_[@]}"; do
   d=$OUT/pmc_${TAG}_$i
-  rocprofv3 --kernel-trace --output-format csv --pmc $g -d $d -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --min-seconds 0.1 > /dev/null 2> $OUT/${TAG}_pmc_$i.err
+  rocprofv3 --kernel-trace --output-format csv --pmc $g -d $d -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --min-seconds 0.1 $BENCH_ARGS > /dev/null 2> $OUT/${TAG}_pmc_$i.err
   python3 - "$d" > $OUT/${TAG}_pmc_$i.txt <<'PY'
 import csv, glob, sys, collections
 rows = collections.defaultdict(lambda: collections.defaultdict(list))

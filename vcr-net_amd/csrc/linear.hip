@@ -502,8 +502,9 @@ int linear_plan(const vcr_linear_args* a, LinearPlan* pl) {
   // 32x32x2 for the BK 16 kernels (qkv / ffn1 / kv / q / conv3: equal within 1 %); DESIGN.md 5.1.
   pl->bk16 = (!a->residual || (variant & 64)) && !(variant & 8);
   pl->ms16 = (variant & 16) ? true : (variant & 1024) ? false : (VCR_LINEAR_MS_DEFAULT == 16 || (VCR_LINEAR_MS_DEFAULT == 0 && !pl->bk16));
+  static_assert(2 * sizeof(TileGT<16>) == 2 * (BM + BN) * 16 * 4 && 2 * sizeof(TileGT<32>) == 2 * (BM + BN) * 32 * 4, "stage size below");
   const int bkv = pl->bk16 ? 16 : 32;
-  const int stage = 2 * BM * bkv * 4 * 2 > 4 * 32 * 68 * 4 ? 2 * BM * bkv * 4 * 2 : 4 * 32 * 68 * 4;   // 2 x TileGT<BK> or the epilogue slices
+  const int stage = 2 * (BM + BN) * bkv * 4 > 4 * 32 * 68 * 4 ? 2 * (BM + BN) * bkv * 4 : 4 * 32 * 68 * 4;   // 2 x TileGT<BK> or the epilogue slices
   pl->lds = stage + (pl->ln_in ? BM * 2 * 4 : 0);
   return VCR_OK;
 }
