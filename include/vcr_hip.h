@@ -65,7 +65,7 @@ int vcr_rows4_pq_f32(const float* x_cf, float* xyz4, int B, int N, const float* 
  * Limits of this library (the reference's knn has none): k <= 40 and N <= 65535, VCR_EUNSUPPORTED beyond.
  * Exact ties at the (k+1)-th value: with tie_scratch the kept SET equals what Tensor.topk (libstdc++ nth_element /
  * partial_sort on the CPU) keeps; without it one of the tied candidates is kept (deterministically, but not by a
- * documented rule).  The replay holds a row's N distances in LDS up to N = 10 196; longer rows need tie_work
+ * documented rule).  The replay holds a row's N distances in LDS up to N = 10 091; longer rows need tie_work
  * (vcr_knn_tie_work_bytes(N) bytes of 16-B aligned device scratch) -- with tie_scratch set and tie_work missing such a
  * call returns VCR_EUNSUPPORTED: the replay is never skipped silently. */
 typedef struct {

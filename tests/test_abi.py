@@ -95,6 +95,52 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 0, 1024) == 0
 
 
+def test_host_side_dispatch_logic_without_a_gpu(lib):
+    """Pure host logic of the round-3 entry points: which kNN calls replay their ties inside the launch, how much
+    scratch the replay of long rows needs, the limits that are refused rather than degraded, argument errors of the
+    paired linear and the grouped / indexed attention."""
+    from vcrnet_amd import native
+    lib.vcr_knn_ties_inline.argtypes = [ctypes.POINTER(native.KnnArgs)]
+    lib.vcr_knn_ties_inline.restype = ctypes.c_int
+    lib.vcr_knn_tie_work_bytes.argtypes, lib.vcr_knn_tie_work_bytes.restype = [ctypes.c_int], ctypes.c_size_t
+
+    def knn_args(B, N, Cc, k, ties=True, waves=0):
+        a = native.KnnArgs()
+        a.x, a.idx, a.sq = 0x1000, 0x2000, 0x3000            # (never dereferenced on the host)
+        a.ldx, a.B, a.N, a.C, a.k, a.waves = Cc, B, N, Cc, k, waves
+        if ties:
+            a.tie_scratch, a.tie_cap = 0x4000, B * N
+        return a
+    inline = lambda *a, **k: lib.vcr_knn_ties_inline(ctypes.byref(knn_args(*a, **k)))
+    assert inline(32, 1024, 64, 20) == 1 and inline(32, 1024, 4, 20) == 1      # BASELINE configs[1]: both searches
+    assert inline(48, 768, 64, 20) == 1 and inline(32, 2048, 64, 20) == 1
+    assert inline(64, 4096, 64, 40) == 0 and inline(64, 4096, 4, 40) == 0      # the row image does not fit the workgroup's LDS
+    assert inline(2, 1024, 64, 20) == 0                                        # small grid: 32-query kernel, separate replay
+    assert inline(32, 1024, 64, 20, waves=1) == 0 and inline(2, 1024, 64, 20, waves=8) == 1
+    assert inline(32, 1024, 64, 20, ties=False) == 0
+    assert lib.vcr_knn_tie_work_bytes(1024) == 0 and lib.vcr_knn_tie_work_bytes(10091) == 0
+    assert lib.vcr_knn_tie_work_bytes(12000) == 64 * 16 * 12000
+    a = knn_args(1, 12000, 4, 20)                          # long rows, replay owed, no scratch: refused, not skipped
+    assert lib.vcr_knn_f32(ctypes.byref(a), None) == -3
+    assert lib.vcr_knn_f32(ctypes.byref(knn_args(4, 1024, 4, 41)), None) == -3 # library limit k <= 40
+    assert lib.vcr_knn_f32(ctypes.byref(knn_args(4, 1024, 4, 20, waves=3)), None) == -1
+    lib.vcr_linear_pair_f32.argtypes = [ctypes.POINTER(native.LinearArgs), ctypes.POINTER(native.LinearArgs), ctypes.c_void_p]
+    lib.vcr_linear_pair_f32.restype = ctypes.c_int
+    la = native.LinearArgs()
+    assert lib.vcr_linear_pair_f32(ctypes.byref(la), ctypes.byref(la), None) == -1
+    la.x, la.w, la.y, la.ldx, la.ldy, la.M, la.N, la.K = 0x1000, 0x2000, 0x3000, 64, 64, 128, 64, 64
+    la.variant = 32                                        # a retired selector
+    assert lib.vcr_linear_f32(ctypes.byref(la), None) == -1
+    sa = native.SdpaArgs()
+    sa.q, sa.k, sa.v, sa.out = 0x1000, 0x2000, 0x3000, 0x4000
+    sa.ldq = sa.ldk = sa.ldv = sa.ldo = 512
+    sa.nbatch, sa.heads, sa.nq, sa.nk, sa.scale = 2, 4, 64, 64, 0.1
+    sa.ngroups, sa.rowstat = 2, 0x5000                     # grouped launches: attention-output form only
+    assert lib.vcr_sdpa_f32(ctypes.byref(sa), None) == -1
+    sa.ngroups, sa.rowstat, sa.key_index, sa.nk_src = 0, None, 0x6000, 0
+    assert lib.vcr_sdpa_f32(ctypes.byref(sa), None) == -1  # indexed keys need nk_src
+
+
 def test_module_contract_on_cpu():
     """Constructor / state-dict contract of the reference module without a GPU."""
     from types import SimpleNamespace

@@ -648,7 +648,7 @@ def test_knn_exact_ties_follow_torch_topk(nat, N, k):
 
 
 def test_knn_long_rows_replay_ties_through_global_scratch(nat):
-    """N = 12 000 (> 10 196: a row's distances no longer fit the replay's LDS image): with tie_work the replay runs out
+    """N = 12 000 (> 10 091: a row's distances no longer fit the replay's LDS image): with tie_work the replay runs out
     of global scratch and the neighbour sets still equal Tensor.topk's on every row of a tie-heavy cloud; WITHOUT
     tie_work the call is refused (VCR_EUNSUPPORTED) instead of silently skipping the replay.  k > 40 is refused too."""
     N, k = 12000, 20

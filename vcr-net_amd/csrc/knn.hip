@@ -1273,6 +1273,9 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->idx) return VCR_EINVAL;
   if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k + 1 > a->N) return VCR_EINVAL;
   if (a->k > 40 || a->N > 65535) return VCR_EUNSUPPORTED;   // limits of this library, not of the operation (see vcr_hip.h)
+  if (a->waves != 0 && a->waves != 1 && a->waves != 2 && a->waves != 4 && a->waves != 8) return VCR_EINVAL;
+  if (a->C != 64 && a->C != 4) return VCR_EUNSUPPORTED;
+  if (a->C == 64 ? (!a->sq || a->ldx < 64 || (a->ldx & 3)) : (a->ldx < 4 || (a->ldx & 3))) return VCR_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (a->tie_scratch) {
     if (a->tie_cap < 1) return VCR_EINVAL;
@@ -1288,7 +1291,6 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   // number of lists (S per query), and measured on MI355X a second wave per SIMD bought with S = 2 only breaks even, so
   // S stays 1 as soon as that gives every SIMD (1024 of them) one wave; smaller grids split to fill the chip.
   // (the fold of S > 1 waves parks the value lists behind the logs: there is room for that with k <= 20 only)
-  if (a->waves != 0 && a->waves != 1 && a->waves != 2 && a->waves != 4 && a->waves != 8) return VCR_EINVAL;
   auto pick_s = [&](long) { return knn_s(a); };
   vcr_knn_args ka = *a;                                  // (tie_inline is the library's own field)
   const bool inl = ties_inline(a);
