@@ -79,6 +79,7 @@ def parse(argv=None):
     ap.add_argument("--no-merge-encdec", action="store_true",
                     help="enc.qkv / dec.qkv and the two self-attentions as separate launches (default: one GEMM + one grouped launch)")
     ap.add_argument("--linear-bk", type=int, default=0, choices=[0, 16, 32], help="k-slab of the fp32 linears (0 = the library's choice)")
+    ap.add_argument("--linear-bm", type=int, default=0, choices=[0, 96, 128], help="tile height of the fp32 linears (0 = the library's choice)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm); gloo only "
                                                       "for exercising the multi-rank control flow on a 1-GPU box")
     return ap.parse_args(argv)
@@ -292,6 +293,7 @@ def run_rank(a):
     net.linear_mode = a.linear_mode
     net.merge_encdec = not a.no_merge_encdec
     net.linear_mfma, net.linear_bk, net.knn_waves = a.linear_mfma, a.linear_bk, a.knn_waves
+    net.linear_bm = a.linear_bm
     net = net.to(dev).eval()
 
     B, N = a.batch, a.points

@@ -129,7 +129,12 @@ typedef struct {
   float* segmax_out; int ld_segmax; int seg_k;
   int variant;                        /* tuning / tests, 0 = automatic (LDS-DMA staging, one 128x128 tile per workgroup:
                                          BK 16, 32x32x2 MFMAs and four workgroups per CU without a residual; BK 32 and
-                                         16x16x4 MFMAs with one).
+                                         16x16x4 MFMAs with one -- those on 96x128 tiles when M-tiles of 128 rows
+                                         would leave a mostly empty last round of workgroups on the 256 CUs, e.g.
+                                         M = 36 864 at BASELINE configs[2]).
+                                         bit11 (2048) force 96-row tiles (16x16x4 MFMAs; not with bit10 / bit2:
+                                         VCR_EINVAL), bit12 (4096) force 128-row tiles: the tile height does not change
+                                         a shape's results;
                                          bit3 (8) force BK 32, bit6 (64) force BK 16; bit4 (16) force the 16x16x4 MFMA
                                          shape, bit10 (1024) force 32x32x2; bit2 (4) the register-staged kernel without
                                          alignment requirements on y / bias / residual (taken automatically when they
@@ -139,7 +144,8 @@ typedef struct {
 int vcr_linear_f32(const vcr_linear_args*, vcr_stream_t);
 /* Two independent linears as ONE launch when both resolve to the same kernel configuration (k-slab, MFMA shape,
  * LayerNorm-in, statistics-out; no fused max), else exactly the two calls: fewer, fuller rounds of workgroups for e.g. the
- * encoder's and the decoder's output projections.  Every tile is computed as in its own launch: identical results. */
+ * encoder's and the decoder's output projections.  The tile height (128 / 96 rows) is chosen for the combined grid unless
+ * a variant bit forces it.  Every element is computed as in its own launch with that MFMA shape. */
 int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_args* b, vcr_stream_t);
 
 /* Fold LayerNorm(a, b) into the Linear (w [N,K], bias [N] or NULL) that consumes it, once per weight:
@@ -426,6 +432,7 @@ typedef struct {
    * 32 = v_mfma_f32_32x32x2_f32 (benchmarks / tests; results agree to fp32 rounding) */
   int linear_mfma;
   int linear_bk;                                   /* 0 = the library's choice, 16 / 32 = that k-slab for every fp32 linear (benchmarks) */
+  int linear_bm;                                   /* 0 = the library's choice, 96 / 128 = that tile height (variant bits 11 / 12; benchmarks) */
   int knn_waves;                                   /* vcr_knn_args.waves of the feature-space kNN (0 = automatic; benchmarks) */
   /* partial mode: the decoder's cross-attention scores ([2B,H,N,N] fp32) are kept between the statistics pass and the
    * key-mass pass when they fit this many MiB of workspace (0 = 4096), and recomputed per head otherwise (< 0: never

@@ -311,7 +311,14 @@ def test_cross_attention_fallback_branches_of_the_driver():
         with pytest.raises(native.VcrHipError):
             net2._forward_fused(s, t, force={"keys": out[6]["keys"]})
         net2.linear_mode = "fp32"
-    np.testing.assert_allclose(split[2].cpu().numpy(), out[2].cpu().numpy(), atol=1e-2)   # (selections may flip between modes)
+    # the two modes round differently, so a near-tie may select differently: same selections -> same pose to rounding;
+    # otherwise at most a handful of flips and a pose that moved by what one or two exchanged pairs move it
+    nflip = sum(len(set(a.tolist()) ^ set(b.tolist())) // 2 for name in ("keys", "sel_src", "sel_tgt")
+                for a, b in zip(out[6][name][0].cpu(), split[6][name][0].cpu()))
+    same_sel = nflip == 0 and all(torch.equal(out[6][name], split[6][name]) for name in ("argmax", "pairs"))
+    dmode = np.abs(split[2].cpu().numpy() - out[2].cpu().numpy()).max()
+    print(f"bf16x3+sdpa vs fp32, ff_dims 512: {nflip} kept-key / overlap-set flips, same hard pairs {same_sel}, max|dR| {dmode:.2e}")
+    assert nflip <= 4 and dmode <= (2e-4 if same_sel else 5e-2)
     same_keys = all(set(a.tolist()) == set(b.tolist()) for a, b in
                     zip(out[6]["keys"][0].cpu(), torch.cat((rec["key_keep_src"], rec["key_keep_tgt"]), 0)))
     same_pairs = torch.equal(out[0].cpu(), ref[0]) and torch.equal(out[1].cpu(), ref[1])

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
 }
 
 // mass[kb][key] = sum_h sum_q exp(S[qb][h][q][key] - m) / l, qb = (kb + shift) % nbatch; 64 keys per block (lanes),
-// the (head, query) rows split over the 4 waves in a fixed order, merged through LDS.
+// the (head, query) rows split over the 4 waves in a fixed order, merged through LDS.  (Row pitch not a multiple of 4.)
 __global__ __launch_bounds__(256) void keymass_kernel(vcr_keymass_args p) {
   __shared__ float mg[4][64];
   const int kb = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -240,12 +240,58 @@ __global__ __launch_bounds__(256) void keymass_kernel(vcr_keymass_args p) {
   if (w == 0 && key < p.nk) p.mass[(size_t)kb * p.nk + key] = ((mg[0][lane] + mg[1][lane]) + mg[2][lane]) + mg[3][lane];
 }
 
+// The same sums with 256 keys per block (16 B per lane: every row contributes one contiguous KiB, where the kernel above
+// reads 256-B pieces 3 KB apart and leaves the DRAM pages to whichever block comes next -- 2.9 TB/s at BASELINE
+// configs[2]); the rows are split over 16 waves in a fixed order, merged through LDS in wave order.
+constexpr int KM_WAVES = 16;
+__global__ __launch_bounds__(64 * KM_WAVES) void keymass4_kernel(vcr_keymass_args p) {
+  __shared__ f32x4 mg[KM_WAVES][64];
+  const int kb = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int key = blockIdx.x * 256 + lane * 4, kc = min(key, (p.nk - 1) & ~3);
+  const int qb = (kb + p.q_batch_shift) % p.nbatch;
+  const int rows = p.heads * p.nq;
+  const float* S = p.score + (size_t)qb * rows * p.ld + kc;
+  const float* rs = p.rowstat + (size_t)qb * rows * 2;
+  const int per = (rows + KM_WAVES - 1) / KM_WAVES, r0 = min(rows, w * per), r1 = min(rows, r0 + per);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {                          // eight rows (8 KiB per wave) in flight; summed in row order
+    f32x4 v[8];
+    float m8[8], l8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { v[u] = ld4(S + (size_t)(r + u) * p.ld); m8[u] = rs[2 * (r + u)]; l8[u] = rs[2 * (r + u) + 1]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += __builtin_amdgcn_exp2f((v[u][e] - m8[u]) * LOG2E) / l8[u];
+  }
+  for (; r < r1; ++r) {
+    const f32x4 v = ld4(S + (size_t)r * p.ld);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += __builtin_amdgcn_exp2f((v[e] - rs[2 * r]) * LOG2E) / rs[2 * r + 1];
+  }
+  mg[w][lane] = acc;
+  __syncthreads();
+  if (w == 0) {
+    f32x4 tot = mg[0][lane];
+#pragma unroll
+    for (int i = 1; i < KM_WAVES; ++i) tot = tot + mg[i][lane];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (key + e < p.nk) p.mass[(size_t)kb * p.nk + key + e] = tot[e];
+  }
+}
+
 }  // namespace
 
 extern "C" int vcr_keymass_f32(const vcr_keymass_args* a, vcr_stream_t stream) {
   if (!a || !a->score || !a->rowstat || !a->mass) return VCR_EINVAL;
   if (a->nbatch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0 || a->ld < a->nk) return VCR_EINVAL;
-  hipLaunchKernelGGL(keymass_kernel, dim3((a->nk + 63) / 64, a->nbatch), dim3(256), 0, (hipStream_t)stream, *a);
+  // 16 B per lane when every row is 16-B aligned and padded to a multiple of 4 keys (vcr_sdpa_f32's score_out is)
+  if ((a->ld & 3) == 0 && (((uintptr_t)a->score) & 15) == 0 && ((a->nk + 3) & ~3) <= a->ld)
+    hipLaunchKernelGGL(keymass4_kernel, dim3((a->nk + 255) / 256, a->nbatch), dim3(64 * KM_WAVES), 0, (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL(keymass_kernel, dim3((a->nk + 63) / 64, a->nbatch), dim3(256), 0, (hipStream_t)stream, *a);
   return VCR_LAUNCH_RC();
 }
 

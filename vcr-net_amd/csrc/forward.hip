@@ -73,12 +73,14 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
     w.xscore = xs * 4 <= xlimit ? bp.take<float>(xs) : nullptr;
     w.xorder = bp.take<int32_t>(M);
     w.rstat = bp.take<float>(B1 * N * 2); w.cstat = bp.take<float>(B1 * N * 2);
-    w.colsum = bp.take<float>(B1 * N);    w.rowsum = bp.take<float>(B1 * N);
+    // source-side block first, target-side block right behind it ([2B, ...] like the embeddings): one rank-select and
+    // one gather launch then serve both clouds
+    w.rowsum = bp.take<float>(2 * B1 * N); w.colsum = w.rowsum + B1 * N;
     w.score = bp.take<float>(B1 * N * ((N + 31) & ~31));
-    w.sel_s = bp.take<int32_t>(B1 * K1);  w.sel_t = bp.take<int32_t>(B1 * K1);
+    w.sel_s = bp.take<int32_t>(2 * B1 * K1); w.sel_t = w.sel_s + B1 * K1;
     w.amax = bp.take<int32_t>(B1 * K1);   w.pick = bp.take<int32_t>(B1 * (K2 ? K2 : 1));
-    w.so_e = bp.take<float>(B1 * K1 * E); w.to_e = bp.take<float>(B1 * K1 * E);
-    w.so_s = bp.take<float>(B1 * K1 * 4); w.to_s = bp.take<float>(B1 * K1 * 4);
+    w.so_e = bp.take<float>(2 * B1 * K1 * E); w.to_e = w.so_e + B1 * K1 * E;
+    w.so_s = bp.take<float>(2 * B1 * K1 * 4); w.to_s = w.so_s + B1 * K1 * 4;
     w.peak = bp.take<float>(B1 * K1 * 2);
   }
   if (emb_kind == 1 && k != 20 && k != 40) {              // (k = 20 / 40 run the chain in one kernel: no per-edge tensor at all)
@@ -315,16 +317,17 @@ struct Runner {
         ok(vcr_scoremass_f32(&a, stream));
       }
     }
-    if (io->force_sel_tgt) copy_idx("select:head.tgt.forced", w.sel_t, io->force_sel_tgt, (size_t)B * K1);
-    else rank("select:head.tgt", w.colsum, 1, B, N, K1, w.sel_t, nullptr, 1);                        // :223
-    if (io->force_sel_src) copy_idx("select:head.src.forced", w.sel_s, io->force_sel_src, (size_t)B * K1);
-    else rank("select:head.src", w.rowsum, 1, B, N, K1, w.sel_s, nullptr, 1);                        // :245
+    if (forced_sets) {
+      copy_idx("select:head.tgt.forced", w.sel_t, io->force_sel_tgt, (size_t)B * K1);
+      copy_idx("select:head.src.forced", w.sel_s, io->force_sel_src, (size_t)B * K1);
+    } else {
+      // :245 (sources by row mass) and :223 (targets by column mass) as one launch over the [2B, N] block rowsum | colsum
+      rank("select:head.src+tgt", w.rowsum, 1, 2 * B, N, K1, w.sel_s, nullptr, 1);
+    }
     if (io->out_sel_tgt) copy_idx("select:head.tgt.out", io->out_sel_tgt, w.sel_t, (size_t)B * K1);
     if (io->out_sel_src) copy_idx("select:head.src.out", io->out_sel_src, w.sel_s, (size_t)B * K1);
-    gather("select:gather.src_emb", se, E, N, w.sel_s, B, K1, E, w.so_e);                            // :251-260
-    gather("select:gather.tgt_emb", te, E, N, w.sel_t, B, K1, E, w.to_e);                            // :235-238
-    gather("select:gather.src_xyz", ss, 4, N, w.sel_s, B, K1, 4, w.so_s);
-    gather("select:gather.tgt_xyz", ts, 4, N, w.sel_t, B, K1, 4, w.to_s);
+    gather("select:gather.emb", se, E, N, w.sel_s, 2 * B, K1, E, w.so_e);    // :251-260 (source) and :235-238 (target), one launch
+    gather("select:gather.xyz", ss, 4, N, w.sel_s, 2 * B, K1, 4, w.so_s);
     // getCopair on the overlap sets: peak soft-max probability = 1/l and its arg-max target (:295-298)
     if (!(io->force_argmax && io->force_pairs))
       stats("pairscore:head.copair", w.so_e, w.to_e, w.so_s, w.to_s, K1, K1, w.peak, w.amax, nullptr, 0);
@@ -358,6 +361,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (W->head_mode < 0 || W->head_mode > 2 || W->linear_mode < 0 || W->linear_mode > 2) return VCR_EINVAL;
   for (int ms : {W->linear_mfma, W->linear_bk})
     if (ms != 0 && ms != 16 && ms != 32) return VCR_EINVAL;
+  if ((W->linear_bm != 0 && W->linear_bm != 96 && W->linear_bm != 128) || (W->linear_bm == 96 && W->linear_mfma == 32)) return VCR_EINVAL;
   if (W->knn_waves != 0 && W->knn_waves != 1 && W->knn_waves != 8) return VCR_EINVAL;
   if (W->partial) {                                      // key pruning in the decoder (+ hard pairs for the topK head)
     if (W->has_pointer != 1 || (W->cycle && W->head_mode == 0)) return VCR_EUNSUPPORTED;
@@ -378,7 +382,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   R.ok(VCR_LAUNCH_RC());
 #define SP(site) (W->linear_mode != 0 ? W->split.site : nullptr)
   R.sdpa_split = W->linear_mode == 2;
-  R.linear_variant = (W->linear_mfma == 16 ? 16 : W->linear_mfma == 32 ? 1024 : 0) | (W->linear_bk == 16 ? 64 : W->linear_bk == 32 ? 8 : 0);
+  R.linear_variant = (W->linear_mfma == 16 ? 16 : W->linear_mfma == 32 ? 1024 : 0) | (W->linear_bk == 16 ? 64 : W->linear_bk == 32 ? 8 : 0) |
+                     (W->linear_bm == 96 ? 2048 : W->linear_bm == 128 ? 4096 : 0);
 
   const float* stats_for_ln = W->has_pointer == 1 ? w.st_emb : nullptr;
   if (W->emb_kind == 1) {
@@ -724,7 +729,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 15; }
+extern "C" int vcr_abi_version(void) { return 16; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

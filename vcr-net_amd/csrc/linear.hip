@@ -174,8 +174,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 3)) void linear_kernel(vcr_lin
 // linear) and to the ds_read_b128 address when reading (both sides or neither).  With 128-B rows two rows
 // share a 256-B bank row, so a 16-lane b128 group (16 distinct rows) hits 16 distinct slots.
 // No VGPRs hold the in-flight slab and there is no ds_write pass.
-template <int BK> struct TileGT { float a[BM][BK]; float b[BN][BK]; };
-using TileG = TileGT<32>;
+template <int BK, int BMV = BM> struct TileGT { float a[BMV][BK]; float b[BN][BK]; };
 
 __device__ __forceinline__ void glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -195,14 +194,22 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 //         16: 64-B rows (16 rows per KiB, pc = lc ^ ((row >> 2) & 3)), 35 KB and ~100 VGPRs, FOUR workgroups per CU (4
 //         waves per SIMD from independent workgroups cover each other's k-step barriers): +2-3 % on the launches
 //         without a residual, which is what the launcher uses it for.  Same k order: results are bit-identical.
+// BMV   : rows per block tile.  128 (wave tile 64 x 64), or 96 with MS = 16 (wave tile 48 x 64 = 3 x 4 tiles of 16 x 16): the
+//         launcher picks 96 when 128-row tiles would leave a mostly empty last round of workgroups (M = 36 864 at BASELINE
+//         configs[2]: 1152 tiles on 512 or 1024 slots = 2.25 / 1.125 rounds; 1536 tiles of 96 rows = 3.0 / 1.5).  Every
+//         output element is the same k-ordered chain as in the 128-row MS = 16 kernel: bit-identical results.
 // MS    : MFMA shape.  32 = v_mfma_f32_32x32x2_f32 (wave tile = 2x2 tiles, k = 8g + 4*half + s); 16 =
 //         v_mfma_f32_16x16x4_f32 (wave tile = 4x4 tiles of 16x16, a lane's quarter q = lane >> 4 owns chunk q of a 16-wide
 //         k group: k = 16g + 4q + s).  Same flops per cycle; the chip sustains a higher clock on the 16x16 shape under
 //         the matrix pipe's power limit (profiles/r2e_mfma_sustained_rates.txt: 132-140 vs 127-136 TFLOP/s).  The two
 //         shapes sum k in different orders: results agree to fp32 rounding, not bitwise.
-template <int BK, bool LN_IN, bool STATS_OUT, int MS>
+template <int BK, bool LN_IN, bool STATS_OUT, int MS, int BMV = BM>
 __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int tiles_m, int tiles_n, int blk) {
-  using Tile = TileGT<BK>;
+  static_assert(BMV == 128 || (BMV == 96 && MS == 16), "96-row tiles are built from 16 x 16 MFMA tiles");
+  using Tile = TileGT<BK, BMV>;
+  constexpr int WR = BMV / 2;                            // rows per wave tile
+  constexpr int EPR = BMV == 128 ? 32 : 16;              // rows per epilogue pass
+  constexpr int NPASS = WR / EPR, NPS = EPR / 4;
   constexpr int CPR = BK / 4;                            // 16-B chunks per LDS row
   constexpr int RPK = 64 / CPR;                          // rows per 1-KiB LDS-DMA wave instruction
   constexpr int NF = 32 / RPK;                           // fills per operand per wave (32 rows each)
@@ -224,29 +231,38 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
   constexpr int GW = 12;
   const int grp = bid / (GW * tiles_m), wg = min(GW, tiles_n - grp * GW), loc = bid - grp * GW * tiles_m;
   const int tm = loc / wg, tn = grp * GW + loc % wg;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BMV, n0 = tn * BN;
   TL(0);
 
   // fill mapping: wave w covers rows w*32 + RPK*i + lane / CPR, physical chunk lane % CPR
+  // (BMV = 96: the A panel is BMV / RPK wave instructions, dealt to the waves round robin -- 3 each at BK 32; 2, 2, 1, 1 at BK 16)
   const int frow = lane / CPR, fpc = lane % CPR;
-  const float* xa[NF];
+  constexpr int NFA = BMV == 128 ? NF : (BMV / RPK + 3) / 4;
+  const float* xa[NFA];
   const float* wb[NF];
+  int arow[NFA];
+#pragma unroll
+  for (int i = 0; i < NFA; ++i) {
+    arow[i] = BMV == 128 ? wave * 32 + RPK * i : (wave + 4 * i) * RPK;      // wave-uniform
+    const int row = min(arow[i], BMV - RPK) + frow;
+    const int lc = fpc ^ ((row >> SWS) & (CPR - 1));
+    xa[i] = p.x + (size_t)min(m0 + row, p.M - 1) * p.ldx + 4 * lc;
+  }
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
     const int row = wave * 32 + RPK * i + frow;
     const int lc = fpc ^ ((row >> SWS) & (CPR - 1));
-    xa[i] = p.x + (size_t)min(m0 + row, p.M - 1) * p.ldx + 4 * lc;
     wb[i] = p.w + (size_t)min(n0 + row, p.N - 1) * p.K + 4 * lc;
   }
   auto fill = [&](int buf, int k0) {
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
-      glds16(xa[i] + k0, &tile[buf].a[wave * 32 + RPK * i][0]);
-      glds16(wb[i] + k0, &tile[buf].b[wave * 32 + RPK * i][0]);
-    }
+    for (int i = 0; i < NFA; ++i)
+      if (BMV == 128 || arow[i] < BMV) glds16(xa[i] + k0, &tile[buf].a[min(arow[i], BMV - RPK)][0]);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) glds16(wb[i] + k0, &tile[buf].b[wave * 32 + RPK * i][0]);
   };
   fill(0, 0);
-  if (LN_IN && t < BM) {
+  if (LN_IN && t < BMV) {
     float mean, var;
     ln_row_moments(p.ln_stats_in + (size_t)min(m0 + t, p.M - 1) * p.ln_nseg * 2, p.ln_nseg, p.K, mean, var);
     rowst[2 * t] = mean;
@@ -255,36 +271,37 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
   __syncthreads();
   TL(1);
 
-  constexpr int NT = MS == 32 ? 2 : 4;                   // MFMA tiles per wave-tile edge (64 rows / columns)
+  constexpr int NT = MS == 32 ? 2 : 4;                   // MFMA tiles per 64-wide wave-tile edge
+  constexpr int NTM = WR / MS;                           // MFMA tile rows per wave tile (BMV 96: 3)
   const int qtr = lane >> 4, l15 = lane & 15;            // MS 16: quarter q supplies k = 4q + s of a 16-wide k group
   f32x16 acc[2][2];                                      // MS 32
-  f32x4 acc4[4][4];                                      // MS 16 (the unused set is dead code)
+  f32x4 acc4[MS == 16 ? NTM : 4][4];                     // MS 16 (the unused set is dead code)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < (MS == 16 ? NTM : 4); ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   int ra_[NT], rb_[NT], sa[NT], sb[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
-    ra_[i] = wm * 64 + i * MS + (MS == 32 ? l31 : l15); sa[i] = (ra_[i] >> SWS) & (CPR - 1);
+    ra_[i] = wm * WR + i * MS + (MS == 32 ? l31 : l15); sa[i] = (ra_[i] >> SWS) & (CPR - 1);     // (i < NTM used)
     rb_[i] = wn * 64 + i * MS + (MS == 32 ? l31 : l15); sb[i] = (rb_[i] >> SWS) & (CPR - 1);
   }
   // BK 32: the residual tile does not depend on the GEMM: fetch this lane's 16 chunks now, so that the epilogue's
   // load -> add -> store chain does not start with an HBM round trip (64 VGPRs; the kernel runs 2 waves per SIMD).
   // BK 16 (four workgroups per CU, ~100 VGPRs): no room for that; a residual is read in the epilogue.
   constexpr bool PREFETCH_RES = BK == 32;
-  f32x4 resv[PREFETCH_RES ? 2 : 1][PREFETCH_RES ? 8 : 1];
+  f32x4 resv[PREFETCH_RES ? NPASS : 1][PREFETCH_RES ? NPS : 1];
   if (PREFETCH_RES) {
     const int colr = n0 + wn * 64 + (lane & 15) * 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NPASS; ++i)
 #pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
-        const int row = m0 + wm * 64 + i * 32 + ps * 4 + (lane >> 4);
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int row = m0 + wm * WR + i * EPR + ps * 4 + (lane >> 4);
         resv[PREFETCH_RES ? i : 0][PREFETCH_RES ? ps : 0] =
             (p.residual && row < p.M && colr < p.N) ? ld4(p.residual + (size_t)row * p.ldr + colr) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -312,15 +329,15 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
     } else {
 #pragma unroll
       for (int g = 0; g < BK / 16; ++g) {
-        f32x4 fa[4], fb[4];
+        f32x4 fa[NTM], fb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = ld4(&T.a[ra_[i]][4 * ((4 * g + qtr) ^ sa[i])]);
+        for (int i = 0; i < NTM; ++i) fa[i] = ld4(&T.a[ra_[i]][4 * ((4 * g + qtr) ^ sa[i])]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = ld4(&T.b[rb_[j]][4 * ((4 * g + qtr) ^ sb[j])]);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < NTM; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc4[i][j] = mfma16(fa[i][s], fb[j][s], acc4[i][j]);
       }
@@ -346,19 +363,19 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
     run_pt = -1;
   };
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NPASS; ++i) {
     if constexpr (MS == 32) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[acc_row(r, half) * EP + j * 32 + l31] = acc[i][j][r];
-    } else {                                             // D[row = 4q + r][col = l15] of tile (2i + ih, jt)
+    } else {                                             // D[row = 4q + r][col = l15] of tile (EPR / 16 * i + ih, jt)
 #pragma unroll
-      for (int ih = 0; ih < 2; ++ih)
+      for (int ih = 0; ih < EPR / 16; ++ih)
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ot[(16 * ih + 4 * qtr + r) * EP + jt * 16 + l15] = acc4[2 * i + ih][jt][r];
+          for (int r = 0; r < 4; ++r) ot[(16 * ih + 4 * qtr + r) * EP + jt * 16 + l15] = acc4[EPR / 16 * i + ih][jt][r];
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -369,9 +386,9 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
       // groups of a ps step when they share the point -- and goes out as ONE integer atomic max per column and run
       // (post-ReLU values are >= 0: their bit patterns order like ints; the target was pre-set to 0 by vcr_edgerows_f32).
 #pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
+      for (int ps = 0; ps < NPS; ++ps) {
         const int rl = ps * 4 + (lane >> 4);
-        const int row0 = m0 + wm * 64 + i * 32 + ps * 4, row = row0 + (lane >> 4);   // row0: wave-uniform
+        const int row0 = m0 + wm * WR + i * EPR + ps * 4, row = row0 + (lane >> 4);   // row0: wave-uniform
         f32x4 v = ld4(&ot[rl * EP + c4e]) + bias;
         v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
         if (row >= p.M || col >= p.N) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -398,16 +415,16 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
           }
         }
       }
-      if (i == 1) seg_flush();
+      if (i == NPASS - 1) seg_flush();
     } else if (col < p.N) {
 #pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
+      for (int ps = 0; ps < NPS; ++ps) {
         const int rl = ps * 4 + (lane >> 4);
-        const int row = m0 + wm * 64 + i * 32 + rl;
+        const int row = m0 + wm * WR + i * EPR + rl;
         if (row < p.M) {
           f32x4 v = ld4(&ot[rl * EP + c4e]);
           if (LN_IN) {
-            const float mean = rowst[2 * (wm * 64 + i * 32 + rl)], inv = rowst[2 * (wm * 64 + i * 32 + rl) + 1];
+            const float mean = rowst[2 * (wm * WR + i * EPR + rl)], inv = rowst[2 * (wm * WR + i * EPR + rl) + 1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaf(inv, fmaf(-mean, csum[e], v[e]), bias[e]);
           } else {
@@ -441,19 +458,19 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
 #endif
 }
 
-template <int BK, bool LN_IN, bool STATS_OUT, int MS>
+template <int BK, bool LN_IN, bool STATS_OUT, int MS, int BMV>
 __global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_kernel(vcr_linear_args p, int tiles_m, int tiles_n) {
-  linear_glds_body<BK, LN_IN, STATS_OUT, MS>(p, tiles_m, tiles_n, (int)blockIdx.x);
+  linear_glds_body<BK, LN_IN, STATS_OUT, MS, BMV>(p, tiles_m, tiles_n, (int)blockIdx.x);
 }
 // Two independent linears of the same kernel configuration as ONE launch (the first n0 workgroups work on p0, the rest
 // on p1): the encoder's and the decoder's output projections, or enc.ffn1 beside dec.cross.q -- fewer, fuller rounds of
 // workgroups; each tile is computed exactly as in its own launch.
-template <int BK, bool LN_IN, bool STATS_OUT, int MS>
+template <int BK, bool LN_IN, bool STATS_OUT, int MS, int BMV>
 __global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_pair_kernel(vcr_linear_args p0, vcr_linear_args p1, int tm0,
                                                                                  int tn0, int tm1, int tn1) {
   const int n0 = tm0 * tn0;
-  if ((int)blockIdx.x < n0) linear_glds_body<BK, LN_IN, STATS_OUT, MS>(p0, tm0, tn0, (int)blockIdx.x);
-  else linear_glds_body<BK, LN_IN, STATS_OUT, MS>(p1, tm1, tn1, (int)blockIdx.x - n0);
+  if ((int)blockIdx.x < n0) linear_glds_body<BK, LN_IN, STATS_OUT, MS, BMV>(p0, tm0, tn0, (int)blockIdx.x);
+  else linear_glds_body<BK, LN_IN, STATS_OUT, MS, BMV>(p1, tm1, tn1, (int)blockIdx.x - n0);
 }
 
 }  // namespace
@@ -469,20 +486,31 @@ extern "C" int vcr_dbg_timeline(unsigned long long* host_dst, int clear) {
 #endif
 
 namespace {
-struct LinearPlan { bool glds, bk16, ms16, ln_in, st_out; int tiles_m, tiles_n, vec, lds; };
+struct LinearPlan { bool glds, bk16, ms16, bm96, bm_free, ln_in, st_out; int tiles_m, tiles_n, vec, lds; long t96, t128; };
+
+// Relative cost of a launch of `tiles` workgroups of `rows`-row tiles on `slots` resident workgroups: full rounds, plus a
+// last partial round that is cheaper than a full one (its workgroups have the CU to themselves) but far from free --
+// 0.25 of a round filled costs about half a round (BASELINE configs[2], profiles/r3g_config3_launch_table.txt).
+double launch_cost(long tiles, int slots, int rows) {
+  const long full = tiles / slots;
+  const double f = (double)(tiles - full * slots) / slots;
+  return ((double)full + (f > 0.0 ? 0.35 + 0.65 * f : 0.0)) * rows;
+}
 
 // validation + kernel choice of one linear (shared by vcr_linear_f32 and vcr_linear_pair_f32)
-int linear_plan(const vcr_linear_args* a, LinearPlan* pl) {
+// (bm_override: 0 = decide here, 96 / 128 = the tile rows a paired launch decided for both of its halves)
+int linear_plan(const vcr_linear_args* a, LinearPlan* pl, int bm_override = 0) {
   if (!a || !a->x || !a->w || (!a->y && !a->segmax_out)) return VCR_EINVAL;
   if (a->segmax_out && (a->seg_k <= 0 || !a->relu || a->residual || a->ln_stats_in || a->stats_out || (a->ld_segmax & 3) ||
                         a->ld_segmax < a->N || ((uintptr_t)a->segmax_out & 15) || (a->variant & 4)))
     return VCR_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % 32) != 0) return VCR_EINVAL;
   const int variant = a->variant;                    // tuning / test selector carried by the call (see vcr_hip.h)
-  if (variant & ~(4 | 8 | 16 | 64 | 1024)) return VCR_EINVAL;     // retired selectors (1, 32, 128, 256, 512) are refused, not ignored
+  if (variant & ~(4 | 8 | 16 | 64 | 1024 | 2048 | 4096)) return VCR_EINVAL;   // retired selectors (1, 32, 128, 256, 512) are refused, not ignored
+  if ((variant & 2048) && (variant & (4096 | 1024 | 4))) return VCR_EINVAL;    // 96-row tiles exist on the LDS-DMA 16x16x4 kernels only
   if ((a->ldx & 3) || a->ldx < a->K || (a->y && a->ldy < a->N) || (a->residual && a->ldr < a->N)) return VCR_EINVAL;
   if (((uintptr_t)a->x | (uintptr_t)a->w) & 15) return VCR_EINVAL;
-  pl->tiles_m = (a->M + BM - 1) / BM; pl->tiles_n = (a->N + BN - 1) / BN;
+  pl->tiles_n = (a->N + BN - 1) / BN;
   pl->vec = (a->N % 4 == 0) && (!a->y || ((a->ldy % 4 == 0) && (((uintptr_t)a->y & 15) == 0))) &&
             (!a->bias || ((uintptr_t)a->bias & 15) == 0) &&
             (!a->residual || ((a->ldr % 4 == 0) && ((uintptr_t)a->residual & 15) == 0));
@@ -502,26 +530,44 @@ int linear_plan(const vcr_linear_args* a, LinearPlan* pl) {
   // 32x32x2 for the BK 16 kernels (qkv / ffn1 / kv / q / conv3: equal within 1 %); DESIGN.md 5.1.
   pl->bk16 = (!a->residual || (variant & 64)) && !(variant & 8);
   pl->ms16 = (variant & 16) ? true : (variant & 1024) ? false : (VCR_LINEAR_MS_DEFAULT == 16 || (VCR_LINEAR_MS_DEFAULT == 0 && !pl->bk16));
-  static_assert(2 * sizeof(TileGT<16>) == 2 * (BM + BN) * 16 * 4 && 2 * sizeof(TileGT<32>) == 2 * (BM + BN) * 32 * 4, "stage size below");
+  // Tile rows: bit 11 (2048) forces 96, bit 12 (4096) forces 128.  Automatic: 96 when the launch cost model above
+  // prefers it by > 2 %, on the BK 32 kernels only (two workgroups per CU; measured at BASELINE configs[2], M = 36 864:
+  // ffn2 0.335 -> 0.309 ms, cross.wo 0.184 -> 0.170, the wo pair 0.357 -> 0.340.  The BK 16 kernels run four
+  // workgroups per CU, their last round costs little, and 96-row tiles measured 0-6 % SLOWER there).
+  const int slots = 256 * (pl->bk16 ? 4 : 2);            // MI355X: 256 CUs x resident workgroups per CU
+  const long t128 = (long)((a->M + 127) / 128) * pl->tiles_n, t96 = (long)((a->M + 95) / 96) * pl->tiles_n;
+  pl->t96 = t96; pl->t128 = t128;
+  pl->bm_free = pl->glds && !(variant & (4096 | 2048 | 1024));       // nothing forces the tile rows or the 32x32x2 shape
+  pl->bm96 = pl->glds && !(variant & (4096 | 1024)) &&
+             ((variant & 2048) || (!pl->bk16 && 1.02 * launch_cost(t96, slots, 96) < launch_cost(t128, slots, 128)));
+  if (bm_override && pl->bm_free) pl->bm96 = bm_override == 96;
+  if ((variant & 2048) && !pl->bm96) return VCR_EUNSUPPORTED;
+  if (pl->bm96) pl->ms16 = true;
+  const int bm = pl->bm96 ? 96 : BM;
+  pl->tiles_m = (a->M + bm - 1) / bm;
+  static_assert(2 * sizeof(TileGT<16>) == 2 * (BM + BN) * 16 * 4 && 2 * sizeof(TileGT<32, 96>) == 2 * (96 + BN) * 32 * 4, "stage size below");
   const int bkv = pl->bk16 ? 16 : 32;
-  const int stage = 2 * (BM + BN) * bkv * 4 > 4 * 32 * 68 * 4 ? 2 * (BM + BN) * bkv * 4 : 4 * 32 * 68 * 4;   // 2 x TileGT<BK> or the epilogue slices
-  pl->lds = stage + (pl->ln_in ? BM * 2 * 4 : 0);
+  const int stage = 2 * (bm + BN) * bkv * 4 > 4 * 32 * 68 * 4 ? 2 * (bm + BN) * bkv * 4 : 4 * 32 * 68 * 4;   // 2 x TileGT<BK, BMV> or the epilogue slices
+  pl->lds = stage + (pl->ln_in ? bm * 2 * 4 : 0);
   return VCR_OK;
 }
 
-// dispatch over the template grid (BK, LN_IN, STATS_OUT, MS): F is a generic lambda taking four integral_constants
+// dispatch over the template grid (BK, LN_IN, STATS_OUT, MS, BMV): F is a generic lambda taking five integral_constants
 template <class F>
 void linear_dispatch(const LinearPlan& pl, F&& f) {
-  auto d3 = [&](auto bk, auto ms) {
-    if (pl.ln_in && pl.st_out) f(bk, std::true_type{}, std::true_type{}, ms);
-    else if (pl.ln_in) f(bk, std::true_type{}, std::false_type{}, ms);
-    else if (pl.st_out) f(bk, std::false_type{}, std::true_type{}, ms);
-    else f(bk, std::false_type{}, std::false_type{}, ms);
+  auto d3 = [&](auto bk, auto ms, auto bm) {
+    if (pl.ln_in && pl.st_out) f(bk, std::true_type{}, std::true_type{}, ms, bm);
+    else if (pl.ln_in) f(bk, std::true_type{}, std::false_type{}, ms, bm);
+    else if (pl.st_out) f(bk, std::false_type{}, std::true_type{}, ms, bm);
+    else f(bk, std::false_type{}, std::false_type{}, ms, bm);
   };
   using I16 = std::integral_constant<int, 16>;
   using I32 = std::integral_constant<int, 32>;
-  if (pl.bk16) { if (pl.ms16) d3(I16{}, I16{}); else d3(I16{}, I32{}); }
-  else { if (pl.ms16) d3(I32{}, I16{}); else d3(I32{}, I32{}); }
+  using I96 = std::integral_constant<int, 96>;
+  using I128 = std::integral_constant<int, 128>;
+  if (pl.bm96) { if (pl.bk16) d3(I16{}, I16{}, I96{}); else d3(I32{}, I16{}, I96{}); }
+  else if (pl.bk16) { if (pl.ms16) d3(I16{}, I16{}, I128{}); else d3(I16{}, I32{}, I128{}); }
+  else { if (pl.ms16) d3(I32{}, I16{}, I128{}); else d3(I32{}, I32{}, I128{}); }
 }
 }  // namespace
 
@@ -530,12 +576,12 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
   const int rc = linear_plan(a, &pl);
   if (rc != VCR_OK) return rc;
   if (pl.glds) {
-    linear_dispatch(pl, [&](auto bk, auto li, auto so, auto ms) {
-      constexpr int BKV = decltype(bk)::value, MSV = decltype(ms)::value;
+    linear_dispatch(pl, [&](auto bk, auto li, auto so, auto ms, auto bm) {
+      constexpr int BKV = decltype(bk)::value, MSV = decltype(ms)::value, BMV = decltype(bm)::value;
       constexpr bool LI = decltype(li)::value, SO = decltype(so)::value;
-      VCR_DYN_LDS((linear_glds_kernel<BKV, LI, SO, MSV>), pl.lds);
-      hipLaunchKernelGGL((linear_glds_kernel<BKV, LI, SO, MSV>), dim3(pl.tiles_m * pl.tiles_n), dim3(256), pl.lds, (hipStream_t)stream,
-                         *a, pl.tiles_m, pl.tiles_n);
+      VCR_DYN_LDS((linear_glds_kernel<BKV, LI, SO, MSV, BMV>), pl.lds);
+      hipLaunchKernelGGL((linear_glds_kernel<BKV, LI, SO, MSV, BMV>), dim3(pl.tiles_m * pl.tiles_n), dim3(256), pl.lds,
+                         (hipStream_t)stream, *a, pl.tiles_m, pl.tiles_n);
     });
   } else {
     // alignment-free fallback (odd N, unaligned y / bias / residual; bit 2 forces it): register staging, scalar epilogue
@@ -554,18 +600,25 @@ extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_ar
   int rc = linear_plan(a, &pa);
   if (rc == VCR_OK) rc = linear_plan(b, &pb);
   if (rc != VCR_OK) return rc;
-  const bool same = pa.glds && pb.glds && pa.bk16 == pb.bk16 && pa.ms16 == pb.ms16 && pa.ln_in == pb.ln_in && pa.st_out == pb.st_out &&
+  if (pa.bm_free && pb.bm_free && pa.bk16 == pb.bk16) {  // tile rows from the COMBINED grid (the two halves share the rounds)
+    const int slots = 256 * (pa.bk16 ? 4 : 2);
+    const int bm = !pa.bk16 && 1.02 * launch_cost(pa.t96 + pb.t96, slots, 96) < launch_cost(pa.t128 + pb.t128, slots, 128) ? 96 : 128;
+    linear_plan(a, &pa, bm);
+    linear_plan(b, &pb, bm);
+  }
+  const bool same = pa.glds && pb.glds && pa.bk16 == pb.bk16 && pa.ms16 == pb.ms16 && pa.bm96 == pb.bm96 && pa.ln_in == pb.ln_in &&
+                    pa.st_out == pb.st_out &&
                     !a->segmax_out && !b->segmax_out;
   if (!same) {
     rc = vcr_linear_f32(a, stream);
     return rc ? rc : vcr_linear_f32(b, stream);
   }
-  linear_dispatch(pa, [&](auto bk, auto li, auto so, auto ms) {
-    constexpr int BKV = decltype(bk)::value, MSV = decltype(ms)::value;
+  linear_dispatch(pa, [&](auto bk, auto li, auto so, auto ms, auto bm) {
+    constexpr int BKV = decltype(bk)::value, MSV = decltype(ms)::value, BMV = decltype(bm)::value;
     constexpr bool LI = decltype(li)::value, SO = decltype(so)::value;
-    VCR_DYN_LDS((linear_glds_pair_kernel<BKV, LI, SO, MSV>), pa.lds);
-    hipLaunchKernelGGL((linear_glds_pair_kernel<BKV, LI, SO, MSV>), dim3(pa.tiles_m * pa.tiles_n + pb.tiles_m * pb.tiles_n), dim3(256),
-                       pa.lds, (hipStream_t)stream, *a, *b, pa.tiles_m, pa.tiles_n, pb.tiles_m, pb.tiles_n);
+    VCR_DYN_LDS((linear_glds_pair_kernel<BKV, LI, SO, MSV, BMV>), pa.lds);
+    hipLaunchKernelGGL((linear_glds_pair_kernel<BKV, LI, SO, MSV, BMV>), dim3(pa.tiles_m * pa.tiles_n + pb.tiles_m * pb.tiles_n),
+                       dim3(256), pa.lds, (hipStream_t)stream, *a, *b, pa.tiles_m, pa.tiles_n, pb.tiles_m, pb.tiles_n);
   });
   return VCR_LAUNCH_RC();
 }

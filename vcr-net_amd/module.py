@@ -200,6 +200,7 @@ class VCRNet(nn.Module):
         self.linear_mode = os.environ.get("VCRNET_LINEAR_MODE", "fp32")
         # MFMA shape / k-slab of the fp32 linears, feature-space kNN kernel: 0 = the library's choice (benchmarks)
         self.linear_mfma, self.linear_bk, self.knn_waves = 0, 0, 0
+        self.linear_bm = 0                  # tile height of the fp32 linears: 0 = the library's choice, 96 / 128 (benchmarks)
         # enc.qkv + dec.qkv as one GEMM and the two self-attentions as one grouped launch (fp32 mode; same arithmetic)
         self.merge_encdec = os.environ.get("VCRNET_MERGE_ENCDEC", "1") == "1"
         self.xscore_limit_mb = 0            # partial mode: keep the cross-attention scores up to this many MiB (0 = 4096)
@@ -220,7 +221,7 @@ class VCRNet(nn.Module):
     def _fingerprint(self):
         ps = list(self.parameters()) + list(self.buffers())
         return (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]), self.emb_nn.k,
-                self.linear_mode, self.linear_mfma, self.linear_bk, self.knn_waves, self.xscore_limit_mb,
+                self.linear_mode, self.linear_mfma, self.linear_bk, self.linear_bm, self.knn_waves, self.xscore_limit_mb,
                 self.merge_encdec)
 
     def _pack(self):
@@ -345,7 +346,7 @@ class VCRNet(nn.Module):
                 P[f"att.w{i}"], P[f"att.b{i}"] = g(f"head.linears_emb.{i}.weight"), g(f"head.linears_emb.{i}.bias")
                 setattr(cw, f"att_w{i}", native.ptr(P[f"att.w{i}"])); setattr(cw, f"att_b{i}", native.ptr(P[f"att.b{i}"]))
         cw.cycle = int(bool(self.cycle))
-        cw.linear_mfma, cw.linear_bk = int(self.linear_mfma), int(self.linear_bk)
+        cw.linear_mfma, cw.linear_bk, cw.linear_bm = int(self.linear_mfma), int(self.linear_bk), int(self.linear_bm)
         cw.knn_waves = int(self.knn_waves)
         cw.xscore_limit_mb = int(self.xscore_limit_mb)
         cw.partial, cw.overlap2 = int(self._partial), self._overlap2

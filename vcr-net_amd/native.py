@@ -177,7 +177,8 @@ class VcrnetWeights(C.Structure):
                 ("fold_encdec_qkv", FoldedW),
                 ("partial", C.c_int), ("overlap2", C.c_double), ("emb_kind", C.c_int), ("dgcnn", DgcnnW),
                 ("att_w0", f32p), ("att_b0", f32p), ("att_w1", f32p), ("att_b1", f32p), ("cycle", C.c_int),
-                ("linear_mfma", C.c_int), ("linear_bk", C.c_int), ("knn_waves", C.c_int), ("xscore_limit_mb", C.c_int)]
+                ("linear_mfma", C.c_int), ("linear_bk", C.c_int), ("linear_bm", C.c_int), ("knn_waves", C.c_int),
+                ("xscore_limit_mb", C.c_int)]
 
 
 class VcrnetIo(C.Structure):
@@ -208,7 +209,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 15         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 16         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):

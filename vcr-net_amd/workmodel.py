@@ -108,10 +108,12 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
             return 0.0, 8.0 * 2 * B * N
         if site.startswith("gather"):
             width = E if site.endswith("emb") else 4
+            if site in ("gather.emb", "gather.xyz"):        # both clouds' overlap sets in one launch
+                return 0.0, 4.0 * 2 * 2 * B * K1 * width
             rows = K1 if ("src_" in site or "tgt_" in site) else K2
             return 0.0, 4.0 * 2 * B * rows * width
         n = K1 if site == "head.pairs" else N
-        nb = 2 * B if site == "dec.cross.keys" else B
+        nb = 2 * B if site in ("dec.cross.keys", "head.src+tgt") else B
         return 1.0 * nb * n * n, 4.0 * nb * n * 2
     if fam == "pose":
         return 18.0 * M1, 4.0 * M1 * 6
