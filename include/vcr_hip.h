@@ -190,6 +190,10 @@ typedef struct {
   float* x1; int ldx1; float* x2; int ldx2;
 } vcr_edgeconv_args;
 int vcr_edgeconv_f32(const vcr_edgeconv_args*, vcr_stream_t);
+/* The same operation with convDG2 (the N*k GEMM on the per-edge rows) on the bf16 matrix pipe as exact 3-way splits
+ * (see vcr_linear_bf16x3_f32): k = 20 / 40 only (VCR_EUNSUPPORTED otherwise), w2 / pq / x1 16-B aligned.  x1 is
+ * bit-identical to vcr_edgeconv_f32's, x2 agrees to fp32-GEMM rounding.  Used by the driver in linear_mode 1 / 2. */
+int vcr_edgeconv_bf16x3_f32(const vcr_edgeconv_args*, vcr_stream_t);
 
 /* ---- kernel 2b: gather + max EdgeConv for a single 1x1 conv (convSN1, lpdnet_model.py:129-132)
  * y[i] = relu(max_j P[nbr_ij] + Q[i]),  C % 4 == 0, C <= 256. */

@@ -263,12 +263,14 @@ def test_module_on_its_own_device_without_set_device():
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "bf16x3+sdpa"])
-@pytest.mark.parametrize("name", ["whole_n256_b2", "whole_n1024_b2"])
+@pytest.mark.parametrize("name", ["whole_n256_b2", "whole_n1024_b2", "whole_k40_n512_b1", "whole_k40_n4096_b2"])
 def test_bf16x3_linear_mode_vs_reference_golden(name, mode):
-    """Opt-in linear_mode='bf16x3' (exact 3-way bf16 splits on the bf16 matrix pipe; '+sdpa': the attention products
-    too) keeps the BASELINE tolerances."""
+    """Opt-in linear_mode='bf16x3' (exact 3-way bf16 splits on the bf16 matrix pipe for the linears and EdgeConv's
+    convDG2; '+sdpa': the attention products too) keeps the BASELINE tolerances, at both k of the path and up to
+    BASELINE configs[4]'s N = 4096."""
     g = golden(name)
     net, _ = build_net()
+    net.emb_nn.k = int(g["k"])
     net.linear_mode = mode
     src, tgt = torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda()
     with torch.no_grad():

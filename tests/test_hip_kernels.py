@@ -380,6 +380,33 @@ def test_edgeconv_and_gathermax(nat, W, N, k):
     torch.testing.assert_close(gx3.cpu().view(B, N, 256), x3.transpose(1, 2), atol=3e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,N,k", [(2, 300, 20), (3, 101, 20), (2, 130, 40), (16, 1024, 20), (1, 203, 7)])
+def test_edgeconv_bf16x3(nat, B, N, k):
+    """vcr_edgeconv_bf16x3_f32 (convDG2 as exact 3-way bf16 splits on the bf16 matrix pipe): x1 -- a max over the same
+    fp32 rows -- is bit-identical to the fp32 kernel's, x2 is as close to fp64 as the fp32-MFMA kernel's; ragged point
+    counts (M not a multiple of the 8- / 4-point group), both k of the path; any other k is refused."""
+    g = torch.Generator().manual_seed(B * N + k)
+    M = B * N
+    pq = dev(torch.randn(M, 256, generator=g))
+    idx = dev(torch.randint(0, N, (M, k), generator=g).int())
+    w2 = dev(torch.randn(128, 128, generator=g) / math.sqrt(128))
+    b2 = dev(torch.randn(128, generator=g) * 0.3)
+    if k not in (20, 40):
+        with pytest.raises(nat.VcrHipError):
+            nat.edgeconv(pq, idx, N, w2, b2, bf16x3=True)
+        return
+    x1, x2 = nat.edgeconv(pq, idx, N, w2, b2)
+    y1, y2 = nat.edgeconv(pq, idx, N, w2, b2, bf16x3=True)
+    assert torch.equal(x1, y1)
+    P, Q = pq[:, :128].cpu().double(), pq[:, 128:].cpu().double()
+    nbr = idx.cpu().long() + (torch.arange(M) // N * N).view(-1, 1)
+    h = torch.relu(P[nbr] + Q[:, None, :]).float().double()      # the kernels round P + Q to fp32 before the GEMM
+    ref = torch.relu((h @ w2.cpu().double().t()).max(1)[0] + b2.cpu().double())
+    e32, e3 = (x2.cpu().double() - ref).abs().max().item(), (y2.cpu().double() - ref).abs().max().item()
+    print(f"edgeconv B={B} N={N} k={k}: max|x2 - fp64|  fp32-MFMA {e32:.2e}  bf16x3 {e3:.2e}")
+    assert e3 <= 4e-6 * math.sqrt(128) + 1e-6 and e32 <= 4e-6 * math.sqrt(128) + 1e-6
+
+
 @pytest.mark.parametrize("bf16x3", [False, True])
 @pytest.mark.parametrize("N,shift", [(256, 0), (192, 0), (1024, 2), (100, 1), (300, 0)])
 def test_sdpa(nat, N, shift, bf16x3):

@@ -454,7 +454,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (R.rc == 0) {
     R.mark("edgeconv:dg1_dg2");
     vcr_edgeconv_args a{w.pq1, 256, w.idx1, k, M2, N, W->dg2_w, W->dg2_b, w.cat, 512, w.cat + 128, 512};
-    R.ok(vcr_edgeconv_f32(&a, R.stream));
+    // (linear_mode 1 / 2: convDG2 as exact bf16 splits at the path's k; other k keep the fp32 kernel)
+    R.ok(W->linear_mode != 0 && (k == 20 || k == 40) ? vcr_edgeconv_bf16x3_f32(&a, R.stream) : vcr_edgeconv_f32(&a, R.stream));
   }
   R.linear("linear:sn1_pq", w.cat + 128, 512, W->sn1_wpq, SP(sn1_pq), W->sn1_bpq, w.pq3, 512, M2, 512, 128, 0);
   if (R.rc == 0) {

@@ -199,7 +199,7 @@ class Trace(C.Structure):
 
 _SIGS = {
     "vcr_pointwise_f32": PointwiseArgs, "vcr_knn_f32": KnnArgs, "vcr_linear_f32": LinearArgs,
-    "vcr_layernorm_f32": LayerNormArgs, "vcr_rowside_f32": RowsideArgs, "vcr_edgeconv_f32": EdgeconvArgs,
+    "vcr_layernorm_f32": LayerNormArgs, "vcr_rowside_f32": RowsideArgs, "vcr_edgeconv_f32": EdgeconvArgs, "vcr_edgeconv_bf16x3_f32": EdgeconvArgs,
     "vcr_gathermax_f32": GathermaxArgs, "vcr_sdpa_f32": SdpaArgs, "vcr_sdpa_bf16x3_f32": SdpaArgs, "vcr_softcorr_f32": SoftcorrArgs,
     "vcr_rigid_svd_f32": RigidSvdArgs, "vcr_pairscore_f32": PairscoreArgs, "vcr_rankselect_f32": RankselectArgs,
     "vcr_gather_rows_f32": GatherArgs, "vcr_scoremass_f32": ScoremassArgs, "vcr_keymass_f32": KeymassArgs, "vcr_make_pairs_f32": MakePairsArgs,
@@ -497,11 +497,11 @@ def rowside(x, xyz4, scale=1.0):
 
 
 @_guarded
-def edgeconv(pq, idx, n_per_cloud, w2, b2):
+def edgeconv(pq, idx, n_per_cloud, w2, b2, bf16x3=False):
     M = pq.shape[0]
     k = idx.shape[-1]
     x1, x2 = _f32(M, 128, device=pq.device), _f32(M, 128, device=pq.device)
-    call("vcr_edgeconv_f32", EdgeconvArgs(ptr(pq), pq.stride(0), ptr(idx), k, M, n_per_cloud, ptr(w2), ptr(b2),
+    call("vcr_edgeconv_bf16x3_f32" if bf16x3 else "vcr_edgeconv_f32", EdgeconvArgs(ptr(pq), pq.stride(0), ptr(idx), k, M, n_per_cloud, ptr(w2), ptr(b2),
                                           ptr(x1), 128, ptr(x2), 128))
     return x1, x2
 
