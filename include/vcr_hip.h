@@ -295,8 +295,15 @@ typedef struct {
   const float* str_stat2; long str_stat_batch_stride; float* mass; int accumulate;
   float* score_out; int ld_score;     /* op 1 only, optional: also keep the scores, S[(b*n_own + o)*ld_score + s];
                                          ld_score % 4 == 0 and >= n_str rounded up to 32 (the pad receives -inf) */
-  int variant;                        /* tuning / tests, 0 = automatic: bit0 one owner tile (32 owners) per block */
+  int variant;                        /* tuning / tests, 0 = automatic: bit0 one owner tile (32 owners) per block; bit2 (4)
+                                         never split the streamed side */
+  /* op 1 without argmax, optional: VCR_PAIRSCORE_MAX_SPLIT * nbatch * n_own * 2 floats of scratch.  With it the launch may
+   * deal the streamed rows to up to that many workgroups per owner block when its grid would otherwise leave a mostly
+   * empty last round on the chip (e.g. 288 workgroups on 256 CUs); the partial (max, sum) pairs are merged in a fixed
+   * order by a second small kernel.  Scores and arg-max are unaffected; the sums merge in a different order. */
+  float* split_work;
 } vcr_pairscore_args;
+#define VCR_PAIRSCORE_MAX_SPLIT 4
 int vcr_pairscore_f32(const vcr_pairscore_args*, vcr_stream_t);
 
 /* ---- both probability masses of selectCom (vcrnet_model.py:217-248) from a STORED score matrix

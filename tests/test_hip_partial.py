@@ -31,6 +31,9 @@ def test_rankselect_and_gather(nat):
     g = torch.Generator().manual_seed(0)
     v = torch.randn(5, 700, generator=g)
     v[0, 10] = v[0, 3]                                        # exact tie -> lower index first
+    v[1, 300] = v[1, 5]; v[2, 699] = v[2, 0]                  # ties across the kernel's 64-candidate windows
+    v[3] = (torch.arange(700) % 7).float()                    # a hundred copies of every value
+    v[4, 640:] = v[4, 0]                                      # a run of ties ending at the ragged tail (700 = 10 x 64 + 60)
     order, mask = nat.rankselect(v.cuda(), 123, want_mask=True)
     ref = torch.sort(v, dim=1, descending=True, stable=True)[1][:, :123]
     assert torch.equal(order.cpu().long(), ref)
@@ -263,6 +266,34 @@ def test_scoremass_strided_rank_and_indirect_gather(nat):
     out = nat.gather_rows(x, order, B, N2, via=via).view(B, 50, 4)
     want = torch.stack([x.view(B, N2, 4)[bb][via[bb].long()[order[bb].long()]] for bb in range(B)])
     assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("B,N1,N2", [(24, 768, 768), (5, 3300, 1030), (2, 200, 173)])
+def test_pairscore_statistics_with_the_streamed_side_split(nat, B, N1, N2):
+    """vcr_pairscore_args.split_work: a statistics pass whose grid would leave a mostly empty last round on the chip (288
+    two-tile workgroups on 256 CUs at BASELINE configs[2]; 260 at the second shape, with a ragged streamed side) deals the streamed rows to several
+    workgroups per owner block and merges the partial (max, sum) pairs: same scores and row maxima bit for bit, the sums
+    to rounding; a grid that does not call for it (third shape) is launched exactly as without the scratch."""
+    g = torch.Generator().manual_seed(B + N1)
+    E = 512
+    dev = lambda t_: t_.cuda()
+    a, b = dev(torch.randn(B * N1, E, generator=g) * 0.2), dev(torch.randn(B * N2, E, generator=g) * 0.2)
+    side = lambda x: torch.cat((torch.zeros(len(x), 3, device=x.device), (x.double() ** 2).sum(1, keepdim=True).float()), 1)
+    ld = (N2 + 31) // 32 * 32
+    S0, S1 = torch.full((B, N1, ld), float("nan"), device="cuda"), torch.full((B, N1, ld), float("nan"), device="cuda")
+    kw = dict(op=1, score=0, own_side4=side(a), str_side4=side(b))
+    st0, _ = nat.pairscore(a, b, B, N1, N2, score_out=S0, **kw)
+    st1, _ = nat.pairscore(a, b, B, N1, N2, score_out=S1, split=True, **kw)
+    assert torch.equal(S0, S1) and torch.equal(st0[:, 0], st1[:, 0])
+    torch.testing.assert_close(st1[:, 1], st0[:, 1], rtol=2e-6, atol=0)
+    if B == 2:
+        assert torch.equal(st0, st1)
+    else:
+        assert not torch.equal(st0[:, 1], st1[:, 1])           # (the split launch really ran: another merge order)
+    st2, _ = nat.pairscore(a, b, B, N1, N2, score_out=S1, split=True, variant=4, **kw)      # bit 2: never split
+    assert torch.equal(st0, st2)
+    _, am = nat.pairscore(a, b, B, N1, N2, want_argmax=True, split=True, **kw)               # with an arg-max: never split
+    assert torch.equal(am.view(B, N1).long(), S0[:, :, :N2].argmax(2))
 
 
 def test_cross_attention_fallback_branches_of_the_driver():

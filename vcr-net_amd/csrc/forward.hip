@@ -31,6 +31,7 @@ struct Ws {
   float* xscore;                                       // [2B,H,N,roundup32(N)] scaled scores, NULL above 4 GB
   int32_t* xorder;                                     // [2B, nkeep] kept keys, heaviest first
   float *rstat, *cstat, *colsum, *rowsum, *score;      // selectCom: [B,N,2] x2, [B,N] x2, [B,N,roundup32(N)]
+  float* rsplit;                                        // vcr_pairscore_args.split_work of the head's statistics pass
   int32_t *sel_s, *sel_t, *amax, *pick;                // [B,K1] x3, [B,K2]
   float *so_e, *to_e, *so_s, *to_s, *peak;             // overlap sets: [B,K1,E] x2, [B,K1,4] x2; [B,K1,2]
   // DGCNN embedding: per-edge activations [2B*N*k, 64 | 64 | 128]
@@ -73,6 +74,7 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
     w.xscore = xs * 4 <= xlimit ? bp.take<float>(xs) : nullptr;
     w.xorder = bp.take<int32_t>(M);
     w.rstat = bp.take<float>(B1 * N * 2); w.cstat = bp.take<float>(B1 * N * 2);
+    w.rsplit = bp.take<float>(VCR_PAIRSCORE_MAX_SPLIT * B1 * N * 2);
     // source-side block first, target-side block right behind it ([2B, ...] like the embeddings): one rank-select and
     // one gather launch then serve both clouds
     w.rowsum = bp.take<float>(2 * B1 * N); w.colsum = w.rowsum + B1 * N;
@@ -302,6 +304,7 @@ struct Runner {
       a.own = own; a.ld_own = E; a.str = str; a.ld_str = E; a.own_side4 = os; a.str_side4 = sd;
       a.nbatch = B; a.n_own = no; a.n_str = ns; a.E = E; a.score = 0; a.scale = 1.f; a.op = 1;
       a.stat2 = stat2; a.argmax = amax; a.score_out = score_out; a.ld_score = ld_score;
+      a.split_work = amax ? nullptr : w.rsplit;
       pairscore(nm, a);
     };
     // score_ij = (-|s_i|^2 + 2 s_i.t_j) - |t_j|^2 (:211-216), computed and stored once with the row soft-max
@@ -730,7 +733,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 16; }
+extern "C" int vcr_abi_version(void) { return 17; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

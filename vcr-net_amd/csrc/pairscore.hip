@@ -27,8 +27,13 @@ constexpr float LOG2E = 1.4426950408889634f;
 // MAC is 1/(32 OT): with one tile the kernel is L2-bandwidth-bound (16 flop/B -> ~6 TB/s at 96 TFLOP/s measured);
 // two tiles, shared by 8 waves, halve that.  Each streamed fragment (MFMA A operand, registers) is then used
 // against both owner tiles (B operand, LDS).
+// nsplit > 1 (OP 1 without arg-max, chosen by the launcher): the streamed tiles are dealt to nsplit workgroups per owner
+// block in contiguous runs -- a grid just above a multiple of the resident workgroups (BASELINE configs[2]: 288
+// two-tile workgroups on 256 CUs = two rounds for 1.125 rounds of work) becomes nsplit times as many workgroups of
+// 1 / nsplit the length.  Each writes its (max, sum) partial to split_work[sp][row]; statmerge_kernel combines them in
+// split order.  The scores themselves (score_out) do not depend on the split.
 template <int OP, int OT>
-__global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_kernel(vcr_pairscore_args p) {
+__global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_kernel(vcr_pairscore_args p, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = 4 * OT;                             // waves per block
   constexpr int NO = 32 * OT;                            // owners per block
@@ -39,6 +44,8 @@ __global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_ker
   const int half = lane >> 5, l31 = lane & 31;
   int bx, b;
   xcd_chunk2(bx, b);                                     // the owner tiles of one cloud stream the same rows: one XCD's L2
+  const int sp = bx % nsplit;                            // (nsplit == 1: sp = 0)
+  bx /= nsplit;
   const int o0 = bx * NO;
   const int sb = (b + p.str_batch_shift) % p.nbatch;
   const int chunks = p.E / 64;
@@ -60,8 +67,10 @@ __global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_ker
   }
   __syncthreads();
 
-  const int ntiles = (p.n_str + 31) / 32;
-  const int my_tiles = (ntiles - w + NW - 1) / NW;       // tiles w, w+NW, ...
+  const int ntiles_all = (p.n_str + 31) / 32;
+  const int per_split = (ntiles_all + nsplit - 1) / nsplit, t0 = sp * per_split;
+  const int ntiles = max(0, min(ntiles_all, t0 + per_split) - t0);   // this workgroup's run of streamed tiles
+  const int my_tiles = max(0, (ntiles - w + NW - 1) / NW);           // tiles t0 + w, t0 + w + NW, ...
   const int nflat = my_tiles * chunks;
   const float* sbase = p.str + (size_t)sb * p.n_str * p.ld_str;
   const float* sside = p.str_side4 ? p.str_side4 + (size_t)sb * p.n_str * 4 : nullptr;
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_ker
 
   f32x4 bufA[8], bufB[8];
   auto load_chunk = [&](int flat, f32x4* dst) {
-    const int tile = w + NW * (flat / chunks), c = flat % chunks;
+    const int tile = t0 + w + NW * (flat / chunks), c = flat % chunks;
     const int row = min(tile * 32 + l31, p.n_str - 1);
     const float* kp = sbase + (size_t)row * p.ld_str + 64 * c + 4 * half;
 #pragma unroll
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_ker
     mass[ot] = 0.f; s[ot] = f32x16{0};
   }
   auto compute = [&](int flat, const f32x4* kf) {
-    const int tile = w + NW * (flat / chunks), c = flat % chunks;
+    const int tile = t0 + w + NW * (flat / chunks), c = flat % chunks;
     if (c == 0) {
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot) s[ot] = f32x16{0};
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_ker
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       const float* g = mg + (i * NO + t) * 5;
-      const float a = __builtin_amdgcn_exp2f((g[0] - M) * LOG2E);   // exp2(-inf) = 0 for a wave with no tiles
+      const float a = g[0] == VCR_NEG_INF ? 0.f : __builtin_amdgcn_exp2f((g[0] - M) * LOG2E);   // a wave with no tiles
       L = fmaf(g[1], a, L);
       if (OP == 0) { X = fmaf(g[2], a, X); Y = fmaf(g[3], a, Y); Z = fmaf(g[4], a, Z); }
       else {
@@ -222,10 +231,25 @@ __global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_ker
     if (OP == 0) {
       st4(p.corr4 + orow * 4, f32x4{X / L, Y / L, Z / L, 0.f});
     } else {
-      p.stat2[orow * 2] = M; p.stat2[orow * 2 + 1] = L;
+      float* st = nsplit > 1 ? p.split_work + (size_t)sp * p.nbatch * p.n_own * 2 : p.stat2;
+      st[orow * 2] = M; st[orow * 2 + 1] = L;
       if (p.argmax) p.argmax[orow] = Bi;
     }
   }
+}
+
+// stat2[row] = merge over the nsplit partial (max, sum) pairs of a row, in split order
+__global__ __launch_bounds__(256) void statmerge_kernel(const float* part, int nsplit, long rows, float* stat2) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float M = VCR_NEG_INF;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part[((size_t)s * rows + r) * 2]);
+  float L = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* g = part + ((size_t)s * rows + r) * 2;
+    L = fmaf(g[1], g[0] == VCR_NEG_INF ? 0.f : __builtin_amdgcn_exp2f((g[0] - M) * LOG2E), L);
+  }
+  stat2[r * 2] = M; stat2[r * 2 + 1] = L;
 }
 
 // ---- light passes over a stored score matrix S[b][i][j] (selectCom, vcrnet_model.py:217-248) ----
@@ -301,16 +325,36 @@ int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
   const int ot = (lds2 <= 160 * 1024 && a->E >= 256 && !(a->variant & 1)) ? 2 : 1;
   const int lds = ot == 2 ? lds2 : lds1;
   if (lds > 160 * 1024) return VCR_EUNSUPPORTED;
-  dim3 grid((a->n_own + 32 * ot - 1) / (32 * ot), a->nbatch);
+  // Split the streamed side when the grid leaves a mostly empty last round of workgroups (statistics passes without an
+  // arg-max, caller scratch given): nsplit in 1..VCR_PAIRSCORE_MAX_SPLIT minimising rounds / nsplit, every wave keeping
+  // at least one streamed tile, taken only when it saves a fifth of the rounds (each workgroup re-reads its owners).
+  const int owner_blocks = (a->n_own + 32 * ot - 1) / (32 * ot);
+  int nsplit = 1;
+  if (a->op == 1 && !a->argmax && a->split_work && !(a->variant & 4)) {
+    const long blocks = (long)owner_blocks * a->nbatch, slots = (long)vcr_cu_count() * (ot == 2 ? 1 : 2);
+    const int ntiles = (a->n_str + 31) / 32;
+    double best = (double)((blocks + slots - 1) / slots);
+    const double base = best;
+    for (int sp = 2; sp <= VCR_PAIRSCORE_MAX_SPLIT; ++sp) {
+      if (ntiles / sp < 4 * ot || (sp - 1) * ((ntiles + sp - 1) / sp) >= ntiles) break;   // a tile per wave, no empty run
+      const double c = (double)((blocks * sp + slots - 1) / slots) / sp;
+      if (c < 0.8 * base && c < best - 1e-9) { best = c; nsplit = sp; }
+    }
+  }
+  dim3 grid(owner_blocks * nsplit, a->nbatch);
   hipStream_t s = (hipStream_t)stream;
 #define VCR_PS_LAUNCH(OPV, OTV)                                                                                         \
   do {                                                                                                                   \
     VCR_DYN_LDS((pairscore_kernel<OPV, OTV>), lds);                                                                      \
-    hipLaunchKernelGGL((pairscore_kernel<OPV, OTV>), grid, dim3(256 * OTV), lds, s, *a);                                \
+    hipLaunchKernelGGL((pairscore_kernel<OPV, OTV>), grid, dim3(256 * OTV), lds, s, *a, nsplit);                        \
   } while (0)
   if (ot == 2) { if (a->op == 0) VCR_PS_LAUNCH(0, 2); else if (a->op == 1) VCR_PS_LAUNCH(1, 2); else VCR_PS_LAUNCH(2, 2); }
   else         { if (a->op == 0) VCR_PS_LAUNCH(0, 1); else if (a->op == 1) VCR_PS_LAUNCH(1, 1); else VCR_PS_LAUNCH(2, 1); }
 #undef VCR_PS_LAUNCH
+  if (nsplit > 1) {
+    const long rows = (long)a->nbatch * a->n_own;
+    hipLaunchKernelGGL(statmerge_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, a->split_work, nsplit, rows, a->stat2);
+  }
   return VCR_LAUNCH_RC();
 }
 

@@ -87,7 +87,7 @@ class PairscoreArgs(C.Structure):
                 ("score", C.c_int), ("scale", C.c_float), ("str_batch_shift", C.c_int), ("op", C.c_int),
                 ("corr4", f32p), ("stat2", f32p), ("argmax", f32p), ("str_stat2", f32p),
                 ("str_stat_batch_stride", C.c_long), ("mass", f32p), ("accumulate", C.c_int),
-                ("score_out", f32p), ("ld_score", C.c_int), ("variant", C.c_int)]
+                ("score_out", f32p), ("ld_score", C.c_int), ("variant", C.c_int), ("split_work", f32p)]
 
 
 class MakePairsArgs(C.Structure):
@@ -209,7 +209,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 16         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 17         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -571,20 +571,22 @@ def rigid_svd(src, corr, want_h=False):
 @_guarded
 def pairscore(own, strm, nbatch, n_own, n_str, op, score=0, scale=1.0, own_side4=None, str_side4=None,
               shift=0, str_stat2=None, str_stat_stride=None, mass=None, accumulate=False, want_argmax=False,
-              score_out=None, variant=0):
+              score_out=None, variant=0, split=False):
     """vcr_pairscore_f32: op 0 -> corr4; op 1 -> (stat2 [nbatch*n_own,2], argmax or None); op 2 -> mass.
-    score_out (op 1): [nbatch, n_own, ld] buffer that also receives the scores."""
+    score_out (op 1): [nbatch, n_own, ld] buffer that also receives the scores.  split: give the launch scratch to split
+    the streamed side over several workgroups when its grid calls for it (op 1 without argmax)."""
     dev = own.device
     corr4 = _f32(nbatch * n_own, 4, device=dev) if op == 0 else None
     stat2 = _f32(nbatch * n_own, 2, device=dev) if op == 1 else None
     amax = torch.empty(nbatch * n_own, dtype=torch.int32, device=dev) if (op == 1 and want_argmax) else None
     if op == 2 and mass is None:
         mass = _f32(nbatch, n_own, device=dev)
+    work = _f32(4 * nbatch * n_own * 2, device=dev) if split else None
     call("vcr_pairscore_f32", PairscoreArgs(
         ptr(own), own.stride(0), ptr(strm), strm.stride(0), ptr(own_side4), ptr(str_side4), nbatch, n_own, n_str,
         own.shape[1], score, scale, shift, op, ptr(corr4), ptr(stat2), ptr(amax), ptr(str_stat2),
         int(str_stat_stride if str_stat_stride is not None else n_str * 2), ptr(mass), int(accumulate),
-        ptr(score_out), score_out.stride(1) if score_out is not None else 0, variant))
+        ptr(score_out), score_out.stride(1) if score_out is not None else 0, variant, ptr(work)))
     if op == 0:
         return corr4
     if op == 1:
