@@ -105,6 +105,33 @@ def test_attention_key_mass(nat):
     torch.testing.assert_close(mass2, mass, atol=1e-4, rtol=1e-5)
 
 
+@pytest.mark.parametrize("nb,N,masked", [(48, 768, False), (20, 600, True), (2, 300, True)])
+def test_sdpa_statistics_pass_with_the_keys_split(nat, nb, N, masked):
+    """vcr_sdpa_args.split_work: a statistics pass whose grid ends in a mostly empty round of workgroups (48 x 4 heads x 6
+    query blocks = 1152 on 512 resident at BASELINE configs[2]) deals the key tiles to several workgroups per query block
+    and merges the partial (max, sum) pairs: same scores and row maxima bit for bit, the sums to rounding -- with a key
+    mask and a ragged key count too (second shape: 400 workgroups, less than one round, nothing to gain: launched exactly
+    as without the scratch; third shape: 24 workgroups, split to fill more of the chip)."""
+    g = torch.Generator().manual_seed(nb + N)
+    h, sc = 4, 1 / math.sqrt(128)
+    q = (torch.randn(nb * N, h * 128, generator=g) * 0.7).cuda()
+    k = (torch.randn(nb * N, h * 128, generator=g) * 0.7).cuda()
+    keep = (torch.rand(nb, N, generator=g) < 0.7).to(torch.uint8).cuda() if masked else None
+    ld = (N + 31) // 32 * 32
+    xs0, xs1 = (torch.full((nb, h, N, ld), float("nan"), device="cuda") for _ in range(2))
+    kw = dict(kv_batch_shift=nb // 2, want_rowstat=True, pv=False, key_keep=keep)
+    _, rs0 = nat.sdpa(q, k, None, nb, h, N, N, sc, score_out=xs0, **kw)
+    _, rs1 = nat.sdpa(q, k, None, nb, h, N, N, sc, score_out=xs1, split=True, **kw)
+    assert torch.equal(xs0, xs1) and torch.equal(rs0[..., 0], rs1[..., 0])
+    torch.testing.assert_close(rs1[..., 1], rs0[..., 1], rtol=2e-6, atol=0)
+    if nb == 20:
+        assert torch.equal(rs0, rs1)
+    else:
+        assert not torch.equal(rs0[..., 1], rs1[..., 1])         # (the split launch really ran: another merge order)
+    _, rs2 = nat.sdpa(q, k, None, nb, h, N, N, sc, split=True, **kw)                        # without keeping the scores
+    assert torch.equal(rs2, rs1)
+
+
 def _sym_diff(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return sum(len(set(x) ^ set(y)) for x, y in zip(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])))

@@ -22,8 +22,11 @@ struct Stage { float k[32][KP]; float v[32][KP]; };
 // sdpa: d_k = d_v = 128 per head.  Block = 4 waves = 128 queries of one (batch, head); K/V tiles of
 // 32 keys are staged global -> registers -> LDS (double buffered, loads issued before the MFMA block
 // and written after it) and shared by the 4 waves; Q (32 x 128 per wave) lives in 64 VGPRs.
+// nsplit > 1 (statistics passes only, chosen by the launcher): the key tiles are dealt to nsplit workgroups per query
+// block in contiguous runs; each writes its (max, sum) partial to split_work[sp][row], rowstat_merge_kernel combines them
+// in split order.  The stored scores do not depend on the split.
 template <bool HAS_MASK, bool DO_PV>
-__global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
+__global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Stage* st = reinterpret_cast<Stage*>(smem);
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -32,13 +35,16 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
   // (batch, head) pairs -- all query blocks of a pair then stream the same K/V through ONE L2 instead of
   // eight (measured before: 1.14 GB fetched per launch = 8 x the K/V bytes).  Speed only, never correctness.
   const int nqb = (p.nq + 127) / 128, nbh = p.nbatch * p.heads * (p.ngroups > 1 ? p.ngroups : 1);
+  const int nqs = nqb * nsplit;                          // (query block, key run) pairs per (batch, head)
   int qb, bh;
   if ((nbh & 7) == 0) {
     const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-    qb = i % nqb; bh = (i / nqb) * 8 + xcd;
+    qb = i % nqs; bh = (i / nqs) * 8 + xcd;
   } else {
-    qb = blockIdx.x % nqb; bh = blockIdx.x / nqb;
+    qb = blockIdx.x % nqs; bh = blockIdx.x / nqs;
   }
+  const int sp = qb % nsplit;
+  qb /= nsplit;
   const int head = bh % p.heads;
   const int grp = (bh / p.heads) / p.nbatch, b = (bh / p.heads) % p.nbatch;   // (grp == 0 unless p.ngroups > 1; grid covers them)
   p.q += (size_t)grp * p.q_group_stride; p.k += (size_t)grp * p.k_group_stride;
@@ -59,7 +65,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
   const float* kbase = p.k + (size_t)kvb * krows * p.ldk + head * 128;
   const float* vbase = p.v + (size_t)kvb * krows * p.ldv + head * 128;
   const int srow = t >> 5, sc4 = (t & 31) * 4;           // staging: rows srow + 8i, one 16-B chunk
-  const int ntiles = (p.nk + 31) / 32;
+  const int ntiles_all = (p.nk + 31) / 32, per_split = (ntiles_all + nsplit - 1) / nsplit;
+  const int t0 = sp * per_split, ntiles = min(ntiles_all, t0 + per_split);   // this workgroup's key tiles: t0 .. ntiles - 1
   int* kidx = reinterpret_cast<int*>(smem + 2 * sizeof(Stage));
   if (p.key_index) {
     for (int i = t; i < p.nk; i += 256) kidx[i] = p.key_index[(size_t)kvb * p.nk + i];
@@ -91,11 +98,11 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
   const bool fast = DO_PV && p.rowstat == nullptr && p.scale > 0.f;   // wave-uniform
   const float c2 = p.scale * LOG2E;
 
-  stage_load(0);
+  stage_load(t0);
   stage_write(0);
   __syncthreads();
   int cur = 0;
-  for (int tile = 0; tile < ntiles; ++tile) {
+  for (int tile = t0; tile < ntiles; ++tile) {
     if (tile + 1 < ntiles) stage_load(tile + 1);
     f32x16 s = {0};
     __builtin_amdgcn_s_setprio(2);                       // matrix phases outrank the other workgroup's soft-max VALU
@@ -189,7 +196,8 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
   }
   const float lt = l + xhalf(l);
   if (p.rowstat && half == 0 && q < p.nq) {
-    float* rs = p.rowstat + (((size_t)b * p.heads + head) * p.nq + q) * 2;
+    float* rs = (nsplit > 1 ? p.split_work + (size_t)sp * p.nbatch * p.heads * p.nq * 2 : p.rowstat) +
+                (((size_t)b * p.heads + head) * p.nq + q) * 2;
     rs[0] = m; rs[1] = lt;
   }
   if (DO_PV) {
@@ -212,6 +220,20 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p) {
       }
     }
   }
+}
+
+// rowstat[row] = merge over the nsplit partial (max, sum) pairs of a row, in split order
+__global__ __launch_bounds__(256) void rowstat_merge_kernel(const float* part, int nsplit, long rows, float* rowstat) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float M = VCR_NEG_INF;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part[((size_t)s * rows + r) * 2]);
+  float L = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* g = part + ((size_t)s * rows + r) * 2;
+    L = fmaf(g[1], g[0] == VCR_NEG_INF ? 0.f : __builtin_amdgcn_exp2f((g[0] - M) * LOG2E), L);
+  }
+  rowstat[r * 2] = M; rowstat[r * 2 + 1] = L;
 }
 
 // mass[kb][key] = sum_h sum_q exp(S[qb][h][q][key] - m) / l, qb = (kb + shift) % nbatch; 64 keys per block (lanes),
@@ -307,16 +329,41 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   const int ng = a->ngroups > 1 ? a->ngroups : 1;
   if (ng > 1 && (!pv || a->key_keep || a->rowstat || a->score_out)) return VCR_EINVAL;
   if (a->key_index && (a->nk_src < 1 || a->key_keep || a->score_out || ng > 1 || a->nk > 16384)) return VCR_EINVAL;
-  dim3 grid(((a->nq + 127) / 128) * a->heads * a->nbatch * ng);
+  // Statistics passes (no P V, caller scratch given) split the keys over nsplit workgroups per query block when that
+  // shortens the launch by a tenth in the round model of linear.hip (a partial last round of f costs 0.35 + 0.65 f):
+  // 1152 workgroups on 512 slots at BASELINE configs[2] = 2.25 rounds -> four times as many of a quarter the length.
+  const long blocks = (long)((a->nq + 127) / 128) * a->heads * a->nbatch * ng;
+  int nsplit = 1;
+  if (!pv && a->split_work) {
+    const long slots = (long)vcr_cu_count() * 2;
+    const int ntiles = (a->nk + 31) / 32;
+    auto cost = [&](int sp) {
+      const long t = blocks * sp, full = t / slots;
+      const double f = (double)(t - full * slots) / slots;
+      return ((double)full + (f > 0.0 ? 0.35 + 0.65 * f : 0.0)) / sp;
+    };
+    double best = cost(1);
+    const double base = best;
+    for (int sp = 2; sp <= VCR_SDPA_MAX_SPLIT; ++sp) {
+      if (ntiles / sp < 4 || (sp - 1) * ((ntiles + sp - 1) / sp) >= ntiles) break;   // >= 4 tiles per run, no empty run
+      const double c = cost(sp);
+      if (c < 0.9 * base && c < best - 1e-9) { best = c; nsplit = sp; }
+    }
+  }
+  dim3 grid((unsigned)(blocks * nsplit));
   const int lds = 2 * sizeof(Stage) + (a->key_index ? ((a->nk * 4 + 15) & ~15) : 0);
   hipStream_t s = (hipStream_t)stream;
 #define VCR_SDPA_LAUNCH(M, P)                                                                                         \
   do {                                                                                                                 \
     VCR_DYN_LDS((sdpa_kernel<M, P>), lds);                                                                             \
-    hipLaunchKernelGGL((sdpa_kernel<M, P>), grid, dim3(256), lds, s, *a);                                             \
+    hipLaunchKernelGGL((sdpa_kernel<M, P>), grid, dim3(256), lds, s, *a, nsplit);                                     \
   } while (0)
   if (a->key_keep) { if (pv) VCR_SDPA_LAUNCH(true, true); else VCR_SDPA_LAUNCH(true, false); }
   else             { if (pv) VCR_SDPA_LAUNCH(false, true); else VCR_SDPA_LAUNCH(false, false); }
 #undef VCR_SDPA_LAUNCH
+  if (nsplit > 1) {
+    const long rows = (long)a->nbatch * a->heads * a->nq;
+    hipLaunchKernelGGL(rowstat_merge_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, a->split_work, nsplit, rows, a->rowstat);
+  }
   return VCR_LAUNCH_RC();
 }

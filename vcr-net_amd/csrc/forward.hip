@@ -28,6 +28,7 @@ struct Ws {
   float *st_emb, *st_e1, *st_e2, *st_d1, *st_d2;       // [M, E/64, 2] LayerNorm partial sums
   // partial-overlap mode
   float *rowstat, *keymass; uint8_t* keep;             // cross-attention: [2B,H,N,2], [2B,N], [2B,N]
+  float* xsplit;                                        // vcr_sdpa_args.split_work of the cross-attention statistics pass
   float* xscore;                                       // [2B,H,N,roundup32(N)] scaled scores, NULL above 4 GB
   int32_t* xorder;                                     // [2B, nkeep] kept keys, heaviest first
   float *rstat, *cstat, *colsum, *rowsum, *score;      // selectCom: [B,N,2] x2, [B,N] x2, [B,N,roundup32(N)]
@@ -69,6 +70,7 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   if (partial) {
     const size_t K1 = (size_t)overlap_k1(N, o2), K2 = (size_t)overlap_k2(N, o2), B1 = (size_t)B;
     w.rowstat = bp.take<float>(M * heads * 2); w.keymass = bp.take<float>(M); w.keep = bp.take<uint8_t>(M);
+    w.xsplit = bp.take<float>(VCR_SDPA_MAX_SPLIT * M * heads * 2);
     const size_t xs = M * heads * ((N + 31) & ~31);       // keep the cross-attention scores if they fit 4 GB
     const size_t xlimit = xscore_limit_mb > 0 ? (size_t)xscore_limit_mb << 20 : xscore_limit_mb < 0 ? 0 : (size_t)4 << 30;
     w.xscore = xs * 4 <= xlimit ? bp.take<float>(xs) : nullptr;
@@ -158,11 +160,12 @@ struct Runner {
   bool sdpa(const char* nm, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
             int ldo, int nb, int heads, int nq, int nk, int shift, const uint8_t* keep = nullptr,
             float* rowstat = nullptr, float* score_out = nullptr, int ld_score = 0, int ngroups = 1, long in_group_stride = 0,
-            long out_group_stride = 0) {
+            long out_group_stride = 0, float* split_work = nullptr) {
     if (rc) return false;
     mark(nm);
     vcr_sdpa_args a{q, ldq, k, ldk, v, ldv, out, ldo, nb, heads, nq, nk, 1.0f / sqrtf(128.f), shift, keep, rowstat,
                     score_out, ld_score};
+    a.split_work = split_work;
     if (ngroups > 1) {
       a.ngroups = ngroups; a.q_group_stride = a.k_group_stride = a.v_group_stride = in_group_stride;
       a.out_group_stride = out_group_stride;
@@ -249,14 +252,15 @@ struct Runner {
         // statistics pass that also keeps the scaled scores; the key mass is then one HBM-bound pass over them
         const int ldS = (N + 31) & ~31;
         sdpa("sdpa:dec.cross.stats", w.qc, E, w.kvc, 2 * E, nullptr, 0, nullptr, 0, nb, H, N, N, B, nullptr, w.rowstat,
-             w.xscore, ldS);
+             w.xscore, ldS, 1, 0, 0, w.xsplit);
         if (rc == 0) {
           mark("scoremass:dec.cross.keymass");
           vcr_keymass_args a{w.xscore, ldS, nb, H, N, N, w.rowstat, B, w.keymass};
           ok(vcr_keymass_f32(&a, stream));
         }
       } else {                                           // score matrix too large to keep: recompute it per head
-        sdpa("sdpa:dec.cross.stats", w.qc, E, w.kvc, 2 * E, nullptr, 0, nullptr, 0, nb, H, N, N, B, nullptr, w.rowstat);
+        sdpa("sdpa:dec.cross.stats", w.qc, E, w.kvc, 2 * E, nullptr, 0, nullptr, 0, nb, H, N, N, B, nullptr, w.rowstat, nullptr, 0,
+             1, 0, 0, w.xsplit);
         for (int h = 0; h < H; ++h) {
           vcr_pairscore_args a{};
           a.own = w.kvc + h * dk; a.ld_own = 2 * E; a.str = w.qc + h * dk; a.ld_str = E;
@@ -733,7 +737,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 17; }
+extern "C" int vcr_abi_version(void) { return 18; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

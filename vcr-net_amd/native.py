@@ -67,7 +67,7 @@ class SdpaArgs(C.Structure):
                 ("nk", C.c_int), ("scale", C.c_float), ("kv_batch_shift", C.c_int), ("key_keep", f32p),
                 ("rowstat", f32p), ("score_out", f32p), ("ld_score", C.c_int),
                 ("ngroups", C.c_int), ("q_group_stride", C.c_long), ("k_group_stride", C.c_long), ("v_group_stride", C.c_long),
-                ("out_group_stride", C.c_long), ("key_index", f32p), ("nk_src", C.c_int)]
+                ("out_group_stride", C.c_long), ("key_index", f32p), ("nk_src", C.c_int), ("split_work", f32p)]
 
 
 class KeymassArgs(C.Structure):
@@ -209,7 +209,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 17         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 18         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -517,7 +517,7 @@ def gathermax(pq, Cc, idx, n_per_cloud):
 
 @_guarded
 def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None, want_rowstat=False, pv=True,
-         score_out=None, bf16x3=False, groups=None, key_index=None, nk_src=0):
+         score_out=None, bf16x3=False, groups=None, key_index=None, nk_src=0, split=False):
     """q [nbatch*nq, >=heads*128] (row views allowed), k/v likewise -> out [nbatch*nq, heads*128].
     score_out [nbatch, heads, nq, ld]: also keep the scaled scores (statistics pass of the partial path).
     groups = (ngroups, q_stride, k_stride, v_stride): that many problems in one launch, group g at element offset
@@ -533,6 +533,8 @@ def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None,
         a.out_group_stride = nbatch * nq * heads * 128
     if key_index is not None:       # int32 [nbatch, nk]: the keys are these rows of the nk_src rows per key batch
         a.key_index, a.nk_src = ptr(key_index), int(nk_src)
+    work = _f32(4 * nbatch * heads * nq * 2, device=q.device) if split else None   # statistics passes may split the keys
+    a.split_work = ptr(work)
     call("vcr_sdpa_bf16x3_f32" if bf16x3 else "vcr_sdpa_f32", a)
     if groups:
         out = out.view(ng, nbatch * nq, heads * 128)
