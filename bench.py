@@ -55,8 +55,8 @@ def parse(argv=None):
                     help="partial-overlap mode (BASELINE configs[2]): clouds cropped to int(points*0.7507) points, "
                          "key pruning + selectCom/getCopair heads; combine with --points 1024 --batch 24 --iters 3")
     ap.add_argument("--iters", type=int, default=1, help="vcrnetIter refinement passes per step (one C call)")
-    ap.add_argument("--emb-nn", default="lpdnet", choices=["lpdnet", "dgcnn"],
-                    help="feature extractor (--emb_nn of the reference; dgcnn uses seeded weights)")
+    ap.add_argument("--emb-nn", default="lpdnet", choices=["lpdnet", "dgcnn", "pointnet"],
+                    help="feature extractor (--emb_nn of the reference; dgcnn / pointnet use seeded weights)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=100.0,
                     help="wall-clock budget of the CPU-baseline thread sweep (each thread count: one warm-up, then up "
@@ -238,7 +238,7 @@ def workload_label(a, Nfull, N, B, kind, world=1):
             "ModelNet40-like whole-to-whole registration, "
     clouds = ("uniform random clouds" if kind == "uniform" else "synthetic object clouds") + \
         " with the reference's transform recipe"
-    emb = "LPDNet" if a.emb_nn == "lpdnet" else "DGCNN"
+    emb = {"lpdnet": "LPDNet", "dgcnn": "DGCNN", "pointnet": "PointNet"}[a.emb_nn]
     wts = "LPD-pretrained emb_nn + seeded Transformer weights" if a.emb_nn == "lpdnet" else "seeded weights"
     return base + "N=%d, batch=%d pairs per GPU, %s(k=%d)+Transformer+VcpTopK+SVD, iter=%d, fp32; %s; %s" % (
         N, B, emb, a.k, a.iters, clouds, wts)
@@ -286,7 +286,7 @@ def run_rank(a):
     from vcrnet_amd.module import VCRNet, vcrnetIter
 
     w = (weights.generate_weights(1234, lpd=weights.load_lpd_fixture()) if a.emb_nn == "lpdnet"
-         else weights.generate_weights(1234, emb_nn="dgcnn"))
+         else weights.generate_weights(1234, emb_nn=a.emb_nn))
     net = VCRNet(model_args(a.partial, a.emb_nn))
     net.load_state_dict(w)
     net.emb_nn.k = a.k

@@ -440,6 +440,13 @@ typedef struct {
   struct {
     const float *c1_wpq, *c1_bpq, *c2_w, *c2_b, *c3_w, *c3_b, *c4_w, *c4_b, *c5_w, *c5_b;
   } dgcnn;
+  /* emb_kind 2: PointNet embedding (vcrnet_model.py:65-87): five pointwise convs + eval-mode BatchNorm (folded by the host
+   * like DGCNN's) + ReLU, no graph (k is ignored).  conv1 / conv2 travel in c1_w [64,3], c1_b, c2_w [64,64], c2_b above
+   * (the LPDNet stem has the same shape); c3 [64,64], c4 [128,64], c5 [E,128] here.  These three linears stay fp32 in
+   * linear_mode 1 / 2. */
+  struct {
+    const float *c3_w, *c3_b, *c4_w, *c4_b, *c5_w, *c5_b;
+  } pointnet;
   /* head_mode 2: VcpAtt's two Linear(E,E) on the source / target embeddings (head.linears_emb.0/1, [E,E] + [E]) */
   const float *att_w0, *att_b0, *att_w1, *att_b1;
   /* args.cycle (vcrnet_model.py:511-513): (R_ba, t_ba) from a second head + solve with the clouds swapped

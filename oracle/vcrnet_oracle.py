@@ -31,7 +31,7 @@ Weights = Dict[str, Tensor]
 
 __all__ = [
     "OracleConfig", "neg_sqdist_knn", "neg_sqdist_head", "knn_indices", "graph_feature",
-    "lpdnet_embed", "dgcnn_embed", "layer_norm", "attention", "multi_head_attention",
+    "lpdnet_embed", "dgcnn_embed", "pointnet_embed", "layer_norm", "attention", "multi_head_attention",
     "feed_forward", "encoder_decoder", "transformer_pointer", "head_topk_whole",
     "head_select_overlap", "head_hard_pairs", "head_topk", "head_by_dis", "head_att",
     "rigid_svd", "vcrnet_forward", "vcrnet_iter", "dcp_forward", "transform_point_cloud",
@@ -44,7 +44,7 @@ class OracleConfig:
     """The subset of the reference's ``args`` the forward path reads
     (model/vcrnet_model.py:464-493, model/lpdnet_model.py:81-84,
     model/transformer.py:244-253)."""
-    emb_nn: str = "lpdnet"          # lpdnet | dgcnn
+    emb_nn: str = "lpdnet"          # lpdnet | dgcnn | pointnet
     pointer: str = "transformer"    # transformer | identity | none
     vcp_nn: str = "topK"            # topK | att | dist
     partial: bool = False
@@ -152,6 +152,15 @@ def dgcnn_embed(w: Weights, x: Tensor, cfg: OracleConfig, prefix: str = "emb_nn.
     cat = torch.cat(outs, dim=1)                                           # :120
     y = F.relu(_bn_eval(w, prefix + "bn5", F.conv2d(cat, w[prefix + "conv5.weight"])))
     return y.view(b, -1, n)                                                # :122
+
+
+def pointnet_embed(w: Weights, x: Tensor, cfg: OracleConfig, prefix: str = "emb_nn.") -> Tensor:
+    """model/vcrnet_model.py:81-87: five pointwise Conv1d(bias=False) + BatchNorm1d (eval mode) + ReLU, no graph."""
+    for i in (1, 2, 3, 4, 5):
+        x = F.relu(_bn_eval(w, f"{prefix}bn{i}", F.conv1d(x, w[f"{prefix}conv{i}.weight"])))
+        if i == 2:
+            cfg.rec("pn_x64", x)
+    return x
 
 
 # ----------------------------------------------------------------------------
@@ -382,6 +391,8 @@ def _embed(w: Weights, x: Tensor, cfg: OracleConfig) -> Tensor:
         return lpdnet_embed(w, x, cfg)
     if cfg.emb_nn == "dgcnn":
         return dgcnn_embed(w, x, cfg)
+    if cfg.emb_nn == "pointnet":
+        return pointnet_embed(w, x, cfg)
     raise Exception("Not implemented")                                      # vcrnet_model.py:475
 
 

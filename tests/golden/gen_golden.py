@@ -131,10 +131,10 @@ def run_vcrnet(name, B, N, first_item, cstride, emb_nn="lpdnet", vcp_nn="topK", 
             out[p + "srcK"], out[p + "corrK"] = srcK.numpy(), corrK.numpy()
             # topk log -> named index sets
             calls = list(tl.calls)
-            nk = 2 if emb_nn == "lpdnet" else 1
+            nk = {"lpdnet": 2, "dgcnn": 1, "pointnet": 0}[emb_nn]            # kNN searches per cloud
             names = []
             for cloud in ("src", "tgt"):
-                names += [f"idx_feat_{cloud}", f"idx_xyz_{cloud}"] if nk == 2 else [f"idx_xyz_{cloud}"]
+                names += [f"idx_feat_{cloud}", f"idx_xyz_{cloud}"] if nk == 2 else [f"idx_xyz_{cloud}"] if nk == 1 else []
             for nm in names:
                 v, i = calls.pop(0)
                 out[p + nm] = i[:, :, 1:].numpy().astype(np.int16)     # rank 0 dropped (util.py:159)
@@ -248,6 +248,10 @@ CASES = {
     "whole_k40_n4096_b2": lambda n: run_vcrnet(n, B=2, N=4096, first_item=140, cstride=128, k=40, kind="uniform"),
     "dgcnn_partial_n192_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=150, cstride=16, emb_nn="dgcnn",
                                                    partial=True, iters=1),
+    # round 3: the third emb_nn of VCRNet.__init__ (model/vcrnet_model.py:468-469)
+    "pointnet_n256_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=160, cstride=16, emb_nn="pointnet"),
+    "pointnet_partial_n192_b2_it2": lambda n: run_vcrnet(n, B=2, N=256, first_item=170, cstride=16, emb_nn="pointnet",
+                                                          partial=True, iters=2),
 }
 
 

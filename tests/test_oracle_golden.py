@@ -117,6 +117,26 @@ def test_dgcnn_partial():
     check_common(g, rec, out, lpd=False)
 
 
+def test_pointnet():
+    """emb_nn = pointnet (model/vcrnet_model.py:65-87, :468-469): whole mode, and the partial-overlap path with every
+    selection of both iterations equal to the reference's."""
+    g, w, cfg, rec = run_case("pointnet_n256_b2", emb_nn="pointnet")
+    out = oracle.vcrnet_forward(w, torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]), cfg)
+    check_common(g, rec, out, lpd=False)
+    g, w, cfg, rec = run_case("pointnet_partial_n192_b2_it2", emb_nn="pointnet", partial=True)
+    tgt = torch.from_numpy(g["tgt"])
+    for it in range(int(g["iters"])):
+        p = f"it{it}_"
+        rec.clear()
+        out = oracle.vcrnet_forward(w, torch.from_numpy(g[p + "in"]), tgt, cfg)
+        for nm in ("sel_tgt", "sel_src"):
+            assert set_mismatch(rec[nm].numpy(), g[p + nm]) == 0
+        assert set_mismatch(rec["key_keep_src"].numpy(), g[p + "keep_dir_src"]) == 0
+        assert set_mismatch(rec["key_keep_tgt"].numpy(), g[p + "keep_dir_tgt"]) == 0
+        assert np.array_equal(rec["pair_src"].numpy(), g[p + "pair_src"])
+        check_common(g, rec, out, p=p, lpd=False)
+
+
 def test_dcp():
     g = golden("dcp_n256_b2")
     w = cfg_weights()

@@ -76,6 +76,21 @@ def dgcnn_embed(net, x_cf: torch.Tensor, rec: Optional[dict] = None):
     return emb, xyz4.view(M, 4)
 
 
+def pointnet_embed(net, x_cf: torch.Tensor, rec: Optional[dict] = None):
+    """PointNet.forward (model/vcrnet_model.py:81-87, eval-mode BN folded): five pointwise convs + ReLU, no graph."""
+    sd = _sd(net)
+    Bc, _, N = x_cf.shape
+    M = Bc * N
+    w = [_fold_bn(sd, f"emb_nn.conv{i}", f"emb_nn.bn{i}") for i in (1, 2, 3, 4, 5)]
+    xyz4, h, _ = native.pointwise(x_cf, w[0][0], w[0][1], w[1][0], w[1][1])
+    h = h.view(M, 64)
+    for wi, bi in w[2:]:
+        h = native.linear(h, wi, bi, relu=True)
+    if rec is not None:
+        rec.update(emb0=h, xyz4=xyz4)
+    return h, xyz4.view(M, 4)
+
+
 def transformer(net, emb: torch.Tensor, B: int, N: int, rec: Optional[dict] = None,
                 key_keep_fn=None) -> torch.Tensor:
     """Both directions of model/transformer.py:264-272 on the 2B-batched rows [2B*N, E] (src then tgt).
@@ -163,7 +178,7 @@ def forward_composed(net, src: torch.Tensor, tgt: torch.Tensor, rec: Optional[di
     x = torch.cat((src, tgt), 0).contiguous().float()
     if net.cycle and (net._partial or net._vcp == "att"):
         raise native.VcrHipError("cycle=True is built for the whole-mode topK / dist heads only")
-    emb, xyz4 = (lpdnet_embed if net._emb_kind == "lpdnet" else dgcnn_embed)(net, x, rec)
+    emb, xyz4 = {"lpdnet": lpdnet_embed, "dgcnn": dgcnn_embed, "pointnet": pointnet_embed}[net._emb_kind](net, x, rec)
     M1 = B * N
     if P and "dec_norm.a" in P:
         d3 = transformer(net, emb, B, N, rec)

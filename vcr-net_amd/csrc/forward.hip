@@ -359,6 +359,10 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   const int B = io->B, N = io->N, E = W->E, F = W->F, k = W->k;
   if (B <= 0 || N <= 0 || E != 512 || W->heads * 128 != E || k <= 0 || k + 1 > N) return VCR_EINVAL;
   if (k > 40 || N > 65535) return VCR_EUNSUPPORTED;     // library limits (vcr_knn_f32)
+  if (W->emb_kind < 0 || W->emb_kind > 2) return VCR_EINVAL;
+  if (W->emb_kind == 2 && !(W->c1_w && W->c1_b && W->c2_w && W->c2_b && W->pointnet.c3_w && W->pointnet.c3_b && W->pointnet.c4_w &&
+                            W->pointnet.c4_b && W->pointnet.c5_w && W->pointnet.c5_b))
+    return VCR_EINVAL;
   if (W->has_pointer == 1 && (F % 128)) return VCR_EINVAL;
   if (W->has_pointer == 1 &&
       !(W->fold_enc_qkv.w && W->fold_enc_ffn1.w && W->fold_dec_qkv.w && W->fold_dec_cross_q.w &&
@@ -439,6 +443,18 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       conv_max("linear:dg_c4", w.eh3, 128, W->dgcnn.c4_w, W->dgcnn.c4_b, nullptr, 256, 256);
     }
     R.linear("linear:conv3", w.cat, 512, W->dgcnn.c5_w, nullptr, W->dgcnn.c5_b, w.emb, E, M2, E, 512, 1, nullptr, 0, nullptr,
+             nullptr, const_cast<float*>(stats_for_ln));
+  } else if (W->emb_kind == 2) {
+    // ---- emb_nn = PointNet on both clouds (vcrnet_model.py:81-87): five pointwise convs + BatchNorm (eval mode, folded
+    // into weight and bias by the host) + ReLU, no graph.  conv1 / conv2 have the shape of LPDNet's stem: same kernel.
+    if (R.rc == 0) {
+      R.mark("pointwise:src+tgt");
+      vcr_pointwise_args a{io->src_cf, B, N, W->c1_w, W->c1_b, W->c2_w, W->c2_b, w.xyz4, w.feat64, w.sq64, io->tgt_cf, B};
+      R.ok(vcr_pointwise_f32(&a, R.stream));
+    }
+    R.linear("linear:pn_c3", w.feat64, 64, W->pointnet.c3_w, nullptr, W->pointnet.c3_b, w.pq1, 64, M2, 64, 64, 1);
+    R.linear("linear:pn_c4", w.pq1, 64, W->pointnet.c4_w, nullptr, W->pointnet.c4_b, w.cat, 128, M2, 128, 64, 1);
+    R.linear("linear:pn_c5", w.cat, 128, W->pointnet.c5_w, nullptr, W->pointnet.c5_b, w.emb, E, M2, E, 128, 1, nullptr, 0, nullptr,
              nullptr, const_cast<float*>(stats_for_ln));
   } else {
   // ---- emb_nn = LPDNet on both clouds (lpdnet_model.py:103-137)
@@ -737,7 +753,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 18; }
+extern "C" int vcr_abi_version(void) { return 19; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

@@ -55,6 +55,19 @@ class _DGCNNParams(nn.Module):
             setattr(self, f"bn{i}", nn.BatchNorm2d(co))
 
 
+class _PointNetParams(nn.Module):
+    """Parameter tree of PointNet (model/vcrnet_model.py:65-79)."""
+
+    def __init__(self, emb_dims: int = 512):
+        super().__init__()
+        self.k = 1                                                          # (no graph: the driver ignores it)
+        chans = [(3, 64), (64, 64), (64, 64), (64, 128), (128, emb_dims)]
+        for i, (ci, co) in enumerate(chans, 1):
+            setattr(self, f"conv{i}", nn.Conv1d(ci, co, kernel_size=1, bias=False))
+        for i, (_, co) in enumerate(chans, 1):
+            setattr(self, f"bn{i}", nn.BatchNorm1d(co))
+
+
 class _Norm(nn.Module):
     def __init__(self, n):
         super().__init__()
@@ -167,12 +180,14 @@ class VCRNet(nn.Module):
         super().__init__()
         self.emb_dims = args.emb_dims
         self.cycle = args.cycle
-        if args.emb_nn == "dgcnn":
+        if args.emb_nn == "pointnet":
+            self.emb_nn = _PointNetParams(emb_dims=self.emb_dims)
+        elif args.emb_nn == "dgcnn":
             self.emb_nn = _DGCNNParams(emb_dims=self.emb_dims)
         elif args.emb_nn == "lpdnet":
             self.emb_nn = _LPDNetParams(args)
         else:
-            raise Exception("Not implemented")                             # vcrnet_model.py:475 (pointnet: out of scope)
+            raise Exception("Not implemented")                             # vcrnet_model.py:475
         if args.pointer == "identity":
             self.pointer = _Identity()
         elif args.pointer == "transformer":
@@ -265,6 +280,16 @@ class VCRNet(nn.Module):
             cw.emb_kind = 1
             for f in ("c1_wpq", "c1_bpq", "c2_w", "c2_b", "c3_w", "c3_b", "c4_w", "c4_b", "c5_w", "c5_b"):
                 setattr(cw.dgcnn, f, native.ptr(P["dg." + f]))
+        if self._emb_kind == "pointnet":
+            # eval-mode BatchNorm1d folded into the bias-free pointwise convs (vcrnet_model.py:81-87)
+            from .composed import _fold_bn
+            for i in (1, 2, 3, 4, 5):
+                P[f"pn.c{i}_w"], P[f"pn.c{i}_b"] = _fold_bn(sd, f"emb_nn.conv{i}", f"emb_nn.bn{i}")
+            cw.emb_kind = 2
+            for i in (1, 2):                                               # same shapes as LPDNet's stem
+                setattr(cw, f"c{i}_w", native.ptr(P[f"pn.c{i}_w"])); setattr(cw, f"c{i}_b", native.ptr(P[f"pn.c{i}_b"]))
+            for f in ("c3_w", "c3_b", "c4_w", "c4_b", "c5_w", "c5_b"):
+                setattr(cw.pointnet, f, native.ptr(P["pn." + f]))
         if isinstance(self.pointer, _TransformerParams):
             pre = "pointer.model."
 
@@ -327,7 +352,7 @@ class VCRNet(nn.Module):
         if self.linear_mode not in LINEAR_MODES:
             raise ValueError(f"linear_mode {self.linear_mode!r}: one of {sorted(LINEAR_MODES)}")
         cw.linear_mode = LINEAR_MODES[self.linear_mode]
-        if cw.linear_mode != 0 and self._emb_kind == "lpdnet":
+        if cw.linear_mode != 0 and self._emb_kind in ("lpdnet", "pointnet"):   # (pointnet: the Transformer's sites only)
             # weights pre-split into exact bf16 triplets for vcr_linear_bf16x3_f32 (fp32-equivalent products)
             # (the six LayerNorm consumers: the FOLDED weight is what their main loop multiplies)
             src = {"dg1_pq": "dg1_wpq", "sn1_pq": "sn1_wpq", "c3": "c3_w", "enc_qkv": "fold.enc_qkv.w",

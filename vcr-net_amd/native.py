@@ -162,6 +162,10 @@ class DgcnnW(C.Structure):
     _fields_ = [(n, f32p) for n in ("c1_wpq", "c1_bpq", "c2_w", "c2_b", "c3_w", "c3_b", "c4_w", "c4_b", "c5_w", "c5_b")]
 
 
+class PointnetW(C.Structure):
+    _fields_ = [(n, f32p) for n in ("c3_w", "c3_b", "c4_w", "c4_b", "c5_w", "c5_b")]
+
+
 class VcrnetWeights(C.Structure):
     _fields_ = [("c1_w", f32p), ("c1_b", f32p), ("c2_w", f32p), ("c2_b", f32p),
                 ("dg1_wpq", f32p), ("dg1_bpq", f32p), ("dg2_w", f32p), ("dg2_b", f32p),
@@ -175,7 +179,7 @@ class VcrnetWeights(C.Structure):
                 ("fold_enc_qkv", FoldedW), ("fold_enc_ffn1", FoldedW), ("fold_dec_qkv", FoldedW),
                 ("fold_dec_cross_q", FoldedW), ("fold_dec_cross_kv", FoldedW), ("fold_dec_ffn1", FoldedW),
                 ("fold_encdec_qkv", FoldedW),
-                ("partial", C.c_int), ("overlap2", C.c_double), ("emb_kind", C.c_int), ("dgcnn", DgcnnW),
+                ("partial", C.c_int), ("overlap2", C.c_double), ("emb_kind", C.c_int), ("dgcnn", DgcnnW), ("pointnet", PointnetW),
                 ("att_w0", f32p), ("att_b0", f32p), ("att_w1", f32p), ("att_b1", f32p), ("cycle", C.c_int),
                 ("linear_mfma", C.c_int), ("linear_bk", C.c_int), ("linear_bm", C.c_int), ("knn_waves", C.c_int),
                 ("xscore_limit_mb", C.c_int)]
@@ -209,7 +213,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 18         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 19         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):

@@ -42,6 +42,13 @@ def param_shapes(emb_nn: str = "lpdnet", pointer: str = "transformer", vcp_nn: s
         for i, (_, co) in enumerate(chans, 1):
             s[f"emb_nn.bn{i}.weight"] = (co,); s[f"emb_nn.bn{i}.bias"] = (co,)
             s[f"emb_nn.bn{i}.running_mean"] = (co,); s[f"emb_nn.bn{i}.running_var"] = (co,)
+    elif emb_nn == "pointnet":                              # model/vcrnet_model.py:65-79: five bias-free Conv1d + BatchNorm1d
+        chans = [(3, 64), (64, 64), (64, 64), (64, 128), (128, E)]
+        for i, (ci, co) in enumerate(chans, 1):
+            s[f"emb_nn.conv{i}.weight"] = (co, ci, 1)
+        for i, (_, co) in enumerate(chans, 1):
+            s[f"emb_nn.bn{i}.weight"] = (co,); s[f"emb_nn.bn{i}.bias"] = (co,)
+            s[f"emb_nn.bn{i}.running_mean"] = (co,); s[f"emb_nn.bn{i}.running_var"] = (co,)
     else:
         raise Exception("Not implemented")
     if pointer == "transformer":

@@ -23,6 +23,7 @@ FAMILY_BOUND = {"pointwise": "hbm", "knn": "mfma", "linear": "mfma", "edgeconv":
 
 _LINEAR_SHAPES = {  # site -> (N_out, K) as multiples resolved below
     "dg1_pq": (256, 64), "sn1_pq": (512, 128), "conv3": ("E", 512),
+    "pn_c3": (64, 64), "pn_c4": (128, 64), "pn_c5": ("E", 128),             # emb_nn = pointnet
     "enc.qkv": ("3E", "E"), "enc.wo": ("E", "E"), "enc.ffn1": ("F", "E"), "enc.ffn2": ("E", "F"),
     "dec.qkv": ("3E", "E"), "encdec.qkv": ("6E", "E"), "dec.self.wo": ("E", "E"), "dec.cross.q": ("E", "E"), "dec.cross.kv": ("2E", "E"),
     "dec.cross.wo": ("E", "E"), "dec.ffn1": ("F", "E"), "dec.ffn2": ("E", "F"),
