@@ -22,7 +22,9 @@ def short(name):
                 "rowside_kernel", "linear_glds16_kernel", "linear_glds_kernel", "linear_persist_kernel",
                 "edgeconv_dg_packed_kernel", "pairscore_kernel", "rankselect_kernel", "knn_tiebreak_kernel",
                 "knn_pair_kernel", "knn64c_kernel", "sdpa16_kernel", "knn_tiebreak2_kernel", "edgechain_kernel",
-                "vcr_copy_words_kernel", "zero_i32_kernel", "pose_step_kernel"):
+                "vcr_copy_words_kernel", "zero_i32_kernel", "pose_step_kernel", "edgeconv_dg_packed_bf16x3_kernel",
+                "keymass4_kernel", "keymass_kernel", "statmerge_kernel", "rowstat_merge_kernel", "score_colpass_kernel",
+                "score_rowpass_kernel", "gather_rows_kernel", "sdpa_bf16x3_kernel", "linear_bf16x3_kernel"):
         if key in name:
             return key + (name[name.index(key) + len(key):].split("(")[0] if "<" in name else "")
     return name[:48]
