@@ -241,7 +241,8 @@ def encoder_decoder(w: Weights, pre: str, src: Tensor, tgt: Tensor, cfg: OracleC
         x = x + multi_head_attention(w, lp + "self_attn.", y, y, y, h)                       # :183
         y = ln(x, lp + "sublayer.1.norm")
         x = x + multi_head_attention(w, lp + "src_attn.", y, mem, mem, h,                    # :184
-                                     is_src=cfg.partial, overlap2=float(cfg.overlap2), cfg=cfg, tag=tag)
+                                     is_src=cfg.partial, overlap2=float(cfg.overlap2), cfg=cfg,
+                                     tag=tag + (f"_l{i}" if cfg.n_blocks > 1 else ""))       # (every layer prunes its own keys)
         x = x + feed_forward(w, lp + "feed_forward.", ln(x, lp + "sublayer.2.norm"))        # :185
     return ln(x, pre + "decoder.norm")                                                        # :131
 

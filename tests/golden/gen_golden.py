@@ -95,12 +95,12 @@ def load_into(net, w):
 
 
 def run_vcrnet(name, B, N, first_item, cstride, emb_nn="lpdnet", vcp_nn="topK", partial=False,
-               cycle=False, k=None, iters=1, pointer="transformer", kind="object"):
+               cycle=False, k=None, iters=1, pointer="transformer", kind="object", n_blocks=1):
     overlap2 = synth.OVERLAP2_0575 if partial else 0.75
     args = ref_args(emb_nn=emb_nn, vcp_nn=vcp_nn, partial=partial, overlap2=overlap2, cycle=cycle,
-                    pointer=pointer)
+                    pointer=pointer, n_blocks=n_blocks)
     net = ref_vcr.VCRNet(args)
-    w = weights.generate_weights(1234, lpd=LPD, emb_nn=emb_nn, vcp_nn=vcp_nn, pointer=pointer)
+    w = weights.generate_weights(1234, lpd=LPD, emb_nn=emb_nn, vcp_nn=vcp_nn, pointer=pointer, n_blocks=n_blocks)
     load_into(net, w)
     if k is not None:
         net.emb_nn.k = k
@@ -140,8 +140,9 @@ def run_vcrnet(name, B, N, first_item, cstride, emb_nn="lpdnet", vcp_nn="topK", 
                 out[p + nm] = i[:, :, 1:].numpy().astype(np.int16)     # rank 0 dropped (util.py:159)
             if partial and pointer == "transformer":
                 for nm in ("keep_dir_src", "keep_dir_tgt"):             # model(src,tgt) then model(tgt,src)
-                    v, i = calls.pop(0)
-                    out[p + nm] = i.reshape(B, -1).numpy().astype(np.int16)
+                    for layer in range(n_blocks):                       # every decoder layer prunes its own keys
+                        v, i = calls.pop(0)
+                        out[p + nm + (f"_l{layer}" if n_blocks > 1 else "")] = i.reshape(B, -1).numpy().astype(np.int16)
             if partial and vcp_nn == "topK":
                 for nm in ("sel_tgt", "sel_src"):
                     v, i = calls.pop(0)
@@ -252,6 +253,9 @@ CASES = {
     "pointnet_n256_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=160, cstride=16, emb_nn="pointnet"),
     "pointnet_partial_n192_b2_it2": lambda n: run_vcrnet(n, B=2, N=256, first_item=170, cstride=16, emb_nn="pointnet",
                                                           partial=True, iters=2),
+    # --n_blocks 2: two encoder and two decoder layers (model/transformer.py:245,257-259)
+    "nblocks2_n256_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=180, cstride=16, n_blocks=2),
+    "nblocks2_partial_n192_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=190, cstride=16, partial=True, n_blocks=2),
 }
 
 

@@ -37,7 +37,7 @@ def build_net(**kw):
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd.module import VCRNet
     net = VCRNet(make_args(**kw))
-    wkw = {k: kw[k] for k in ("emb_nn", "vcp_nn", "pointer") if k in kw}
+    wkw = {k: kw[k] for k in ("emb_nn", "vcp_nn", "pointer", "n_blocks") if k in kw}
     w = cfg_weights(**wkw)
     missing = net.load_state_dict(w, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys

@@ -139,6 +139,51 @@ def test_pointnet_embedding_whole_and_partial():
         np.testing.assert_allclose(out[3].cpu().numpy(), g[p + "t"], atol=T_TOL)
 
 
+def test_two_transformer_blocks():
+    """args.n_blocks = 2: the layers run kernel by kernel through the C-ABI (composed.transformer_layers; the one-call
+    driver covers the reference's default of one block).  Whole mode against the reference golden at the BASELINE
+    tolerance; partial mode (every decoder layer prunes its own keys) free-running: the same kept keys per layer and the
+    same hard pairs as the reference, hence its pose."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import composed
+    g = golden("nblocks2_n256_b2")
+    net, _ = build_net(n_blocks=2)
+    assert not net.fused_supported()
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda())
+        it = vcrnetIter_(net, g)
+    check(g, out)
+    np.testing.assert_allclose(it[2].cpu().numpy(), g["it0_R"], atol=R_TOL)       # vcrnetIter takes the Python loop here
+    print("n_blocks=2 whole: max|dR|", np.abs(out[2].cpu().numpy() - g["it0_R"]).max(), "max|dt|",
+          np.abs(out[3].cpu().numpy() - g["it0_t"]).max())
+    g = golden("nblocks2_partial_n192_b2")
+    net, _ = build_net(n_blocks=2, partial=True, overlap2=float(g["overlap2"]))
+    rec = {}
+    with torch.no_grad():
+        net._pack()
+        out = composed.forward_composed(net, torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda(), rec)
+    B = g["src"].shape[0]
+    for layer in (0, 1):
+        keep = rec[f"key_keep.{layer}"].cpu().numpy().astype(bool)                # [2B, N] mask; rows: keys of src, then of tgt
+        for d, name in enumerate(("src", "tgt")):
+            want = g[f"it0_keep_dir_{name}_l{layer}"]
+            for b in range(B):
+                assert set(np.nonzero(keep[d * B + b])[0]) == set(want[b].tolist()), (layer, name, b)
+    # the head's selections are free-running here (the composition has no forcing): a near-tie may exchange a hard pair
+    pairs = lambda s_, c_: [set(map(tuple, np.round(np.concatenate((s_[b], c_[b]), 0).T, 6))) for b in range(B)]
+    flips = sum(len(x ^ y) // 2 for x, y in zip(pairs(out[0].cpu().numpy(), out[1].cpu().numpy()),
+                                                pairs(g["it0_srcK"], g["it0_corrK"])))
+    dR, dt = np.abs(out[2].cpu().numpy() - g["it0_R"]).max(), np.abs(out[3].cpu().numpy() - g["it0_t"]).max()
+    print(f"n_blocks=2 partial: kept keys of both layers equal the reference's; hard-pair flips {flips}, max|dR| {dR:.2e} max|dt| {dt:.2e}")
+    assert flips <= 2
+    assert (dR <= R_TOL and dt <= T_TOL) if flips == 0 else dR <= 2e-2
+
+
+def vcrnetIter_(net, g):
+    from vcrnet_amd.module import vcrnetIter
+    return vcrnetIter(net, torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda(), iter=1)
+
+
 def test_dcp_model():
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd.module import DCP

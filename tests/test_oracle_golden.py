@@ -14,7 +14,7 @@ torch.set_num_threads(8)
 
 def run_case(name, **cfgkw):
     g = golden(name)
-    wkw = {k: cfgkw[k] for k in ("emb_nn", "vcp_nn", "pointer") if k in cfgkw}
+    wkw = {k: cfgkw[k] for k in ("emb_nn", "vcp_nn", "pointer", "n_blocks") if k in cfgkw}
     w = cfg_weights(**wkw)
     rec = {}
     cfg = oracle.OracleConfig(k=int(g["k"]), overlap2=float(g["overlap2"]), record=rec, **cfgkw)
@@ -135,6 +135,23 @@ def test_pointnet():
         assert set_mismatch(rec["key_keep_tgt"].numpy(), g[p + "keep_dir_tgt"]) == 0
         assert np.array_equal(rec["pair_src"].numpy(), g[p + "pair_src"])
         check_common(g, rec, out, p=p, lpd=False)
+
+
+def test_two_transformer_blocks():
+    """args.n_blocks = 2 (model/transformer.py:245,257-259): two encoder and two decoder layers, whole mode and
+    partial-overlap mode with every decoder layer's kept keys equal to the reference's."""
+    g, w, cfg, rec = run_case("nblocks2_n256_b2", n_blocks=2)
+    out = oracle.vcrnet_forward(w, torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]), cfg)
+    check_common(g, rec, out)
+    g, w, cfg, rec = run_case("nblocks2_partial_n192_b2", n_blocks=2, partial=True)
+    out = oracle.vcrnet_forward(w, torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]), cfg)
+    for layer in (0, 1):
+        assert set_mismatch(rec[f"key_keep_src_l{layer}"].numpy(), g[f"it0_keep_dir_src_l{layer}"]) == 0
+        assert set_mismatch(rec[f"key_keep_tgt_l{layer}"].numpy(), g[f"it0_keep_dir_tgt_l{layer}"]) == 0
+    for nm in ("sel_tgt", "sel_src"):
+        assert set_mismatch(rec[nm].numpy(), g["it0_" + nm]) == 0
+    assert np.array_equal(rec["pair_src"].numpy(), g["it0_pair_src"])
+    check_common(g, rec, out)
 
 
 def test_dcp():

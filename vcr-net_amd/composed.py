@@ -133,6 +133,54 @@ def transformer(net, emb: torch.Tensor, B: int, N: int, rec: Optional[dict] = No
     return d3
 
 
+def transformer_layers(net, emb: torch.Tensor, B: int, N: int, rec: Optional[dict] = None) -> torch.Tensor:
+    """The same for ANY number of encoder / decoder layers (args.n_blocks, model/transformer.py:108-131,245,257-259): every
+    encoder layer feeds the next, the decoder layers all attend to the encoder's final-norm output, and -- partial mode --
+    every decoder layer prunes its own keys (clones() copies src_attn.is_src, transformer.py:9-10,252-255).  Weights are
+    read per layer from the state dict; used for n_blocks != 1, which the one-call driver does not cover."""
+    sd = _sd(net)
+    E, H = net.emb_dims, net._n_heads
+    sc = 1.0 / math.sqrt(E // H)
+    nb = 2 * B
+    pre = "pointer.model."
+    ln = lambda x, name: native.layernorm(x, sd[name + ".a_2"], sd[name + ".b_2"])
+    lin = lambda x, name, **kw: native.linear(x, sd[name + ".weight"], sd[name + ".bias"], **kw)
+
+    def ffn(x, lp, sub):
+        hid = lin(ln(x, f"{lp}sublayer.{sub}.norm"), lp + "feed_forward.w_1", relu=True)
+        return lin(hid, lp + "feed_forward.w_2", residual=x)
+
+    def self_attn(x, lp):
+        y = ln(x, lp + "sublayer.0.norm")
+        q, k, v = (lin(y, f"{lp}self_attn.linears.{i}") for i in range(3))
+        return lin(native.sdpa(q, k, v, nb, H, N, N, sc), lp + "self_attn.linears.3", residual=x)
+
+    x = emb
+    for i in range(net.pointer.N):
+        lp = f"{pre}encoder.layers.{i}."
+        x = ffn(self_attn(x, lp), lp, 1)
+    mem = ln(x, pre + "encoder.norm")
+    x = emb
+    for i in range(net.pointer.N):
+        lp = f"{pre}decoder.layers.{i}."
+        d1 = self_attn(x, lp)
+        qc = lin(ln(d1, lp + "sublayer.1.norm"), lp + "src_attn.linears.0")
+        kc, vc = lin(mem, lp + "src_attn.linears.1"), lin(mem, lp + "src_attn.linears.2")
+        keep = None
+        if net._partial:                                   # transformer.py:35-53, per layer
+            xs = torch.empty(nb, H, N, (N + 31) // 32 * 32, dtype=torch.float32, device=emb.device)
+            _, rs = native.sdpa(qc, kc, None, nb, H, N, N, sc, kv_batch_shift=B, want_rowstat=True, pv=False, score_out=xs)
+            mass = native.keymass(xs, rs, N, B)
+            _, keep = native.rankselect(mass, int(N * net._overlap2), want_order=False, want_mask=True)
+            if rec is not None:
+                rec[f"key_keep.{i}"] = keep
+        att = native.sdpa(qc, kc, vc, nb, H, N, N, sc, kv_batch_shift=B, key_keep=keep)
+        x = ffn(lin(att, lp + "src_attn.linears.3", residual=d1), lp, 2)
+    if rec is not None:
+        rec.update(mem=mem, d3=x)
+    return x
+
+
 def _partial_head(net, src, embf, side4, B: int, N: int, rec: Optional[dict]):
     """VcpTopK partial mode: selectCom (model/vcrnet_model.py:190-262) + getCopair (:264-332) + SVD.
     The score matrix is computed and written ONCE (with its row soft-max statistics); the two soft-maxes are
@@ -181,7 +229,7 @@ def forward_composed(net, src: torch.Tensor, tgt: torch.Tensor, rec: Optional[di
     emb, xyz4 = {"lpdnet": lpdnet_embed, "dgcnn": dgcnn_embed, "pointnet": pointnet_embed}[net._emb_kind](net, x, rec)
     M1 = B * N
     if P and "dec_norm.a" in P:
-        d3 = transformer(net, emb, B, N, rec)
+        d3 = (transformer if net.pointer.N == 1 else transformer_layers)(net, emb, B, N, rec)
         embf, side4 = native.layernorm(d3, P["dec_norm.a"], P["dec_norm.b"], residual=emb, xyz4=xyz4)
     else:
         from .module import _Identity

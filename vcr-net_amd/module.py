@@ -207,8 +207,6 @@ class VCRNet(nn.Module):
         self._partial = bool(getattr(args, "partial", False))
         self._overlap2 = float(getattr(args, "overlap2", 0.75))            # sympy Float in the reference
         self._n_heads, self._ff = args.n_heads, args.ff_dims
-        if getattr(args, "n_blocks", 1) != 1 and args.pointer == "transformer":
-            raise Exception("Not implemented")                             # reference default n_blocks = 1
         # "fp32": every linear on v_mfma_f32_32x32x2_f32 (default).  "bf16x3": the same products as exact 3-way bf16
         # splits on the bf16 matrix pipe (fp32-equivalent accuracy, ~1.5x faster linears); fused whole-forward only.
         # "bf16x3+sdpa": that, and the attention products (Q K^T, P V) the same way (vcr_sdpa_bf16x3_f32).
@@ -390,10 +388,12 @@ class VCRNet(nn.Module):
     def fused_supported(self) -> bool:
         """True when one vcr_vcrnet_forward_f32 / vcr_vcrnet_iter_f32 call covers this configuration: every
         embedding / pointer / head / cycle / partial combination except the corner cases below, which run kernel by
-        kernel from composed.py (DGCNN with bf16x3 linears, partial mode without the Transformer, cycle with the
-        partial topK head -- the last one is not defined by the reference either)."""
+        kernel from composed.py (DGCNN with bf16x3 linears, more than one Transformer block, partial mode without the
+        Transformer, cycle with the partial topK head -- the last one is not defined by the reference either)."""
         if self._emb_kind == "dgcnn" and self.linear_mode != "fp32":
             return False
+        if isinstance(self.pointer, _TransformerParams) and self.pointer.N != 1:
+            return False                                   # args.n_blocks > 1: the layers run kernel by kernel (composed.py)
         if self._partial:
             if not isinstance(self.pointer, _TransformerParams):
                 return False
