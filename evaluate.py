@@ -5,6 +5,8 @@ test set, then the ``==FINAL TEST==`` / ``A--------->B`` log lines.
 
     python evaluate.py --items 64 --batch 16                       # whole mode, N=1024, iter 1
     python evaluate.py --partial --iters 3 --batch 24 --items 48   # BASELINE configs[2]
+    python evaluate.py --model-path checkpoints/.../model.best.t7  # a checkpoint of the reference (main.py --model_path)
+    python evaluate.py --emb-nn dgcnn --pointer identity --vcp-nn dist --cycle   # the other constructor options
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 evaluate.py --items 1024
 
 One process per GPU; items are sharded contiguously over ranks (vcrnet_amd.shard), the per-rank metric sums are
@@ -38,6 +40,12 @@ def main(argv=None):
     ap.add_argument("--first-item", type=int, default=0)
     ap.add_argument("--loss", default="pose", help="args.loss of the reference: pose | point | anything else = pose + 0.1 point")
     ap.add_argument("--vcp-nn", default="topK", choices=("topK", "att", "dist"))
+    ap.add_argument("--emb-nn", default="lpdnet", choices=("lpdnet", "dgcnn", "pointnet"))
+    ap.add_argument("--pointer", default="transformer", choices=("transformer", "identity", "none"))
+    ap.add_argument("--n-blocks", type=int, default=1, help="Transformer blocks (args.n_blocks; > 1 runs layer by layer)")
+    ap.add_argument("--model-path", default=None,
+                    help="a checkpoint of the reference (torch.save(net.state_dict()), with or without the DataParallel "
+                         "'module.' prefix), loaded with strict=False like util/initPara.py:254; default: the seeded weights")
     ap.add_argument("--backend", default="nccl")
     a = ap.parse_args(argv)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -52,13 +60,21 @@ def main(argv=None):
     from vcrnet_amd import evalmetrics, shard, synth, weights
     from vcrnet_amd.module import VCRNet, vcrnetIcpNet, vcrnetIter
 
-    args = SimpleNamespace(emb_dims=512, cycle=a.cycle, emb_nn="lpdnet", pointer="transformer", vcp_nn=a.vcp_nn,
+    args = SimpleNamespace(emb_dims=512, cycle=a.cycle, emb_nn=a.emb_nn, pointer=a.pointer, vcp_nn=a.vcp_nn,
                            partial=a.partial, overlap2=synth.OVERLAP2_0575 if a.partial else 0.75, t3d=False, tfea=False,
-                           n_blocks=1, dropout=0.0, ff_dims=1024, n_heads=4, max_iterations=50)
-    w = weights.generate_weights(1234, lpd=weights.load_lpd_fixture(), vcp_nn=a.vcp_nn)
+                           n_blocks=a.n_blocks, dropout=0.0, ff_dims=1024, n_heads=4, max_iterations=50)
+    w = weights.generate_weights(1234, lpd=weights.load_lpd_fixture(), vcp_nn=a.vcp_nn, emb_nn=a.emb_nn, pointer=a.pointer,
+                                 n_blocks=a.n_blocks)
     net = VCRNet(args)
     net.load_state_dict(w)
-    net.emb_nn.k = a.k
+    if a.model_path:                                                            # util/initPara.py:248-254
+        if not os.path.exists(a.model_path):
+            raise FileNotFoundError(f"can't find pretrained model {a.model_path}")
+        res = net.load_state_dict(torch.load(a.model_path, map_location="cpu"), strict=False)
+        if rank == 0:
+            print(f"load pretrained model {a.model_path}: {len(res.missing_keys)} missing, {len(res.unexpected_keys)} unexpected keys")
+    if a.emb_nn != "pointnet":
+        net.emb_nn.k = a.k
     net = net.to(dev).eval()
 
     lo, hi = shard.shard_range(a.items, rank, world)

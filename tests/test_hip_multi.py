@@ -151,6 +151,42 @@ def test_evaluate_main_matches_oracle_metrics(capsys):
     assert ("rot_MSE: %f" % res["ab"]["rot_mse"]) in line
 
 
+def test_evaluate_loads_a_reference_checkpoint(tmp_path, capsys):
+    """evaluate.py --model-path: a checkpoint as the reference writes it (torch.save of a DataParallel state dict, keys
+    prefixed 'module.') is loaded with strict=False (util/initPara.py:248-254) and is what the run evaluates -- the
+    figures equal those of a module loaded with the same tensors directly; and the other constructor options of the
+    reference's command line (--emb-nn / --pointer / --n-blocks) reach the module."""
+    sys.path.insert(0, ROOT)
+    import evaluate
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import evalmetrics, synth, weights
+    from vcrnet_amd.module import vcrnetIter
+    from test_hip_forward import make_args
+    from vcrnet_amd.module import VCRNet
+    w2 = weights.generate_weights(4321, lpd=weights.load_lpd_fixture())
+    path = str(tmp_path / "model.best.t7")
+    torch.save({"module." + k: v for k, v in w2.items()}, path)
+    argv = ["--items", "8", "--batch", "8", "--points", "256", "--first-item", "7000"]
+    r0 = evaluate.main(argv)
+    r1 = evaluate.main(argv + ["--model-path", path])
+    assert "load pretrained model" in capsys.readouterr().out
+    assert r0["ab"]["rot_mse"] != r1["ab"]["rot_mse"]
+    net = VCRNet(make_args())
+    net.load_state_dict(w2)
+    net = net.cuda().eval()
+    acc = evalmetrics.EvalAccumulator()
+    src, tgt, R, t, eul = synth.make_batch_device(7000, 8, 256, device=torch.device("cuda"))
+    with torch.no_grad():
+        acc.add_batch(src, tgt, torch.from_numpy(R).cuda(), torch.from_numpy(t).cuda(), eul, vcrnetIter(net, src, tgt, iter=1))
+    assert acc.final() == r1["ab"]
+    with pytest.raises(FileNotFoundError):
+        evaluate.main(argv + ["--model-path", path + ".missing"])
+    for extra in (["--emb-nn", "pointnet"], ["--emb-nn", "dgcnn", "--pointer", "identity"], ["--n-blocks", "2"],
+                  ["--pointer", "none", "--vcp-nn", "dist"]):
+        r = evaluate.main(argv + extra)
+        assert r["pairs"] == 8 and np.isfinite(r["ab"]["rot_mse"]) and r["ab"]["rot_mse"] != r0["ab"]["rot_mse"], extra
+
+
 def test_evaluate_sharded_two_ranks_equals_one():
     """Two evaluate.py ranks (sharing the GPU, gloo) print the same FINAL line as one process: contiguous shards +
     EvalAccumulator.merge (one all-reduce, one all-gather) lose nothing."""
