@@ -330,7 +330,7 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   if (ng > 1 && (!pv || a->key_keep || a->rowstat || a->score_out)) return VCR_EINVAL;
   if (a->key_index && (a->nk_src < 1 || a->key_keep || a->score_out || ng > 1 || a->nk > 16384)) return VCR_EINVAL;
   // Statistics passes (no P V, caller scratch given) split the keys over nsplit workgroups per query block when that
-  // shortens the launch by a tenth in the round model of linear.hip (a partial last round of f costs 0.35 + 0.65 f):
+  // shortens the launch by a tenth in a simple round model (a partial last round filled to f costs 0.35 + 0.65 f of a round):
   // 1152 workgroups on 512 slots at BASELINE configs[2] = 2.25 rounds -> four times as many of a quarter the length.
   const long blocks = (long)((a->nq + 127) / 128) * a->heads * a->nbatch * ng;
   int nsplit = 1;

@@ -488,13 +488,19 @@ extern "C" int vcr_dbg_timeline(unsigned long long* host_dst, int clear) {
 namespace {
 struct LinearPlan { bool glds, bk16, ms16, bm96, bm_free, ln_in, st_out; int tiles_m, tiles_n, vec, lds; long t96, t128; };
 
-// Relative cost of a launch of `tiles` workgroups of `rows`-row tiles on `slots` resident workgroups: full rounds, plus a
-// last partial round that is cheaper than a full one (its workgroups have the CU to themselves) but far from free --
-// 0.25 of a round filled costs about half a round (BASELINE configs[2], profiles/r3g_config3_launch_table.txt).
+// Relative cost of a launch of `tiles` workgroups of `rows`-row tiles on `slots` resident workgroups (two per CU), fitted to
+// a sweep of M at both tile heights (profiles/r3z_sweep_bm.txt: 56 shapes; the choice it makes loses 0.2 % on average and
+// 5 % at worst against the better height, always-128 loses 8.9 % on average):  full rounds cost 1 each;  a LAST partial
+// round filled to f costs half a round up to f = 0.3 (its workgroups have a CU to themselves), a whole one from f = 0.7
+// (the dispatcher pairs them up on the CUs that free first), linear in between;  a launch of less than one round costs
+// 0.6 while every workgroup gets its own CU (f <= 0.5) and 1 beyond.
 double launch_cost(long tiles, int slots, int rows) {
   const long full = tiles / slots;
   const double f = (double)(tiles - full * slots) / slots;
-  return ((double)full + (f > 0.0 ? 0.35 + 0.65 * f : 0.0)) * rows;
+  double c;
+  if (full == 0) c = f <= 0.0 ? 0.0 : f <= 0.5 ? 0.6 : 1.0;
+  else c = (double)full + (f <= 0.0 ? 0.0 : f <= 0.3 ? 0.5 : f >= 0.7 ? 1.0 : 0.5 + (f - 0.3) * 1.25);
+  return c * rows;
 }
 
 // validation + kernel choice of one linear (shared by vcr_linear_f32 and vcr_linear_pair_f32)
