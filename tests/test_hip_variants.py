@@ -50,6 +50,11 @@ def test_dgcnn_embedding():
     assert net.fused_supported()                       # net(...) = ONE vcr_vcrnet_forward_f32 call with emb_kind = DGCNN
     check(g, out2)
     np.testing.assert_allclose(out2[2].cpu().numpy(), out[2].cpu().numpy(), atol=2e-5)
+    for mode in ("bf16x3", "bf16x3+sdpa"):             # the Transformer in the exact-split modes, the DGCNN chain fp32: one call
+        net.linear_mode = mode
+        assert net.fused_supported()
+        with torch.no_grad():
+            check(g, net(src, tgt))
 
 
 def test_vcp_att_head():

@@ -400,8 +400,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (W->emb_kind == 1) {
     // ---- emb_nn = DGCNN on both clouds (vcrnet_model.py:104-123): one Cartesian kNN, conv1 via the neighbour/centre
     // split (per-point P/Q + gather), conv2..conv4 as N*k-row GEMMs, max over the k edges after each, conv5 on the
-    // 512-wide concatenation.  BatchNorm (eval mode) is folded into the weights by the host.
-    if (W->linear_mode != 0) return VCR_EUNSUPPORTED;
+    // 512-wide concatenation.  BatchNorm (eval mode) is folded into the weights by the host.  (linear_mode 1 / 2: the
+    // embedding's own GEMMs stay fp32 MFMA -- the chain kernel has no split variant -- the Transformer takes the mode.)
     for (int c = 0; c < 2 && R.rc == 0; ++c) {             // rows (x, y, z, |p|^2) and conv1's per-point (P | Q), one pass
       R.mark(c ? "pointwise:tgt" : "pointwise:src");
       R.ok(vcr_rows4_pq_f32(c ? io->tgt_cf : io->src_cf, w.xyz4 + (size_t)c * M1 * 4, B, N, W->dgcnn.c1_wpq, 32,

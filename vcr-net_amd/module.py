@@ -350,7 +350,7 @@ class VCRNet(nn.Module):
         if self.linear_mode not in LINEAR_MODES:
             raise ValueError(f"linear_mode {self.linear_mode!r}: one of {sorted(LINEAR_MODES)}")
         cw.linear_mode = LINEAR_MODES[self.linear_mode]
-        if cw.linear_mode != 0 and self._emb_kind in ("lpdnet", "pointnet"):   # (pointnet: the Transformer's sites only)
+        if cw.linear_mode != 0:                                           # (dgcnn / pointnet: the Transformer's sites only)
             # weights pre-split into exact bf16 triplets for vcr_linear_bf16x3_f32 (fp32-equivalent products)
             # (the six LayerNorm consumers: the FOLDED weight is what their main loop multiplies)
             src = {"dg1_pq": "dg1_wpq", "sn1_pq": "sn1_wpq", "c3": "c3_w", "enc_qkv": "fold.enc_qkv.w",
@@ -388,10 +388,8 @@ class VCRNet(nn.Module):
     def fused_supported(self) -> bool:
         """True when one vcr_vcrnet_forward_f32 / vcr_vcrnet_iter_f32 call covers this configuration: every
         embedding / pointer / head / cycle / partial combination except the corner cases below, which run kernel by
-        kernel from composed.py (DGCNN with bf16x3 linears, more than one Transformer block, partial mode without the
-        Transformer, cycle with the partial topK head -- the last one is not defined by the reference either)."""
-        if self._emb_kind == "dgcnn" and self.linear_mode != "fp32":
-            return False
+        kernel from composed.py (more than one Transformer block, partial mode without the Transformer, cycle with the
+        partial topK head -- the last one is not defined by the reference either)."""
         if isinstance(self.pointer, _TransformerParams) and self.pointer.N != 1:
             return False                                   # args.n_blocks > 1: the layers run kernel by kernel (composed.py)
         if self._partial:
