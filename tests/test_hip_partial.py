@@ -76,10 +76,12 @@ def test_pairscore_stats_and_mass(nat, N1, N2):
     torch.testing.assert_close(rowsum.cpu(), torch.softmax(S, 1).sum(2), atol=2e-5, rtol=2e-5)
 
 
-def test_attention_key_mass(nat):
-    """transformer.py:40: probability mass per key summed over heads and queries, with the batch shift."""
+@pytest.mark.parametrize("N", [160, 301, 77])
+def test_attention_key_mass(nat, N):
+    """transformer.py:40: probability mass per key summed over heads and queries, with the batch shift; ragged key counts
+    (the 16-B-per-lane kernel's clamped tail lanes) and a row pitch that is not a multiple of 4 (the 4-B kernel)."""
     g = torch.Generator().manual_seed(4)
-    nb, h, N = 4, 4, 160
+    nb, h = 4, 4
     q, k = (torch.randn(nb, N, h * 128, generator=g) for _ in range(2))
     sc = 1 / math.sqrt(128)
     qd, kd = q.view(nb * N, -1).cuda(), k.view(nb * N, -1).cuda()
@@ -103,6 +105,9 @@ def test_attention_key_mass(nat):
     mass2 = nat.keymass(xs, rs, N, 2)
     torch.testing.assert_close(mass2.cpu(), ref, atol=2e-4, rtol=2e-5)
     torch.testing.assert_close(mass2, mass, atol=1e-4, rtol=1e-5)
+    xs_odd = torch.full((nb, h, N, xs.shape[-1] + 1), float("nan"), device="cuda")     # pitch % 4 != 0: the scalar kernel
+    xs_odd[..., :xs.shape[-1]] = xs
+    torch.testing.assert_close(nat.keymass(xs_odd, rs, N, 2), mass2, atol=1e-5, rtol=1e-5)
 
 
 @pytest.mark.parametrize("nb,N,masked", [(48, 768, False), (20, 600, True), (2, 300, True)])
