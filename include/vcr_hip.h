@@ -281,6 +281,7 @@ int vcr_keymass_f32(const vcr_keymass_args*, vcr_stream_t);
 typedef struct {
   const float* q; int ldq; const float* k; int ldk; const float* qside4; const float* kside4;
   float* corr4; int nbatch, nq, nk, E; int mode; float scale;
+  float* split_work;                  /* optional: vcr_pairscore_args.split_work of the underlying op-0 launch */
 } vcr_softcorr_args;
 int vcr_softcorr_f32(const vcr_softcorr_args*, vcr_stream_t);
 
@@ -303,10 +304,11 @@ typedef struct {
                                          ld_score % 4 == 0 and >= n_str rounded up to 32 (the pad receives -inf) */
   int variant;                        /* tuning / tests, 0 = automatic: bit0 one owner tile (32 owners) per block; bit2 (4)
                                          never split the streamed side */
-  /* op 1 without argmax, optional: VCR_PAIRSCORE_MAX_SPLIT * nbatch * n_own * 2 floats of scratch.  With it the launch may
-   * deal the streamed rows to up to that many workgroups per owner block when its grid would otherwise leave a mostly
-   * empty last round on the chip (e.g. 288 workgroups on 256 CUs); the partial (max, sum) pairs are merged in a fixed
-   * order by a second small kernel.  Scores and arg-max are unaffected; the sums merge in a different order. */
+  /* op 0, or op 1 without argmax, optional: VCR_PAIRSCORE_MAX_SPLIT * nbatch * n_own * 8 floats of scratch (op 1: * 2).
+   * With it the launch may deal the streamed rows to up to that many workgroups per owner block when its grid would
+   * otherwise leave a mostly empty last round on the chip (e.g. 288 or 320 workgroups on 256 CUs) or fill only part of it;
+   * the partial (max, sum[, weighted xyz]) records are merged in a fixed order by a second small kernel.  Scores and
+   * arg-max are unaffected; the sums merge in a different order. */
   float* split_work;
 } vcr_pairscore_args;
 #define VCR_PAIRSCORE_MAX_SPLIT 4

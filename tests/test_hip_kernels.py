@@ -491,6 +491,28 @@ def test_softcorr(nat, N, mode):
     corr4 = nat.softcorr(dev(se.transpose(1, 2).reshape(B * N, E)), dev(te.transpose(1, 2).reshape(B * N, E)),
                          side(se, src), side(te, tgt), B, N, N, mode=mode, scale=1 / math.sqrt(E))
     torch.testing.assert_close(corr4.cpu().view(B, N, 4)[..., :3], ref.transpose(1, 2), atol=3e-6, rtol=1e-5)
+    # with scratch the launch may deal the streamed rows to several workgroups per owner block (here: a grid far below
+    # one round of the chip) and merge the partial (max, sum, weighted xyz) records: the same soft correspondences
+    args = (dev(se.transpose(1, 2).reshape(B * N, E)), dev(te.transpose(1, 2).reshape(B * N, E)), side(se, src), side(te, tgt),
+            B, N, N)
+    c_split = nat.softcorr(*args, mode=mode, scale=1 / math.sqrt(E), split=True)
+    torch.testing.assert_close(c_split, corr4, atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(c_split.cpu().view(B, N, 4)[..., :3], ref.transpose(1, 2), atol=3e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,N", [(20, 1024), (3, 1500)])
+def test_softcorr_split_grids(nat, B, N):
+    """Grids that do not fill the chip evenly (20 clouds of 1024: 320 two-tile workgroups on 256 CUs; 3 of 1500: 72, ragged):
+    the split launch equals the plain one to rounding and is really taken."""
+    g = torch.Generator().manual_seed(B)
+    E = 512
+    q, k = dev(torch.randn(B * N, E, generator=g) * 0.3), dev(torch.randn(B * N, E, generator=g) * 0.3)
+    sd = lambda e: torch.cat((torch.rand(len(e), 3, device=e.device), (e.double() ** 2).sum(1, keepdim=True).float()), 1)
+    qs, ks = sd(q), sd(k)
+    c0 = nat.softcorr(q, k, qs, ks, B, N, N, mode=0)
+    c1 = nat.softcorr(q, k, qs, ks, B, N, N, mode=0, split=True)
+    torch.testing.assert_close(c1, c0, atol=2e-6, rtol=1e-5)
+    assert not torch.equal(c1, c0)
 
 
 def test_rigid_svd(nat):

@@ -24,7 +24,7 @@ struct Ws {
   float *xyz4, *feat64, *sq64, *pq1, *cat, *pq3, *emb;
   int32_t *idx1, *idx3, *ties;                         // ties: 2 x (count + one slot per row) for the kNN tie replay
   unsigned char* tie_work; size_t tie_work_each;       // 2 x vcr_knn_tie_work_bytes(N): replay scratch of long rows (else NULL)
-  float *qkv, *att, *e1, *e2, *hid, *d1, *d2, *d3, *qc, *kvc, *embf, *side4;
+  float *qkv, *att, *e1, *e2, *hid, *d1, *d2, *d3, *qc, *kvc, *embf, *side4, *csplit;
   float *st_emb, *st_e1, *st_e2, *st_d1, *st_d2;       // [M, E/64, 2] LayerNorm partial sums
   // partial-overlap mode
   float *rowstat, *keymass; uint8_t* keep;             // cross-attention: [2B,H,N,2], [2B,N], [2B,N]
@@ -64,6 +64,7 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   w.d1 = bp.take<float>(M * E);     w.d2 = bp.take<float>(M * E);      w.d3 = bp.take<float>(M * E);
   w.qc = bp.take<float>(M * E);     w.kvc = bp.take<float>(M * 2 * E);
   w.embf = bp.take<float>(M * E);   w.side4 = bp.take<float>(M * 4);
+  w.csplit = bp.take<float>(VCR_PAIRSCORE_MAX_SPLIT * (M / 2) * 8);   // vcr_softcorr_args.split_work of the soft heads
   const size_t sn = M * (E / 64) * 2;
   w.st_emb = bp.take<float>(sn); w.st_e1 = bp.take<float>(sn); w.st_e2 = bp.take<float>(sn);
   w.st_d1 = bp.take<float>(sn);  w.st_d2 = bp.take<float>(sn);
@@ -581,7 +582,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     if (R.rc) return;
     R.mark(nm);
     vcr_softcorr_args a{head_emb + q0 * E, E, head_emb + k0 * E, E, side + q0 * 4, side + k0 * 4,
-                        corr, B, N, N, E, W->head_mode == 1 ? 1 : 0, 1.0f / sqrtf((float)E)};
+                        corr, B, N, N, E, W->head_mode == 1 ? 1 : 0, 1.0f / sqrtf((float)E), w.csplit};
     R.ok(vcr_softcorr_f32(&a, R.stream));
   };
   if (hard_pairs) {
@@ -753,7 +754,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 19; }
+extern "C" int vcr_abi_version(void) { return 20; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

@@ -229,13 +229,34 @@ __global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_ker
       }
     }
     if (OP == 0) {
-      st4(p.corr4 + orow * 4, f32x4{X / L, Y / L, Z / L, 0.f});
+      if (nsplit > 1) {                                  // partial (max, sum, weighted xyz) of this run of streamed tiles
+        float* pw = p.split_work + ((size_t)sp * p.nbatch * p.n_own + orow) * 8;
+        st4(pw, f32x4{M, L, X, Y});
+        pw[4] = Z;
+      } else {
+        st4(p.corr4 + orow * 4, f32x4{X / L, Y / L, Z / L, 0.f});
+      }
     } else {
       float* st = nsplit > 1 ? p.split_work + (size_t)sp * p.nbatch * p.n_own * 2 : p.stat2;
       st[orow * 2] = M; st[orow * 2 + 1] = L;
       if (p.argmax) p.argmax[orow] = Bi;
     }
   }
+}
+
+// corr4[row] = merge over the nsplit partial (max, sum, weighted xyz) records of a row, in split order
+__global__ __launch_bounds__(256) void corrmerge_kernel(const float* part, int nsplit, long rows, float* corr4) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float M = VCR_NEG_INF;
+  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part[((size_t)s * rows + r) * 8]);
+  float L = 0.f, X = 0.f, Y = 0.f, Z = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* g = part + ((size_t)s * rows + r) * 8;
+    const float a = g[0] == VCR_NEG_INF ? 0.f : __builtin_amdgcn_exp2f((g[0] - M) * LOG2E);
+    L = fmaf(g[1], a, L); X = fmaf(g[2], a, X); Y = fmaf(g[3], a, Y); Z = fmaf(g[4], a, Z);
+  }
+  st4(corr4 + r * 4, f32x4{X / L, Y / L, Z / L, 0.f});
 }
 
 // stat2[row] = merge over the nsplit partial (max, sum) pairs of a row, in split order
@@ -330,7 +351,7 @@ int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
   // at least one streamed tile, taken only when it saves a fifth of the rounds (each workgroup re-reads its owners).
   const int owner_blocks = (a->n_own + 32 * ot - 1) / (32 * ot);
   int nsplit = 1;
-  if (a->op == 1 && !a->argmax && a->split_work && !(a->variant & 4)) {
+  if ((a->op == 0 || (a->op == 1 && !a->argmax)) && a->split_work && !(a->variant & 4)) {
     const long blocks = (long)owner_blocks * a->nbatch, slots = (long)vcr_cu_count() * (ot == 2 ? 1 : 2);
     const int ntiles = (a->n_str + 31) / 32;
     double best = (double)((blocks + slots - 1) / slots);
@@ -353,7 +374,9 @@ int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
 #undef VCR_PS_LAUNCH
   if (nsplit > 1) {
     const long rows = (long)a->nbatch * a->n_own;
-    hipLaunchKernelGGL(statmerge_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, a->split_work, nsplit, rows, a->stat2);
+    const dim3 mg((unsigned)((rows + 255) / 256));
+    if (a->op == 0) hipLaunchKernelGGL(corrmerge_kernel, mg, dim3(256), 0, s, a->split_work, nsplit, rows, a->corr4);
+    else hipLaunchKernelGGL(statmerge_kernel, mg, dim3(256), 0, s, a->split_work, nsplit, rows, a->stat2);
   }
   return VCR_LAUNCH_RC();
 }
@@ -379,5 +402,6 @@ extern "C" int vcr_softcorr_f32(const vcr_softcorr_args* a, vcr_stream_t stream)
   p.own_side4 = a->qside4; p.str_side4 = a->kside4;
   p.nbatch = a->nbatch; p.n_own = a->nq; p.n_str = a->nk; p.E = a->E;
   p.score = a->mode; p.scale = a->scale; p.str_batch_shift = 0; p.op = 0; p.corr4 = a->corr4;
+  p.split_work = a->split_work;
   return launch(&p, stream);
 }

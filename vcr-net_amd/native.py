@@ -78,7 +78,7 @@ class KeymassArgs(C.Structure):
 class SoftcorrArgs(C.Structure):
     _fields_ = [("q", f32p), ("ldq", C.c_int), ("k", f32p), ("ldk", C.c_int), ("qside4", f32p), ("kside4", f32p),
                 ("corr4", f32p), ("nbatch", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("E", C.c_int),
-                ("mode", C.c_int), ("scale", C.c_float)]
+                ("mode", C.c_int), ("scale", C.c_float), ("split_work", f32p)]
 
 
 class PairscoreArgs(C.Structure):
@@ -213,7 +213,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 19         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 20         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -555,10 +555,11 @@ def keymass(score, rowstat, nk, q_batch_shift):
 
 
 @_guarded
-def softcorr(q, k, qside4, kside4, nbatch, nq, nk, mode=0, scale=1.0):
+def softcorr(q, k, qside4, kside4, nbatch, nq, nk, mode=0, scale=1.0, split=False):
     corr4 = _f32(nbatch * nq, 4, device=q.device)
+    work = _f32(4 * nbatch * nq * 8, device=q.device) if split else None
     call("vcr_softcorr_f32", SoftcorrArgs(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(qside4), ptr(kside4),
-                                          ptr(corr4), nbatch, nq, nk, q.shape[1], mode, scale))
+                                          ptr(corr4), nbatch, nq, nk, q.shape[1], mode, scale, ptr(work)))
     return corr4
 
 
@@ -587,7 +588,7 @@ def pairscore(own, strm, nbatch, n_own, n_str, op, score=0, scale=1.0, own_side4
     amax = torch.empty(nbatch * n_own, dtype=torch.int32, device=dev) if (op == 1 and want_argmax) else None
     if op == 2 and mass is None:
         mass = _f32(nbatch, n_own, device=dev)
-    work = _f32(4 * nbatch * n_own * 2, device=dev) if split else None
+    work = _f32(4 * nbatch * n_own * (8 if op == 0 else 2), device=dev) if split else None
     call("vcr_pairscore_f32", PairscoreArgs(
         ptr(own), own.stride(0), ptr(strm), strm.stride(0), ptr(own_side4), ptr(str_side4), nbatch, n_own, n_str,
         own.shape[1], score, scale, shift, op, ptr(corr4), ptr(stat2), ptr(amax), ptr(str_stat2),
