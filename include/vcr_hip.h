@@ -250,11 +250,14 @@ typedef struct {
    * rows of k / v (duplicates allowed; vcr_sdpa_f32 only, not with key_keep / score_out / ngroups).  The same set of
    * keys as a key_keep mask, with no masked scores computed and no dense copy of the kept rows. */
   const int32_t* key_index; int nk_src;
-  /* Optional, statistics passes (out == NULL): VCR_SDPA_MAX_SPLIT * nbatch * heads * nq * 2 floats of scratch.  With it
-   * the launch may deal the key tiles to up to that many workgroups per query block when its grid would otherwise end in
-   * a mostly empty round of workgroups (1152 on 512 resident at BASELINE configs[2]); the partial (max, sum) pairs are
-   * merged in a fixed order by a second small kernel.  Scores are unaffected; the sums merge in a different order. */
-  float* split_work;
+  /* Optional scratch of split_work_floats floats.  Statistics passes (out == NULL) need VCR_SDPA_MAX_SPLIT * nbatch *
+   * heads * nq * 2: with it the launch may deal the key tiles to up to that many workgroups per query block when its grid
+   * would otherwise end in a mostly empty round of workgroups (1152 on 512 resident at BASELINE configs[2]); the partial
+   * (max, sum) pairs are merged in a fixed order by a second small kernel.  Attention-output launches of less than one
+   * round of workgroups (small batches) split the keys too when nsplit * G * (nbatch * nq * ldo + nbatch * heads * nq * 2)
+   * floats fit (G = max(ngroups, 1); no key_keep / key_index / rowstat): partial outputs merged by sdpa_merge_kernel.
+   * Scores are unaffected; sums and outputs merge in a different order.  A scratch too small for a split: no split. */
+  float* split_work; long split_work_floats;
 } vcr_sdpa_args;
 #define VCR_SDPA_MAX_SPLIT 4
 int vcr_sdpa_f32(const vcr_sdpa_args*, vcr_stream_t);

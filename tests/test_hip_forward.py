@@ -394,6 +394,30 @@ def test_merged_encoder_decoder_launches_change_nothing(partial):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("nb,N,grouped", [(2, 1024, False), (2, 1024, True), (3, 300, False), (16, 1024, False)])
+def test_sdpa_output_with_the_keys_split(nb, N, grouped):
+    """vcr_sdpa_args.split_work on attention-OUTPUT launches: grids of less than one round of workgroups (small batches;
+    the grouped encoder + decoder self-attention included, ragged key counts too) deal the keys to several workgroups per
+    query block, each writing an unnormalised partial output and its (max, sum), merged by one more kernel -- the plain
+    launch's output to rounding.  A grid of a full round or more (last shape) is launched as without the scratch."""
+    import math
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native
+    g = torch.Generator().manual_seed(nb + N)
+    h, sc = 4, 1 / math.sqrt(128)
+    if grouped:
+        qkv2 = (torch.randn(nb * N, 6 * 512, generator=g) * 0.7).cuda()
+        args = (qkv2[:, :512], qkv2[:, 512:1024], qkv2[:, 1024:1536], nb, h, N, N, sc)
+        kw = dict(kv_batch_shift=1, groups=(2, 1536, 1536, 1536))
+    else:
+        q, k, v = ((torch.randn(nb * N, 512, generator=g) * 0.7).cuda() for _ in range(3))
+        args, kw = (q, k, v, nb, h, N, N, sc), dict(kv_batch_shift=nb // 2)
+    plain = native.sdpa(*args, **kw)
+    split = native.sdpa(*args, split=True, **kw)
+    torch.testing.assert_close(split, plain, atol=3e-6, rtol=1e-5)
+    assert torch.equal(split, plain) == (nb == 16)
+
+
 def test_grouped_sdpa_equals_separate_launches():
     import math
     import vcrnet_amd  # noqa: F401

@@ -203,7 +203,18 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p, int nspli
   if (DO_PV) {
     // O^T (d rows in registers, query on the lane) -> [query][d] rows through this wave's LDS slice,
     // then 512-B contiguous row stores.  The stage buffers are free (all waves passed the last barrier).
-    const float inv = 1.f / lt;
+    // nsplit > 1 (fast path only): the UNNORMALISED partial output of this run of keys goes to plane sp of the scratch,
+    // its (running max in log2 units, sum) next to it; sdpa_merge_kernel combines the planes.
+    const float inv = nsplit > 1 ? 1.f : 1.f / lt;
+    const size_t grows = (size_t)(p.ngroups > 1 ? p.ngroups : 1) * p.nbatch * p.nq;      // rows of one plane
+    if (nsplit > 1) {
+      p.out = p.split_work + ((size_t)sp * grows + (size_t)grp * p.nbatch * p.nq) * p.ldo;   // (the group offset was added above:
+      if (half == 0 && q < p.nq) {                                                           //  undone by the caller, see launcher)
+        float* ml = p.split_work + (size_t)nsplit * grows * p.ldo +
+                    (((size_t)sp * (p.ngroups > 1 ? p.ngroups : 1) + grp) * p.nbatch * p.heads * p.nq + ((size_t)b * p.heads + head) * p.nq + q) * 2;
+        ml[0] = m; ml[1] = lt;
+      }
+    }
     float* ot = reinterpret_cast<float*>(smem) + (size_t)w * 32 * KP;
 #pragma unroll
     for (int r = 0; r < 16; ++r)   // o[dg][r] = O[query l31][d = 4*acc_row(r, half) + dg]
@@ -234,6 +245,35 @@ __global__ __launch_bounds__(256) void rowstat_merge_kernel(const float* part, i
     L = fmaf(g[1], g[0] == VCR_NEG_INF ? 0.f : __builtin_amdgcn_exp2f((g[0] - M) * LOG2E), L);
   }
   rowstat[r * 2] = M; rowstat[r * 2 + 1] = L;
+}
+
+// out[g][row][c] = sum_s O_s[g][row][c] 2^(m_s - M) / sum_s l_s 2^(m_s - M): the planes of a key-split attention-output
+// launch (running maxima in log2 units), merged in split order; one wave per row, 16 B per lane.
+__global__ __launch_bounds__(256) void sdpa_merge_kernel(const float* work, int nsplit, int ngroups, int nbatch, int heads, int nq,
+                                                         int ldo, float* out, long out_group_stride) {
+  const int lane = threadIdx.x & 63;
+  const long grows = (long)ngroups * nbatch * nq;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);            // (group, batch, query)
+  if (row >= grows) return;
+  const int g = (int)(row / ((long)nbatch * nq)), b = (int)((row / nq) % nbatch), q = (int)(row % nq);
+  const float* ml = work + (size_t)nsplit * grows * ldo;
+  for (int c = lane * 4; c < heads * 128; c += 256) {
+    const int head = c >> 7;
+    float M = VCR_NEG_INF;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ml[((((size_t)s * ngroups + g) * nbatch + b) * heads + head) * nq * 2 + (size_t)q * 2]);
+    float L = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) {
+      const float* r2 = ml + ((((size_t)s * ngroups + g) * nbatch + b) * heads + head) * nq * 2 + (size_t)q * 2;
+      const float a = r2[0] == VCR_NEG_INF ? 0.f : __builtin_amdgcn_exp2f(r2[0] - M);
+      L = fmaf(r2[1], a, L);
+      const f32x4 o = ld4(work + ((size_t)s * grows + row) * ldo + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(o[e], a, acc[e]);
+    }
+    const float inv = 1.f / L;
+    st4(out + (size_t)g * out_group_stride + ((size_t)b * nq + q) * ldo + c, f32x4{acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv});
+  }
 }
 
 // mass[kb][key] = sum_h sum_q exp(S[qb][h][q][key] - m) / l, qb = (kb + shift) % nbatch; 64 keys per block (lanes),
@@ -334,7 +374,7 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   // 1152 workgroups on 512 slots at BASELINE configs[2] = 2.25 rounds -> four times as many of a quarter the length.
   const long blocks = (long)((a->nq + 127) / 128) * a->heads * a->nbatch * ng;
   int nsplit = 1;
-  if (!pv && a->split_work) {
+  if (!pv && a->split_work && a->split_work_floats >= (long)VCR_SDPA_MAX_SPLIT * a->nbatch * a->heads * a->nq * 2) {
     const long slots = (long)vcr_cu_count() * 2;
     const int ntiles = (a->nk + 31) / 32;
     auto cost = [&](int sp) {
@@ -350,6 +390,20 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
       if (c < 0.9 * base && c < best - 1e-9) { best = c; nsplit = sp; }
     }
   }
+  // Attention-output launches of LESS than one round of workgroups (small batches: 64 .. 512 on 512 resident) split the
+  // keys too: every workgroup writes its unnormalised partial output and (max, sum) to a plane of the scratch, one more
+  // kernel merges the planes (partial outputs: nsplit x the output bytes -- only worth it while that is a few MB).
+  if (pv && a->split_work && !a->rowstat && !a->score_out && a->scale > 0.f && !a->key_keep && !a->key_index) {
+    const long slots = (long)vcr_cu_count() * 2;
+    const int ntiles = (a->nk + 31) / 32;
+    const size_t plane = (size_t)ng * a->nbatch * a->nq * a->ldo * 4;
+    for (int sp = VCR_SDPA_MAX_SPLIT; sp >= 2; sp >>= 1)
+      if (blocks * sp <= slots && ntiles / sp >= 4 && (sp - 1) * ((ntiles + sp - 1) / sp) < ntiles && plane * sp <= ((size_t)64 << 20) &&
+          (size_t)a->split_work_floats * 4 >= sp * (plane + (size_t)ng * a->nbatch * a->heads * a->nq * 8)) {
+        nsplit = sp;
+        break;
+      }
+  }
   dim3 grid((unsigned)(blocks * nsplit));
   const int lds = 2 * sizeof(Stage) + (a->key_index ? ((a->nk * 4 + 15) & ~15) : 0);
   hipStream_t s = (hipStream_t)stream;
@@ -361,7 +415,11 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   if (a->key_keep) { if (pv) VCR_SDPA_LAUNCH(true, true); else VCR_SDPA_LAUNCH(true, false); }
   else             { if (pv) VCR_SDPA_LAUNCH(false, true); else VCR_SDPA_LAUNCH(false, false); }
 #undef VCR_SDPA_LAUNCH
-  if (nsplit > 1) {
+  if (nsplit > 1 && pv) {
+    const long grows = (long)ng * a->nbatch * a->nq;
+    hipLaunchKernelGGL(sdpa_merge_kernel, dim3((unsigned)((grows + 3) / 4)), dim3(256), 0, s, a->split_work, nsplit, ng, a->nbatch, a->heads,
+                       a->nq, a->ldo, a->out, ng > 1 ? a->out_group_stride : 0L);
+  } else if (nsplit > 1) {
     const long rows = (long)a->nbatch * a->heads * a->nq;
     hipLaunchKernelGGL(rowstat_merge_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, a->split_work, nsplit, rows, a->rowstat);
   }

@@ -24,7 +24,8 @@ struct Ws {
   float *xyz4, *feat64, *sq64, *pq1, *cat, *pq3, *emb;
   int32_t *idx1, *idx3, *ties;                         // ties: 2 x (count + one slot per row) for the kNN tie replay
   unsigned char* tie_work; size_t tie_work_each;       // 2 x vcr_knn_tie_work_bytes(N): replay scratch of long rows (else NULL)
-  float *qkv, *att, *e1, *e2, *hid, *d1, *d2, *d3, *qc, *kvc, *embf, *side4, *csplit;
+  float *qkv, *att, *e1, *e2, *hid, *d1, *d2, *d3, *qc, *kvc, *embf, *side4, *csplit, *asplit;
+  long asplit_floats;
   float *st_emb, *st_e1, *st_e2, *st_d1, *st_d2;       // [M, E/64, 2] LayerNorm partial sums
   // partial-overlap mode
   float *rowstat, *keymass; uint8_t* keep;             // cross-attention: [2B,H,N,2], [2B,N], [2B,N]
@@ -65,6 +66,14 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   w.qc = bp.take<float>(M * E);     w.kvc = bp.take<float>(M * 2 * E);
   w.embf = bp.take<float>(M * E);   w.side4 = bp.take<float>(M * 4);
   w.csplit = bp.take<float>(VCR_PAIRSCORE_MAX_SPLIT * (M / 2) * 8);   // vcr_softcorr_args.split_work of the soft heads
+  {
+    // planes of a key-split attention-output launch (vcr_sdpa_args.split_work; the grouped self-attention has 2 M rows):
+    // the library only splits while the planes stay below 64 MB, i.e. at small batches -- no more than that is set aside
+    const size_t rows = 2 * M, ml = (size_t)VCR_SDPA_MAX_SPLIT * rows * heads * 2;
+    const size_t want = (size_t)VCR_SDPA_MAX_SPLIT * rows * E, cap = ((size_t)64 << 20) / 4;
+    w.asplit_floats = (long)((want < cap ? want : cap) + ml);
+    w.asplit = bp.take<float>((size_t)w.asplit_floats);
+  }
   const size_t sn = M * (E / 64) * 2;
   w.st_emb = bp.take<float>(sn); w.st_e1 = bp.take<float>(sn); w.st_e2 = bp.take<float>(sn);
   w.st_d1 = bp.take<float>(sn);  w.st_d2 = bp.take<float>(sn);
@@ -161,12 +170,15 @@ struct Runner {
   bool sdpa(const char* nm, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out,
             int ldo, int nb, int heads, int nq, int nk, int shift, const uint8_t* keep = nullptr,
             float* rowstat = nullptr, float* score_out = nullptr, int ld_score = 0, int ngroups = 1, long in_group_stride = 0,
-            long out_group_stride = 0, float* split_work = nullptr) {
+            long out_group_stride = 0, float* split_work = nullptr, long split_floats = 0) {
     if (rc) return false;
     mark(nm);
     vcr_sdpa_args a{q, ldq, k, ldk, v, ldv, out, ldo, nb, heads, nq, nk, 1.0f / sqrtf(128.f), shift, keep, rowstat,
                     score_out, ld_score};
-    a.split_work = split_work;
+    // key split: statistics passes bring their own scratch; attention-output launches share the driver's planes (only
+    // taken by vcr_sdpa_f32 for grids of less than one round, i.e. small batches)
+    a.split_work = split_work ? split_work : out ? pv_split : nullptr;
+    a.split_work_floats = split_work ? split_floats : out ? pv_split_floats : 0;
     if (ngroups > 1) {
       a.ngroups = ngroups; a.q_group_stride = a.k_group_stride = a.v_group_stride = in_group_stride;
       a.out_group_stride = out_group_stride;
@@ -202,6 +214,7 @@ struct Runner {
   // tied rows itself (long rows) is listed in `deferred` and replayed by knn_ties() before the first consumer of the indices
   const vcr_vcrnet_io* io_ = nullptr;
   bool sdpa_split = false;                               // linear_mode 2
+  float* pv_split = nullptr; long pv_split_floats = 0;   // vcr_sdpa_args.split_work of the attention-output launches
   int linear_variant = 0;                                // MFMA shape / k-slab forced by vcr_vcrnet_weights.linear_mfma / linear_bk
   vcr_knn_args deferred[2];                              // kNN launches whose tie replay is still owed (knn_ties)
   int n_deferred = 0;
@@ -253,7 +266,7 @@ struct Runner {
         // statistics pass that also keeps the scaled scores; the key mass is then one HBM-bound pass over them
         const int ldS = (N + 31) & ~31;
         sdpa("sdpa:dec.cross.stats", w.qc, E, w.kvc, 2 * E, nullptr, 0, nullptr, 0, nb, H, N, N, B, nullptr, w.rowstat,
-             w.xscore, ldS, 1, 0, 0, w.xsplit);
+             w.xscore, ldS, 1, 0, 0, w.xsplit, (long)VCR_SDPA_MAX_SPLIT * nb * H * N * 2);
         if (rc == 0) {
           mark("scoremass:dec.cross.keymass");
           vcr_keymass_args a{w.xscore, ldS, nb, H, N, N, w.rowstat, B, w.keymass};
@@ -261,7 +274,7 @@ struct Runner {
         }
       } else {                                           // score matrix too large to keep: recompute it per head
         sdpa("sdpa:dec.cross.stats", w.qc, E, w.kvc, 2 * E, nullptr, 0, nullptr, 0, nb, H, N, N, B, nullptr, w.rowstat, nullptr, 0,
-             1, 0, 0, w.xsplit);
+             1, 0, 0, w.xsplit, (long)VCR_SDPA_MAX_SPLIT * nb * H * N * 2);
         for (int h = 0; h < H; ++h) {
           vcr_pairscore_args a{};
           a.own = w.kvc + h * dk; a.ld_own = 2 * E; a.str = w.qc + h * dk; a.ld_str = E;
@@ -394,6 +407,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   R.ok(VCR_LAUNCH_RC());
 #define SP(site) (W->linear_mode != 0 ? W->split.site : nullptr)
   R.sdpa_split = W->linear_mode == 2;
+  R.pv_split = w.asplit; R.pv_split_floats = w.asplit_floats;
   R.linear_variant = (W->linear_mfma == 16 ? 16 : W->linear_mfma == 32 ? 1024 : 0) | (W->linear_bk == 16 ? 64 : W->linear_bk == 32 ? 8 : 0) |
                      (W->linear_bm == 96 ? 2048 : W->linear_bm == 128 ? 4096 : 0);
 
@@ -754,7 +768,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 20; }
+extern "C" int vcr_abi_version(void) { return 21; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

@@ -67,7 +67,8 @@ class SdpaArgs(C.Structure):
                 ("nk", C.c_int), ("scale", C.c_float), ("kv_batch_shift", C.c_int), ("key_keep", f32p),
                 ("rowstat", f32p), ("score_out", f32p), ("ld_score", C.c_int),
                 ("ngroups", C.c_int), ("q_group_stride", C.c_long), ("k_group_stride", C.c_long), ("v_group_stride", C.c_long),
-                ("out_group_stride", C.c_long), ("key_index", f32p), ("nk_src", C.c_int), ("split_work", f32p)]
+                ("out_group_stride", C.c_long), ("key_index", f32p), ("nk_src", C.c_int), ("split_work", f32p),
+                ("split_work_floats", C.c_long)]
 
 
 class KeymassArgs(C.Structure):
@@ -213,7 +214,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 20         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 21         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -537,8 +538,9 @@ def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None,
         a.out_group_stride = nbatch * nq * heads * 128
     if key_index is not None:       # int32 [nbatch, nk]: the keys are these rows of the nk_src rows per key batch
         a.key_index, a.nk_src = ptr(key_index), int(nk_src)
-    work = _f32(4 * nbatch * heads * nq * 2, device=q.device) if split else None   # statistics passes may split the keys
-    a.split_work = ptr(work)
+    # scratch for a key split: statistics passes (small), attention-output launches of less than one round (planes)
+    work = _f32(4 * ng * (nbatch * nq * heads * 128 * (1 if pv else 0) + nbatch * heads * nq * 2), device=q.device) if split else None
+    a.split_work, a.split_work_floats = ptr(work), (work.numel() if split else 0)
     call("vcr_sdpa_bf16x3_f32" if bf16x3 else "vcr_sdpa_f32", a)
     if groups:
         out = out.view(ng, nbatch * nq, heads * 128)
