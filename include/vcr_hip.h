@@ -134,7 +134,9 @@ typedef struct {
                                          M = 36 864 at BASELINE configs[2]).
                                          bit11 (2048) force 96-row tiles (16x16x4 MFMAs; not with bit10 / bit2:
                                          VCR_EINVAL), bit12 (4096) force 128-row tiles: the tile height does not change
-                                         a shape's results;
+                                         a shape's results; bit13 (8192) / bit14 (16384) force 64- / 32-row tiles (BK 32,
+                                         16x16x4 MFMAs; taken automatically, with variant == 0, by launches of far less
+                                         than one round of workgroups -- one or two pairs per call);
                                          bit3 (8) force BK 32, bit6 (64) force BK 16; bit4 (16) force the 16x16x4 MFMA
                                          shape, bit10 (1024) force 32x32x2; bit2 (4) the register-staged kernel without
                                          alignment requirements on y / bias / residual (taken automatically when they

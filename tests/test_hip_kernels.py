@@ -194,13 +194,16 @@ def test_linear_mfma_shapes_and_staging_variants(nat, M, N, K, relu, res, ln):
     assert torch.equal(unpack(run(8 | 16)), y16) and torch.equal(unpack(run(64 | 16)), y16)
     # 96-row tiles (bit 11; 3 x 4 tiles of 16x16 per wave): every element is the same k-ordered chain as in the
     # 128-row 16x16x4 kernel, so outputs AND statistics are bit-identical, at both k-slabs; bit 12 pins 128 rows
-    for v in (2048, 2048 | 8, 2048 | 64, 4096 | 16):
+    for v in (2048, 2048 | 8, 2048 | 64, 4096 | 16, 8192, 16384, 8192 | 8):      # (bits 13 / 14: 64- / 32-row tiles)
         o = run(v)
         assert torch.equal(unpack(o), y16), v
         if stats_ok:
             assert torch.equal(o[1], s16), v
     with pytest.raises(nat.VcrHipError):                   # 96-row tiles do not exist for the 32x32x2 shape
         run(2048 | 1024)
+    for bad in (8192 | 16384, 8192 | 64, 16384 | 1024):   # nor the lower ones, which are BK 32 kernels
+        with pytest.raises(nat.VcrHipError):
+            run(bad)
     if not ln and not stats_ok:
         assert torch.equal(nat.linear(x, w, b, relu=relu, residual=r, variant=4), y32)      # register-staged fallback
     for bad in (1, 32, 128, 512):                          # retired selectors are refused
@@ -253,13 +256,13 @@ def test_linear_with_fused_edge_max(nat, M, k, K, N, store):
     assert torch.isnan(cat[:, :192]).all() and torch.isnan(cat[:, 192 + N:]).all()
     if store:
         assert torch.equal(y, y_ref)
-    for v in (16, 2048):                                   # the fused max on both tile heights of the 16x16x4 kernels
+    for v in (16, 2048, 8192, 16384):                      # the fused max on every tile height of the 16x16x4 kernels
         out.zero_()
         nat.linear(x, w, b, relu=True, segmax=(out, k), store=False, variant=v)
         torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
         if v == 16:
             out16 = out.clone()
-    assert torch.equal(out, out16)
+        assert torch.equal(out, out16), v
 
 
 def test_edgerows_with_max_and_zero_base(nat):
@@ -762,7 +765,7 @@ def test_linear_pair_equals_two_launches(nat):
         # 16x16x4 kernels give the same bits at either height
         ya16, sa16 = nat.linear(xa, wa, ba, residual=ra, want_stats=True, variant=16)
         yb16, sb16 = nat.linear(xb, wb, bb, residual=rb, want_stats=True, variant=16)
-        for v in (2048, 4096 | 16):
+        for v in (2048, 4096 | 16, 8192, 16384):
             A.variant = Bq.variant = v
             for t_ in (ya2, yb2, sa2, sb2):
                 t_.fill_(float("nan"))

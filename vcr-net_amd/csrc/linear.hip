@@ -197,7 +197,10 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 // BMV   : rows per block tile.  128 (wave tile 64 x 64), or 96 with MS = 16 (wave tile 48 x 64 = 3 x 4 tiles of 16 x 16): the
 //         launcher picks 96 when 128-row tiles would leave a mostly empty last round of workgroups (M = 36 864 at BASELINE
 //         configs[2]: 1152 tiles on 512 or 1024 slots = 2.25 / 1.125 rounds; 1536 tiles of 96 rows = 3.0 / 1.5).  Every
-//         output element is the same k-ordered chain as in the 128-row MS = 16 kernel: bit-identical results.
+//         output element is the same k-ordered chain as in the 128-row MS = 16 kernel: bit-identical results.  64 and 32 rows
+//         (wave tiles 32 x 64 / 16 x 64, BK 32 only) serve launches of far less than one round of workgroups -- one or two
+//         pairs per call -- where a launch takes as long as ONE workgroup: four times as many workgroups of a quarter the
+//         length.
 // MS    : MFMA shape.  32 = v_mfma_f32_32x32x2_f32 (wave tile = 2x2 tiles, k = 8g + 4*half + s); 16 =
 //         v_mfma_f32_16x16x4_f32 (wave tile = 4x4 tiles of 16x16, a lane's quarter q = lane >> 4 owns chunk q of a 16-wide
 //         k group: k = 16g + 4q + s).  Same flops per cycle; the chip sustains a higher clock on the 16x16 shape under
@@ -205,7 +208,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 //         shapes sum k in different orders: results agree to fp32 rounding, not bitwise.
 template <int BK, bool LN_IN, bool STATS_OUT, int MS, int BMV = BM>
 __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int tiles_m, int tiles_n, int blk) {
-  static_assert(BMV == 128 || (BMV == 96 && MS == 16), "96-row tiles are built from 16 x 16 MFMA tiles");
+  static_assert(BMV == 128 || ((BMV == 96 || BMV == 64 || BMV == 32) && MS == 16), "the lower tiles are built from 16 x 16 MFMA tiles");
   using Tile = TileGT<BK, BMV>;
   constexpr int WR = BMV / 2;                            // rows per wave tile
   constexpr int EPR = BMV == 128 ? 32 : 16;              // rows per epilogue pass
@@ -486,7 +489,23 @@ extern "C" int vcr_dbg_timeline(unsigned long long* host_dst, int clear) {
 #endif
 
 namespace {
-struct LinearPlan { bool glds, bk16, ms16, bm96, bm_free, ln_in, st_out; int tiles_m, tiles_n, vec, lds; long t96, t128; };
+struct LinearPlan { bool glds, bk16, ms16, bm_free, small_free, ln_in, st_out; int bm, tiles_m, tiles_n, vec, lds; long t96, t128; };
+
+// Launches of less than one round (t128 < 2 x CUs): tile height in {128, 96, 64, 32} minimising g(ceil(tiles / CUs)) x
+// (rows + 24) -- workgroups spread one per CU first; a workgroup costs its rows plus a fixed prologue / epilogue /
+// pipeline-fill share (~24 rows' worth); two co-resident ones take 1.75 x one (profiles/r3z_sweep_bm.txt), a third
+// waits for a slot.  tiles_by_h: the launch's (or the pair's) tile counts at the four heights.
+int small_grid_rows(const long* tiles_by_h) {
+  static const int hs[4] = {128, 96, 64, 32};
+  int best = 128;
+  double bc = 1e30;
+  for (int i = 0; i < 4; ++i) {
+    const long per_cu = (tiles_by_h[i] + 255) / 256;
+    const double c = ((double)(per_cu / 2) * 1.75 + (double)(per_cu & 1)) * (hs[i] + 24);
+    if (c < bc - 1e-9) { bc = c; best = hs[i]; }
+  }
+  return best;
+}
 
 // Relative cost of a launch of `tiles` workgroups of `rows`-row tiles on `slots` resident workgroups (two per CU), fitted to
 // a sweep of M at both tile heights (profiles/r3z_sweep_bm.txt: 56 shapes; the choice it makes loses 0.2 % on average and
@@ -504,7 +523,8 @@ double launch_cost(long tiles, int slots, int rows) {
 }
 
 // validation + kernel choice of one linear (shared by vcr_linear_f32 and vcr_linear_pair_f32)
-// (bm_override: 0 = decide here, 96 / 128 = the tile rows a paired launch decided for both of its halves)
+// (bm_override: 0 = decide here, else the tile rows a paired launch decided for both of its halves; 64 / 32 also mean the
+//  small-grid configuration BK 32 + 16x16x4)
 int linear_plan(const vcr_linear_args* a, LinearPlan* pl, int bm_override = 0) {
   if (!a || !a->x || !a->w || (!a->y && !a->segmax_out)) return VCR_EINVAL;
   if (a->segmax_out && (a->seg_k <= 0 || !a->relu || a->residual || a->ln_stats_in || a->stats_out || (a->ld_segmax & 3) ||
@@ -512,8 +532,10 @@ int linear_plan(const vcr_linear_args* a, LinearPlan* pl, int bm_override = 0) {
     return VCR_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % 32) != 0) return VCR_EINVAL;
   const int variant = a->variant;                    // tuning / test selector carried by the call (see vcr_hip.h)
-  if (variant & ~(4 | 8 | 16 | 64 | 1024 | 2048 | 4096)) return VCR_EINVAL;   // retired selectors (1, 32, 128, 256, 512) are refused, not ignored
+  if (variant & ~(4 | 8 | 16 | 64 | 1024 | 2048 | 4096 | 8192 | 16384)) return VCR_EINVAL;   // retired selectors (1, 32, 128, 256, 512) are refused, not ignored
   if ((variant & 2048) && (variant & (4096 | 1024 | 4))) return VCR_EINVAL;    // 96-row tiles exist on the LDS-DMA 16x16x4 kernels only
+  if ((variant & (8192 | 16384)) && ((variant & (4096 | 2048 | 1024 | 64 | 4)) || (variant & (8192 | 16384)) == (8192 | 16384)))
+    return VCR_EINVAL;                                   // 64- / 32-row tiles: LDS-DMA, BK 32, 16x16x4 only
   if ((a->ldx & 3) || a->ldx < a->K || (a->y && a->ldy < a->N) || (a->residual && a->ldr < a->N)) return VCR_EINVAL;
   if (((uintptr_t)a->x | (uintptr_t)a->w) & 15) return VCR_EINVAL;
   pl->tiles_n = (a->N + BN - 1) / BN;
@@ -543,13 +565,30 @@ int linear_plan(const vcr_linear_args* a, LinearPlan* pl, int bm_override = 0) {
   const int slots = 256 * (pl->bk16 ? 4 : 2);            // MI355X: 256 CUs x resident workgroups per CU
   const long t128 = (long)((a->M + 127) / 128) * pl->tiles_n, t96 = (long)((a->M + 95) / 96) * pl->tiles_n;
   pl->t96 = t96; pl->t128 = t128;
-  pl->bm_free = pl->glds && !(variant & (4096 | 2048 | 1024));       // nothing forces the tile rows or the 32x32x2 shape
-  pl->bm96 = pl->glds && !(variant & (4096 | 1024)) &&
-             ((variant & 2048) || (!pl->bk16 && 1.02 * launch_cost(t96, slots, 96) < launch_cost(t128, slots, 128)));
-  if (bm_override && pl->bm_free) pl->bm96 = bm_override == 96;
-  if ((variant & 2048) && !pl->bm96) return VCR_EUNSUPPORTED;
-  if (pl->bm96) pl->ms16 = true;
-  const int bm = pl->bm96 ? 96 : BM;
+  pl->bm_free = pl->glds && !(variant & (4096 | 2048 | 1024 | 8192 | 16384));   // nothing forces the tile rows or the 32x32x2 shape
+  // Small problems (M < 16 384 rows: up to 7 pairs of 1024 points per call), nothing forced (tests and benchmarks that
+  // pin BK / the MFMA shape keep what they ask for): ALWAYS the 16x16x4 shape, so that the results of a launch do not
+  // depend on which tile height its grid makes it take (all heights are bit-identical on that shape) -- the merged and
+  // the separate projections of one forward, for example, give the same bits at any size.
+  pl->small_free = pl->glds && variant == 0 && a->M < 16384;
+  if (pl->small_free) pl->ms16 = true;
+  bool bm96 = pl->glds && !(variant & (4096 | 1024 | 8192 | 16384)) &&
+              ((variant & 2048) || (!pl->bk16 && 1.02 * launch_cost(t96, slots, 96) < launch_cost(t128, slots, 128)));
+  if ((variant & 2048) && !bm96) return VCR_EUNSUPPORTED;
+  int bm = bm96 ? 96 : BM;
+  if (variant & (8192 | 16384)) {
+    if (!pl->glds) return VCR_EUNSUPPORTED;
+    bm = (variant & 8192) ? 64 : 32;
+  } else if (bm_override && pl->bm_free && (bm_override >= 96 || pl->small_free)) {
+    bm = bm_override;
+  } else if (!bm_override && pl->small_free && t128 < 512) {
+    const long th[4] = {t128, t96, (long)((a->M + 63) / 64) * pl->tiles_n, (long)((a->M + 31) / 32) * pl->tiles_n};
+    bm = small_grid_rows(th);
+    if (bm >= 96) bm = bm96 ? 96 : 128;                  // (>= 96 rows: the regular choice above, with its k-slab and shape)
+  }
+  if (bm < 96) pl->bk16 = false;                         // 64 / 32 rows: the small-grid configuration
+  if (bm < 128) pl->ms16 = true;
+  pl->bm = bm;
   pl->tiles_m = (a->M + bm - 1) / bm;
   static_assert(2 * sizeof(TileGT<16>) == 2 * (BM + BN) * 16 * 4 && 2 * sizeof(TileGT<32, 96>) == 2 * (96 + BN) * 32 * 4, "stage size below");
   const int bkv = pl->bk16 ? 16 : 32;
@@ -571,7 +610,10 @@ void linear_dispatch(const LinearPlan& pl, F&& f) {
   using I32 = std::integral_constant<int, 32>;
   using I96 = std::integral_constant<int, 96>;
   using I128 = std::integral_constant<int, 128>;
-  if (pl.bm96) { if (pl.bk16) d3(I16{}, I16{}, I96{}); else d3(I32{}, I16{}, I96{}); }
+  using I64 = std::integral_constant<int, 64>;
+  if (pl.bm == 64) d3(I32{}, I16{}, I64{});
+  else if (pl.bm == 32) d3(I32{}, I16{}, I32{});
+  else if (pl.bm == 96) { if (pl.bk16) d3(I16{}, I16{}, I96{}); else d3(I32{}, I16{}, I96{}); }
   else if (pl.bk16) { if (pl.ms16) d3(I16{}, I16{}, I128{}); else d3(I16{}, I32{}, I128{}); }
   else { if (pl.ms16) d3(I32{}, I16{}, I128{}); else d3(I32{}, I32{}, I128{}); }
 }
@@ -606,13 +648,26 @@ extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_ar
   int rc = linear_plan(a, &pa);
   if (rc == VCR_OK) rc = linear_plan(b, &pb);
   if (rc != VCR_OK) return rc;
-  if (pa.bm_free && pb.bm_free && pa.bk16 == pb.bk16) {  // tile rows from the COMBINED grid (the two halves share the rounds)
-    const int slots = 256 * (pa.bk16 ? 4 : 2);
-    const int bm = !pa.bk16 && 1.02 * launch_cost(pa.t96 + pb.t96, slots, 96) < launch_cost(pa.t128 + pb.t128, slots, 128) ? 96 : 128;
-    linear_plan(a, &pa, bm);
-    linear_plan(b, &pb, bm);
+  int joint = 0;                                         // tile rows from the COMBINED grid (the two halves share the rounds)
+  if (pa.small_free && pb.small_free && pa.t128 + pb.t128 < 512) {     // a small grid even together
+    const long th[4] = {pa.t128 + pb.t128, pa.t96 + pb.t96,
+                        (long)((a->M + 63) / 64) * pa.tiles_n + (long)((b->M + 63) / 64) * pb.tiles_n,
+                        (long)((a->M + 31) / 32) * pa.tiles_n + (long)((b->M + 31) / 32) * pb.tiles_n};
+    joint = small_grid_rows(th);
   }
-  const bool same = pa.glds && pb.glds && pa.bk16 == pb.bk16 && pa.ms16 == pb.ms16 && pa.bm96 == pb.bm96 && pa.ln_in == pb.ln_in &&
+  if (joint >= 96 || (joint == 0 && pa.bm_free && pb.bm_free)) {
+    const bool r = a->residual != nullptr, rb = b->residual != nullptr;     // (the regular k-slab: BK 32 iff a residual)
+    joint = 0;
+    if (r == rb) {
+      const int slots = 256 * (r ? 2 : 4);
+      joint = r && 1.02 * launch_cost(pa.t96 + pb.t96, slots, 96) < launch_cost(pa.t128 + pb.t128, slots, 128) ? 96 : 128;
+    }
+  }
+  if (joint) {
+    linear_plan(a, &pa, joint);
+    linear_plan(b, &pb, joint);
+  }
+  const bool same = pa.glds && pb.glds && pa.bk16 == pb.bk16 && pa.ms16 == pb.ms16 && pa.bm == pb.bm && pa.ln_in == pb.ln_in &&
                     pa.st_out == pb.st_out &&
                     !a->segmax_out && !b->segmax_out;
   if (!same) {
