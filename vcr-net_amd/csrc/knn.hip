@@ -793,6 +793,21 @@ __global__ __launch_bounds__(256, (COL16 ? 4 : 2)) void knn_pair_kernel(vcr_knn_
   }
 }
 
+// The same for SMALL grids (a few pairs per call), where both searches run their candidate-split kernels (S64 / S3 waves
+// share a group of queries): launched one after the other each is a latency-bound handful of workgroups (63 + 44 us at one
+// pair); together they take as long as the longer one.
+template <int KS, int S64, int S3>
+__global__ __launch_bounds__(256, 2) void knn_pair_small_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
+  const int bid = (int)blockIdx.x;
+  if (bid < n64) {
+    const int lin = xcd_chunk(bid, n64);
+    knn64_body<KS, S64, 4>(a64, lin % gx64, lin / gx64);
+  } else {
+    const int lin = xcd_chunk(bid - n64, (int)gridDim.x - n64);
+    knn3_body<KS, S3>(a3, lin % gx3, lin / gx3);
+  }
+}
+
 // ---------------------------------------------------------------- exact replica of Tensor.topk's tie-breaking
 // Sequential port of libstdc++'s std::nth_element (__introselect: median-of-three to first, unguarded partition,
 // depth limit 2 log2 n with __heap_select fallback, final insertion sort) and of std::partial_sort's __heap_select,
@@ -1235,6 +1250,36 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
                        (a64->waves == 0 || a64->waves == 1 || a64->waves == 8) && a3->waves == 0 &&
                        (long)((a64->N + (col16 ? 15 : 31)) / (col16 ? 16 : 32)) * a64->B >= 1024 && (long)((a3->N + 15) / 16) * a3->B >= 1024 &&
                        (a64->tie_scratch != nullptr) == (a3->tie_scratch != nullptr) && a64->tie_defer == a3->tie_defer;
+  // small grids: the candidate-split kernels of both searches as one launch (k <= 20, automatic kernel choice)
+  const bool small = !fusable && a64->k == a3->k && a64->k <= 20 && a64->waves == 0 && a3->waves == 0 && !col16 &&
+                     (a64->tie_scratch != nullptr) == (a3->tie_scratch != nullptr) && a64->tie_defer == a3->tie_defer &&
+                     a64->B > 0 && a3->B > 0 && a64->N > 0 && a3->N > 0 && a64->k > 0 && a64->k + 1 <= a64->N && a3->k + 1 <= a3->N &&
+                     a64->N <= 65535 && a3->N <= 65535 && a64->sq && a64->ldx >= 64 && !(a64->ldx & 3) && a3->ldx >= 4 && !(a3->ldx & 3) &&
+                     !(a64->tie_scratch && (a64->tie_cap < 1 || a3->tie_cap < 1)) && !tie_work_missing(a64) && !tie_work_missing(a3) &&
+                     knn_s(a64) != 1;                     // (an unsplit feature-space search on a small grid: the separate launches)
+  if (small) {
+    hipStream_t s = (hipStream_t)stream;
+    for (const vcr_knn_args* a : {a64, a3})
+      if (a->tie_scratch && !a->tie_zeroed) {
+        const int e = zero_count(a->tie_scratch, s);
+        if (e != 0) return e;
+      }
+    const int S64 = knn_s(a64), S3 = knn_s(a3);
+    const int gx64 = (a64->N + 32 * (4 / S64) - 1) / (32 * (4 / S64)), gx3 = (a3->N + 16 * (4 / S3) - 1) / (16 * (4 / S3));
+    const int n64 = gx64 * a64->B, n3 = gx3 * a3->B;
+    vcr_knn_args k64 = *a64, k3 = *a3;
+    k64.tie_inline = 0; k3.tie_inline = ties_inline(a3) ? 1 : 0;       // (only an unsplit Cartesian search replays in place)
+    const size_t lds64 = (size_t)4 * 2 * (pend_of<GeomMfma, 22>() + 1) * 32 * 4;
+    const size_t lds3 = knn_lds_bytes(a3, k3.tie_inline != 0), lds = lds64 > lds3 ? lds64 : lds3;
+    const dim3 grid(n64 + n3);
+    int rc = VCR_EUNSUPPORTED;
+#define VCR_KPS(A, B_) rc = launch<knn_pair_small_kernel<22, A, B_>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3)
+    if (S64 == 4) { if (S3 == 4) VCR_KPS(4, 4); else if (S3 == 2) VCR_KPS(4, 2); else VCR_KPS(4, 1); }
+    else if (S64 == 2) { if (S3 == 4) VCR_KPS(2, 4); else if (S3 == 2) VCR_KPS(2, 2); else VCR_KPS(2, 1); }
+#undef VCR_KPS
+    if (rc == 0 && a64->tie_scratch && !a64->tie_defer) rc = vcr_knn_ties_f32(a64, k3.tie_inline ? nullptr : a3, stream);
+    return rc;
+  }
   if (!fusable) {
     const int rc = vcr_knn_f32(a3, stream);
     return rc ? rc : vcr_knn_f32(a64, stream);
