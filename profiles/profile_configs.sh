@@ -13,6 +13,8 @@ python bench.py --points 4096 --k 40 --batch 32 --stages --no-cpu-baseline > $OU
 python bench.py --emb-nn dgcnn --stages --no-cpu-baseline > $OUT/${TAG}_dgcnn_bench.json 2> $OUT/${TAG}_dgcnn_launch_table.txt
 python bench.py --linear-mode bf16x3 --no-cpu-baseline > $OUT/${TAG}_bf16x3_bench.json 2>/dev/null
 python bench.py --linear-mode bf16x3+sdpa --stages --no-cpu-baseline > $OUT/${TAG}_bf16x3_sdpa_bench.json 2> $OUT/${TAG}_bf16x3_sdpa_launch_table.txt
+python bench.py --emb-nn pointnet --stages --no-cpu-baseline > $OUT/${TAG}_pointnet_bench.json 2> $OUT/${TAG}_pointnet_launch_table.txt
+for b in 1 2 4; do python bench.py --batch $b --stages --no-cpu-baseline --min-seconds 3 > $OUT/${TAG}_batch${b}_bench.json 2> $OUT/${TAG}_batch${b}_launch_table.txt; done
 python bench.py --gpus 2 --backend gloo --no-cpu-baseline > $OUT/${TAG}_selfspawn_2ranks_1gpu_bench.json 2>/dev/null
 python -m pytest tests/test_hip_forced.py tests/test_hip_forward.py tests/test_hip_variants.py tests/test_selfdiv.py tests/test_eval_golden.py tests/test_hip_partial.py -m gpu -q -s 2>&1 | grep -E "max\||flips|config|passed|failed|vs the reference|HIP vs|kept-key|ff_dims" > $OUT/${TAG}_parity_printout.txt
 python evaluate.py --items 64 --batch 16 > $OUT/${TAG}_evaluate_whole.txt 2>&1
