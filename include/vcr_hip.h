@@ -145,6 +145,10 @@ typedef struct {
                                          sum k in different orders (fp32-rounding apart).  Any other bit: VCR_EINVAL. */
 } vcr_linear_args;
 int vcr_linear_f32(const vcr_linear_args*, vcr_stream_t);
+/* Host-only query (nothing is launched, no device needed): the kernel configuration vcr_linear_f32 would pick for these
+ * arguments -- tile rows | k-slab << 8 | (16x16x4 MFMAs ? 1 << 16 : 0) | (LDS-DMA kernel ? 1 << 17 : 0) -- or a negative
+ * VCR_E* code.  For tests and for reading a profile. */
+int vcr_linear_config(const vcr_linear_args*);
 /* Two independent linears as ONE launch when both resolve to the same kernel configuration (k-slab, MFMA shape,
  * LayerNorm-in, statistics-out; no fused max), else exactly the two calls: fewer, fuller rounds of workgroups for e.g. the
  * encoder's and the decoder's output projections.  The tile height (128 / 96 rows) is chosen for the combined grid unless

@@ -141,6 +141,47 @@ def test_host_side_dispatch_logic_without_a_gpu(lib):
     assert lib.vcr_sdpa_f32(ctypes.byref(sa), None) == -1  # indexed keys need nk_src
 
 
+def test_linear_launch_choice_against_the_recorded_sweep(lib):
+    """vcr_linear_config (host-only): the kernel configuration per launch.  The BASELINE shapes take what DESIGN says
+    (128-row tiles at configs[1]; 96-row tiles for the residual launches of configs[2]; 32-row tiles and the 16x16x4 shape
+    for one pair per call), and replayed against the sweep recorded on the GPU (profiles/r3z_sweep_bm_after.txt: both
+    forced heights timed at 56 shapes) the automatic height never loses more than 6 % to the better one."""
+    import os
+    import re
+    from vcrnet_amd import native
+    lib.vcr_linear_config.argtypes, lib.vcr_linear_config.restype = [ctypes.POINTER(native.LinearArgs)], ctypes.c_int
+
+    def cfg(M, N, K, residual, variant=0):
+        a = native.LinearArgs()
+        a.x, a.w, a.y, a.bias = 0x1000, 0x2000, 0x3000, 0x4000            # (never dereferenced on the host)
+        a.ldx, a.ldy, a.M, a.N, a.K, a.variant = K, N, M, N, K, variant
+        if residual:
+            a.residual, a.ldr, a.stats_out = 0x5000, N, 0x6000
+        c = lib.vcr_linear_config(ctypes.byref(a))
+        assert c > 0, c
+        return c & 0xFF, (c >> 8) & 0xFF, bool(c & (1 << 16))
+    assert cfg(32768, 512, 512, True) == (128, 32, True) and cfg(32768, 1536, 512, False) == (128, 16, False)     # configs[1]
+    assert cfg(36864, 512, 512, True) == (96, 32, True) and cfg(36864, 512, 1024, True) == (96, 32, True)          # configs[2]
+    assert cfg(36864, 1024, 512, False) == (128, 16, False)                                                          # (BK 16: no)
+    assert cfg(2048, 512, 512, True) == (32, 32, True) and cfg(2048, 512, 512, False) == (32, 32, True)            # one pair
+    assert cfg(2048, 3072, 512, False)[0] in (64, 128) and cfg(2048, 3072, 512, False)[2]
+    assert cfg(8192, 512, 512, True) == (128, 32, True)               # 256 tiles: exactly one per CU (the first model took 96: -34 %)
+    assert cfg(32768, 512, 512, True, variant=2048)[0] == 96 and cfg(2048, 512, 512, True, variant=4096 | 16)[0] == 128
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r3z_sweep_bm_after.txt")
+    worst, n = 0.0, 0
+    for line in open(path):
+        m = re.match(r"K=(\d+) M=\s*(\d+) tiles128=\s*\d+: auto\s+[\d.]+\s+bm128\s+([\d.]+)\s+bm96\s+([\d.]+)", line)
+        if not m:
+            continue
+        K, M, t128, t96 = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))
+        if M < 16384:
+            continue                                              # (small problems may take 64 / 32 rows: not in this sweep)
+        rows = cfg(M, 512, K, True)[0]
+        assert rows in (96, 128)
+        worst, n = max(worst, (t96 if rows == 96 else t128) / min(t96, t128) - 1), n + 1
+    assert n >= 30 and worst <= 0.06, (n, worst)
+
+
 def test_module_contract_on_cpu():
     """Constructor / state-dict contract of the reference module without a GPU."""
     from types import SimpleNamespace

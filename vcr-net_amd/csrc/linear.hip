@@ -619,6 +619,16 @@ void linear_dispatch(const LinearPlan& pl, F&& f) {
 }
 }  // namespace
 
+// Host-only: the kernel configuration vcr_linear_f32 would launch for these arguments, nothing launched.  Returns
+// rows | k-slab << 8 | (16x16x4 ? 1 << 16 : 0) | (LDS-DMA ? 1 << 17 : 0), or a negative VCR_E* code.
+extern "C" int vcr_linear_config(const vcr_linear_args* a) {
+  LinearPlan pl{};
+  const int rc = linear_plan(a, &pl);
+  if (rc != VCR_OK) return rc;
+  if (!pl.glds) return 128 | (32 << 8);
+  return pl.bm | ((pl.bk16 ? 16 : 32) << 8) | (pl.ms16 ? 1 << 16 : 0) | (1 << 17);
+}
+
 extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
   LinearPlan pl{};
   const int rc = linear_plan(a, &pl);
