@@ -519,9 +519,16 @@ __global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
 // the distance is bit-for-bit the same k-ascending fma chain as in knn64_body and in the reference's CPU sgemm; the
 // -sq_j/2 term rides as a 17th step.  Operands are read from the natural [N][64] rows as 16-B chunks and transposed
 // across the four lane rows of a column in registers (see load_raw / transpose).
-template <int KS, int W>
+// C == 4 (the Cartesian search, rows (x, y, z, |p|^2)): the whole distance is ONE MFMA -- lane row q4 < 3 supplies
+// coordinate q4 of its candidate row (A) and of its query (B), lane row 3 supplies -|c|^2 / 2 and 1: the hardware's
+// k-ascending chain is ((x x' + y y') + z z') - |c|^2 / 2, exactly the fma chain + norm step of the C = 64 case and of the
+// VALU kernel knn3_body (whose (2 dot - |c|^2) - |q|^2 is the same rounding: doubling is exact).  The Cartesian
+// search's distances then cost the idle matrix pipe one instruction per 16 x 16 tile instead of 16 VALU FMAs per wave.
+template <int KS, int W, int C = 64>
 __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b) {
   using G = GeomCol16;
+  static_assert(C == 64 || C == 4, "feature rows of 64 floats or xyz4 rows");
+  constexpr int NST = C == 64 ? 16 : 1;                  // MFMA steps of the dot product
   constexpr int PEND = pend_of<G, KS>();
   constexpr int CT = 16;                                 // candidates per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -534,18 +541,24 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   float* lv = reinterpret_cast<float*>(smem) + wave * (2 * LROWS * 16);
   Selector<G, KS> sel;
   const float* xb = a.x + (size_t)b * a.N * a.ldx;
-  const float* sqb = a.sq + (size_t)b * a.N;
+  const float* sqb = C == 64 ? a.sq + (size_t)b * a.N : nullptr;
   const int q = min(q0 + col, a.N - 1);
-  // Operand fetch.  MFMA step s needs x[row][4 s + q4] in lane row q4: every fourth float of the row.  Fetched as such
+  // Operand fetch (C == 64).  MFMA step s needs x[row][4 s + q4] in lane row q4: every fourth float of the row.  Fetched as such
   // (16 x global_load_dword) the texture path sees 4-byte requests -- 8x the requests of knn64_body per byte, and the
   // kernel is bound by them (measured: 145 of a wave's 208 us at N = 1024).  Instead lane row q4 loads the 16-B chunks
   // 4 g + q4 (g = 0..3; four global_load_dwordx4) and a 4 x 4 transpose between lane rows and vector components --
   // v_permlane16_swap on the register pairs (0,1) (2,3), then v_permlane32_swap on (0,2) (1,3) -- leaves
   // component j of chunk register g = x[row][4 (4 g + j) + q4], i.e. the operand of step s = 4 g + j.
+  // (C == 4: one float per lane -- element q4 of the xyz4 row; raw[0][0] carries it, raw[0][1] the row's |p|^2)
   auto load_raw = [&](int row, f32x4* raw) {
-    const float* rp = xb + (size_t)row * a.ldx + 4 * q4;
+    if constexpr (C == 64) {
+      const float* rp = xb + (size_t)row * a.ldx + 4 * q4;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) raw[g] = ld4(rp + 16 * g);
+      for (int g = 0; g < 4; ++g) raw[g] = ld4(rp + 16 * g);
+    } else {
+      const float* rp = xb + (size_t)row * a.ldx;
+      raw[0][0] = rp[q4];
+    }
   };
   auto swap16 = [](float& x, float& y) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(x), __float_as_int(y), false, false);
@@ -556,6 +569,10 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
     x = __int_as_float(r[0]); y = __int_as_float(r[1]);
   };
   auto transpose = [&](const f32x4* raw, float* dst) {   // dst[4 g + j] = operand of MFMA step 4 g + j
+    if constexpr (C == 4) {
+      dst[0] = q4 == 3 ? -0.5f * raw[0][0] : raw[0][0];  // candidate side: (x, y, z, -|c|^2 / 2)
+      return;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float r0 = raw[g][0], r1 = raw[g][1], r2 = raw[g][2], r3 = raw[g][3];
@@ -564,13 +581,14 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
       dst[4 * g] = r0; dst[4 * g + 1] = r1; dst[4 * g + 2] = r2; dst[4 * g + 3] = r3;
     }
   };
-  float qf[16];
+  float qf[NST];
   {
     f32x4 raw[4];
     load_raw(q, raw);
     transpose(raw, qf);
+    if constexpr (C == 4) qf[0] = q4 == 3 ? 1.f : raw[0][0];              // query side: (x, y, z, 1)
   }
-  const float sq_q = sqb[q];
+  const float sq_q = C == 64 ? sqb[q] : xb[(size_t)q * a.ldx + 3];
   const int ntiles = (a.N + CT - 1) / CT;
 
   sel.init(lv, reinterpret_cast<int*>(lv + LROWS * 16), lane);
@@ -582,20 +600,22 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   KTL_DECL;
   // Two candidate tiles per step: their two 17-MFMA chains are independent and issue alternately (a dependent
   // v_mfma_f32_16x16x4_f32 chain leaves 8 of every 40 cycles empty), and the next two tiles' rows are in flight meanwhile.
-  float cf[2][16];
-  f32x4 nraw[2][4];
-  float csq[2], nsq[2] = {0.f, 0.f};
+  float cf[2][NST];
+  f32x4 nraw[2][C == 64 ? 4 : 1];
+  float csq[2] = {0.f, 0.f}, nsq[2] = {0.f, 0.f};
+  auto scan_prologue = [&]() {
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int c = min(u * CT + col, a.N - 1);
-    load_raw(c, nraw[u]);
-    csq[u] = sqb[c];
-  }
+    for (int u = 0; u < 2; ++u) {
+      const int c = min(u * CT + col, a.N - 1);
+      load_raw(c, nraw[u]);
+      if constexpr (C == 64) csq[u] = sqb[c];
+    }
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    transpose(nraw[u], cf[u]);                           // (VALU consumers: the first tiles have arrived before the loop)
-    asm volatile("" : "+v"(csq[u]));
-  }
+    for (int u = 0; u < 2; ++u) {
+      transpose(nraw[u], cf[u]);                         // (VALU consumers: the first tiles have arrived before the loop)
+      asm volatile("" : "+v"(csq[u]));
+    }
+  };
   // the selection proper for one tile: 16 new distances per query (4 per lane: candidate rows 4 q4 + r)
   auto select_tile = [&](int tile, const f32x4& acc) {
     sel.make_room();
@@ -629,6 +649,8 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
     if (__any(sel.cnt - sel.done > 16)) sel.drain();     // keep the threshold fresh
     KTL(5);
   };
+  auto scan_all = [&]() {
+  scan_prologue();
   for (int tile = 0; tile < ntiles; tile += 2) {
     const bool more = tile + 2 < ntiles;
     if (more) {
@@ -636,18 +658,21 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
       for (int u = 0; u < 2; ++u) {                      // (a tile beyond the last one re-reads the last row: masked in select_tile)
         const int c = min((tile + 2 + u) * CT + col, a.N - 1);
         load_raw(c, nraw[u]);
-        nsq[u] = sqb[c];
+        if constexpr (C == 64) nsq[u] = sqb[c];
       }
     }
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int st = 0; st < 16; ++st) {
+    for (int st = 0; st < NST; ++st) {
       acc[0] = mfma16(cf[0][st], qf[st], acc[0]);
       acc[1] = mfma16(cf[1][st], qf[st], acc[1]);
     }
     // 17th k-step: A[cand][k*] = -sq_cand/2 (row 0 of the lanes), B[k*][q] = 1  ->  acc = dot - sq_j/2, rounded once
+    // (C == 4: the norm is the 4th k of the one MFMA above)
+    if constexpr (C == 64) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) acc[u] = mfma16(q4 == 0 ? -0.5f * csq[u] : 0.f, q4 == 0 ? 1.f : 0.f, acc[u]);
+      for (int u = 0; u < 2; ++u) acc[u] = mfma16(q4 == 0 ? -0.5f * csq[u] : 0.f, q4 == 0 ? 1.f : 0.f, acc[u]);
+    }
     KTL(0);                                              // prefetch issue + MFMA chains
     select_tile(tile, acc[0]);
     if (tile + 1 < ntiles) select_tile(tile + 1, acc[1]);
@@ -661,6 +686,32 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
     }
     KTL(3);                                              // wait for the prefetched rows + transpose
   }
+  };
+  // C == 4: filter floor from a sample (see SampleNet): the first 256 candidates' values only -- 16 MFMAs -- give a
+  // threshold the scan proper starts with (the VALU kernel: 75 -> 65 us; distances are one MFMA per tile here, so the
+  // pre-pass costs next to nothing.  C == 64 recomputes 17 MFMAs per sampled tile: measured a wash, off).
+  if constexpr (C == 4) {
+    constexpr int T0 = SAMPLE / CT, R0 = (KS + 1 + G::LPQ - 1) / G::LPQ;     // LPQ * R0 - 1 >= KS
+    if (ntiles >= 2 * T0 + 1) {
+      SampleNet<R0> net;
+      net.init();
+      for (int t = 0; t < T0; ++t) {                     // (full tiles: 16 T0 <= N)
+        const float cv = xb[(size_t)(t * CT + col) * a.ldx + q4];
+        const f32x4 acc = mfma16(q4 == 3 ? -0.5f * cv : cv, qf[0], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+        for (int r = 0; r < 4; ++r) net.insert(fmaf(2.f, acc[r], -sq_q));
+      }
+      sel.init(lv, reinterpret_cast<int*>(lv + LROWS * 16), lane, col_min<G>(net.s[R0 - 1], sel.sg));
+    }
+  }
+  scan_all();
+  if constexpr (C == 4) {
+    sel.drain();
+    if (__any(!sel.floor_held())) {                      // the sample misjudged some query of this wave: scan without a floor
+      sel.init(lv, reinterpret_cast<int*>(lv + LROWS * 16), lane);
+      scan_all();
+    }
+  }
   KTL_FLUSH;
   finish<G, KS, 1>(sel, a, b, q0 + col, wave, 0, smem, blk_ties);
   if (blk_ties) replay_block_ties(a, blk_ties, smem);
@@ -669,7 +720,14 @@ template <int KS, int W>
 __global__ __launch_bounds__(64 * W, 4) void knn64c_kernel(vcr_knn_args a) {
   int bx, b;
   xcd_chunk2(bx, b);
-  knn64c_body<KS, W>(a, bx, b);
+  knn64c_body<KS, W, 64>(a, bx, b);
+}
+// the Cartesian search on the same body (distances = one MFMA per tile): the unsplit (S = 1) kernel of C == 4
+template <int KS, int W>
+__global__ __launch_bounds__(64 * W, 4) void knn3c_kernel(vcr_knn_args a) {
+  int bx, b;
+  xcd_chunk2(bx, b);
+  knn64c_body<KS, W, 4>(a, bx, b);
 }
 
 // ---------------------------------------------------------------- C == 4 (xyz4, VALU)
@@ -789,7 +847,7 @@ __global__ __launch_bounds__(256, (COL16 ? 4 : 2)) void knn_pair_kernel(vcr_knn_
     else knn64_body<KS, 1, 4>(a64, lin % gx64, lin / gx64);
   } else {
     const int lin = xcd_chunk(bid - n64, (int)gridDim.x - n64);
-    knn3_body<KS, 1>(a3, lin % gx3, lin / gx3);
+    knn64c_body<KS, 4, 4>(a3, lin % gx3, lin / gx3);
   }
 }
 
@@ -804,7 +862,8 @@ __global__ __launch_bounds__(256, 2) void knn_pair_small_kernel(vcr_knn_args a64
     knn64_body<KS, S64, 4>(a64, lin % gx64, lin / gx64);
   } else {
     const int lin = xcd_chunk(bid - n64, (int)gridDim.x - n64);
-    knn3_body<KS, S3>(a3, lin % gx3, lin / gx3);
+    if constexpr (S3 == 1) knn64c_body<KS, 4, 4>(a3, lin % gx3, lin / gx3);   // (unsplit: the MFMA body, as vcr_knn_f32 launches it)
+    else knn3_body<KS, S3>(a3, lin % gx3, lin / gx3);
   }
 }
 
@@ -1216,10 +1275,13 @@ static bool use_col16(const vcr_knn_args* a) {
 
 // In-kernel tie replay: the launch's workgroups are 4 waves of 16 queries (knn64c_body / knn3_body with S = 1) and a row's
 // replay image fits beside nothing else in <= 40 KB of LDS (N <= ~2400): see replay_block_ties.
+static int knn_s(const vcr_knn_args* a);
 static size_t knn_log_bytes(const vcr_knn_args* a) {       // LDS of the four logs of such a workgroup
   const bool k20 = a->k <= 20;
-  return a->C == 64 ? (size_t)4 * 2 * ((k20 ? pend_of<GeomCol16, 22>() : pend_of<GeomCol16, 42>()) + 4) * 16 * 4
-                    : (size_t)4 * 2 * ((k20 ? pend_of<GeomQuad, 22>() : pend_of<GeomQuad, 42>()) + 1) * 16 * 4;
+  const size_t col16 = (size_t)4 * 2 * ((k20 ? pend_of<GeomCol16, 22>() : pend_of<GeomCol16, 42>()) + 4) * 16 * 4;
+  if (a->C == 64) return col16;
+  // the Cartesian search: unsplit = the MFMA body (same log as the feature-space kernel), split = the quad kernel
+  return knn_s(a) == 1 ? col16 : (size_t)4 * 2 * ((k20 ? pend_of<GeomQuad, 22>() : pend_of<GeomQuad, 42>()) + 1) * 16 * 4;
 }
 static int knn_s(const vcr_knn_args* a) {                  // candidate split of the 32-query / Cartesian kernels (vcr_knn_f32)
   if (a->k > 20) return 1;
@@ -1360,8 +1422,8 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
     const int S = pick_s((long)((a->N + 15) / 16) * a->B);
     const dim3 grid((a->N + 16 * (4 / S) - 1) / (16 * (4 / S)), a->B);
     const size_t lds = knn_lds_bytes(a, inl);
-    rc = !k20 ? launch<knn3_kernel<42, 1>>(grid, dim3(256), lds, s, ka)
-         : S == 1 ? launch<knn3_kernel<22, 1>>(grid, dim3(256), lds, s, ka)
+    rc = !k20 ? launch<knn3c_kernel<42, 4>>(grid, dim3(256), lds, s, ka)
+         : S == 1 ? launch<knn3c_kernel<22, 4>>(grid, dim3(256), lds, s, ka)
          : S == 2 ? launch<knn3_kernel<22, 2>>(grid, dim3(256), lds, s, *a)
                   : launch<knn3_kernel<22, 4>>(grid, dim3(256), lds, s, *a);
   }
