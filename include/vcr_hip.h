@@ -49,6 +49,11 @@ typedef struct {
   float* xyz4; float* feat64; float* sq64;
   const float* x_cf2; int B2;         /* optional second block of B2 clouds (same N) processed by the same launch; its rows
                                          follow the first block's in xyz4 / feat64 / sq64 (the forward: src, then tgt) */
+  /* Optional (pq != NULL): LPDNet's first EdgeConv projection per point from the same launch,
+   * pq[row][0:256] = feat64[row] pq_w^T + pq_b  (pq_w [256,64], pq_b [256]: the neighbour | centre halves of convDG1 after
+   * the SURVEY-F7 split, lpdnet_model.py:122; what vcr_linear_f32 computes from feat64).  The launch then runs conv2 and
+   * this projection on the matrix pipe; xyz4 / feat64 / sq64 are bit-identical to the plain launch's. */
+  const float* pq_w; const float* pq_b; float* pq; int ldpq;
 } vcr_pointwise_args;
 int vcr_pointwise_f32(const vcr_pointwise_args*, vcr_stream_t);
 

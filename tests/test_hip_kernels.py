@@ -78,6 +78,18 @@ def test_pointwise_matches_cpu_rounding_bit_for_bit(nat, W, N):
     h = F.relu(F.conv1d(h, W["emb_nn.conv2_lpd.weight"], W["emb_nn.conv2_lpd.bias"]))
     assert torch.equal(f64.cpu(), h.transpose(1, 2))
     assert torch.equal(sq.cpu(), (h ** 2).sum(1))
+    # the same launch with the first EdgeConv's P | Q projection fused in: conv2 and the projection on the matrix pipe (an
+    # MFMA is a k-ascending fma chain that starts at its accumulator = the bias) -- the three stem outputs do not move by a
+    # bit, and P | Q is what vcr_linear_f32 makes of feat64 to fp32 rounding
+    w1 = W["emb_nn.convDG1.0.weight"].view(128, 128)
+    wpq = dev(torch.cat((w1[:, :64], w1[:, 64:]), 0).contiguous())
+    bpq = dev(torch.cat((torch.zeros(128), W["emb_nn.convDG1.0.bias"])))
+    xyz4b, f64b, sqb, pq = nat.pointwise(dev(x), dev(W["emb_nn.conv1_lpd.weight"].view(64, 3)), dev(W["emb_nn.conv1_lpd.bias"]),
+                                         dev(W["emb_nn.conv2_lpd.weight"].view(64, 64)), dev(W["emb_nn.conv2_lpd.bias"]), wpq, bpq)
+    assert torch.equal(f64b, f64) and torch.equal(sqb, sq) and torch.equal(xyz4b, _)
+    ref_pq = (f64.cpu().double().view(-1, 64) @ wpq.cpu().double().t() + bpq.cpu().double())
+    assert (pq.cpu().double() - ref_pq).abs().max().item() <= 4e-6 * 8 + 1e-6
+    torch.testing.assert_close(pq, nat.linear(f64.view(-1, 64), wpq, bpq), atol=2e-6, rtol=1e-6)
 
 
 @pytest.mark.parametrize("N,k", [(256, 20), (1024, 20), (192, 20), (100, 20), (512, 40), (64, 5)])

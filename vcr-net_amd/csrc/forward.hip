@@ -473,9 +473,13 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
              nullptr, const_cast<float*>(stats_for_ln));
   } else {
   // ---- emb_nn = LPDNet on both clouds (lpdnet_model.py:103-137)
+  // fp32 mode: the first EdgeConv's per-point projection P | Q (K = 64) rides on the stem launch (conv2 and the projection
+  // on the matrix pipe, pointwise.hip); the split modes keep the separate launch on their pre-split weight
+  const bool pq_fused = W->linear_mode == 0;
   if (R.rc == 0) {                                       // both clouds in one launch: rows 0..M1-1 = src, then tgt
-    R.mark("pointwise:src+tgt");
+    R.mark(pq_fused ? "pointwise:src+tgt+dg1_pq" : "pointwise:src+tgt");
     vcr_pointwise_args a{io->src_cf, B, N, W->c1_w, W->c1_b, W->c2_w, W->c2_b, w.xyz4, w.feat64, w.sq64, io->tgt_cf, B};
+    if (pq_fused) { a.pq_w = W->dg1_wpq; a.pq_b = W->dg1_bpq; a.pq = w.pq1; a.ldpq = 256; }
     R.ok(vcr_pointwise_f32(&a, R.stream));
   }
   // The feature-space and the Cartesian kNN (lpdnet_model.py:113,129) are independent: one launch for both, and one
@@ -487,7 +491,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     a64.tie_work_bytes = a3.tie_work_bytes = w.tie_work_each;
     R.knn_pair("knn:feat64+xyz", a64, a3);
   }
-  R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
+  if (!pq_fused) R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
   R.knn_ties();                                          // both tie replays in one launch (one latency instead of two)
   if (R.rc == 0) {
     R.mark("edgeconv:dg1_dg2");
@@ -768,7 +772,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 21; }
+extern "C" int vcr_abi_version(void) { return 22; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

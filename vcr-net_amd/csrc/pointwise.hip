@@ -95,6 +95,150 @@ __global__ __launch_bounds__(256) void pointwise12_kernel(vcr_pointwise_args a) 
   }
 }
 
+// The same outputs, bit for bit, with conv2 on the matrix pipe, and the first EdgeConv projection of LPDNet
+// (lpdnet_model.py:122 after the SURVEY-F7 split: P | Q = feat64 Wpq^T + bpq, K = 64, N = 256) computed from the tile while it
+// is in LDS -- the separate pointwise launch + `linear:dg1_pq` launch (K = 64: 52 TFLOP/s) of the forward become one.
+//   v_mfma_f32_16x16x4_f32 is a k-ascending fma chain that STARTS at its accumulator operand: with the accumulator preset
+//   to the bias and k = 4 s + (lane >> 4) ascending over the 16 steps, D is exactly "bias first, one fma per input channel
+//   in ascending order" -- the rounding order of the reference's conv that pointwise12_kernel spells out on the VALU.
+// Wave = tiles of 16 points (MFMA rows).  conv1 (K = 3) stays on the VALU: lane (q4, l15) computes h1[point l15][k = 4 s + q4],
+// which IS its A operand of step s -- no staging.  conv2's weights sit in 64 VGPRs as B fragments; D goes through a
+// per-wave LDS tile [16][64] (ReLU applied), from which (a) four lanes per point read 16 consecutive channels each and run
+// pointwise12_kernel's epilogue unchanged (|feat|^2 in ATen's association, 16-B stores) and (b) the lanes re-read A
+// fragments for the P | Q projection, whose 64 KB of weights lie in LDS in fragment order (one ds_read_b128 per four MFMAs).
+constexpr int TP = 68;                                   // tile pitch: the 64 lanes' A-fragment reads hit 64 distinct banks
+constexpr int PQW = 8;                                   // waves per workgroup (two per SIMD: one wave's LDS / store phases under the other's MFMAs)
+__global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwise_args a, int tiles_per_cloud, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float pw_smem[];
+  float* wfrag = pw_smem;                                // [16 col tiles][4 step quads][64 lanes][4 steps]: Wpq as B fragments
+  float* w1s = wfrag + 16 * 4 * 64 * 4;                  // [64][4] = (w0, w1, w2, b1)
+  float* tiles = w1s + 64 * 4;                           // [PQW waves][16][TP]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int q4 = lane >> 4, l15 = lane & 15;
+  for (int i = t; i < 256 * 64; i += 64 * PQW) {         // coalesced read of Wpq [256][64], scattered into fragment order
+    const int n = i >> 6, k = i & 63, j = n >> 4, st = k >> 2;
+    wfrag[(((j * 4 + (st >> 2)) * 64) + (k & 3) * 16 + (n & 15)) * 4 + (st & 3)] = a.pq_w[i];
+  }
+  if (t < 64) {
+    w1s[t * 4 + 0] = a.w1[t * 3 + 0]; w1s[t * 4 + 1] = a.w1[t * 3 + 1]; w1s[t * 4 + 2] = a.w1[t * 3 + 2];
+    w1s[t * 4 + 3] = a.b1[t];
+  }
+  float w2r[4][16];                                      // conv2 B fragments: w2[16 j + l15][4 s + q4]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int st = 0; st < 16; ++st) w2r[j][st] = a.w2[(16 * j + l15) * 64 + 4 * st + q4];
+  float b2r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b2r[j] = a.b2[16 * j + l15];
+  __syncthreads();
+  float* T = tiles + wave * 16 * TP;
+  const int p = lane >> 2, g = lane & 3;                 // epilogue mapping: four lanes per point, 16 channels each
+  for (int tile = (int)blockIdx.x * PQW + wave; tile < total_tiles; tile += (int)gridDim.x * PQW) {
+    const int b = tile / tiles_per_cloud, n0 = (tile - b * tiles_per_cloud) * 16;
+    const float* xb = b < a.B ? a.x_cf + (size_t)b * 3 * a.N : a.x_cf2 + (size_t)(b - a.B) * 3 * a.N;
+    float h[16];
+    {
+      const int nc = min(n0 + l15, a.N - 1);
+      const float x = xb[nc], y = xb[a.N + nc], z = xb[2 * a.N + nc];
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {                  // conv1 + ReLU for this lane's k = 4 st + q4 (same chain as pointwise12_kernel)
+        const f32x4 w = ld4(&w1s[(4 * st + q4) * 4]);
+        h[st] = fmaxf(fmaf(w[2], z, fmaf(w[1], y, fmaf(w[0], x, w[3]))), 0.f);
+      }
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{b2r[j], b2r[j], b2r[j], b2r[j]};   // bias first
+#pragma unroll
+    for (int st = 0; st < 16; ++st)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = mfma16(h[st], w2r[j][st], acc[j]);     // k ascending
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(4 * q4 + r) * TP + 16 * j + l15] = fmaxf(acc[j][r], 0.f);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // ---- pointwise12_kernel's epilogue on the tile: point p of the tile, channels 16 g .. 16 g + 15
+    {
+      const int n = n0 + p;
+      const bool live = n < a.N;
+      const int nc = live ? n : a.N - 1;
+      const float x = xb[nc], y = xb[a.N + nc], z = xb[2 * a.N + nc];
+      float f[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = ld4(&T[p * TP + 16 * g + 4 * q]);
+        f[4 * q] = v[0]; f[4 * q + 1] = v[1]; f[4 * q + 2] = v[2]; f[4 * q + 3] = v[3];
+      }
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) ss = ss + f[j] * f[j];
+      const int base = lane & ~3;
+      {
+        const float s0 = __shfl(ss, base, 64), s1 = __shfl(ss, base + 1, 64);
+        const float s2 = __shfl(ss, base + 2, 64), s3 = __shfl(ss, base + 3, 64);
+        ss = ((s0 + s1) + s2) + s3;
+      }
+      const bool tail = live && n >= (a.N & ~31);        // (ATen's scalar tail loop: see pointwise12_kernel)
+      if (__builtin_amdgcn_ballot_w64(tail) != 0) {
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sgrp = 0; sgrp < 4; ++sgrp) {
+          if (g == sgrp) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a4[j & 3] = a4[j & 3] + f[j] * f[j];
+          }
+#pragma unroll
+          for (int l = 0; l < 4; ++l) a4[l] = __shfl(a4[l], base + sgrp, 64);
+        }
+        if (tail) ss = ((a4[0] + a4[1]) + a4[2]) + a4[3];
+      }
+      if (live) {
+        const size_t row = (size_t)b * a.N + n;
+        float* o = a.feat64 + row * 64 + g * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st4(o + q * 4, f32x4{f[q * 4], f[q * 4 + 1], f[q * 4 + 2], f[q * 4 + 3]});
+        if (g == 0) {
+          a.sq64[row] = ss;
+          st4(a.xyz4 + row * 4, f32x4{x, y, z, (x * x + y * y) + z * z});
+        }
+      }
+    }
+    // ---- P | Q = feat64 Wpq^T + bpq for the tile's 16 points (bias first, k ascending)
+    float af[16];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) af[st] = T[l15 * TP + 4 * st + q4];
+#pragma unroll 1
+    for (int jg = 0; jg < 4; ++jg) {
+      f32x4 pa[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float bq = a.pq_b[16 * (4 * jg + jj) + l15];
+        pa[jj] = f32x4{bq, bq, bq, bq};
+      }
+#pragma unroll
+      for (int sq = 0; sq < 4; ++sq)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x4 wf = ld4(&wfrag[(((4 * jg + jj) * 4 + sq) * 64 + lane) * 4]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pa[jj] = mfma16(af[4 * sq + e], wf[e], pa[jj]);
+        }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + 4 * q4 + r;
+          if (n < a.N) a.pq[((size_t)b * a.N + n) * a.ldpq + 16 * (4 * jg + jj) + l15] = pa[jj][r];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // the tile is rewritten by the next iteration
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // [B,3,N] channels-first points -> [B,N,4] rows (x, y, z, |p|^2): the layout the kNN / ICP kernels read.
 __global__ __launch_bounds__(256) void rows4_kernel(const float* x_cf, float* xyz4, int B, int N) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -148,6 +292,15 @@ extern "C" int vcr_rows4_f32(const float* x_cf, float* xyz4, int B, int N, vcr_s
 extern "C" int vcr_pointwise_f32(const vcr_pointwise_args* a, vcr_stream_t stream) {
   if (!a || !a->x_cf || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->xyz4 || !a->feat64 || !a->sq64) return VCR_EINVAL;
   if (a->B <= 0 || a->N <= 0 || a->B2 < 0 || (a->B2 > 0 && !a->x_cf2)) return VCR_EINVAL;
+  if (a->pq) {                                           // fused with the P | Q projection: the MFMA kernel
+    if (!a->pq_w || !a->pq_b || a->ldpq < 256 || (a->ldpq & 3)) return VCR_EINVAL;
+    const int tpc = (a->N + 15) / 16, total = tpc * (a->B + a->B2);
+    const int cus = vcr_cu_count(), blocks = (total + PQW - 1) / PQW < cus ? (total + PQW - 1) / PQW : cus;
+    const size_t lds = (size_t)(16 * 4 * 64 * 4 + 64 * 4 + PQW * 16 * TP) * sizeof(float);
+    VCR_DYN_LDS(pointwise12_pq_kernel, lds);
+    hipLaunchKernelGGL(pointwise12_pq_kernel, dim3(blocks), dim3(64 * PQW), lds, (hipStream_t)stream, *a, tpc, total);
+    return VCR_LAUNCH_RC();
+  }
   dim3 grid((a->N + PTS - 1) / PTS, a->B + a->B2);
   hipLaunchKernelGGL(pointwise12_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
   return VCR_LAUNCH_RC();

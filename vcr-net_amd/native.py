@@ -21,7 +21,8 @@ f32p = C.c_void_p  # device pointers travel as integers
 
 class PointwiseArgs(C.Structure):
     _fields_ = [("x_cf", f32p), ("B", C.c_int), ("N", C.c_int), ("w1", f32p), ("b1", f32p), ("w2", f32p),
-                ("b2", f32p), ("xyz4", f32p), ("feat64", f32p), ("sq64", f32p), ("x_cf2", f32p), ("B2", C.c_int)]
+                ("b2", f32p), ("xyz4", f32p), ("feat64", f32p), ("sq64", f32p), ("x_cf2", f32p), ("B2", C.c_int),
+                ("pq_w", f32p), ("pq_b", f32p), ("pq", f32p), ("ldpq", C.c_int)]
 
 
 class KnnArgs(C.Structure):
@@ -214,7 +215,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 21         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 22         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -352,13 +353,19 @@ def _f32(*shape, device):
 
 
 @_guarded
-def pointwise(x_cf, w1, b1, w2, b2):
+def pointwise(x_cf, w1, b1, w2, b2, pq_w=None, pq_b=None):
+    """conv1_lpd + conv2_lpd (+ ReLU) -> (xyz4, feat64, sq64); with pq_w [256,64] / pq_b [256] also the P | Q projection
+    of the first EdgeConv from the same (MFMA) launch -> (xyz4, feat64, sq64, pq [B*N,256])."""
     B, _, N = x_cf.shape
     x_cf = x_cf.contiguous()
     xyz4, f64, sq = _f32(B, N, 4, device=x_cf.device), _f32(B, N, 64, device=x_cf.device), _f32(B, N, device=x_cf.device)
-    call("vcr_pointwise_f32", PointwiseArgs(ptr(x_cf), B, N, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(xyz4),
-                                            ptr(f64), ptr(sq)))
-    return xyz4, f64, sq
+    a = PointwiseArgs(ptr(x_cf), B, N, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(xyz4), ptr(f64), ptr(sq))
+    pq = None
+    if pq_w is not None:
+        pq = _f32(B * N, 256, device=x_cf.device)
+        a.pq_w, a.pq_b, a.pq, a.ldpq = ptr(pq_w), ptr(pq_b), ptr(pq), 256
+    call("vcr_pointwise_f32", a)
+    return (xyz4, f64, sq) if pq is None else (xyz4, f64, sq, pq)
 
 
 @_guarded
