@@ -48,7 +48,16 @@ constexpr int TILE = 32;            // candidates per MFMA tile
 #define VCR_KNN_PEND_MFMA 64
 #endif
 struct GeomMfma;
-template <class G, int KS> constexpr int pend_of() { return KS > 22 ? 96 : std::is_same<G, GeomMfma>::value ? VCR_KNN_PEND_MFMA : 64; }
+struct GeomCol16;
+// 16-query kernels (k <= 20): 72 -- the most that keeps four workgroups per CU (4 x (76 rows x 16 queries x 8 B x 4 waves
+// + the tie list) = 157 KB of the 160): a compaction then frees 35 slots instead of 27.  Measured against 64: the pair
+// launch 151.4 -> 147.7 us at BASELINE configs[1], 147.5 -> 136.7 at N = 768 (configs[2]), 439 -> 432 at N = 2048.
+#ifndef VCR_KNN_PEND_COL16
+#define VCR_KNN_PEND_COL16 72
+#endif
+template <class G, int KS> constexpr int pend_of() {
+  return KS > 22 ? 96 : std::is_same<G, GeomMfma>::value ? VCR_KNN_PEND_MFMA : std::is_same<G, GeomCol16>::value ? VCR_KNN_PEND_COL16 : 64;
+}
 
 #ifdef VCR_TIMELINE
 // Experiment-only (profiles/timeline_knn.py, -DVCR_TIMELINE builds): wave 0 of every workgroup accumulates the 100 MHz
