@@ -108,6 +108,9 @@ __device__ __forceinline__ void report_tie(int32_t* ties, int cap, int row) {
 // is selected per lane (DPP / permlane reads of switched-off lanes return 0).
 struct GeomMfma {                    // 32 query columns, lanes l and l+32 share one: segment = lane >> 5
   static constexpr int COLS = 32, LPQ = 2;
+  static constexpr bool SPLIT_COMPACT = false;
+  __device__ static __forceinline__ int ord(int) { return 0; }
+  __device__ static __forceinline__ int prefix(int x, int, int& total) { total = x; return 0; }
   __device__ static __forceinline__ int col(int lane) { return lane & 31; }
   __device__ static __forceinline__ int seg(int lane) { return lane >> 5; }
   // x of segment `which` (0 / 1), in every lane of the column (v_permlane32_swap: result 0 = the lower half's values
@@ -146,9 +149,22 @@ struct GeomCol16 {                   // v_mfma_f32_16x16x4_f32 layout: 16 query 
     const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
     return x + ((q >> 1) ? b[0] : b[1]);
   }
+  // exclusive prefix of x over the four lanes of a column in ROW order (row = lane >> 4), and the total
+  static constexpr bool SPLIT_COMPACT = true;            // log rows PEND .. PEND + 3 exist (one trash row per lane row)
+  __device__ static __forceinline__ int ord(int lane) { return lane >> 4; }
+  __device__ static __forceinline__ int prefix(int x, int row, int& total) {
+    const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);      // {even row, odd row} of the pair
+    const int pair_total = a[0] + a[1];
+    const auto b = __builtin_amdgcn_permlane32_swap(pair_total, pair_total, false, false);   // {rows 0+1, rows 2+3}
+    total = b[0] + b[1];
+    return ((row & 1) ? a[0] : 0) + ((row >> 1) ? b[0] : 0);
+  }
 };
 struct GeomQuad {                    // 16 queries, one DPP quad each: segment = lane & 3
   static constexpr int COLS = 16, LPQ = 4;
+  static constexpr bool SPLIT_COMPACT = false;
+  __device__ static __forceinline__ int ord(int) { return 0; }
+  __device__ static __forceinline__ int prefix(int x, int, int& total) { total = x; return 0; }
   __device__ static __forceinline__ int col(int lane) { return lane >> 2; }
   __device__ static __forceinline__ int seg(int lane) { return lane & 3; }
   __device__ static __forceinline__ int from_seg(int x, int which) {
@@ -179,10 +195,10 @@ struct Selector {
   int cnt, done;                                         // entries logged / already inserted (same in a query's lanes)
   float thr;                                             // max(thr0, rank KS-1 value): nothing <= thr can be a neighbour
   float thr0;                                            // filter floor taken from a sample of the candidates (see sample_floor)
-  int col, sg;
+  int col, sg, od;
 
   __device__ __forceinline__ void init(float* lv_, int* li_, int lane, float floor0 = VCR_NEG_INF) {
-    lv = lv_; li = li_; cnt = 0; done = 0; thr = thr0 = floor0; col = G::col(lane); sg = G::seg(lane);
+    lv = lv_; li = li_; cnt = 0; done = 0; thr = thr0 = floor0; col = G::col(lane); sg = G::seg(lane); od = G::ord(lane);
 #pragma unroll
     for (int t = 0; t < T; ++t) v[t] = VCR_NEG_INF;
   }
@@ -230,6 +246,31 @@ struct Selector {
   }
   // keep the log entries above x, plus at most `emax` equal to x (the earliest logged); cnt = done = kept
   __device__ __forceinline__ void compact(float x, int emax) {
+    if constexpr (G::SPLIT_COMPACT) {
+      // the four lanes of a column take one entry each per round (the loop below has every lane walk all four: four
+      // times the LDS instructions): keep flags and write positions come from prefixes over the lanes in row order, so
+      // the kept entries stay in logging order and the "at most emax equal to x, the earliest" rule is unchanged
+      int w = 0, ne = 0;
+      for (int i = 0; __any(i < cnt); i += 4) {
+        const int ii = i + od;
+        const bool valid = ii < cnt;
+        const int ic = min(ii, PEND - 1);
+        const float d = lv[ic * G::COLS + col];
+        const int j = li[ic * G::COLS + col];
+        const bool eq = valid && d == x;
+        int etot, ktot;
+        const int epre = G::prefix(eq ? 1 : 0, od, etot);
+        const bool keep = valid && (d > x || (eq && ne + epre < emax));
+        const int kpre = G::prefix(keep ? 1 : 0, od, ktot);
+        const int wr = keep ? w + kpre : PEND + od;      // w + kpre <= i + od: in place; reads of the round precede its writes
+        lv[wr * G::COLS + col] = d;
+        li[wr * G::COLS + col] = j;
+        w += ktot;
+        ne = min(max(emax, ne), ne + etot);
+      }
+      cnt = done = w;
+      return;
+    }
     int w = 0, ne = 0;
     for (int i = 0; __any(i < cnt); i += 4) {
       float d[4];
