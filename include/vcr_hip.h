@@ -54,6 +54,9 @@ typedef struct {
    * the SURVEY-F7 split, lpdnet_model.py:122; what vcr_linear_f32 computes from feat64).  The launch then runs conv2 and
    * this projection on the matrix pipe; xyz4 / feat64 / sq64 are bit-identical to the plain launch's. */
   const float* pq_w; const float* pq_b; float* pq; int ldpq;
+  /* Optional: a second copy of feat64 in the layout the 16-query kNN waves consume without shuffling (vcr_knn_args.xt):
+   * every group of 16 channels transposed as a 4 x 4 block, feat64t[row][16 g + 4 a + b] = feat64[row][16 g + 4 b + a]. */
+  float* feat64t;
 } vcr_pointwise_args;
 int vcr_pointwise_f32(const vcr_pointwise_args*, vcr_stream_t);
 
@@ -90,6 +93,13 @@ typedef struct {
   int tie_defer;
   void* tie_work; size_t tie_work_bytes;   /* see above: NULL / 0 unless vcr_knn_tie_work_bytes(N) > 0 */
   int tie_inline;                     /* the library's own (set on its copy of the struct; callers' value is ignored) */
+  /* Optional, C == 64: the same rows as x (same ldx) with every group of 16 channels stored as its 4 x 4 transpose,
+   * xt[row][16 g + 4 a + b] = x[row][16 g + 4 b + a] (vcr_pointwise_args.feat64t writes it).  The 16-query-wave kernel
+   * feeds v_mfma_f32_16x16x4_f32 one k per lane row; from x it fetches 16-B chunks and transposes them between lane rows
+   * for every (query wave, candidate tile) -- 14 of a wave's 87 us at N = 1024; from xt the chunks ARE the operands.
+   * Same operands, same k order: the result does not depend on whether xt is given.  x is still required (tie replay,
+   * the 32-query kernel). */
+  const float* xt;
 } vcr_knn_args;
 int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
 size_t vcr_knn_tie_work_bytes(int N);

@@ -90,6 +90,24 @@ def test_pointwise_matches_cpu_rounding_bit_for_bit(nat, W, N):
     ref_pq = (f64.cpu().double().view(-1, 64) @ wpq.cpu().double().t() + bpq.cpu().double())
     assert (pq.cpu().double() - ref_pq).abs().max().item() <= 4e-6 * 8 + 1e-6
     torch.testing.assert_close(pq, nat.linear(f64.view(-1, 64), wpq, bpq), atol=2e-6, rtol=1e-6)
+    # the optional transposed copy (every group of 16 channels as its 4 x 4 transpose: the operand layout of the 16-query
+    # kNN waves) from both launches, and the kNN reading it: same bits, same neighbours
+    ft_a, ft_b = torch.full_like(f64, float("nan")), torch.full_like(f64, float("nan"))
+    nat.pointwise(dev(x), dev(W["emb_nn.conv1_lpd.weight"].view(64, 3)), dev(W["emb_nn.conv1_lpd.bias"]),
+                  dev(W["emb_nn.conv2_lpd.weight"].view(64, 64)), dev(W["emb_nn.conv2_lpd.bias"]), feat_t=ft_a)
+    nat.pointwise(dev(x), dev(W["emb_nn.conv1_lpd.weight"].view(64, 3)), dev(W["emb_nn.conv1_lpd.bias"]),
+                  dev(W["emb_nn.conv2_lpd.weight"].view(64, 64)), dev(W["emb_nn.conv2_lpd.bias"]), wpq, bpq, feat_t=ft_b)
+    want_t = f64.view(4, N, 4, 4, 4).transpose(3, 4).reshape(4, N, 64)
+    assert torch.equal(ft_a, want_t) and torch.equal(ft_b, want_t)
+    if N >= 64:
+        k = 20
+        for waves in (0, 8):
+            plain = nat.knn(f64, sq, k, waves=waves)
+            assert torch.equal(nat.knn(f64, sq, k, waves=waves, xt=ft_a), plain)
+        xyz4c = _.contiguous()
+        i64, i3 = nat.knn_pair(f64, sq, xyz4c, k)
+        j64, j3 = nat.knn_pair(f64, sq, xyz4c, k, xt=ft_a)
+        assert torch.equal(i64, j64) and torch.equal(i3, j3)
 
 
 @pytest.mark.parametrize("N,k", [(256, 20), (1024, 20), (192, 20), (100, 20), (512, 40), (64, 5)])

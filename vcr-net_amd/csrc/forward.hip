@@ -480,6 +480,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     R.mark(pq_fused ? "pointwise:src+tgt+dg1_pq" : "pointwise:src+tgt");
     vcr_pointwise_args a{io->src_cf, B, N, W->c1_w, W->c1_b, W->c2_w, W->c2_b, w.xyz4, w.feat64, w.sq64, io->tgt_cf, B};
     if (pq_fused) { a.pq_w = W->dg1_wpq; a.pq_b = W->dg1_bpq; a.pq = w.pq1; a.ldpq = 256; }
+    a.feat64t = W->E >= 64 ? w.emb : nullptr;                                   // operand layout of the 16-query kNN waves (w.emb is free until conv3)
     R.ok(vcr_pointwise_f32(&a, R.stream));
   }
   // The feature-space and the Cartesian kNN (lpdnet_model.py:113,129) are independent: one launch for both, and one
@@ -489,6 +490,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     vcr_knn_args a3{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
     a64.tie_work = w.tie_work; a3.tie_work = w.tie_work ? w.tie_work + w.tie_work_each : nullptr;
     a64.tie_work_bytes = a3.tie_work_bytes = w.tie_work_each;
+    a64.xt = W->E >= 64 ? w.emb : nullptr;
     R.knn_pair("knn:feat64+xyz", a64, a3);
   }
   if (!pq_fused) R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
@@ -772,7 +774,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 22; }
+extern "C" int vcr_abi_version(void) { return 23; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

@@ -574,7 +574,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
 // k-ascending chain is ((x x' + y y') + z z') - |c|^2 / 2, exactly the fma chain + norm step of the C = 64 case and of the
 // VALU kernel knn3_body (whose (2 dot - |c|^2) - |q|^2 is the same rounding: doubling is exact).  The Cartesian
 // search's distances then cost the idle matrix pipe one instruction per 16 x 16 tile instead of 16 VALU FMAs per wave.
-template <int KS, int W, int C = 64>
+template <int KS, int W, int C = 64, bool XT = false>
 __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b) {
   using G = GeomCol16;
   static_assert(C == 64 || C == 4, "feature rows of 64 floats or xyz4 rows");
@@ -591,6 +591,10 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   float* lv = reinterpret_cast<float*>(smem) + wave * (2 * LROWS * 16);
   Selector<G, KS> sel;
   const float* xb = a.x + (size_t)b * a.N * a.ldx;
+  // (C == 64) rows whose 16-channel groups are stored transposed (vcr_knn_args.xt): lane row q4's chunks 4 g + q4 are its
+  // operands of steps 4 g .. 4 g + 3 as they lie -- same addresses, no shuffles
+  constexpr bool pre = C == 64 && XT;                  // (a compile-time variant: the launcher picks it when a.xt is set)
+  const float* xl = pre ? a.xt + (size_t)b * a.N * a.ldx : xb;
   const float* sqb = C == 64 ? a.sq + (size_t)b * a.N : nullptr;
   const int q = min(q0 + col, a.N - 1);
   // Operand fetch (C == 64).  MFMA step s needs x[row][4 s + q4] in lane row q4: every fourth float of the row.  Fetched as such
@@ -602,7 +606,7 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   // (C == 4: one float per lane -- element q4 of the xyz4 row; raw[0][0] carries it, raw[0][1] the row's |p|^2)
   auto load_raw = [&](int row, f32x4* raw) {
     if constexpr (C == 64) {
-      const float* rp = xb + (size_t)row * a.ldx + 4 * q4;
+      const float* rp = xl + (size_t)row * a.ldx + 4 * q4;
 #pragma unroll
       for (int g = 0; g < 4; ++g) raw[g] = ld4(rp + 16 * g);
     } else {
@@ -626,8 +630,10 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float r0 = raw[g][0], r1 = raw[g][1], r2 = raw[g][2], r3 = raw[g][3];
-      swap16(r0, r1); swap16(r2, r3);
-      swap32(r0, r2); swap32(r1, r3);
+      if constexpr (!pre) {
+        swap16(r0, r1); swap16(r2, r3);
+        swap32(r0, r2); swap32(r1, r3);
+      }
       dst[4 * g] = r0; dst[4 * g + 1] = r1; dst[4 * g + 2] = r2; dst[4 * g + 3] = r3;
     }
   };
@@ -766,11 +772,11 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   finish<G, KS, 1>(sel, a, b, q0 + col, wave, 0, smem, blk_ties);
   if (blk_ties) replay_block_ties(a, blk_ties, smem);
 }
-template <int KS, int W>
+template <int KS, int W, bool XT>
 __global__ __launch_bounds__(64 * W, 4) void knn64c_kernel(vcr_knn_args a) {
   int bx, b;
   xcd_chunk2(bx, b);
-  knn64c_body<KS, W, 64>(a, bx, b);
+  knn64c_body<KS, W, 64, XT>(a, bx, b);
 }
 // the Cartesian search on the same body (distances = one MFMA per tile): the unsplit (S = 1) kernel of C == 4
 template <int KS, int W>
@@ -888,12 +894,12 @@ __global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
 // are independent): the first n64 workgroups run the MFMA kernel's body, the rest the Cartesian one.  Either kernel
 // alone is latency-bound at one wave per SIMD (1024 waves on 1024 SIMDs); launched together the second fills the
 // first one's idle issue slots, and the pair costs little more than the longer of the two.
-template <int KS, bool COL16>
+template <int KS, bool COL16, bool XT = false>
 __global__ __launch_bounds__(256, (COL16 ? 4 : 2)) void knn_pair_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
   const int bid = (int)blockIdx.x;
   if (bid < n64) {
     const int lin = xcd_chunk(bid, n64);
-    if constexpr (COL16) knn64c_body<KS, 4>(a64, lin % gx64, lin / gx64);
+    if constexpr (COL16) knn64c_body<KS, 4, 64, XT>(a64, lin % gx64, lin / gx64);
     else knn64_body<KS, 1, 4>(a64, lin % gx64, lin / gx64);
   } else {
     const int lin = xcd_chunk(bid - n64, (int)gridDim.x - n64);
@@ -1415,7 +1421,8 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
   k64.tie_inline = ties_inline(a64) ? 1 : 0; k3.tie_inline = ties_inline(a3) ? 1 : 0;
   const size_t lds64 = col16 ? knn_lds_bytes(a64, k64.tie_inline != 0) : (size_t)4 * 2 * (pend_of<GeomMfma, 22>() + 1) * 32 * 4;
   const size_t lds3 = knn_lds_bytes(a3, k3.tie_inline != 0), lds = lds64 > lds3 ? lds64 : lds3;
-  int rc = col16 ? launch<knn_pair_kernel<22, true>>(dim3(n64 + n3), dim3(256), lds, s, k64, k3, n64, gx64, gx3)
+  int rc = col16 ? (a64->xt ? launch<knn_pair_kernel<22, true, true>>(dim3(n64 + n3), dim3(256), lds, s, k64, k3, n64, gx64, gx3)
+                            : launch<knn_pair_kernel<22, true>>(dim3(n64 + n3), dim3(256), lds, s, k64, k3, n64, gx64, gx3))
                  : launch<knn_pair_kernel<22, false>>(dim3(n64 + n3), dim3(256), lds, s, k64, k3, n64, gx64, gx3);
   // whatever was not replayed inside the launch: one replay launch, now or (tie_defer) when the caller asks for it
   if (rc == 0 && a64->tie_scratch && !a64->tie_defer) {
@@ -1457,7 +1464,8 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
     const dim3 grid((a->N + 63) / 64, a->B);
     const size_t lds = knn_lds_bytes(a, inl);
-    rc = k20 ? launch<knn64c_kernel<22, 4>>(grid, dim3(256), lds, s, ka) : launch<knn64c_kernel<42, 4>>(grid, dim3(256), lds, s, ka);
+    if (a->xt) rc = k20 ? launch<knn64c_kernel<22, 4, true>>(grid, dim3(256), lds, s, ka) : launch<knn64c_kernel<42, 4, true>>(grid, dim3(256), lds, s, ka);
+    else rc = k20 ? launch<knn64c_kernel<22, 4, false>>(grid, dim3(256), lds, s, ka) : launch<knn64c_kernel<42, 4, false>>(grid, dim3(256), lds, s, ka);
   } else if (a->C == 64) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
     const int S = pick_s((long)((a->N + 31) / 32) * a->B), W = k20 ? 4 : 2;

@@ -88,6 +88,11 @@ __global__ __launch_bounds__(256) void pointwise12_kernel(vcr_pointwise_args a) 
     float* o = a.feat64 + row * 64 + g * 16;
 #pragma unroll
     for (int q = 0; q < 4; ++q) st4(o + q * 4, f32x4{acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]});
+    if (a.feat64t) {                                     // the 4 x 4 transposed copy of this lane's 16 channels (vcr_knn_args.xt)
+      float* ot = a.feat64t + row * 64 + g * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) st4(ot + q * 4, f32x4{acc[q], acc[4 + q], acc[8 + q], acc[12 + q]});
+    }
     if (g == 0) {
       a.sq64[row] = ss;
       st4(a.xyz4 + row * 4, f32x4{x, y, z, (x * x + y * y) + z * z});   // torch.sum order for 3 rows: sequential
@@ -200,6 +205,11 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
         float* o = a.feat64 + row * 64 + g * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) st4(o + q * 4, f32x4{f[q * 4], f[q * 4 + 1], f[q * 4 + 2], f[q * 4 + 3]});
+        if (a.feat64t) {                                 // the 4 x 4 transposed copy of this lane's 16 channels (vcr_knn_args.xt)
+          float* ot = a.feat64t + row * 64 + g * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) st4(ot + q * 4, f32x4{f[q], f[4 + q], f[8 + q], f[12 + q]});
+        }
         if (g == 0) {
           a.sq64[row] = ss;
           st4(a.xyz4 + row * 4, f32x4{x, y, z, (x * x + y * y) + z * z});

@@ -22,14 +22,15 @@ f32p = C.c_void_p  # device pointers travel as integers
 class PointwiseArgs(C.Structure):
     _fields_ = [("x_cf", f32p), ("B", C.c_int), ("N", C.c_int), ("w1", f32p), ("b1", f32p), ("w2", f32p),
                 ("b2", f32p), ("xyz4", f32p), ("feat64", f32p), ("sq64", f32p), ("x_cf2", f32p), ("B2", C.c_int),
-                ("pq_w", f32p), ("pq_b", f32p), ("pq", f32p), ("ldpq", C.c_int)]
+                ("pq_w", f32p), ("pq_b", f32p), ("pq", f32p), ("ldpq", C.c_int), ("feat64t", f32p)]
 
 
 class KnnArgs(C.Structure):
     _fields_ = [("x", f32p), ("ldx", C.c_int), ("sq", f32p), ("B", C.c_int), ("N", C.c_int), ("C", C.c_int),
                 ("k", C.c_int), ("idx", f32p), ("tie_scratch", f32p), ("tie_cap", C.c_int), ("waves", C.c_int),
                 ("tie_zeroed", C.c_int),
-                ("tie_defer", C.c_int), ("tie_work", C.c_void_p), ("tie_work_bytes", C.c_size_t), ("tie_inline", C.c_int)]
+                ("tie_defer", C.c_int), ("tie_work", C.c_void_p), ("tie_work_bytes", C.c_size_t), ("tie_inline", C.c_int),
+                ("xt", f32p)]
 
 
 class LinearArgs(C.Structure):
@@ -215,7 +216,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 22         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 23         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -353,9 +354,10 @@ def _f32(*shape, device):
 
 
 @_guarded
-def pointwise(x_cf, w1, b1, w2, b2, pq_w=None, pq_b=None):
+def pointwise(x_cf, w1, b1, w2, b2, pq_w=None, pq_b=None, feat_t=None):
     """conv1_lpd + conv2_lpd (+ ReLU) -> (xyz4, feat64, sq64); with pq_w [256,64] / pq_b [256] also the P | Q projection
-    of the first EdgeConv from the same (MFMA) launch -> (xyz4, feat64, sq64, pq [B*N,256])."""
+    of the first EdgeConv from the same (MFMA) launch -> (xyz4, feat64, sq64, pq [B*N,256]).  feat_t: a [B,N,64] tensor
+    that receives the copy of feat64 with its 16-channel groups transposed (what knn(..., xt=) reads)."""
     B, _, N = x_cf.shape
     x_cf = x_cf.contiguous()
     xyz4, f64, sq = _f32(B, N, 4, device=x_cf.device), _f32(B, N, 64, device=x_cf.device), _f32(B, N, device=x_cf.device)
@@ -364,12 +366,13 @@ def pointwise(x_cf, w1, b1, w2, b2, pq_w=None, pq_b=None):
     if pq_w is not None:
         pq = _f32(B * N, 256, device=x_cf.device)
         a.pq_w, a.pq_b, a.pq, a.ldpq = ptr(pq_w), ptr(pq_b), ptr(pq), 256
+    a.feat64t = ptr(feat_t)
     call("vcr_pointwise_f32", a)
     return (xyz4, f64, sq) if pq is None else (xyz4, f64, sq, pq)
 
 
 @_guarded
-def knn(x, sq, k, exact_ties=True, waves=0, tie_work=True):
+def knn(x, sq, k, exact_ties=True, waves=0, tie_work=True, xt=None):
     """x [B,N,C] rows (C = 64 with sq [B,N], or C = 4 xyz4 rows) -> int32 idx [B,N,k].  exact_ties: rows whose
     (k+1)-th and (k+2)-th distances are equal get Tensor.topk's (libstdc++'s) pick instead of the lower index."""
     B, N, Cc = x.shape
@@ -381,12 +384,13 @@ def knn(x, sq, k, exact_ties=True, waves=0, tie_work=True):
     need = L.vcr_knn_tie_work_bytes(N) if (exact_ties and tie_work) else 0
     work = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None            # long rows: replay scratch
     a.tie_work, a.tie_work_bytes = ptr(work), need
+    a.xt = ptr(xt)               # the rows with their 16-channel groups transposed (pointwise(..., feat_t=)): same result
     call("vcr_knn_f32", a)
     return idx
 
 
 @_guarded
-def knn_pair(feat, sq, xyz4, k):
+def knn_pair(feat, sq, xyz4, k, xt=None):
     """vcr_knn_pair_f32: the feature-space (feat [B,N,64], sq [B,N]) and the Cartesian (xyz4 [B,N,4]) kNN in one launch
     -> (idx_feat, idx_xyz), tie replay included."""
     L = lib()
@@ -397,6 +401,7 @@ def knn_pair(feat, sq, xyz4, k):
         ties = torch.empty(1 + B * N, dtype=torch.int32, device=x.device)
         args.append(KnnArgs(ptr(x), x.stride(1), ptr(s_), B, N, Cc, k, ptr(idx), ptr(ties), B * N, 0))
         out.append(idx); keep.append(ties)
+    args[0].xt = ptr(xt)
     L.vcr_knn_pair_f32.argtypes = [C.POINTER(KnnArgs), C.POINTER(KnnArgs), C.c_void_p]
     L.vcr_knn_pair_f32.restype = C.c_int
     check(L.vcr_knn_pair_f32(C.byref(args[0]), C.byref(args[1]), C.c_void_p(stream_ptr())), "vcr_knn_pair_f32")

@@ -48,7 +48,7 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
             return 0.0, 4.0 * M2 * (4 + 32)
         g = 2 if site.startswith("src+tgt") else 1         # both clouds in one launch
         if site.endswith("+dg1_pq"):                       # ... with the first EdgeConv's P | Q projection (K = 64, N = 256)
-            return g * 2.0 * M1 * (3 * 64 + 64 * 64 + 64 * 256), g * 4.0 * M1 * (3 + 4 + 64 + 1 + 256)
+            return g * 2.0 * M1 * (3 * 64 + 64 * 64 + 64 * 256), g * 4.0 * M1 * (3 + 4 + 64 + 64 + 1 + 256)        # (+ 64: feat64's transposed copy for the kNN)
         return g * 2.0 * M1 * (3 * 64 + 64 * 64), g * 4.0 * M1 * (3 + 4 + 64 + 1)
     if fam == "knn":
         if site == "feat64+xyz":                           # both searches in one launch
