@@ -119,7 +119,8 @@ struct GeomMfma {                    // 32 query columns, lanes l and l+32 share
     const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
     return which ? r[1] : r[0];
   }
-  __device__ static __forceinline__ int from_prev(int x, int) { return from_seg(x, 0); }   // only segment 1 has a predecessor
+  __device__ static __forceinline__ int from_prev(int x, int, int) { return from_seg(x, 0); }   // only segment 1 has a predecessor
+  __device__ static __forceinline__ int prev_addr(int) { return 0; }
   __device__ static __forceinline__ int col_sum(int x, int sg) { return x + from_seg(x, sg ^ 1); }
 };
 struct GeomCol16 {                   // v_mfma_f32_16x16x4_f32 layout: 16 query columns, lanes c, c+16, c+32, c+48 share one.
@@ -137,11 +138,16 @@ struct GeomCol16 {                   // v_mfma_f32_16x16x4_f32 layout: 16 query 
     const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
     return (q >> 1) ? b[1] : b[0];
   }
-  __device__ static __forceinline__ int from_prev(int x, int sg) {        // segment sg - 1's value (sg == 0: unused)
-    const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-    return sg == 1 ? a[0] : sg == 2 ? b[0] : a[1];     // row 1 <- row 0; row 3 <- row 1; row 2 <- row 3
+  // segment sg - 1's value (sg == 0: unused): row 1 <- row 0; row 3 <- row 1; row 2 <- row 3.  ONE ds_bpermute_b32 on the
+  // otherwise idle LDS crossbar instead of both row swaps, their operand copies and the selects (9 VALU instructions of
+  // the 17 an insertion cost -- the drains are bound by VALU issue, four waves per SIMD cover the longer latency).
+  // (The same exchange for the per-tile / per-compaction-round prefixes was measured and is slower: those chains are
+  // short and wait for the crossbar.)
+  __device__ static __forceinline__ int prev_addr(int lane) {
+    const int q = lane >> 4, pq = q == 1 ? 0 : q == 3 ? 1 : q == 2 ? 3 : 0;
+    return 4 * (16 * pq + (lane & 15));
   }
+  __device__ static __forceinline__ int from_prev(int x, int, int pa) { return __builtin_amdgcn_ds_bpermute(pa, x); }
   __device__ static __forceinline__ int col_sum(int x, int sg) {
     const int q = sg ^ (sg >> 1);
     const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
@@ -172,7 +178,8 @@ struct GeomQuad {                    // 16 queries, one DPP quad each: segment =
     const int c = __builtin_amdgcn_mov_dpp(x, 0xAA, 0xF, 0xF, true), d = __builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true);
     return which == 0 ? a : which == 1 ? b : which == 2 ? c : d;
   }
-  __device__ static __forceinline__ int from_prev(int x, int) { return __builtin_amdgcn_mov_dpp(x, 0x90, 0xF, 0xF, true); }
+  __device__ static __forceinline__ int from_prev(int x, int, int) { return __builtin_amdgcn_mov_dpp(x, 0x90, 0xF, 0xF, true); }
+  __device__ static __forceinline__ int prev_addr(int) { return 0; }
   __device__ static __forceinline__ int col_sum(int x, int) {
     x += __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
     x += __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
@@ -184,6 +191,12 @@ template <class G> __device__ __forceinline__ float gf_from_seg(float x, int whi
 }
 
 // ---- per-query selection state of one wave: sorted top-KS values in registers (T per lane), (value, index) log in LDS
+// v_med3_f32 a, b, (+-inf in an SGPR): see Selector::insert
+__device__ __forceinline__ float med3_inf(float a, float b, float inf) {
+  float r;
+  asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(inf));
+  return r;
+}
 template <class G, int KS>
 struct Selector {
   static constexpr int PEND = pend_of<G, KS>();
@@ -195,21 +208,23 @@ struct Selector {
   int cnt, done;                                         // entries logged / already inserted (same in a query's lanes)
   float thr;                                             // max(thr0, rank KS-1 value): nothing <= thr can be a neighbour
   float thr0;                                            // filter floor taken from a sample of the candidates (see sample_floor)
-  int col, sg, od;
+  int col, sg, od, pa;
 
   __device__ __forceinline__ void init(float* lv_, int* li_, int lane, float floor0 = VCR_NEG_INF) {
-    lv = lv_; li = li_; cnt = 0; done = 0; thr = thr0 = floor0; col = G::col(lane); sg = G::seg(lane); od = G::ord(lane);
+    lv = lv_; li = li_; cnt = 0; done = 0; thr = thr0 = floor0; col = G::col(lane); sg = G::seg(lane); od = G::ord(lane); pa = G::prev_addr(lane);
 #pragma unroll
     for (int t = 0; t < T; ++t) v[t] = VCR_NEG_INF;
   }
   // one value into the query's list, all segments at once (inserting -inf or anything <= the last value is a no-op)
   __device__ __forceinline__ void insert(float d) {
-    const float pb = __int_as_float(G::from_prev(__float_as_int(v[T - 1]), sg));
-    // (v_med3_f32 with an infinite third operand: min / max without the NaN-quieting v_max x,x pairs fminf / fmaxf cost)
-    d = sg ? __builtin_amdgcn_fmed3f(d, pb, VCR_NEG_INF) : d;
+    const float pb = __int_as_float(G::from_prev(__float_as_int(v[T - 1]), sg, pa));
+    // (v_med3_f32 with an infinite third operand: min / max in ONE instruction.  Spelled as inline assembly: hipcc folds
+    // the builtin with an infinite constant back into v_min / v_max plus a NaN-quieting v_max x, x per operand -- four
+    // instructions for the clamp, three for the head of the list)
+    d = sg ? med3_inf(d, pb, VCR_NEG_INF) : d;
 #pragma unroll
     for (int t = T - 1; t >= 1; --t) v[t] = __builtin_amdgcn_fmed3f(v[t - 1], d, v[t]);
-    v[0] = __builtin_amdgcn_fmed3f(v[0], d, __builtin_huge_valf());
+    v[0] = med3_inf(v[0], d, __builtin_huge_valf());
   }
   __device__ __forceinline__ void refresh_thr() {
     const float mine = v[TS];
@@ -329,7 +344,7 @@ struct SampleNet {
   __device__ __forceinline__ void insert(float d) {
 #pragma unroll
     for (int t = R - 1; t >= 1; --t) s[t] = __builtin_amdgcn_fmed3f(s[t - 1], d, s[t]);
-    s[0] = fmaxf(s[0], d);
+    s[0] = med3_inf(s[0], d, __builtin_huge_valf());
   }
 };
 template <class G> __device__ __forceinline__ float col_min(float x, int sg) {   // min over the lanes of a query
