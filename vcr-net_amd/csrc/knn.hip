@@ -221,7 +221,7 @@ struct Selector {
     // (v_med3_f32 with an infinite third operand: min / max in ONE instruction.  Spelled as inline assembly: hipcc folds
     // the builtin with an infinite constant back into v_min / v_max plus a NaN-quieting v_max x, x per operand -- four
     // instructions for the clamp, three for the head of the list)
-    d = sg ? med3_inf(d, pb, VCR_NEG_INF) : d;
+    d = med3_inf(d, sg ? pb : __builtin_huge_valf(), VCR_NEG_INF);       // min(d, predecessor's last); segment 0 has none
 #pragma unroll
     for (int t = T - 1; t >= 1; --t) v[t] = __builtin_amdgcn_fmed3f(v[t - 1], d, v[t]);
     v[0] = med3_inf(v[0], d, __builtin_huge_valf());
