@@ -272,16 +272,19 @@ struct Selector {
         const int ic = min(ii, PEND - 1);
         const float d = lv[ic * G::COLS + col];
         const int j = li[ic * G::COLS + col];
-        const bool eq = valid && d == x;
-        int etot, ktot;
-        const int epre = G::prefix(eq ? 1 : 0, od, etot);
-        const bool keep = valid && (d > x || (eq && ne + epre < emax));
-        const int kpre = G::prefix(keep ? 1 : 0, od, ktot);
+        const bool gt = valid && d > x, eq = valid && d == x;
+        // ONE prefix for both counts (packed: entries above x in the low half, entries equal to x in the high half); of
+        // the equal ones the first `cap` still wanted are kept, so their kept-prefix is min(prefix, cap)
+        int tot;
+        const int pre = G::prefix((gt ? 1 : 0) | (eq ? 0x10000 : 0), od, tot);
+        const int cap = max(emax - ne, 0), epre = pre >> 16, etot = tot >> 16;
+        const bool keep = gt || (eq && epre < cap);
+        const int kpre = (pre & 0xffff) + min(epre, cap);
         const int wr = keep ? w + kpre : PEND + od;      // w + kpre <= i + od: in place; reads of the round precede its writes
         lv[wr * G::COLS + col] = d;
         li[wr * G::COLS + col] = j;
-        w += ktot;
-        ne = min(max(emax, ne), ne + etot);
+        w += (tot & 0xffff) + min(etot, cap);
+        ne += min(etot, cap);
       }
       cnt = done = w;
       return;
