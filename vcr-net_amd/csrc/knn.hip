@@ -208,10 +208,10 @@ struct Selector {
   int cnt, done;                                         // entries logged / already inserted (same in a query's lanes)
   float thr;                                             // max(thr0, rank KS-1 value): nothing <= thr can be a neighbour
   float thr0;                                            // filter floor taken from a sample of the candidates (see sample_floor)
-  int col, sg, od, pa;
+  int col, sg, pa;
 
   __device__ __forceinline__ void init(float* lv_, int* li_, int lane, float floor0 = VCR_NEG_INF) {
-    lv = lv_; li = li_; cnt = 0; done = 0; thr = thr0 = floor0; col = G::col(lane); sg = G::seg(lane); od = G::ord(lane); pa = G::prev_addr(lane);
+    lv = lv_; li = li_; cnt = 0; done = 0; thr = thr0 = floor0; col = G::col(lane); sg = G::seg(lane); pa = G::prev_addr(lane);
 #pragma unroll
     for (int t = 0; t < T; ++t) v[t] = VCR_NEG_INF;
   }
@@ -266,6 +266,7 @@ struct Selector {
       // times the LDS instructions): keep flags and write positions come from prefixes over the lanes in row order, so
       // the kept entries stay in logging order and the "at most emax equal to x, the earliest" rule is unchanged
       int w = 0, ne = 0;
+      const int od = G::ord((int)__lane_id());            // (recomputed here: a register less across the scan)
       for (int i = 0; __any(i < cnt); i += 4) {
         const int ii = i + od;
         const bool valid = ii < cnt;
