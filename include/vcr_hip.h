@@ -112,9 +112,9 @@ int vcr_knn_ties_inline(const vcr_knn_args*);
  * Cartesian and the feature-space kNN of LPDNet -- pay for it once. */
 int vcr_knn_ties_f32(const vcr_knn_args* a, const vcr_knn_args* b, vcr_stream_t);
 /* LPDNet's two independent searches (lpdnet_model.py:113,129) -- a64: C == 64 feature space, a3: C == 4 Cartesian -- as ONE
- * launch when they have the same k <= 20 and the automatic kernel choice (waves == 0): the unsplit kernels side by side
- * at >= 1024 query groups each (the regime of the path), the candidate-split kernels side by side on small grids (a few
- * pairs per call); otherwise exactly the two vcr_knn_f32 calls.  Same results either way. */
+ * launch when they have the same k and the automatic kernel choice (waves == 0): the unsplit kernels side by side
+ * at >= 1024 query groups each (the regime of the path; k <= 40), the candidate-split kernels side by side on small
+ * grids (a few pairs per call; k <= 20); otherwise exactly the two vcr_knn_f32 calls.  Same results either way. */
 int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3, vcr_stream_t);
 
 /* ---- pointwise linear / 1x1 conv: Y = act(X W^T + bias) (+ residual) ----

@@ -52,11 +52,14 @@ struct GeomCol16;
 // 16-query kernels (k <= 20): 72 -- the most that keeps four workgroups per CU (4 x (76 rows x 16 queries x 8 B x 4 waves
 // + the tie list) = 157 KB of the 160): a compaction then frees 35 slots instead of 27.  Measured against 64: the pair
 // launch 151.4 -> 147.7 us at BASELINE configs[1], 147.5 -> 136.7 at N = 768 (configs[2]), 439 -> 432 at N = 2048.
+#ifndef VCR_KNN_PEND_K40
+#define VCR_KNN_PEND_K40 96                              // k = 21 .. 40 (lists of 42)
+#endif
 #ifndef VCR_KNN_PEND_COL16
 #define VCR_KNN_PEND_COL16 72
 #endif
 template <class G, int KS> constexpr int pend_of() {
-  return KS > 22 ? 96 : std::is_same<G, GeomMfma>::value ? VCR_KNN_PEND_MFMA : std::is_same<G, GeomCol16>::value ? VCR_KNN_PEND_COL16 : 64;
+  return KS > 22 ? VCR_KNN_PEND_K40 : std::is_same<G, GeomMfma>::value ? VCR_KNN_PEND_MFMA : std::is_same<G, GeomCol16>::value ? VCR_KNN_PEND_COL16 : 64;
 }
 
 #ifdef VCR_TIMELINE
@@ -1383,7 +1386,7 @@ extern "C" int vcr_knn_ties_inline(const vcr_knn_args* a) {
 extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3, vcr_stream_t stream) {
   if (!a64 || !a3 || !a64->x || !a3->x || !a64->idx || !a3->idx || a64->C != 64 || a3->C != 4) return VCR_EINVAL;
   const bool col16 = use_col16(a64);
-  const bool fusable = a64->k == a3->k && a64->k <= 20 &&
+  const bool fusable = a64->k == a3->k && (a64->k <= 20 || (col16 && a64->k <= 40)) &&      // (k > 20: the 16-query bodies only)
                        (a64->waves == 0 || a64->waves == 1 || a64->waves == 8) && a3->waves == 0 &&
                        (long)((a64->N + (col16 ? 15 : 31)) / (col16 ? 16 : 32)) * a64->B >= 1024 && (long)((a3->N + 15) / 16) * a3->B >= 1024 &&
                        (a64->tie_scratch != nullptr) == (a3->tie_scratch != nullptr) && a64->tie_defer == a3->tie_defer;
@@ -1440,9 +1443,13 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
   k64.tie_inline = ties_inline(a64) ? 1 : 0; k3.tie_inline = ties_inline(a3) ? 1 : 0;
   const size_t lds64 = col16 ? knn_lds_bytes(a64, k64.tie_inline != 0) : (size_t)4 * 2 * (pend_of<GeomMfma, 22>() + 1) * 32 * 4;
   const size_t lds3 = knn_lds_bytes(a3, k3.tie_inline != 0), lds = lds64 > lds3 ? lds64 : lds3;
-  int rc = col16 ? (a64->xt ? launch<knn_pair_kernel<22, true, true>>(dim3(n64 + n3), dim3(256), lds, s, k64, k3, n64, gx64, gx3)
-                            : launch<knn_pair_kernel<22, true>>(dim3(n64 + n3), dim3(256), lds, s, k64, k3, n64, gx64, gx3))
-                 : launch<knn_pair_kernel<22, false>>(dim3(n64 + n3), dim3(256), lds, s, k64, k3, n64, gx64, gx3);
+  const dim3 grid(n64 + n3);
+  int rc;
+  if (!col16) rc = launch<knn_pair_kernel<22, false>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3);
+  else if (a64->k <= 20) rc = a64->xt ? launch<knn_pair_kernel<22, true, true>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3)
+                                      : launch<knn_pair_kernel<22, true>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3);
+  else rc = a64->xt ? launch<knn_pair_kernel<42, true, true>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3)
+                    : launch<knn_pair_kernel<42, true>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3);
   // whatever was not replayed inside the launch: one replay launch, now or (tie_defer) when the caller asks for it
   if (rc == 0 && a64->tie_scratch && !a64->tie_defer) {
     if (!k64.tie_inline && !k3.tie_inline) rc = vcr_knn_ties_f32(a64, a3, stream);
