@@ -684,7 +684,7 @@ def test_linear_with_fused_layernorm(nat):
     assert err3 <= 5e-5, err3
 
 
-@pytest.mark.parametrize("B,N,k", [(32, 1024, 20), (2, 1024, 20), (16, 2048, 20), (4, 777, 9), (4, 1024, 40)])
+@pytest.mark.parametrize("B,N,k", [(32, 1024, 20), (2, 1024, 20), (16, 2048, 20), (4, 777, 9), (4, 1024, 40), (32, 1024, 40), (18, 1500, 33)])
 def test_knn_pair_equals_the_two_launches(nat, B, N, k):
     """vcr_knn_pair_f32 (LPDNet's two searches in one launch; falls back to two launches outside the path's regime):
     the same indices as the self-contained calls, ties included."""
