@@ -111,32 +111,79 @@ __global__ __launch_bounds__(256) void pointwise12_kernel(vcr_pointwise_args a) 
 // per-wave LDS tile [16][64] (ReLU applied), from which (a) four lanes per point read 16 consecutive channels each and run
 // pointwise12_kernel's epilogue unchanged (|feat|^2 in ATen's association, 16-B stores) and (b) the lanes re-read A
 // fragments for the P | Q projection, whose 64 KB of weights lie in LDS in fragment order (one ds_read_b128 per four MFMAs).
+#ifdef VCR_TIMELINE
+// Experiment-only (profiles/timeline_stem.py): waves 0 and 7 of every workgroup accumulate the 100 MHz wall clock per phase.
+__device__ unsigned long long vcr_tl_stem[512 * 8];
+#define STL_DECL unsigned long long stl_t = wall_clock64(), stl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STL(slot) do { const unsigned long long n_ = wall_clock64(); stl_acc[slot] += n_ - stl_t; stl_t = n_; } while (0)
+#define STL_FLUSH do { if ((threadIdx.x == 0 || threadIdx.x == 448) && blockIdx.x < 256) for (int i_ = 0; i_ < 8; ++i_) vcr_tl_stem[(blockIdx.x * 2 + (threadIdx.x != 0)) * 8 + i_] = stl_acc[i_]; } while (0)
+extern "C" int vcr_dbg_timeline_stem(unsigned long long* host_dst, int clear) {
+  if (clear) {
+    static unsigned long long zeros[512 * 8];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(vcr_tl_stem), zeros, sizeof(zeros));
+  }
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(vcr_tl_stem), sizeof(unsigned long long) * 512 * 8);
+}
+#else
+#define STL_DECL ((void)0)
+#define STL(slot) ((void)0)
+#define STL_FLUSH ((void)0)
+#endif
 constexpr int TP = 68;                                   // tile pitch: the 64 lanes' A-fragment reads hit 64 distinct banks
 constexpr int PQW = 8;                                   // waves per workgroup (two per SIMD: one wave's LDS / store phases under the other's MFMAs)
 __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwise_args a, int tiles_per_cloud, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) float pw_smem[];
+  STL_DECL;
   float* wfrag = pw_smem;                                // [16 col tiles][4 step quads][64 lanes][4 steps]: Wpq as B fragments
   float* w1s = wfrag + 16 * 4 * 64 * 4;                  // [64][4] = (w0, w1, w2, b1)
   float* tiles = w1s + 64 * 4;                           // [PQW waves][16][TP]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
-  for (int i = t; i < 256 * 64; i += 64 * PQW) {         // coalesced read of Wpq [256][64], scattered into fragment order
-    const int n = i >> 6, k = i & 63, j = n >> 4, st = k >> 2;
-    wfrag[(((j * 4 + (st >> 2)) * 64) + (k & 3) * 16 + (n & 15)) * 4 + (st & 3)] = a.pq_w[i];
-  }
+  // The prologue is a third of this launch (every wave runs ONE tile at the path's sizes): all its loads are issued
+  // back to back as 16-B requests -- conv2's B fragments first, then this thread's eight chunks of Wpq -- and only then
+  // consumed (the first version loaded Wpq dword by dword with an LDS write behind every load, and w2 as 64 strided
+  // dwords per lane: 15 us before the first MFMA).
+  f32x4 w2c[4][4];                                       // w2[16 j + l15][16 g + 4 q4 .. + 3]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w2c[j][g] = ld4(a.w2 + (16 * j + l15) * 64 + 16 * g + 4 * q4);
+  float b2r[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b2r[j] = a.b2[16 * j + l15];
+  f32x4 wq[8];                                           // Wpq [256][64] as 4096 chunks of 16 B: chunks t, t + 512, ...
+#pragma unroll
+  for (int it = 0; it < 8; ++it) wq[it] = ld4(a.pq_w + 4 * (t + 64 * PQW * it));
   if (t < 64) {
     w1s[t * 4 + 0] = a.w1[t * 3 + 0]; w1s[t * 4 + 1] = a.w1[t * 3 + 1]; w1s[t * 4 + 2] = a.w1[t * 3 + 2];
     w1s[t * 4 + 3] = a.b1[t];
   }
-  float w2r[4][16];                                      // conv2 B fragments: w2[16 j + l15][4 s + q4]
+  // conv2 B fragments w2[16 j + l15][4 s + q4]: the 4 x 4 transpose between lane rows and chunk components that the kNN
+  // kernel describes (v_permlane16_swap on (0,1) (2,3), v_permlane32_swap on (0,2) (1,3))
+  float w2r[4][16];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int st = 0; st < 16; ++st) w2r[j][st] = a.w2[(16 * j + l15) * 64 + 4 * st + q4];
-  float b2r[4];
+    for (int g = 0; g < 4; ++g) {
+      int r0 = __float_as_int(w2c[j][g][0]), r1 = __float_as_int(w2c[j][g][1]);
+      int r2 = __float_as_int(w2c[j][g][2]), r3 = __float_as_int(w2c[j][g][3]);
+      auto s01 = __builtin_amdgcn_permlane16_swap(r0, r1, false, false); r0 = s01[0]; r1 = s01[1];
+      auto s23 = __builtin_amdgcn_permlane16_swap(r2, r3, false, false); r2 = s23[0]; r3 = s23[1];
+      auto s02 = __builtin_amdgcn_permlane32_swap(r0, r2, false, false); r0 = s02[0]; r2 = s02[1];
+      auto s13 = __builtin_amdgcn_permlane32_swap(r1, r3, false, false); r1 = s13[0]; r3 = s13[1];
+      w2r[j][4 * g] = __int_as_float(r0); w2r[j][4 * g + 1] = __int_as_float(r1);
+      w2r[j][4 * g + 2] = __int_as_float(r2); w2r[j][4 * g + 3] = __int_as_float(r3);
+    }
+  // Wpq into fragment order: chunk c holds Wpq[n = c / 16][k = 4 (c % 16) .. + 3], i.e. MFMA step st = c % 16, lane rows 0..3
 #pragma unroll
-  for (int j = 0; j < 4; ++j) b2r[j] = a.b2[16 * j + l15];
+  for (int it = 0; it < 8; ++it) {
+    const int c = t + 64 * PQW * it, n = c >> 4, st = c & 15, j = n >> 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wfrag[(((j * 4 + (st >> 2)) * 64) + e * 16 + (n & 15)) * 4 + (st & 3)] = wq[it][e];
+  }
+  STL(0);                                                // weight loads issued
   __syncthreads();
+  STL(1);                                                // ... arrived, LDS filled
   float* T = tiles + wave * 16 * TP;
   const int p = lane >> 2, g = lane & 3;                 // epilogue mapping: four lanes per point, 16 channels each
   for (int tile = (int)blockIdx.x * PQW + wave; tile < total_tiles; tile += (int)gridDim.x * PQW) {
@@ -152,6 +199,7 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
         h[st] = fmaxf(fmaf(w[2], z, fmaf(w[1], y, fmaf(w[0], x, w[3]))), 0.f);
       }
     }
+    STL(2);                                              // x loads + conv1
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{b2r[j], b2r[j], b2r[j], b2r[j]};   // bias first
@@ -165,6 +213,7 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
       for (int r = 0; r < 4; ++r) T[(4 * q4 + r) * TP + 16 * j + l15] = fmaxf(acc[j][r], 0.f);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    STL(3);                                              // conv2 MFMAs + tile to LDS
     // ---- pointwise12_kernel's epilogue on the tile: point p of the tile, channels 16 g .. 16 g + 15
     {
       const int n = n0 + p;
@@ -216,6 +265,7 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
         }
       }
     }
+    STL(4);                                              // feature epilogue (stores issued)
     // ---- P | Q = feat64 Wpq^T + bpq for the tile's 16 points (bias first, k ascending)
     float af[16];
 #pragma unroll
@@ -244,9 +294,15 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
           if (n < a.N) a.pq[((size_t)b * a.N + n) * a.ldpq + 16 * (4 * jg + jj) + l15] = pa[jj][r];
         }
     }
+    STL(5);                                              // P | Q MFMAs + stores issued
     __builtin_amdgcn_s_waitcnt(0xc07f);                  // the tile is rewritten by the next iteration
     __builtin_amdgcn_wave_barrier();
+#ifdef VCR_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0);                       // (timeline builds: the stores' acknowledgement is a phase of its own)
+#endif
+    STL(6);
   }
+  STL_FLUSH;
 }
 
 // [B,3,N] channels-first points -> [B,N,4] rows (x, y, z, |p|^2): the layout the kNN / ICP kernels read.
