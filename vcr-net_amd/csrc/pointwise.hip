@@ -136,7 +136,8 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
   STL_DECL;
   float* wfrag = pw_smem;                                // [16 col tiles][4 step quads][64 lanes][4 steps]: Wpq as B fragments
   float* w1s = wfrag + 16 * 4 * 64 * 4;                  // [64][4] = (w0, w1, w2, b1)
-  float* tiles = w1s + 64 * 4;                           // [PQW waves][16][TP]
+  float* pqb = w1s + 64 * 4;                             // [256] P | Q bias (an LDS read per accumulator instead of an L2 round trip)
+  float* tiles = pqb + 256;                              // [PQW waves][16][TP]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int q4 = lane >> 4, l15 = lane & 15;
   // The prologue is a third of this launch (every wave runs ONE tile at the path's sizes): all its loads are issued
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
   f32x4 wq[8];                                           // Wpq [256][64] as 4096 chunks of 16 B: chunks t, t + 512, ...
 #pragma unroll
   for (int it = 0; it < 8; ++it) wq[it] = ld4(a.pq_w + 4 * (t + 64 * PQW * it));
+  if (t >= 256) pqb[t - 256] = a.pq_b[t - 256];
   if (t < 64) {
     w1s[t * 4 + 0] = a.w1[t * 3 + 0]; w1s[t * 4 + 1] = a.w1[t * 3 + 1]; w1s[t * 4 + 2] = a.w1[t * 3 + 2];
     w1s[t * 4 + 3] = a.b1[t];
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
       f32x4 pa[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
-        const float bq = a.pq_b[16 * (4 * jg + jj) + l15];
+        const float bq = pqb[16 * (4 * jg + jj) + l15];
         pa[jj] = f32x4{bq, bq, bq, bq};
       }
 #pragma unroll
@@ -362,7 +364,7 @@ extern "C" int vcr_pointwise_f32(const vcr_pointwise_args* a, vcr_stream_t strea
     if (!a->pq_w || !a->pq_b || a->ldpq < 256 || (a->ldpq & 3)) return VCR_EINVAL;
     const int tpc = (a->N + 15) / 16, total = tpc * (a->B + a->B2);
     const int cus = vcr_cu_count(), blocks = (total + PQW - 1) / PQW < cus ? (total + PQW - 1) / PQW : cus;
-    const size_t lds = (size_t)(16 * 4 * 64 * 4 + 64 * 4 + PQW * 16 * TP) * sizeof(float);
+    const size_t lds = (size_t)(16 * 4 * 64 * 4 + 64 * 4 + 256 + PQW * 16 * TP) * sizeof(float);
     VCR_DYN_LDS(pointwise12_pq_kernel, lds);
     hipLaunchKernelGGL(pointwise12_pq_kernel, dim3(blocks), dim3(64 * PQW), lds, (hipStream_t)stream, *a, tpc, total);
     return VCR_LAUNCH_RC();
