@@ -216,8 +216,10 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     STL(3);                                              // conv2 MFMAs + tile to LDS
-    // ---- pointwise12_kernel's epilogue on the tile: point p of the tile, channels 16 g .. 16 g + 15
-    {
+    // The two waves of a SIMD (w, w + 4) take the two halves of the tile's work in opposite order -- the feature epilogue
+    // (LDS reads, global stores) and the P | Q product (256 MFMAs) -- so that one wave's MFMAs run under the other's stores
+    // instead of all eight waves queueing for the matrix pipe at once.  Both halves only read the tile.
+    auto feature_epilogue = [&]() {
       const int n = n0 + p;
       const bool live = n < a.N;
       const int nc = live ? n : a.N - 1;
@@ -266,8 +268,8 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
           st4(a.xyz4 + row * 4, f32x4{x, y, z, (x * x + y * y) + z * z});
         }
       }
-    }
-    STL(4);                                              // feature epilogue (stores issued)
+    };
+    auto pq_product = [&]() {
     // ---- P | Q = feat64 Wpq^T + bpq for the tile's 16 points (bias first, k ascending)
     float af[16];
 #pragma unroll
@@ -296,6 +298,9 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
           if (n < a.N) a.pq[((size_t)b * a.N + n) * a.ldpq + 16 * (4 * jg + jj) + l15] = pa[jj][r];
         }
     }
+    };
+    if (wave < PQW / 2) { feature_epilogue(); STL(4); pq_product(); }
+    else { pq_product(); STL(4); feature_epilogue(); }
     STL(5);                                              // P | Q MFMAs + stores issued
     __builtin_amdgcn_s_waitcnt(0xc07f);                  // the tile is rewritten by the next iteration
     __builtin_amdgcn_wave_barrier();
