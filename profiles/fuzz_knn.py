@@ -1,5 +1,3 @@
-"""kNN kernels against each other on random and tie-heavy shapes: 16-query waves (waves=8) vs 32-query waves (waves=1), the
-Cartesian kernel with and without a candidate split, the one-launch pair vs the single launches.  python profiles/fuzz_knn.py <seed> <trials>"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -39,7 +37,12 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     d3 = int((c != e).any(-1).sum()) if not tie else 0          # (duplicate points: rank 0 ambiguous)
     p64, p3 = nat.knn_pair(f, sq, x4, k)
     dp = int(((np.sort(p64.cpu().numpy(), -1) != a).any(-1) & ok).sum()) + (int((np.sort(p3.cpu().numpy(), -1) != c).any(-1).sum()) if not tie else 0)
-    flag = "" if d64 == 0 and d3 == 0 and dp == 0 else "   <<<<<< MISMATCH"
+    # the pre-transposed operand rows (vcr_knn_args.xt): bit-for-bit the result of the plain rows, single and pair
+    ft = f.view(B, N, 4, 4, 4).transpose(3, 4).reshape(B, N, 64).contiguous()
+    dx = int((nat.knn(f, sq, k, waves=8, xt=ft) != nat.knn(f, sq, k, waves=8)).any(-1).sum().item())
+    q64, q3 = nat.knn_pair(f, sq, x4, k, xt=ft)
+    dx += int((q64 != p64).any(-1).sum().item()) + int((q3 != p3).any(-1).sum().item())
+    flag = "" if d64 == 0 and d3 == 0 and dp == 0 and dx == 0 else "   <<<<<< MISMATCH"
     bad += bool(flag)
-    print(f"B={B:3d} N={N:5d} k={k:2d} tie={int(tie)}: feat64 16q-vs-32q rows differing {d64}, xyz {d3}, pair-vs-single {dp}{flag}", flush=True)
+    print(f"B={B:3d} N={N:5d} k={k:2d} tie={int(tie)}: feat64 16q-vs-32q rows differing {d64}, xyz {d3}, pair-vs-single {dp}, xt-vs-plain {dx}{flag}", flush=True)
 print("mismatching trials:", bad, "elapsed", round(time.time() - t0, 1))
