@@ -525,7 +525,7 @@ double launch_cost(long tiles, int slots, int rows) {
 // validation + kernel choice of one linear (shared by vcr_linear_f32 and vcr_linear_pair_f32)
 // (bm_override: 0 = decide here, else the tile rows a paired launch decided for both of its halves; 64 / 32 also mean the
 //  small-grid configuration BK 32 + 16x16x4)
-int linear_plan(const vcr_linear_args* a, LinearPlan* pl, int bm_override = 0) {
+int linear_plan(const vcr_linear_args* a, LinearPlan* pl, int bm_override = 0, bool in_pair = false) {
   if (!a || !a->x || !a->w || (!a->y && !a->segmax_out)) return VCR_EINVAL;
   if (a->segmax_out && (a->seg_k <= 0 || !a->relu || a->residual || a->ln_stats_in || a->stats_out || (a->ld_segmax & 3) ||
                         a->ld_segmax < a->N || ((uintptr_t)a->segmax_out & 15) || (a->variant & 4)))
@@ -556,7 +556,13 @@ int linear_plan(const vcr_linear_args* a, LinearPlan* pl, int bm_override = 0) {
   // MFMA shape: bit 4 (16) forces 16x16x4, bit 10 (1024) forces 32x32x2.  Automatic: 16x16x4 for the launches with a
   // residual (the BK 32 kernels: measured in the pipeline at BASELINE configs[1], wo 155 -> 151 us, ffn2 276 -> 266 us),
   // 32x32x2 for the BK 16 kernels (qkv / ffn1 / kv / q / conv3: equal within 1 %); DESIGN.md 5.1.
-  pl->bk16 = (!a->residual || (variant & 64)) && !(variant & 8);
+  // ... except a launch of its own whose grid is at most ONE round of the BK 16 kernel's 1024 slots (conv3 at BASELINE
+  // configs[1]: 1024 tiles): every workgroup then stores its tile at the same time with no k loop left to run under the
+  // stores; two rounds of the BK 32 kernel's 512 slots drift apart instead.  Measured inside the forward on one box
+  // (profiles/r3r_ab_conv3_bk32.txt): conv3 0.148 -> 0.1425 ms.  K >= 512 only (sn1_pq, K = 128: 0.047 -> 0.049 with BK 32).
+  const bool one_round16 = !in_pair && variant == 0 && a->M >= 16384 && a->K >= 512 &&
+                           (long)((a->M + 127) / 128) * pl->tiles_n <= 1024;
+  pl->bk16 = ((!a->residual && !one_round16) || (variant & 64)) && !(variant & 8);
   pl->ms16 = (variant & 16) ? true : (variant & 1024) ? false : (VCR_LINEAR_MS_DEFAULT == 16 || (VCR_LINEAR_MS_DEFAULT == 0 && !pl->bk16));
   // Tile rows: bit 11 (2048) forces 96, bit 12 (4096) forces 128.  Automatic: 96 when the launch cost model above
   // prefers it by > 2 %, on the BK 32 kernels only (two workgroups per CU; measured at BASELINE configs[2], M = 36 864:
@@ -655,8 +661,8 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
 // LayerNorm-in, statistics-out; neither with a fused max); otherwise exactly the two vcr_linear_f32 calls.  Same results.
 extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_args* b, vcr_stream_t stream) {
   LinearPlan pa{}, pb{};
-  int rc = linear_plan(a, &pa);
-  if (rc == VCR_OK) rc = linear_plan(b, &pb);
+  int rc = linear_plan(a, &pa, 0, true);
+  if (rc == VCR_OK) rc = linear_plan(b, &pb, 0, true);
   if (rc != VCR_OK) return rc;
   int joint = 0;                                         // tile rows from the COMBINED grid (the two halves share the rounds)
   if (pa.small_free && pb.small_free && pa.t128 + pb.t128 < 512) {     // a small grid even together
@@ -674,8 +680,8 @@ extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_ar
     }
   }
   if (joint) {
-    linear_plan(a, &pa, joint);
-    linear_plan(b, &pb, joint);
+    linear_plan(a, &pa, joint, true);
+    linear_plan(b, &pb, joint, true);
   }
   const bool same = pa.glds && pb.glds && pa.bk16 == pb.bk16 && pa.ms16 == pb.ms16 && pa.bm == pb.bm && pa.ln_in == pb.ln_in &&
                     pa.st_out == pb.st_out &&
