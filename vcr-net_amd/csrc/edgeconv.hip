@@ -264,6 +264,63 @@ __global__ __launch_bounds__(256) void gathermax_kernel(vcr_gathermax_args p) {
   st4(p.y + (size_t)pt * p.ldy + c, y);
 }
 
+// The same result with the gathers served by LDS instead of L2: a workgroup owns one cloud and a slice of CS channels,
+// stages the slice of all the cloud's P rows ([N][CS], pitch CS + 4 floats: 16-B aligned, rows spread over the banks) with
+// coalesced 16-B loads, and every point then picks its k neighbour rows out of LDS (CS / 4 lanes per point, one
+// ds_read_b128 per neighbour).  gathermax_kernel moves N k C floats through L2 per cloud (655 MB per step at BASELINE
+// configs[1], 19 TB/s: the launch is bound by exactly that); here L2 / HBM see every P row once, and the chip's LDS
+// delivers ~4x the L2's gather rate.  Max is exact, so the result is bit-identical.
+// (KQ = k / 4 index quads per point, read as 16-B loads one point AHEAD of the gathers that use them: the loop is a chain
+// of L2 round trips otherwise)
+template <int CS, int KQ>
+__global__ __launch_bounds__(512, 1) void gathermax_lds_kernel(vcr_gathermax_args p, int slices) {
+  constexpr int PITCH = CS + 4, LPP = CS / 4;            // floats per staged row; lanes per point
+  extern __shared__ __attribute__((aligned(16))) float gm_smem[];
+  const int t = threadIdx.x;
+  const int cloud = (int)blockIdx.x / slices, sl = (int)blockIdx.x - cloud * slices;
+  const int N = p.n_per_cloud, c0 = sl * CS;
+  const size_t base = (size_t)cloud * N;
+  const int sub = t % LPP, c4 = 4 * sub;
+  if (c0 + c4 >= p.C) {                                  // (C not a multiple of CS: the lanes beyond it only attend the barrier)
+    __syncthreads();
+    return;
+  }
+  for (int n = t / LPP; n < N; n += 512 / LPP)
+    st4(&gm_smem[n * PITCH + c4], ld4(p.pq + (base + n) * p.ldpq + c0 + c4));
+  __syncthreads();
+  using i32x4 = __attribute__((ext_vector_type(4))) int;
+  i32x4 idn[KQ];
+  f32x4 qn;
+  auto fetch = [&](int n) {
+    const i32x4* id = reinterpret_cast<const i32x4*>(p.idx + (base + n) * (4 * KQ));
+#pragma unroll
+    for (int u = 0; u < KQ; ++u) idn[u] = id[u];
+    qn = ld4(p.pq + (base + n) * p.ldpq + p.C + c0 + c4);
+  };
+  int n = t / LPP;
+  if (n < N) fetch(n);
+  for (; n < N; n += 512 / LPP) {
+    i32x4 idc[KQ];
+#pragma unroll
+    for (int u = 0; u < KQ; ++u) idc[u] = idn[u];
+    const f32x4 q = qn;
+    if (n + 512 / LPP < N) fetch(n + 512 / LPP);
+    f32x4 m = ld4(&gm_smem[idc[0][0] * PITCH + c4]);
+#pragma unroll
+    for (int u = 0; u < KQ; ++u)
+#pragma unroll
+      for (int e = (u == 0 ? 1 : 0); e < 4; ++e) {
+        const f32x4 a0 = ld4(&gm_smem[idc[u][e] * PITCH + c4]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], a0[i]);
+      }
+    f32x4 y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = fmaxf(m[i] + q[i], 0.f);
+    st4(p.y + (base + n) * p.ldy + c0 + c4, y);
+  }
+}
+
 // Per-edge feature rows for EdgeConv CHAINS (DGCNN, model/vcrnet_model.py:104-118): conv2..conv4 act on the
 // post-ReLU per-edge tensor, so every layer is a true N*k GEMM (vcr_linear_f32 over [M*k, C] edge rows) and
 // only the first conv enjoys the F7 split.  h[(i,j)] = relu(P[nbr_ij] + Q[i]).
@@ -372,6 +429,27 @@ extern "C" int vcr_gathermax_f32(const vcr_gathermax_args* a, vcr_stream_t strea
   if (!a || !a->pq || !a->idx || !a->y) return VCR_EINVAL;
   if (a->M <= 0 || a->k <= 0 || a->C <= 0 || a->C > 256 || (a->C & 3)) return VCR_EINVAL;
   if (a->n_per_cloud <= 0 || (a->M % a->n_per_cloud) || a->ldpq < 2 * a->C || (a->ldpq & 3) || (a->ldy & 3)) return VCR_EINVAL;
+  // LDS-staged gathers when a 32-channel slice of one cloud's P rows fits a workgroup's LDS (N <= 1066), the grid fills
+  // most of the chip (one workgroup per CU: >= 192 of them) and the 16-B accesses are aligned.  Measured on MI355X
+  // (profiles/experiments/bench_gathermax.py): 32 clouds x 1024, k = 20, C = 256: 35.4 -> 23.0 us; 48 x 768: 39.5 -> 31.6;
+  // 4 clouds x 1024 x 128 channels (16 workgroups): 11.1 -> 14.9, and 8-channel slices at N = 2048: 69 -> 121 -- those
+  // keep the L2 gathers.
+  const int N = a->n_per_cloud;
+  const bool aligned = !(((uintptr_t)a->pq | (uintptr_t)a->y | (uintptr_t)a->idx) & 15) && (a->k == 20 || a->k == 40);
+  const size_t budget = 150 * 1024;
+  int cs = aligned && (size_t)N * 36 * 4 <= budget && (long)(a->M / N) * ((a->C + 31) / 32) >= 192 ? 32 : 0;
+  if (const char* e = getenv("VCR_GATHERMAX")) cs = (e[0] == 'l' && e[1] == 'd') ? (aligned && (size_t)N * 36 * 4 <= budget ? 32 : 0) : 0;   // "lds" / "l2": benchmarks
+  if (cs) {
+    const int slices = (a->C + cs - 1) / cs, clouds = a->M / N;
+    const size_t lds = (size_t)N * (cs + 4) * 4;
+    const dim3 grid(clouds * slices);
+#define VCR_GM(CS_, KQ_) do { VCR_DYN_LDS((gathermax_lds_kernel<CS_, KQ_>), lds); \
+      hipLaunchKernelGGL((gathermax_lds_kernel<CS_, KQ_>), grid, dim3(512), lds, (hipStream_t)stream, *a, slices); } while (0)
+    if (a->k == 20) { if (cs == 32) VCR_GM(32, 5); else if (cs == 16) VCR_GM(16, 5); else VCR_GM(8, 5); }
+    else { if (cs == 32) VCR_GM(32, 10); else if (cs == 16) VCR_GM(16, 10); else VCR_GM(8, 10); }
+#undef VCR_GM
+    return VCR_LAUNCH_RC();
+  }
   hipLaunchKernelGGL(gathermax_kernel, dim3((a->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
   return VCR_LAUNCH_RC();
 }
