@@ -418,7 +418,8 @@ def run_rank(a):
         roof["avg_launch_ms"] = fam_ms[dom] / max(1, roof["launches_per_step"] * nt)
         roof["timed_with"] = f"HIP events on {nt} of the {a.steps} steps of the last timed block"
         # gbs = HBM-compulsory bytes (each distinct row once) over the launch time; l2_gather_gbs = the k-fold
-        # neighbour re-reads the EdgeConv kernels pull through L2 (not HBM traffic: never priced against 8 TB/s)
+        # neighbour re-reads the EdgeConv kernels pull through L2 -- or, gathermax at the path's sizes, out of LDS -- (not
+        # HBM traffic: never priced against 8 TB/s)
         stages = {f: {"ms_per_step": fam_ms[f] / nt, "share": fam_ms[f] / total_ms,
                       "tflops": fam_flops[f] / (fam_ms[f] * 1e-3) / 1e12, "gbs": fam_bytes[f] / (fam_ms[f] * 1e-3) / 1e9,
                       **({"l2_gather_gbs": fam_gather[f] / (fam_ms[f] * 1e-3) / 1e9} if fam_gather[f] else {})}
@@ -444,7 +445,7 @@ def run_rank(a):
             for n, r in sorted(rows.items(), key=lambda kv: -kv[1][0]):
                 ms = r[0] / r[3]
                 print(f"{n:28s} {ms:8.3f} ms  {r[1] / ms / 1e9:8.2f} TF/s  {r[2] / ms / 1e6:9.1f} GB/s"
-                      + (f"  (+{r[4] / ms / 1e6:8.1f} GB/s L2 gathers)" if r[4] else ""), file=sys.stderr)
+                      + (f"  (+{r[4] / ms / 1e6:8.1f} GB/s neighbour gathers, L2 / LDS)" if r[4] else ""), file=sys.stderr)
         pairs = B * world * a.steps
         line = {
             "metric": "point-cloud pairs/sec (N=%d, batch %d per GPU)" % (Nfull, B) if not a.strong else
