@@ -223,6 +223,9 @@ typedef struct {
   const float* pq; int ldpq; int C; const int32_t* idx; int k; int M; int n_per_cloud;
   float* y; int ldy;
 } vcr_gathermax_args;
+/* (k = 20 / 40, n_per_cloud <= 1066, >= 192 (cloud, 32-channel slice) workgroups, 16-B aligned pq / y / idx: the neighbour
+ * rows are gathered out of LDS -- a workgroup stages its slice of one cloud's P rows once -- instead of through L2;
+ * same bits.  Environment VCR_GATHERMAX = lds | l2 forces one or the other: benchmarks.) */
 int vcr_gathermax_f32(const vcr_gathermax_args*, vcr_stream_t);
 
 /* ---- EdgeConv chains (DGCNN, vcrnet_model.py:104-118): per-edge rows h[(i,j)] = relu(P[nbr_ij] + Q[i])

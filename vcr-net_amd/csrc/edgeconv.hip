@@ -438,7 +438,8 @@ extern "C" int vcr_gathermax_f32(const vcr_gathermax_args* a, vcr_stream_t strea
   const bool aligned = !(((uintptr_t)a->pq | (uintptr_t)a->y | (uintptr_t)a->idx) & 15) && (a->k == 20 || a->k == 40);
   const size_t budget = 150 * 1024;
   int cs = aligned && (size_t)N * 36 * 4 <= budget && (long)(a->M / N) * ((a->C + 31) / 32) >= 192 ? 32 : 0;
-  if (const char* e = getenv("VCR_GATHERMAX")) cs = (e[0] == 'l' && e[1] == 'd') ? (aligned && (size_t)N * 36 * 4 <= budget ? 32 : 0) : 0;   // "lds" / "l2": benchmarks
+  static const char* const e = getenv("VCR_GATHERMAX");   // (read once)
+  if (e) cs = (e[0] == 'l' && e[1] == 'd') ? (aligned && (size_t)N * 36 * 4 <= budget ? 32 : 0) : 0;   // "lds" / "l2": benchmarks
   if (cs) {
     const int slices = (a->C + cs - 1) / cs, clouds = a->M / N;
     const size_t lds = (size_t)N * (cs + 4) * 4;
