@@ -413,6 +413,25 @@ def test_edgeconv_and_gathermax(nat, W, N, k):
     torch.testing.assert_close(gx3.cpu().view(B, N, 256), x3.transpose(1, 2), atol=3e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,N,k,C", [(32, 1024, 20, 256), (48, 768, 20, 256), (24, 1000, 40, 256), (64, 333, 20, 96),
+                                     (200, 64, 20, 32), (32, 1066, 20, 256), (32, 1067, 20, 256), (4, 1024, 20, 256)])
+def test_gathermax_lds_and_l2_paths_are_exact(nat, B, N, k, C):
+    """vcr_gathermax_f32 picks the LDS-staged kernel on large grids of clouds of <= 1066 points (k = 20 / 40) and the L2
+    gathers otherwise (the last two shapes): y = relu(max_j P[nbr_j] + Q) either way, to the bit (a max is exact, the add
+    and the ReLU are the same two fp32 operations as in torch)."""
+    g = torch.Generator().manual_seed(B * N + k)
+    pq = dev(torch.randn(B * N, 2 * C, generator=g))
+    idx = dev(torch.randint(0, N, (B * N, k), generator=g, dtype=torch.int32))
+    y = nat.gathermax(pq, C, idx, N)
+    P, Q = pq[:, :C].view(B, N, C), pq[:, C:].view(B, N, C)
+    gathered = torch.gather(P.unsqueeze(1).expand(B, N, N, C), 2,
+                            idx.view(B, N, k, 1).long().expand(B, N, k, C)) if B * N * N * C < 2 ** 27 else None
+    if gathered is None:
+        gathered = torch.stack([P[b][idx.view(B, N, k)[b].long()] for b in range(B)])
+    ref = torch.relu(gathered.max(2).values + Q).view(B * N, C)
+    assert torch.equal(y, ref)
+
+
 @pytest.mark.parametrize("B,N,k", [(2, 300, 20), (3, 101, 20), (2, 130, 40), (16, 1024, 20), (1, 203, 7)])
 def test_edgeconv_bf16x3(nat, B, N, k):
     """vcr_edgeconv_bf16x3_f32 (convDG2 as exact 3-way bf16 splits on the bf16 matrix pipe): x1 -- a max over the same
