@@ -1,5 +1,8 @@
+"""Record of the convSN1-as-one-launch experiment (graphconv_lds_kernel.hip in this directory): needs that kernel dropped
+into edgeconv.hip with its vcr_graphconv_f32 entry point and a native.graphconv() ctypes wrapper; not runnable against the
+shipped library."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import vcrnet_amd  # noqa
 from vcrnet_amd import native
 g = torch.Generator().manual_seed(0)
