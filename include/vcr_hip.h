@@ -45,7 +45,7 @@ int vcr_abi_version(void);   /* bumped on any signature change */
 typedef struct {
   const float* x_cf; int B, N;
   const float* w1; const float* b1;   /* [64,3], [64]  */
-  const float* w2; const float* b2;   /* [64,64], [64] */
+  const float* w2; const float* b2;   /* [64,64] (16-B aligned, like pq_w below), [64] */
   float* xyz4; float* feat64; float* sq64;
   const float* x_cf2; int B2;         /* optional second block of B2 clouds (same N) processed by the same launch; its rows
                                          follow the first block's in xyz4 / feat64 / sq64 (the forward: src, then tgt) */

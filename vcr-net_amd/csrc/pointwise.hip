@@ -13,7 +13,17 @@ __global__ __launch_bounds__(256) void pointwise12_kernel(vcr_pointwise_args a) 
   __shared__ float w1s[64][4];        // (w0,w1,w2,b1)
   __shared__ float b2s[64];
   const int t = threadIdx.x;
-  for (int i = t; i < 64 * 64; i += 256) w2t[i & 63][i >> 6] = a.w2[i];   // w2[c][k] -> [k][c]
+  {                                                     // w2[c][k] -> [k][c]: four 16-B loads per thread, all issued before any is consumed
+    f32x4 wv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wv[u] = ld4(a.w2 + 4 * (t + 256 * u));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = 4 * (t + 256 * u), c = i >> 6, k = i & 63;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w2t[k + e][c] = wv[u][e];
+    }
+  }
   if (t < 64) {
     w1s[t][0] = a.w1[t * 3 + 0]; w1s[t][1] = a.w1[t * 3 + 1]; w1s[t][2] = a.w1[t * 3 + 2];
     w1s[t][3] = a.b1[t]; b2s[t] = a.b2[t];
@@ -364,6 +374,7 @@ extern "C" int vcr_rows4_f32(const float* x_cf, float* xyz4, int B, int N, vcr_s
 
 extern "C" int vcr_pointwise_f32(const vcr_pointwise_args* a, vcr_stream_t stream) {
   if (!a || !a->x_cf || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->xyz4 || !a->feat64 || !a->sq64) return VCR_EINVAL;
+  if (((uintptr_t)a->w2 | (uintptr_t)a->pq_w) & 15) return VCR_EINVAL;   // the weights are fetched as 16-B chunks
   if (a->B <= 0 || a->N <= 0 || a->B2 < 0 || (a->B2 > 0 && !a->x_cf2)) return VCR_EINVAL;
   if (a->pq) {                                           // fused with the P | Q projection: the MFMA kernel
     if (!a->pq_w || !a->pq_b || a->ldpq < 256 || (a->ldpq & 3)) return VCR_EINVAL;
