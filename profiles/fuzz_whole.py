@@ -1,4 +1,6 @@
-"""Random-shape parity sweep of the whole forward (HIP path vs the CPU oracle; run on the GPU box: python profiles/fuzz_whole.py <seed> <trials>)."""
+"""Random-shape, random-WEIGHTS parity sweep of the whole forward (HIP path vs the CPU oracle; run on the GPU box:
+python profiles/fuzz_whole.py <seed> <trials>).  Each trial draws a weight regime (vcrnet_amd.weights.regime_weights), a weight
+seed and, for the trained-like regime, the scale factor (1.5 .. 4)."""
 import torch, numpy as np, sys, time
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 import vcrnet_amd
@@ -13,9 +15,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv)>2 else 12):
     k=int(rs.choice([5,20,20,40])); B=int(rs.randint(2,9)); N=int(rs.randint(k+1,900)) if rs.rand()<0.8 else int(rs.choice([k+1,k+2,1024,1025,1279]))
     kind=str(rs.choice(["whole","dist","identity"]))
     kw={"whole":{},"dist":dict(vcp_nn="dist"),"identity":dict(pointer="identity")}[kind]
-    key=(kind,)
-    if key not in nets: nets[key]=build_net(**kw)
-    net,w=nets[key]; net.emb_nn.k=k; net.knn_waves=8 if trial%2 else 0
+    regime=str(rs.choice(["default","seed4321","trained","trained","randemb"])); wseed=int(rs.randint(0,10**6)); scale=float(rs.uniform(1.5,4.0))
+    net,w=build_net(regime=regime,seed=wseed,scale=scale,**kw); net.emb_nn.k=k; net.knn_waves=8 if trial%2 else 0
     src,tgt,_,_,_=synth.make_batch(int(rs.randint(0,1000)),B,N)
     s,t=torch.from_numpy(src),torch.from_numpy(tgt)
     rec={}
@@ -32,5 +33,5 @@ for trial in range(int(sys.argv[2]) if len(sys.argv)>2 else 12):
     dR=float((out[2].cpu()-ref[2])[keep].abs().max()) if keep.any() else 0
     dt=float((out[3].cpu()-ref[3])[keep].abs().max()) if keep.any() else 0
     flag="" if (dR<=1e-4 and dt<=(3e-5 if N<=128 else 1e-5)) else "  <<<<<< FAIL"
-    print(f"{kind:8s} B={B} N={N:5d} k={k:2d} amb={int(amb.sum())} dR={dR:.2e} dt={dt:.2e}{flag}", flush=True)
+    print(f"{kind:8s} {regime:8s} wseed={wseed:6d} scale={scale:.2f} B={B} N={N:5d} k={k:2d} amb={int(amb.sum())} dR={dR:.2e} dt={dt:.2e}{flag}", flush=True)
 print("elapsed",time.time()-t0)

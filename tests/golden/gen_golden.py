@@ -95,19 +95,24 @@ def load_into(net, w):
 
 
 def run_vcrnet(name, B, N, first_item, cstride, emb_nn="lpdnet", vcp_nn="topK", partial=False,
-               cycle=False, k=None, iters=1, pointer="transformer", kind="object", n_blocks=1):
+               cycle=False, k=None, iters=1, pointer="transformer", kind="object", n_blocks=1, regime="default"):
     overlap2 = synth.OVERLAP2_0575 if partial else 0.75
     args = ref_args(emb_nn=emb_nn, vcp_nn=vcp_nn, partial=partial, overlap2=overlap2, cycle=cycle,
                     pointer=pointer, n_blocks=n_blocks)
     net = ref_vcr.VCRNet(args)
-    w = weights.generate_weights(1234, lpd=LPD, emb_nn=emb_nn, vcp_nn=vcp_nn, pointer=pointer, n_blocks=n_blocks)
+    # regime "default" = generate_weights(1234, lpd=LPD, ...): rounds 1-3 fixtures are unchanged by the weights axis
+    w = weights.regime_weights(regime, lpd=LPD, emb_nn=emb_nn, vcp_nn=vcp_nn, pointer=pointer, n_blocks=n_blocks)
     load_into(net, w)
     if k is not None:
         net.emb_nn.k = k
+    twin = None
+    if regime != "default":      # the reference's own float64 twin (same code, weights, inputs): its distance is the
+        import copy              # spread the fp32 reference shows against itself under this weight regime
+        twin = copy.deepcopy(net).double()
     src, tgt, R_gt, t_gt, eul = synth.make_batch(first_item, B, N, partial=partial, kind=kind)
     src_t, tgt_t = torch.from_numpy(src), torch.from_numpy(tgt)
     out = dict(src=src, tgt=tgt, R_gt=R_gt, t_gt=t_gt, euler_gt=eul, cstride=np.int32(cstride),
-               overlap2=np.float64(overlap2), k=np.int32(k or 20), iters=np.int32(iters))
+               overlap2=np.float64(overlap2), k=np.int32(k or 20), iters=np.int32(iters), regime=np.str_(regime))
     mods = {"emb": net.emb_nn, "head": net.head, "svd": net.svd}
     if pointer == "transformer":
         mods["pointer"] = net.pointer
@@ -126,6 +131,12 @@ def run_vcrnet(name, B, N, first_item, cstride, emb_nn="lpdnet", vcp_nn="topK", 
                 h.remove()
             p = f"it{it}_"
             out[p + "in"] = cur.numpy().copy()
+            if twin is not None:
+                o64 = twin(cur.double(), tgt_t.double())
+                out[p + "R_f64"], out[p + "t_f64"] = o64[2].numpy(), o64[3].numpy()
+                if pointer == "transformer":   # how peaked the soft-maxes are under this regime: mean over queries of the
+                    pa = net.pointer.model.decoder.layers[0].src_attn.attn / 4     # largest head-averaged cross-attention
+                    out[p + "peak_cross_attn"] = np.float32(pa.max(-1)[0].mean())  # probability (uniform = 1 / keys)
             out[p + "R"], out[p + "t"] = R.numpy(), t.numpy()
             out[p + "R_ba"], out[p + "t_ba"] = R_ba.numpy(), t_ba.numpy()
             out[p + "srcK"], out[p + "corrK"] = srcK.numpy(), corrK.numpy()
@@ -257,6 +268,17 @@ CASES = {
     "nblocks2_n256_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=180, cstride=16, n_blocks=2),
     "nblocks2_partial_n192_b2": lambda n: run_vcrnet(n, B=2, N=256, first_item=190, cstride=16, partial=True, n_blocks=2),
 }
+
+
+# round 4: the weights axis (vcrnet_amd.weights.regime_weights) -- the three shapes the HIP path is held to
+# (whole N = 1024, k = 40, partial N = 768 with three teacher-forced passes and every discrete selection) under a
+# second seed, a trained-like regime (peaky soft-maxes, large LayerNorm offsets) and a random feature extractor
+for _r, _base in (("seed4321", 600), ("trained", 700), ("randemb", 800)):
+    CASES[f"{_r}_whole_n1024_b2"] = lambda n, r=_r, f=_base: run_vcrnet(n, B=2, N=1024, first_item=f, cstride=32, regime=r)
+    CASES[f"{_r}_whole_k40_n512_b1"] = lambda n, r=_r, f=_base: run_vcrnet(n, B=1, N=512, first_item=f + 10, cstride=32,
+                                                                           k=40, regime=r)
+    CASES[f"{_r}_partial_n768_b2_it3"] = lambda n, r=_r, f=_base: run_vcrnet(n, B=2, N=1024, first_item=f + 20, cstride=64,
+                                                                             partial=True, iters=3, regime=r)
 
 
 if __name__ == "__main__":

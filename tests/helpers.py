@@ -23,7 +23,11 @@ def sl(t, cs):
     return t[:, ::cs, :].contiguous().numpy()
 
 
-def cfg_weights(**kw):
+def cfg_weights(regime="default", **kw):      # kw: emb_nn / vcp_nn / pointer / n_blocks, and seed / scale overrides
+    """regime "default" = generate_weights(1234, lpd fixture): the weights of every fixture recorded before round 4."""
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import weights
-    return weights.generate_weights(1234, lpd=weights.load_lpd_fixture(), **kw)
+    return weights.regime_weights(regime, lpd=weights.load_lpd_fixture(), **kw)
+
+
+REGIMES = ("seed4321", "trained", "randemb")          # the non-default points of vcrnet_amd.weights.REGIMES

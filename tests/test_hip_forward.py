@@ -36,9 +36,12 @@ def make_args(**kw):
 def build_net(**kw):
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd.module import VCRNet
+    regime = kw.pop("regime", "default")
+    over = {k: kw.pop(k) for k in ("seed", "scale") if k in kw}          # weight-regime overrides (profiles/fuzz_*.py)
     net = VCRNet(make_args(**kw))
     wkw = {k: kw[k] for k in ("emb_nn", "vcp_nn", "pointer", "n_blocks") if k in kw}
-    w = cfg_weights(**wkw)
+    wkw.update(over)
+    w = cfg_weights(regime, **wkw)
     missing = net.load_state_dict(w, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return net.cuda().eval(), w

@@ -146,6 +146,46 @@ def generate_weights(seed: int = 1234, lpd: Optional[Dict[str, torch.Tensor]] = 
     return out
 
 
+REGIMES = ("default", "seed4321", "trained", "randemb")
+
+
+def regime_weights(regime: str = "default", lpd: Optional[Dict[str, torch.Tensor]] = None,
+                   seed: Optional[int] = None, scale: float = 3.0, **shape_kwargs) -> "OrderedDict[str, torch.Tensor]":
+    """Named points in weight space for the parity fixtures (the reference loads arbitrary checkpoints,
+    util/initPara.py:248-254, and the trained VCR-Net ones are unavailable -- SURVEY F2):
+
+      * ``default``  : ``generate_weights(1234, lpd)`` -- every fixture of rounds 1-3
+      * ``seed4321`` : the same recipe, second seed
+      * ``trained``  : what training does to the default-scale recipe, exaggerated: every ``pointer.*`` weight matrix and
+        ``emb_nn.conv3_lpd.weight`` x 3 (peaky soft-maxes in transformer.py:29-34 and vcrnet_model.py:337-345),
+        LayerNorm ``a_2 ~ U(0.5, 2)``, ``b_2 ~ N(0, 0.5)`` (large-offset residual streams, transformer.py:141-144);
+        drawn from ``generate_weights(2024, lpd)`` plus a second generator seeded 2025 for the LayerNorm affines
+      * ``randemb``  : ``generate_weights(777, lpd=None)`` -- a random (non-LPD-pretrained) feature extractor
+    ``seed`` replaces the regime's base seed and ``scale`` the trained regime's factor 3 (the fuzzers under profiles/ draw
+    both per trial; the recorded fixtures use the defaults).
+    """
+    if regime == "default":
+        return generate_weights(1234 if seed is None else seed, lpd=lpd, **shape_kwargs)
+    if regime == "seed4321":
+        return generate_weights(4321 if seed is None else seed, lpd=lpd, **shape_kwargs)
+    if regime == "randemb":
+        return generate_weights(777 if seed is None else seed, lpd=None, **shape_kwargs)
+    if regime != "trained":
+        raise KeyError(regime)
+    w = generate_weights(2024 if seed is None else seed, lpd=lpd, **shape_kwargs)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(2025 if seed is None else seed + 1)
+    for key in w:
+        leaf = key.rsplit(".", 1)[-1]
+        if leaf == "a_2":
+            w[key] = (0.5 + 1.5 * torch.rand(w[key].shape, generator=g, dtype=torch.float32)).contiguous()
+        elif leaf == "b_2":
+            w[key] = (0.5 * torch.randn(w[key].shape, generator=g, dtype=torch.float32)).contiguous()
+        elif leaf == "weight" and (key.startswith("pointer.") or key == "emb_nn.conv3_lpd.weight"):
+            w[key] = (float(scale) * w[key]).contiguous()
+    return w
+
+
 def strip_module_prefix(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Accept DataParallel-saved checkpoints (``module.`` prefix; SURVEY section 5 gotcha,
     util/initPara.py:25-35,260)."""
