@@ -132,7 +132,8 @@ def run_vcrnet(name, B, N, first_item, cstride, emb_nn="lpdnet", vcp_nn="topK", 
             p = f"it{it}_"
             out[p + "in"] = cur.numpy().copy()
             if twin is not None:
-                o64 = twin(cur.double(), tgt_t.double())
+                with TopkLog() as tl64:
+                    o64 = twin(cur.double(), tgt_t.double())
                 out[p + "R_f64"], out[p + "t_f64"] = o64[2].numpy(), o64[3].numpy()
                 if pointer == "transformer":   # how peaked the soft-maxes are under this regime: mean over queries of the
                     pa = net.pointer.model.decoder.layers[0].src_attn.attn / 4     # largest head-averaged cross-attention
@@ -161,6 +162,20 @@ def run_vcrnet(name, B, N, first_item, cstride, emb_nn="lpdnet", vcp_nn="topK", 
                 v, i = calls.pop(0); out[p + "argmax_tgt"] = i.reshape(B, -1).numpy().astype(np.int16)
                 v, i = calls.pop(0); out[p + "argmax_val"] = v.reshape(B, -1).numpy()
                 v, i = calls.pop(0); out[p + "pair_src"] = i.reshape(B, -1).numpy().astype(np.int16)
+                if twin is not None and pointer == "transformer" and n_blocks == 1:
+                    # the float64 twin's selections on the same input vs the fp32 run's: (kept keys, overlap sets, hard pairs)
+                    # flipped, counted as tests/test_hip_forced.py:count_flips does
+                    c64 = [i.reshape(B, -1).numpy() for _, i in tl64.calls[2 * nk:]]
+                    t64 = dict(keep_dir_src=c64[0], keep_dir_tgt=c64[1], sel_tgt=c64[2], sel_src=c64[3], argmax_tgt=c64[4],
+                               pair_src=c64[6])
+                    sd = lambda a, b: sum(len(set(x) ^ set(y)) // 2 for x, y in zip(a, b))
+                    prs = lambda d: {(b, int(d["sel_src"][b, i]), int(d["sel_tgt"][b, d["argmax_tgt"][b, i]]))
+                                     for b in range(B) for i in d["pair_src"][b]}
+                    f32 = {k_: out[p + k_] for k_ in t64}
+                    out[p + "twin_flips"] = np.array(
+                        [sd(f32["keep_dir_src"], t64["keep_dir_src"]) + sd(f32["keep_dir_tgt"], t64["keep_dir_tgt"]),
+                         sd(f32["sel_src"], t64["sel_src"]) + sd(f32["sel_tgt"], t64["sel_tgt"]),
+                         len(prs(f32) ^ prs(t64)) // 2], dtype=np.int32)
             assert cycle or not calls, len(calls)
             # sub-module outputs
             e_src, e_tgt = store["emb"][0][1], store["emb"][1][1]

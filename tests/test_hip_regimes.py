@@ -71,11 +71,17 @@ def test_partial_forced_under_regime(regime, mode):
         fl = count_flips(free[6], force)
         fR, ft = np.abs(free[2].cpu().numpy() - g[p + "R"]).max(), np.abs(free[3].cpu().numpy() - g[p + "t"]).max()
         print(f"{regime}/partial/{mode} it{it}: forced max|dR| {dR:.2e} max|dt| {dt:.2e}; free-running flips {fl}, "
-              f"max|dR| {fR:.2e} (reference vs its float64 twin, free-running: {np.abs(g[p + 'R'] - g[p + 'R_f64']).max():.2e})")
+              f"max|dR| {fR:.2e} (reference vs its float64 twin, free-running: flips {g[p + 'twin_flips'].tolist()}, "
+              f"max|dR| {np.abs(g[p + 'R'] - g[p + 'R_f64']).max():.2e})")
         assert dR <= R_TOL and dt <= T_TOL, (it, dR, dt)
         B, N = cur.shape[0], cur.shape[2]
-        assert fl["keys"] <= max(2, 2 * B * N // 100) and fl["overlap"] <= max(4, B * N // 50)
-        assert fl["pairs"] <= max(2, fl["n_pairs"] // 20), fl
+        # free-running flips: the bounds of tests/test_hip_forced.py, or twice (+2) what the reference's own float64 twin
+        # flips against it on this very input (it*_twin_flips; a random feature extractor leaves the hard-pair scores
+        # nearly tied: the twin moves 22-37 of the 392 pairs there, 0 under the second seed)
+        tw = g[p + "twin_flips"]
+        assert fl["keys"] <= max(2, 2 * B * N // 100, 2 * int(tw[0]) + 2), (fl, tw)
+        assert fl["overlap"] <= max(4, B * N // 50, 2 * int(tw[1]) + 2), (fl, tw)
+        assert fl["pairs"] <= max(2, fl["n_pairs"] // 20, 2 * int(tw[2]) + 2), (fl, tw)
         if fl["keys"] == fl["overlap"] == fl["pairs"] == 0:
             assert fR <= R_TOL and ft <= T_TOL, (it, fR, ft)
 
