@@ -64,6 +64,11 @@ def parse(argv=None):
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="SURVEY 8d protocol without a budget: every thread count, B = --batch, median of 5")
     ap.add_argument("--min-seconds", type=float, default=12.0, help="repeat the timed K-step block for this long")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="the default single-GPU run appends `other_configs` (BASELINE configs[2], configs[3]'s per-GPU share, "
+                         "configs[4] and the bf16x3+sdpa line, --other-seconds of timed blocks each) AFTER the headline has "
+                         "been measured; this switch leaves them out")
+    ap.add_argument("--other-seconds", type=float, default=2.0, help="timed seconds per entry of `other_configs`")
     ap.add_argument("--stages", action="store_true", help="print the per-launch table to stderr")
     ap.add_argument("--trace-every", type=int, default=5,
                     help="record the per-launch HIP events (roofline / stage table) on every N-th step of each timed "
@@ -245,7 +250,8 @@ def workload_label(a, Nfull, N, B, kind, world=1):
         N, B, emb, a.k, a.iters, clouds, wts)
 
 
-def run_rank(a):
+def setup_rank(a):
+    """Process-level setup of one rank: stdout discipline, device, process group.  Returns the context `measure` needs."""
     # stdout carries exactly ONE line, the JSON: libraries that chat on file descriptor 1 (gloo's "Rank 0 is connected
     # ...", RCCL's version banner) are sent to stderr for the life of the process; the line goes out through a copy
     sys.stdout.flush()
@@ -282,6 +288,21 @@ def run_rank(a):
         print(f"rank {rank}: injected failure", file=sys.stderr, flush=True)
         os._exit(3)
 
+    return SimpleNamespace(json_fd=json_fd, world=world, rank=rank, dev=dev, dist=dist, ndev=ndev)
+
+
+def rccl_version():
+    """RCCL's version as this process sees it (torch.cuda.nccl.version() -> the library torch loaded)."""
+    try:
+        return ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as e:          # noqa: BLE001 -- a diagnostic field must not fail the run
+        return f"unavailable ({type(e).__name__})"
+
+
+def measure(a, ctx, min_seconds):
+    """One workload (the flags in `a`) on this rank: build the module, warm up, time K-step blocks for `min_seconds`,
+    return the JSON line as a dict on rank 0 (None elsewhere)."""
+    world, rank, dev, dist = ctx.world, ctx.rank, ctx.dev, ctx.dist
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import native, shard, synth, weights, workmodel
     from vcrnet_amd.module import VCRNet, vcrnetIter
@@ -311,13 +332,21 @@ def run_rank(a):
     Nfull, N = N, src.shape[2]                     # partial mode crops the clouds (1024 -> 768)
     assert src.shape == (B, 3, N) and src.is_cuda, src.shape
 
+    gather_ev = []            # (start, end) HIP events around the collective, on the stream the forward was enqueued on
+
     def step(trace=None):
         net.launch_trace = trace                # profiling hook of the module: per-launch HIP events on traced steps
         with torch.no_grad():
             out = vcrnetIter(net, src, tgt, iter=a.iters)      # the public entry point SURVEY 8d names (one C call)
         pose = torch.cat((out[2].view(B, 9), out[3]), 1)
         if world > 1:
+            if trace is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             pose = shard.all_gather_poses(pose, world)
+            if trace is not None:
+                e1.record()
+                gather_ev.append((e0, e1))
         return pose
 
     # one-time initialisation, not a warm-up step: the first call loads the code objects, packs / folds the weights,
@@ -349,6 +378,7 @@ def run_rank(a):
             step(traces[i].trace if i in traces else None)
         fence()
         el = time.perf_counter() - t0
+        own_blocks.append(el)
         if world > 1:
             tt = torch.tensor([el], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -357,10 +387,36 @@ def run_rank(a):
 
     # EXACTLY K steps per block; blocks repeat until min_seconds of load (every rank must agree on the count, so the
     # decision uses the MAX-reduced times, identical on all ranks)
+    own_blocks = []
     blocks = [timed_block()]
-    while sum(blocks) < a.min_seconds and len(blocks) < 1000:
+    while sum(blocks) < min_seconds and len(blocks) < 1000:
         blocks.append(timed_block())
     elapsed = float(np.median(blocks))
+    multi = None
+    if world > 1:
+        # what the first real 8-GPU run needs to explain itself: every rank's own median step time (before the MAX), the
+        # collective's share (HIP events around the all-gather on traced steps; the first records also absorb the wait
+        # for the slowest rank), what this rank sees of the machine
+        torch.cuda.synchronize()
+        ag = [e0.elapsed_time(e1) for e0, e1 in gather_ev]
+        mine = torch.tensor([float(np.median(own_blocks)) / a.steps * 1e3, float(np.median(ag)) if ag else 0.0,
+                             float(max(ag)) if ag else 0.0], dtype=torch.float64,
+                            device=dev if a.backend == "nccl" else "cpu")
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per = torch.stack(allr).cpu().numpy()
+        multi = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                 "rccl_version": rccl_version() if a.backend == "nccl" else None,
+                 "n_devices_visible": ctx.ndev, "device_of_rank0": torch.cuda.get_device_name(dev),
+                 "per_rank_ms_per_step": [round(float(x), 4) for x in per[:, 0]],
+                 "per_rank_ms_per_step_min": float(per[:, 0].min()), "per_rank_ms_per_step_max": float(per[:, 0].max()),
+                 "all_gather_ms": float(np.median(per[:, 1])), "all_gather_ms_per_rank": [round(float(x), 4) for x in per[:, 1]],
+                 "all_gather_ms_worst": float(per[:, 2].max()),
+                 "all_gather_timed_with": ("HIP events on the forward's stream around shard.all_gather_poses, traced steps; "
+                                           "median per rank, then median over ranks"
+                                           + ("" if a.backend == "nccl" else
+                                              f"; backend {a.backend}: the poses are staged through the host, so this is a "
+                                              "device-to-host copy + a CPU collective, not RCCL"))}
 
     # per-launch durations from the HIP events recorded inside the (last) timed block
     fam_ms, fam_flops, fam_bytes, fam_gather, rows = {}, {}, {}, {}, {}
@@ -408,11 +464,18 @@ def run_rank(a):
             # a family can be several template instantiations (linear: plain / statistics-out / LayerNorm-in):
             # launch-weighted mean over the entries whose name starts with the family's kernel name
             ents = [e for k_, e in json.load(open(pmcs[-1])).items()
-                    if kname and k_.startswith(kname) and "hbm_bytes_per_launch" in e]
+                    if kname and k_.startswith(kname) and isinstance(e, dict) and "hbm_bytes_per_launch" in e]
             if ents:
                 nd = [e["FETCH_SIZE"]["dispatches"] for e in ents]
                 roof["traffic"] = sum(e["hbm_bytes_per_launch"] * n for e, n in zip(ents, nd)) / sum(nd)
                 roof["traffic_source"] = os.path.relpath(pmcs[-1], ROOT)
+                # were those counters taken on this code?  (the summary records a hash of csrc/ + include/; no .git on the box)
+                from vcrnet_amd import build as vb
+                meta = json.load(open(pmcs[-1])).get("_meta", {})
+                roof["traffic_source_kernel_sources"] = (
+                    "identical to this build" if meta.get("kernel_sources_sha16") == vb.sources_sha16() else
+                    "summary taken on kernel sources %s, this build is %s: the counters predate later kernel commits"
+                    % (meta.get("kernel_sources_sha16", "(unrecorded)"), vb.sources_sha16()))
         total_ms = sum(fam_ms.values())
         roof["launches_per_step"] = sum(r[3] for n, r in rows.items() if n.startswith(dom + ":")) // nt
         roof["avg_launch_ms"] = fam_ms[dom] / max(1, roof["launches_per_step"] * nt)
@@ -433,7 +496,7 @@ def run_rank(a):
         emb_bytes = 2.0 * N * (7448 + 784 * a.k) * B * a.iters
         emb_gf = a.iters * sum(workmodel.launch_work(n, B, N, a.k)[0] for n in
                                ("linear:dg1_pq", "edgeconv:dg1_dg2", "linear:sn1_pq", "linear:conv3")) / 1e9
-        emb_stage = {"ms_per_step": emb_ms, "algorithmic_bytes_per_pair": emb_bytes / B / a.iters, "iters": a.iters,
+        emb_stage = None if a.emb_nn != "lpdnet" else {"ms_per_step": emb_ms, "algorithmic_bytes_per_pair": emb_bytes / B / a.iters, "iters": a.iters,
                      "achieved_gbs": emb_bytes / (emb_ms * 1e-3) / 1e9,
                      "hbm_frac": emb_bytes / (emb_ms * 1e-3) / 1e9 / workmodel.PEAK_HBM_GBS,
                      "knn_ms_per_step": sum(r[0] for n, r in rows.items() if n.startswith("knn:")) / nt,
@@ -457,7 +520,9 @@ def run_rank(a):
             "data": "synthetic",
             "config": {"workload": workload_label(a, Nfull, N, B, kind, world),
                        "num_points": N, "batch_per_gpu": B, "global_batch": B * world, "k": a.k, "iters": a.iters,
-                       "parallelism": f"dp{world} (pairs sharded per rank, RCCL all-gather of R,t)",
+                       "parallelism": f"dp{world} (pairs sharded per rank" + (
+                           ")" if world == 1 else ", RCCL all-gather of R,t)" if a.backend == "nccl" else
+                           f", {a.backend} all-gather of R,t staged through the host -- NOT RCCL)"),
                        "entry_point": "vcrnet_amd.module.vcrnetIter(net, src, tgt, iter) -> vcr_vcrnet_iter_f32"},
             "timed_blocks": {"count": len(blocks), "steps_per_block": a.steps, "reported": "median",
                              "seconds": [round(b, 6) for b in blocks[:64]],
@@ -465,15 +530,66 @@ def run_rank(a):
                                                   "records runs ~2 % longer: the stage times sum to that step, not to ms_per_step)"},
             "roofline": roof,
             "stages": stages,
-            "knn_edgeconv_stage": emb_stage,
             "flops_per_pair_reference": workmodel.reference_flops_per_pair(N, a.k)["total"],
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if emb_stage is not None:          # the stage BASELINE prices exists only for the kNN-graph LPDNet embedding
+            line["knn_edgeconv_stage"] = emb_stage
+        if multi is not None:
+            line["multi_gpu"] = multi
+        line["_weights"], line["_Nfull"], line["_B"] = w, Nfull, B          # for the caller's CPU baseline; stripped
+        return line
+    return None
+
+
+# the BASELINE configs that are not the headline, and the labelled split-arithmetic line, as bench.py flag overrides
+OTHER_CONFIGS = [
+    ("configs[2]", dict(partial=True, points=1024, batch=24, iters=3)),
+    ("configs[3] (one GPU's share)", dict(points=2048, batch=16)),
+    ("configs[4]", dict(points=4096, k=40, batch=32)),
+    ("configs[1], --linear-mode bf16x3+sdpa", dict(linear_mode="bf16x3+sdpa")),
+]
+
+
+def is_headline(a):
+    d = parse([])
+    return all(getattr(a, k) == getattr(d, k) for k in ("gpus", "batch", "points", "k", "partial", "iters", "emb_nn", "strong",
+                                                        "linear_mode", "linear_mfma", "linear_bk", "linear_bm", "knn_waves",
+                                                        "no_merge_encdec"))
+
+
+def run_rank(a):
+    ctx = setup_rank(a)
+    line = measure(a, ctx, a.min_seconds)
+    if ctx.rank == 0:
+        w, Nfull, B = line.pop("_weights"), line.pop("_Nfull"), line.pop("_B")
+        if ctx.world == 1 and is_headline(a) and not a.no_other_configs:
+            # measured AFTER the headline (which is untouched by them), same process, same protocol, shorter blocks
+            others = []
+            for tag, over in OTHER_CONFIGS:
+                b = argparse.Namespace(**vars(a))
+                for k_, v_ in over.items():
+                    setattr(b, k_, v_)
+                b.stages = False
+                t0 = time.perf_counter()
+                o = measure(b, ctx, a.other_seconds)
+                for k_ in ("_weights", "_Nfull", "_B"):
+                    o.pop(k_)
+                r = o["roofline"]
+                others.append({"baseline_config": tag, "workload": o["config"]["workload"], "value": o["value"],
+                               "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+                               "timed_blocks": o["timed_blocks"]["count"], "dtype": o["dtype"],
+                               "roofline": {k_: r[k_] for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac")},
+                               "knn_edgeconv_stage": {k_: o["knn_edgeconv_stage"][k_] for k_ in
+                                                      ("ms_per_step", "hbm_frac", "achieved_gbs", "knn_ms_per_step")},
+                               "wall_s": round(time.perf_counter() - t0, 2)})
+                torch.cuda.empty_cache()
+            line["other_configs"] = others
+        if ctx.world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, B, Nfull, a.k, a.partial, a.iters, a.cpu_budget_s, a.cpu_baseline_full)
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        os.write(ctx.json_fd, (json.dumps(line) + "\n").encode())
+    if ctx.world > 1:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 def main():

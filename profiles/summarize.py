@@ -58,6 +58,12 @@ def main():
             e["hbm_bytes_per_launch"] = (2.0 * fetch + write) * 1024.0     # gfx950 FETCH_SIZE correction
         out[k] = e
     if out:
+        sys.path.insert(0, os.path.dirname(HERE))
+        import vcrnet_amd  # noqa: F401
+        from vcrnet_amd import build as vb
+        import datetime
+        out["_meta"] = {"kernel_sources_sha16": vb.sources_sha16(), "tag": tag,
+                        "date_utc": datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M")}
         json.dump(out, open(os.path.join(HERE, f"{tag}_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     print("wrote", tag, len(rows), "kernels,", len(out), "pmc entries")
 

@@ -66,8 +66,9 @@ def test_whole_vs_reference_golden(name):
     np.testing.assert_allclose(R.cpu().numpy(), g["it0_R"], atol=R_TOL)
     np.testing.assert_allclose(t.cpu().numpy(), g["it0_t"], atol=T_TOL)
     np.testing.assert_allclose(R_ba.cpu().numpy(), g["it0_R_ba"], atol=R_TOL)
-    # t_ba = -R^T t is derived (vcrnet_model.py:516): it inherits |dR|*|t| + |dt|, so allow 3x the t tolerance
-    np.testing.assert_allclose(t_ba.cpu().numpy(), g["it0_t_ba"], atol=3 * T_TOL)
+    # t_ba = -R^T t is derived (vcrnet_model.py:516) and inherits |dR|*|t| + |dt|; held to the plain t tolerance
+    print(f"{name}: max|dt_ba|={np.abs(t_ba.cpu().numpy() - g['it0_t_ba']).max():.2e}")
+    np.testing.assert_allclose(t_ba.cpu().numpy(), g["it0_t_ba"], atol=T_TOL)
     np.testing.assert_allclose(out[2].cpu().numpy(), R.cpu().numpy(), atol=0)
     print(f"{name}: max|dR|={np.abs(R.cpu().numpy() - g['it0_R']).max():.2e} max|dt|={np.abs(t.cpu().numpy() - g['it0_t']).max():.2e}")
 
@@ -88,11 +89,18 @@ def test_whole_vs_oracle(B, N, kind):
     # those samples match.
     # Tiny clouds (down to N = k+1 = 21, the smallest legal one): the covariance averages over few correspondences,
     # the fp32 oracle itself sits 3e-6 from its fp64 twin there and its multi-threaded rounding varies run to run on
-    # the 256-core box, so t gets 3x the tolerance that BASELINE quotes for N >= 768.
-    t_tol = 3 * T_TOL if N <= 128 else T_TOL
+    # the 256-core box: these two shapes are the n77 / n21 cases of tests/golden/selfdiv.npz (same items), and t gets the
+    # BASELINE tolerance plus the spread the reference showed over its own four runs there (3.8e-6 / 5.3e-6).
+    r_tol, t_tol = R_TOL, T_TOL
+    if N <= 128:
+        sd = golden("selfdiv")
+        tag = f"n{N}"
+        assert (int(sd[tag + "/first"]), int(sd[tag + "/B"]), int(sd[tag + "/N"])) == (200, B, N)
+        r_tol, t_tol = R_TOL + float(sd[tag + "/spread_R"]), T_TOL + float(sd[tag + "/spread_t"])
     assert_mostly_close(out[1].cpu().numpy(), ref[1].numpy(), atol=5e-4)
-    np.testing.assert_allclose(out[2].cpu().numpy(), ref[2].numpy(), atol=R_TOL)
-    np.testing.assert_allclose(out[3].cpu().numpy(), ref[3].numpy(), atol=t_tol)
+    dR, dt = np.abs(out[2].cpu().numpy() - ref[2].numpy()).max(), np.abs(out[3].cpu().numpy() - ref[3].numpy()).max()
+    print(f"whole vs oracle B={B} N={N}: max|dR| {dR:.2e} max|dt| {dt:.2e} (tolerance {r_tol:.2e} / {t_tol:.2e})")
+    assert dR <= r_tol and dt <= t_tol, (dR, dt)
 
 
 def test_config5_shape_vs_oracle():

@@ -101,6 +101,60 @@ def test_bench_kills_the_run_when_a_rank_dies_after_rendezvous():
     assert "injected failure" in j["rank_stderr_tail"]["1"]
 
 
+def _bench_env(**extra):
+    env = dict(os.environ, **extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_bench_eight_ranks_on_the_one_gpu_explains_itself():
+    """`python bench.py --gpus 8` as the driver's scaling sweep launches it, with the only substitution a 1-GPU lease
+    allows (--backend gloo: eight fresh rank processes sharing cuda:0): one JSON line whose `multi_gpu` object carries what
+    a first real 8-GPU run needs to be read -- world size, backend, every rank's own step time, the collective's time,
+    the devices visible -- and per-rank logs."""
+    import tempfile
+    logdir = tempfile.mkdtemp(prefix="vcr_bench_logs_")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--batch", "1",
+                        "--points", "64", "--steps", "3", "--warmup", "1", "--min-seconds", "0.2", "--deadline-s", "500"],
+                       capture_output=True, text=True, timeout=900, env=_bench_env(VCR_BENCH_LOGDIR=logdir))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    m = j["multi_gpu"]
+    assert j["n_gpus"] == 8 and j["config"]["global_batch"] == 8 and m["world_size"] == 8
+    assert m["backend"] == "gloo" and m["rccl_version"] is None and "NOT RCCL" in j["config"]["parallelism"]
+    assert len(m["per_rank_ms_per_step"]) == 8 and len(m["all_gather_ms_per_rank"]) == 8
+    assert 0 < m["per_rank_ms_per_step_min"] <= m["per_rank_ms_per_step_max"] <= j["ms_per_step"] * 1.05
+    assert m["all_gather_ms"] > 0 and m["n_devices_visible"] >= 1
+    assert sorted(os.listdir(logdir)) == [f"rank{i}.err" for i in range(8)]
+    assert "other_configs" not in j and "cpu_baseline" not in j
+
+
+def test_bench_eight_ranks_rank_five_dies():
+    import tempfile
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--batch", "1",
+                        "--points", "64", "--steps", "3", "--warmup", "1", "--min-seconds", "0.2", "--deadline-s", "500"],
+                       capture_output=True, text=True, timeout=900,
+                       env=_bench_env(VCR_BENCH_FAIL_RANK="5", VCR_BENCH_LOGDIR=tempfile.mkdtemp(prefix="vcr_bench_logs_")))
+    assert r.returncode != 0 and time.time() - t0 < 400, (r.returncode, time.time() - t0)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["value"] is None and j["n_gpus"] == 8 and "rank 5 exited with code 3" in j["error"]
+    assert "injected failure" in j["rank_stderr_tail"]["5"]
+
+
+def test_rccl_version_is_reported():
+    sys.path.insert(0, ROOT)
+    import bench
+    v = bench.rccl_version()
+    assert v and "unavailable" not in v and v[0].isdigit(), v
+
+
 def test_bench_strong_scaling_shards_the_global_batch():
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
