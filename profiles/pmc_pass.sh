@@ -12,7 +12,7 @@ IFS=',' read -ra GROUPS_ <<< "$*"
 i=0
 for g in "${GROUPS_[@]}"; do
   d=$OUT/pmc_${TAG}_$i
-  rocprofv3 --kernel-trace --output-format csv --pmc $g -d $d -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --min-seconds 0.1 $BENCH_ARGS > /dev/null 2> $OUT/${TAG}_pmc_$i.err
+  rocprofv3 --kernel-trace --output-format csv --pmc $g -d $d -- python3 bench.py --no-cpu-baseline --no-other-configs --steps 3 --warmup 1 --min-seconds 0.1 $BENCH_ARGS > /dev/null 2> $OUT/${TAG}_pmc_$i.err
   python3 - "$d" > $OUT/${TAG}_pmc_$i.txt <<'PY'
 import csv, glob, sys, collections
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -22,5 +22,6 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
 for k in sorted(rows):
     print(k, {c: round(sum(v) / len(v), 1) for c, v in rows[k].items()}, "launches", len(next(iter(rows[k].values()))))
 PY
+  rm -rf $d          # the raw counter CSVs are tens of MB per pass; gpurun copies back at most 64 MiB
   i=$((i+1))
 done

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Experiment: phase breakdown of the kNN kernels (wave 0 of every workgroup of cloud 0 accumulates the 100 MHz wall
-clock per phase).  Needs the -DVCR_TIMELINE scratch library (python profiles/timeline_linear.py build)."""
+clock per phase).  Needs the probe library scratch/libvcr_probe.so (python profiles/experiments/probe_build.py)."""
 import ctypes as C
 import os
 import sys
@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "scratch", "libvcr_tl.so")
+LIB = os.path.join(ROOT, "scratch", "libvcr_probe.so")
 
 
 def main():
@@ -18,10 +18,10 @@ def main():
     from vcrnet_amd import native
     native.LIB_PATH = LIB
     L = native.lib()
-    L.vcr_dbg_timeline_knn.argtypes = [C.c_void_p, C.c_int]
-    L.vcr_dbg_timeline_knn.restype = C.c_int
+    L.vcr_dbg_probe_knn.argtypes = [C.c_void_p, C.c_int]
+    L.vcr_dbg_probe_knn.restype = C.c_int
     g = torch.Generator().manual_seed(0)
-    buf = np.zeros((4096, 8), np.uint64)
+    full = np.zeros((4096, 32), np.uint64)
     names = {"feat64": ["prefetch issue", "MFMA wait+filter", "make_room", "pick", "log push", "drain", "-", "-"],
              "xyz": ["dist+filter", "log+drain", "-", "-", "-", "-", "-", "-"]}
     for B, N, k in ((32, 1024, 20), (64, 4096, 40)):
@@ -34,10 +34,11 @@ def main():
                 for _ in range(2):
                     native.knn(x, s, k, exact_ties=False, waves=waves)
                 torch.cuda.synchronize()
-                L.vcr_dbg_timeline_knn(None, 1)
+                L.vcr_dbg_probe_knn(None, 1)
                 native.knn(x, s, k, exact_ties=False, waves=waves)
                 torch.cuda.synchronize()
-                L.vcr_dbg_timeline_knn(buf.ctypes.data, 0)
+                L.vcr_dbg_probe_knn(full.ctypes.data, 0)
+                buf = full[:, :8]
                 t = buf.astype(np.float64) * 0.01
                 used = t.sum(1) > 0
                 med = np.median(t[used], 0)

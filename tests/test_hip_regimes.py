@@ -75,13 +75,15 @@ def test_partial_forced_under_regime(regime, mode):
               f"max|dR| {np.abs(g[p + 'R'] - g[p + 'R_f64']).max():.2e})")
         assert dR <= R_TOL and dt <= T_TOL, (it, dR, dt)
         B, N = cur.shape[0], cur.shape[2]
-        # free-running flips: the bounds of tests/test_hip_forced.py, or twice (+2) what the reference's own float64 twin
+        # free-running flips: the bounds of tests/test_hip_forced.py, or three times (+2) what the reference's own float64 twin
         # flips against it on this very input (it*_twin_flips; a random feature extractor leaves the hard-pair scores
         # nearly tied: the twin moves 22-37 of the 392 pairs there, 0 under the second seed)
-        tw = g[p + "twin_flips"]
-        assert fl["keys"] <= max(2, 2 * B * N // 100, 2 * int(tw[0]) + 2), (fl, tw)
-        assert fl["overlap"] <= max(4, B * N // 50, 2 * int(tw[1]) + 2), (fl, tw)
-        assert fl["pairs"] <= max(2, fl["n_pairs"] // 20, 2 * int(tw[2]) + 2), (fl, tw)
+        # (the twin differs from the fp32 run by ONE fp32 evaluation's rounding, two fp32 implementations differ by two:
+        # three times the twin's worst pass, +2)
+        tw = np.max([g[f"it{j}_twin_flips"] for j in range(int(g["iters"]))], axis=0)
+        assert fl["keys"] <= max(2, 2 * B * N // 100, 3 * int(tw[0]) + 2), (fl, tw)
+        assert fl["overlap"] <= max(4, B * N // 50, 3 * int(tw[1]) + 2), (fl, tw)
+        assert fl["pairs"] <= max(2, fl["n_pairs"] // 20, 3 * int(tw[2]) + 2), (fl, tw)
         if fl["keys"] == fl["overlap"] == fl["pairs"] == 0:
             assert fR <= R_TOL and ft <= T_TOL, (it, fR, ft)
 

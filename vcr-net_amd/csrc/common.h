@@ -54,7 +54,30 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // their squared deviations from the SEGMENT mean): combined as in Chan et al. -- M2 = sum_s (M2_s + n_s (mean_s - mean)^2)
 // -- so a row with |mean| >> std loses nothing to cancellation (the one-pass sum(x^2) - sum(x)^2 / n form does).
 // var is the unbiased one of Tensor.std() (transformer.py:142).
+// nseg = 8 (K = 512, the path's case): the row's 64 B arrive as four 16-B loads issued together -- ONE memory round trip.
+// The scalar loop below compiles to one load per iteration, each waited for before the next is issued: eight round
+// trips, 16-20 us of a workgroup's prologue under load (profiles/r4c_timeline_linear.txt).  Same values, same order.
 __device__ __forceinline__ void ln_row_moments(const float* sp, int nseg, int K, float& mean, float& var) {
+  if (nseg == 8 && (((uintptr_t)sp) & 15) == 0) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 a = *reinterpret_cast<const v4*>(sp), b = *reinterpret_cast<const v4*>(sp + 4),
+             c = *reinterpret_cast<const v4*>(sp + 8), d = *reinterpret_cast<const v4*>(sp + 12);
+    const float su[8] = {a[0], a[2], b[0], b[2], c[0], c[2], d[0], d[2]};
+    const float sq[8] = {a[1], a[3], b[1], b[3], c[1], c[3], d[1], d[3]};
+    float s1 = 0.f;
+#pragma unroll
+    for (int sg = 0; sg < 8; ++sg) s1 += su[sg];
+    mean = s1 / (float)K;
+    const float nsg = (float)(K / 8), rn = 1.f / nsg;
+    float m2 = 0.f;
+#pragma unroll
+    for (int sg = 0; sg < 8; ++sg) {
+      const float dd = su[sg] * rn - mean;
+      m2 += sq[sg] + nsg * (dd * dd);
+    }
+    var = m2 / (float)(K - 1);
+    return;
+  }
   float s1 = 0.f;
   for (int sg = 0; sg < nseg; ++sg) s1 += sp[2 * sg];                  // fixed order
   mean = s1 / (float)K;

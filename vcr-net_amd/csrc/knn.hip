@@ -44,36 +44,19 @@ constexpr int TILE = 32;            // candidates per MFMA tile
 // Log capacity per query.  Measured for the MFMA kernel at k = 20 (MI355X, 32 clouds): 96 / 128 entries make the kernel
 // alone 7 % faster at N = 1024 (fewer compactions) but cost the second workgroup per CU at N = 2048 (+20 %) and the
 // co-residency of the one-launch kNN pair (+20 %): 64 stays.
-#ifndef VCR_KNN_PEND_MFMA
-#define VCR_KNN_PEND_MFMA 64
-#endif
+constexpr int KNN_PEND_MFMA = 64;
 struct GeomMfma;
 struct GeomCol16;
 // 16-query kernels (k <= 20): 72 -- the most that keeps four workgroups per CU (4 x (76 rows x 16 queries x 8 B x 4 waves
 // + the tie list) = 157 KB of the 160): a compaction then frees 35 slots instead of 27.  Measured against 64: the pair
 // launch 151.4 -> 147.7 us at BASELINE configs[1], 147.5 -> 136.7 at N = 768 (configs[2]), 439 -> 432 at N = 2048.
-#ifndef VCR_KNN_PEND_K40
-#define VCR_KNN_PEND_K40 96                              // k = 21 .. 40 (lists of 42)
-#endif
-#ifndef VCR_KNN_PEND_COL16
-#define VCR_KNN_PEND_COL16 72
-#endif
+constexpr int KNN_PEND_K40 = 96;                         // k = 21 .. 40 (lists of 42)
+constexpr int KNN_PEND_COL16 = 72;                       // (the sweeps: profiles/experiments/probe_build.py --set NAME=VALUE)
 template <class G, int KS> constexpr int pend_of() {
-  return KS > 22 ? VCR_KNN_PEND_K40 : std::is_same<G, GeomMfma>::value ? VCR_KNN_PEND_MFMA : std::is_same<G, GeomCol16>::value ? VCR_KNN_PEND_COL16 : 64;
+  return KS > 22 ? KNN_PEND_K40 : std::is_same<G, GeomMfma>::value ? KNN_PEND_MFMA : std::is_same<G, GeomCol16>::value ? KNN_PEND_COL16 : 64;
 }
 
-#ifdef VCR_TIMELINE
-// Experiment-only (profiles/timeline_knn.py, -DVCR_TIMELINE builds): wave 0 of every workgroup accumulates the 100 MHz
-// wall clock over the phases of its scan.
-__device__ unsigned long long vcr_tl_knn[4096 * 8];
-#define KTL_DECL unsigned long long ktl_t = wall_clock64(), ktl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define KTL(slot) do { const unsigned long long n_ = wall_clock64(); ktl_acc[slot] += n_ - ktl_t; ktl_t = n_; } while (0)
-#define KTL_FLUSH do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) for (int i_ = 0; i_ < 8; ++i_) vcr_tl_knn[blockIdx.x * 8 + i_] = ktl_acc[i_]; } while (0)
-#else
-#define KTL_DECL ((void)0)
-#define KTL(slot) ((void)0)
-#define KTL_FLUSH ((void)0)
-#endif
+// "//@probe ..." lines: inert here, uncommented by profiles/experiments/probe_build.py (phase clocks of wave 0).
 
 // In-kernel tie replay (vcr_knn_args.tie_inline, set by the host when a row's replay image fits the workgroup's LDS): the
 // rows of a workgroup whose (k+1)-th and (k+2)-th values tie are listed in LDS and replayed by that workgroup itself
@@ -468,7 +451,7 @@ __device__ __forceinline__ void knn64_body(const vcr_knn_args& a, int bx, int b)
   const float sq_q = sqb[q];
 
   const int ntiles = (a.N + TILE - 1) / TILE;
-  KTL_DECL;
+  //@probe VCR_PROBE_ACC_DECL;
   // walk candidate tiles t0, t0 + S, ... < t1: operands prefetched one tile ahead as raw rows (64 VGPRs), the MFMA
   // chain, then body(tile, acc)
   auto scan_tiles = [&](int t0, int t1, auto&& body) {
@@ -500,13 +483,13 @@ __device__ __forceinline__ void knn64_body(const vcr_knn_args& a, int bx, int b)
       // accumulator lands in AGPRs (seen in the k = 40 build: register 15, the last one written, was read stale).
       // Tie the wait states to the accumulator itself so they cannot be scheduled away.
       if (KS > 22) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
-      KTL(0);                                            // prefetch issue + MFMA chain
+      //@probe VCR_PROBE_ACC(0);                                            // prefetch issue + MFMA chain
       body(tile, acc);
       if (tile + S < t1) {
         pick(nraw, cf);
         csq = nsq;
       }
-      KTL(3);                                            // operand pick (waits for the prefetched rows)
+      //@probe VCR_PROBE_ACC(3);                                            // operand pick (waits for the prefetched rows)
     }
   };
   // the selection proper: filter against sel.thr, log, drain
@@ -517,7 +500,7 @@ __device__ __forceinline__ void knn64_body(const vcr_knn_args& a, int bx, int b)
 #pragma unroll
     for (int hs = 0; hs < 2; ++hs) {
       sel.make_room();
-      KTL(2);
+      //@probe VCR_PROBE_ACC(2);
       float dd[8];
       unsigned m = 0;
 #pragma unroll
@@ -530,7 +513,7 @@ __device__ __forceinline__ void knn64_body(const vcr_knn_args& a, int bx, int b)
         for (int r = 0; r < 8; ++r) m &= (jbase + acc_row(8 * hs + r, half) < a.N) ? ~0u : ~(1u << r);
       }
       const unsigned om = (unsigned)G::from_seg((int)m, half ^ 1);
-      KTL(1);
+      //@probe VCR_PROBE_ACC(1);
       if (__any(m != 0)) {                               // the two lanes of a column append to ONE log: upper half first
         const int base = sel.cnt + (half ? __popc(om) : 0);
 #pragma unroll
@@ -541,9 +524,9 @@ __device__ __forceinline__ void knn64_body(const vcr_knn_args& a, int bx, int b)
         }
       }
       sel.cnt += __popc(m) + __popc(om);
-      KTL(4);
+      //@probe VCR_PROBE_ACC(4);
       if (__any(sel.cnt - sel.done > 16)) sel.drain();   // keep the threshold fresh
-      KTL(5);
+      //@probe VCR_PROBE_ACC(5);
     }
   };
   // sample pre-pass over this wave's first SAMPLE candidates (full tiles only), when it has at least twice as many
@@ -571,7 +554,7 @@ __device__ __forceinline__ void knn64_body(const vcr_knn_args& a, int bx, int b)
     sel.init(lv, reinterpret_cast<int*>(lv + (PEND + 1) * 32), lane);
     scan_tiles(part, ntiles, select_body);
   }
-  KTL_FLUSH;
+  //@probe VCR_PROBE_ACC_FLUSH(threadIdx.x == 0 && blockIdx.y == 0, blockIdx.x);
   finish<G, KS, S>(sel, a, b, q0 + col, wave, part, smem);
 }
 template <int KS, int S, int W>
@@ -675,7 +658,7 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
     if (threadIdx.x == 0) blk_ties[0] = 0;
     __syncthreads();
   }
-  KTL_DECL;
+  //@probe VCR_PROBE_ACC_DECL;
   // Two candidate tiles per step: their two 17-MFMA chains are independent and issue alternately (a dependent
   // v_mfma_f32_16x16x4_f32 chain leaves 8 of every 40 cycles empty), and the next two tiles' rows are in flight meanwhile.
   float cf[2][NST];
@@ -697,7 +680,7 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   // the selection proper for one tile: 16 new distances per query (4 per lane: candidate rows 4 q4 + r)
   auto select_tile = [&](int tile, const f32x4& acc) {
     sel.make_room();
-    KTL(2);
+    //@probe VCR_PROBE_ACC(2);
     const int jbase = tile * CT + 4 * q4;
     float dd[4];
     unsigned m = 0;
@@ -712,7 +695,7 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
     const int pair_total = pa[0] + pa[1];
     const auto pb = __builtin_amdgcn_permlane32_swap(pair_total, pair_total, false, false);   // {rows 0+1, rows 2+3}
     const int pre = ((q4 & 1) ? pa[0] : 0) + ((q4 >> 1) ? pb[0] : 0);
-    KTL(1);                                              // distances + filter + prefix
+    //@probe VCR_PROBE_ACC(1);                                              // distances + filter + prefix
     if (__any(m != 0)) {
       const int base = sel.cnt + pre;
 #pragma unroll
@@ -723,9 +706,9 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
       }
     }
     sel.cnt += pb[0] + pb[1];
-    KTL(4);                                              // log push
+    //@probe VCR_PROBE_ACC(4);                                              // log push
     if (__any(sel.cnt - sel.done > 16)) sel.drain();     // keep the threshold fresh
-    KTL(5);
+    //@probe VCR_PROBE_ACC(5);
   };
   auto scan_all = [&]() {
   scan_prologue();
@@ -751,7 +734,7 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
 #pragma unroll
       for (int u = 0; u < 2; ++u) acc[u] = mfma16(q4 == 0 ? -0.5f * csq[u] : 0.f, q4 == 0 ? 1.f : 0.f, acc[u]);
     }
-    KTL(0);                                              // prefetch issue + MFMA chains
+    //@probe VCR_PROBE_ACC(0);                                              // prefetch issue + MFMA chains
     select_tile(tile, acc[0]);
     if (tile + 1 < ntiles) select_tile(tile + 1, acc[1]);
     if (more) {
@@ -762,7 +745,7 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
         asm volatile("" : "+v"(csq[u]));
       }
     }
-    KTL(3);                                              // wait for the prefetched rows + transpose
+    //@probe VCR_PROBE_ACC(3);                                              // wait for the prefetched rows + transpose
   }
   };
   // C == 4: filter floor from a sample (see SampleNet): the first 256 candidates' values only -- 16 MFMAs -- give a
@@ -790,7 +773,7 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
       scan_all();
     }
   }
-  KTL_FLUSH;
+  //@probe VCR_PROBE_ACC_FLUSH(threadIdx.x == 0 && blockIdx.y == 0, blockIdx.x);
   finish<G, KS, 1>(sel, a, b, q0 + col, wave, 0, smem, blk_ties);
   if (blk_ties) replay_block_ties(a, blk_ties, smem);
 }
@@ -828,7 +811,7 @@ __device__ __forceinline__ void knn3_body(const vcr_knn_args& a, int bx, int b) 
   // 16 candidates per step, 4 per lane: j = j0 + 4u + s (the quad reads 64 contiguous bytes per load); the next
   // step's rows are in flight while this one is filtered
   const int nsteps = (a.N + 15) / 16;
-  KTL_DECL;
+  //@probe VCR_PROBE_ACC_DECL;
   auto scan_steps = [&](int s0, int s1, auto&& body) {
     f32x4 c[4], cn[4];
     auto load = [&](f32x4* dst, int st) {
@@ -856,7 +839,7 @@ __device__ __forceinline__ void knn3_body(const vcr_knn_args& a, int bx, int b) 
     unsigned m = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) m |= (dd[u] > sel.thr && j0 + 4 * u + s < a.N) ? (1u << u) : 0u;
-    KTL(0);                                              // distances + filter
+    //@probe VCR_PROBE_ACC(0);                                              // distances + filter
     // the quad appends to ONE log: exclusive prefix of the lanes' survivor counts
     const int c0 = __popc(m);
     const int p1 = __builtin_amdgcn_mov_dpp(c0, 0x90, 0xF, 0xF, true);     // lane s <- lane s-1 (lane 0: itself)
@@ -875,7 +858,7 @@ __device__ __forceinline__ void knn3_body(const vcr_knn_args& a, int bx, int b) 
     }
     sel.cnt += total;
     if ((it < 3 && !(sel.thr0 > VCR_NEG_INF)) || __any(sel.cnt - sel.done > 12)) sel.drain();   // no floor: settle the threshold quickly
-    KTL(1);                                              // log + drains
+    //@probe VCR_PROBE_ACC(1);                                              // log + drains
   };
   constexpr int ST0 = SAMPLE / 16, R0 = (KS + 1 + G::LPQ - 1) / G::LPQ;    // LPQ * R0 - 1 >= KS
   const int my_steps = part < nsteps ? (nsteps - part + S - 1) / S : 0;
@@ -901,7 +884,7 @@ __device__ __forceinline__ void knn3_body(const vcr_knn_args& a, int bx, int b) 
     sel.init(lv, reinterpret_cast<int*>(lv + (PEND + 1) * 16), lane);
     scan_steps(part, nsteps, select_body);
   }
-  KTL_FLUSH;
+  //@probe VCR_PROBE_ACC_FLUSH(threadIdx.x == 0 && blockIdx.y == 0, blockIdx.x);
   finish<G, KS, S>(sel, a, b, qi, wave, part, smem, blk_ties);
   if (blk_ties) replay_block_ties(a, blk_ties, smem);
 }
@@ -1299,16 +1282,6 @@ int launch(dim3 grid, dim3 block, size_t lds, hipStream_t s, const Args&... a) {
 }
 
 }  // namespace
-
-#ifdef VCR_TIMELINE
-extern "C" int vcr_dbg_timeline_knn(unsigned long long* host_dst, int clear) {
-  if (clear) {
-    static unsigned long long zeros[4096 * 8];
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(vcr_tl_knn), zeros, sizeof(zeros));
-  }
-  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(vcr_tl_knn), sizeof(unsigned long long) * 4096 * 8);
-}
-#endif
 
 // the tie counter is zeroed by a kernel, not hipMemsetAsync: a memset NODE in a captured HIP graph made replays on the
 // default stream hang on this ROCm build (see forward.hip)

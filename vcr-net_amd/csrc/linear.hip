@@ -17,21 +17,10 @@ namespace {
 
 constexpr int BM = 128, BN = 128;
 // MFMA shape of the LDS-DMA kernels when the call does not force one (vcr_linear_args.variant bits 4 / 10)
-#ifndef VCR_LINEAR_MS_DEFAULT
-#define VCR_LINEAR_MS_DEFAULT 0      /* 0 = per launch (see vcr_linear_f32), 16 / 32 = that shape everywhere */
-#endif
+constexpr int LINEAR_MS_DEFAULT = 0;   // 0 = per launch (see vcr_linear_f32), 16 / 32 = that shape everywhere (probe_build.py --set)
 
-#ifdef VCR_TIMELINE
-// Experiment-only instrumentation (profiles/timeline_linear.py builds a scratch library with -DVCR_TIMELINE): wave 0 of
-// every workgroup stamps the 100 MHz wall clock at its start, after every tile's k loop and at its end.
-__device__ unsigned long long vcr_tl[4096 * 16];
-__device__ __forceinline__ void tl_mark(int slot) {
-  if (threadIdx.x == 0 && blockIdx.x < 4096 && slot < 16) vcr_tl[blockIdx.x * 16 + slot] = wall_clock64();
-}
-#define TL(slot) tl_mark(slot)
-#else
-#define TL(slot) ((void)0)
-#endif
+// Lines that start with "//@probe " are inert here: profiles/experiments/probe_build.py uncomments them in a scratch copy
+// built against profiles/experiments/probes.h (in-kernel clock stamps; DESIGN.md, measurement protocol).
 
 template <int BK> struct TileT { float a[BM][BK + 4]; float b[BN][BK + 4]; };
 
@@ -235,8 +224,7 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
   const int grp = bid / (GW * tiles_m), wg = min(GW, tiles_n - grp * GW), loc = bid - grp * GW * tiles_m;
   const int tm = loc / wg, tn = grp * GW + loc % wg;
   const int m0 = tm * BMV, n0 = tn * BN;
-  TL(0);
-
+  //@probe VCR_PROBE_STAMP(0);
   // fill mapping: wave w covers rows w*32 + RPK*i + lane / CPR, physical chunk lane % CPR
   // (BMV = 96: the A panel is BMV / RPK wave instructions, dealt to the waves round robin -- 3 each at BK 32; 2, 2, 1, 1 at BK 16)
   const int frow = lane / CPR, fpc = lane % CPR;
@@ -272,7 +260,7 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
     rowst[2 * t + 1] = 1.f / (sqrtf(var) + p.ln_eps);
   }
   __syncthreads();
-  TL(1);
+  //@probe VCR_PROBE_STAMP(1);
 
   constexpr int NT = MS == 32 ? 2 : 4;                   // MFMA tiles per 64-wide wave-tile edge
   constexpr int NTM = WR / MS;                           // MFMA tile rows per wave tile (BMV 96: 3)
@@ -347,7 +335,7 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
     }
     __syncthreads();                                     // drains the LDS-DMA (vmcnt(0)) and orders the buffers
   }
-  TL(2);
+  //@probe VCR_PROBE_STAMP(2);
 
   // epilogue: transpose the wave's 64x64 tile through its slice of the (now free) staging LDS so that every lane owns 4
   // consecutive columns: bias / LayerNorm / ReLU / residual / store all move 16 B per lane
@@ -382,6 +370,7 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    //@probe if (i == 0) VCR_PROBE_STAMP(4);                 // the wave's accumulators are complete and in LDS
     if (p.segmax_out) {
       // (uniform) fused EdgeConv max-pool, DGCNN conv2..conv4 -- no LayerNorm / residual / statistics here.  Rows are
       // edges, seg_k consecutive rows per point.  The wave walks its 64 rows in ascending order (i, then ps, then
@@ -420,8 +409,11 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
       }
       if (i == NPASS - 1) seg_flush();
     } else if (col < p.N) {
+      //@probe if (i == 0) { __builtin_amdgcn_s_waitcnt(0); VCR_PROBE_STAMP(9); }   // (bias / column sums have arrived)
 #pragma unroll
       for (int ps = 0; ps < NPS; ++ps) {
+        //@probe if (i == 0 && ps == 1) VCR_PROBE_STAMP(7);
+        //@probe if (i == 0 && ps == 4) VCR_PROBE_STAMP(8);
         const int rl = ps * 4 + (lane >> 4);
         const int row = m0 + wm * WR + i * EPR + rl;
         if (row < p.M) {
@@ -454,11 +446,9 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    //@probe VCR_PROBE_STAMP(5 + i);                         // pass i: stores issued
   }
-#ifdef VCR_TIMELINE
-  __builtin_amdgcn_s_waitcnt(0);                         // stores acknowledged
-  TL(3);
-#endif
+  //@probe __builtin_amdgcn_s_waitcnt(0); VCR_PROBE_STAMP(3);     // (stores acknowledged)
 }
 
 template <int BK, bool LN_IN, bool STATS_OUT, int MS, int BMV>
@@ -477,16 +467,6 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_pair_kern
 }
 
 }  // namespace
-
-#ifdef VCR_TIMELINE
-extern "C" int vcr_dbg_timeline(unsigned long long* host_dst, int clear) {
-  if (clear) {
-    static unsigned long long zeros[4096 * 16];
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(vcr_tl), zeros, sizeof(zeros));
-  }
-  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(vcr_tl), sizeof(unsigned long long) * 4096 * 16);
-}
-#endif
 
 namespace {
 struct LinearPlan { bool glds, bk16, ms16, bm_free, small_free, ln_in, st_out; int bm, tiles_m, tiles_n, vec, lds; long t96, t128; };
@@ -563,7 +543,7 @@ int linear_plan(const vcr_linear_args* a, LinearPlan* pl, int bm_override = 0, b
   const bool one_round16 = !in_pair && variant == 0 && a->M >= 16384 && a->K >= 512 &&
                            (long)((a->M + 127) / 128) * pl->tiles_n <= 1024;
   pl->bk16 = ((!a->residual && !one_round16) || (variant & 64)) && !(variant & 8);
-  pl->ms16 = (variant & 16) ? true : (variant & 1024) ? false : (VCR_LINEAR_MS_DEFAULT == 16 || (VCR_LINEAR_MS_DEFAULT == 0 && !pl->bk16));
+  pl->ms16 = (variant & 16) ? true : (variant & 1024) ? false : (LINEAR_MS_DEFAULT == 16 || (LINEAR_MS_DEFAULT == 0 && !pl->bk16));
   // Tile rows: bit 11 (2048) forces 96, bit 12 (4096) forces 128.  Automatic: 96 when the launch cost model above
   // prefers it by > 2 %, on the BK 32 kernels only (two workgroups per CU; measured at BASELINE configs[2], M = 36 864:
   // ffn2 0.335 -> 0.309 ms, cross.wo 0.184 -> 0.170, the wo pair 0.357 -> 0.340.  The BK 16 kernels run four

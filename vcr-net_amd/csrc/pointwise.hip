@@ -121,29 +121,12 @@ __global__ __launch_bounds__(256) void pointwise12_kernel(vcr_pointwise_args a) 
 // per-wave LDS tile [16][64] (ReLU applied), from which (a) four lanes per point read 16 consecutive channels each and run
 // pointwise12_kernel's epilogue unchanged (|feat|^2 in ATen's association, 16-B stores) and (b) the lanes re-read A
 // fragments for the P | Q projection, whose 64 KB of weights lie in LDS in fragment order (one ds_read_b128 per four MFMAs).
-#ifdef VCR_TIMELINE
-// Experiment-only (profiles/timeline_stem.py): waves 0 and 7 of every workgroup accumulate the 100 MHz wall clock per phase.
-__device__ unsigned long long vcr_tl_stem[512 * 8];
-#define STL_DECL unsigned long long stl_t = wall_clock64(), stl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define STL(slot) do { const unsigned long long n_ = wall_clock64(); stl_acc[slot] += n_ - stl_t; stl_t = n_; } while (0)
-#define STL_FLUSH do { if ((threadIdx.x == 0 || threadIdx.x == 448) && blockIdx.x < 256) for (int i_ = 0; i_ < 8; ++i_) vcr_tl_stem[(blockIdx.x * 2 + (threadIdx.x != 0)) * 8 + i_] = stl_acc[i_]; } while (0)
-extern "C" int vcr_dbg_timeline_stem(unsigned long long* host_dst, int clear) {
-  if (clear) {
-    static unsigned long long zeros[512 * 8];
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(vcr_tl_stem), zeros, sizeof(zeros));
-  }
-  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(vcr_tl_stem), sizeof(unsigned long long) * 512 * 8);
-}
-#else
-#define STL_DECL ((void)0)
-#define STL(slot) ((void)0)
-#define STL_FLUSH ((void)0)
-#endif
+// "//@probe ..." lines: inert here, uncommented by profiles/experiments/probe_build.py (phase clocks of waves 0 and 7).
 constexpr int TP = 68;                                   // tile pitch: the 64 lanes' A-fragment reads hit 64 distinct banks
 constexpr int PQW = 8;                                   // waves per workgroup (two per SIMD: one wave's LDS / store phases under the other's MFMAs)
 __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwise_args a, int tiles_per_cloud, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) float pw_smem[];
-  STL_DECL;
+  //@probe VCR_PROBE_ACC_DECL;
   float* wfrag = pw_smem;                                // [16 col tiles][4 step quads][64 lanes][4 steps]: Wpq as B fragments
   float* w1s = wfrag + 16 * 4 * 64 * 4;                  // [64][4] = (w0, w1, w2, b1)
   float* pqb = w1s + 64 * 4;                             // [256] P | Q bias (an LDS read per accumulator instead of an L2 round trip)
@@ -193,9 +176,9 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
 #pragma unroll
     for (int e = 0; e < 4; ++e) wfrag[(((j * 4 + (st >> 2)) * 64) + e * 16 + (n & 15)) * 4 + (st & 3)] = wq[it][e];
   }
-  STL(0);                                                // weight loads issued
+  //@probe VCR_PROBE_ACC(0);                                                // weight loads issued
   __syncthreads();
-  STL(1);                                                // ... arrived, LDS filled
+  //@probe VCR_PROBE_ACC(1);                                                // ... arrived, LDS filled
   float* T = tiles + wave * 16 * TP;
   const int p = lane >> 2, g = lane & 3;                 // epilogue mapping: four lanes per point, 16 channels each
   for (int tile = (int)blockIdx.x * PQW + wave; tile < total_tiles; tile += (int)gridDim.x * PQW) {
@@ -211,7 +194,7 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
         h[st] = fmaxf(fmaf(w[2], z, fmaf(w[1], y, fmaf(w[0], x, w[3]))), 0.f);
       }
     }
-    STL(2);                                              // x loads + conv1
+    //@probe VCR_PROBE_ACC(2);                                              // x loads + conv1
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{b2r[j], b2r[j], b2r[j], b2r[j]};   // bias first
@@ -225,7 +208,7 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
       for (int r = 0; r < 4; ++r) T[(4 * q4 + r) * TP + 16 * j + l15] = fmaxf(acc[j][r], 0.f);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    STL(3);                                              // conv2 MFMAs + tile to LDS
+    //@probe VCR_PROBE_ACC(3);                                              // conv2 MFMAs + tile to LDS
     // The two waves of a SIMD (w, w + 4) take the two halves of the tile's work in opposite order -- the feature epilogue
     // (LDS reads, global stores) and the P | Q product (256 MFMAs) -- so that one wave's MFMAs run under the other's stores
     // instead of all eight waves queueing for the matrix pipe at once.  Both halves only read the tile.
@@ -309,17 +292,22 @@ __global__ __launch_bounds__(64 * PQW, 1) void pointwise12_pq_kernel(vcr_pointwi
         }
     }
     };
-    if (wave < PQW / 2) { feature_epilogue(); STL(4); pq_product(); }
-    else { pq_product(); STL(4); feature_epilogue(); }
-    STL(5);                                              // P | Q MFMAs + stores issued
+    if (wave < PQW / 2) {
+      feature_epilogue();
+      //@probe VCR_PROBE_ACC(4);
+      pq_product();
+    } else {
+      pq_product();
+      //@probe VCR_PROBE_ACC(4);
+      feature_epilogue();
+    }
+    //@probe VCR_PROBE_ACC(5);                                              // P | Q MFMAs + stores issued
     __builtin_amdgcn_s_waitcnt(0xc07f);                  // the tile is rewritten by the next iteration
     __builtin_amdgcn_wave_barrier();
-#ifdef VCR_TIMELINE
-    __builtin_amdgcn_s_waitcnt(0);                       // (timeline builds: the stores' acknowledgement is a phase of its own)
-#endif
-    STL(6);
+    //@probe __builtin_amdgcn_s_waitcnt(0);              // (probe builds: the stores' acknowledgement is a phase of its own)
+    //@probe VCR_PROBE_ACC(6);
   }
-  STL_FLUSH;
+  //@probe VCR_PROBE_ACC_FLUSH(threadIdx.x == 0 || threadIdx.x == 448, blockIdx.x * 2 + (threadIdx.x != 0));
 }
 
 // [B,3,N] channels-first points -> [B,N,4] rows (x, y, z, |p|^2): the layout the kNN / ICP kernels read.
