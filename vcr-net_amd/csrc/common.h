@@ -139,6 +139,17 @@ __device__ __forceinline__ xcd_slice_t xcd_slice(int n) {
   return xcd_slice_t{lo + slot, slots, slot < len ? (len - slot + slots - 1) / slots : 0};
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence over ALL address spaces plus
+// s_barrier: hipcc emits s_waitcnt vmcnt(0) in front of it, so every global load still in flight (index / row prefetches
+// issued tiles ahead) and every global STORE (a group's outputs: a full write round trip, ~3 us under load) is waited for
+// at each barrier.  Here only the LDS accesses are fenced (s_waitcnt lgkmcnt(0); s_barrier): use it where the barrier
+// guards LDS buffers and nothing in global memory is exchanged between the workgroup's threads.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // exchange with the lane 32 away (the other half of the wave)
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 

@@ -219,6 +219,156 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_kernel(vcr_edgeconv
   }
 }
 
+// The packed kernel again, with every wave's instruction stream laid out by hand for the matrix pipe it shares.
+//
+// Measured (profiles/r4f_mfma_valu_coissue.txt): beside a wave that issues fp32 MFMAs back to back, another wave of the
+// same SIMD gets ONE vector / LDS instruction through per ~20 cycles (alone: 2.5-6), while a wave's OWN vector
+// instructions issue freely in the 64-cycle shadow of its own MFMA.  The kernel above runs two workgroups per CU; per tile
+// a wave has 64 MFMAs (4096 cycles of the pipe) and ~200 other instructions, which hipcc groups in front of and behind
+// the MFMA block -- where they crawl beside the partner's MFMAs, ~4000 cycles: the pipe is busy 0.73 of the time.  Here a
+// tile is 16 CHUNKS fenced by sched_barrier(0) -- one k-group each: the next group's fragment read, four MFMAs, and a
+// sixteenth of everything else --, which takes straight-line tiles:
+//   * the index loads run two tiles ahead and the row loads one tile ahead of the tile being multiplied, without
+//     conditions (past the block's last group they re-read it);
+//   * the x1 column pass splits the tile's rows by PARITY between the two thread halves: k is even, so rows 2m and 2m+1
+//     belong to the same point and both halves follow one compile-time row -> point map (no branch); one row per chunk,
+//     folded one chunk after it was requested;
+//   * the previous tile's accumulator is folded into the per-point maxima one register per chunk (two accumulators).
+// Results are bit-identical to the kernel above (same MFMA order per output; max is exact).
+constexpr int FRAG_AHEAD = 1;                            // 1 or 2 (profiles/r4i_edgeconv_ab.txt)
+template <int KE>
+__global__ __launch_bounds__(256, 2) void edgeconv_dg_pipe_kernel(vcr_edgeconv_args p) {
+  static_assert(KE % 2 == 0 && 160 % KE == 0, "parity split of the x1 pass");
+  constexpr int G = 160 / KE;                            // points per group
+  __shared__ __attribute__((aligned(16))) float Hs[2][32][HP];
+  __shared__ __attribute__((aligned(16))) float x1half[2][G][128];   // per-point column maxima of the two row parities
+  __shared__ __attribute__((aligned(16))) float x2half[2][G][128];   // per-point maxima of the MFMA rows held by the two lane halves
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int rs = lane >> 3, cg = lane & 7;
+  const int ch = 32 * w + 4 * cg;
+  const int colc = threadIdx.x & 127, rowp = threadIdx.x >> 7;       // x1 pass: one channel, the 16 rows of one parity
+
+  f32x4 wf[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) wf[g] = ld4(p.w2 + (size_t)(32 * w + l31) * 128 + 8 * g + 4 * half);
+  const f32x4 bias4 = ld4(p.b2 + 4 * (threadIdx.x & 31));           // the group-end pass: this thread's four channels
+
+  const int ngroups = (p.M + G - 1) / G;
+  const xcd_slice_t sl = xcd_slice(ngroups);
+  if (sl.count == 0) return;
+  const int my_groups = sl.count;
+  const int grp_last = sl.first + (my_groups - 1) * sl.stride;
+
+  int nb[4], nbn[4];                                     // neighbour indices of the next tile / the one after
+  f32x4 hr[4], hq[4];                                    // the next tile's gathered P rows and centre Q rows
+  auto load_idx1 = [&](int grp, int t, int i, int (&dst)[4]) {
+    const int e = 32 * t + rs + 8 * i;
+    const int pl = e / KE, j = e - pl * KE;
+    const int pt = min(grp * G + pl, p.M - 1);
+    dst[i] = p.idx[(size_t)pt * KE + j];
+  };
+  auto load_row1 = [&](int grp, int t, int i) {
+    const int e = 32 * t + rs + 8 * i;
+    const int pt = min(grp * G + e / KE, p.M - 1);
+    const int base = (pt / p.n_per_cloud) * p.n_per_cloud;
+    hr[i] = ld4(p.pq + (size_t)(base + nb[i]) * p.ldpq + ch);
+    hq[i] = ld4(p.pq + (size_t)pt * p.ldpq + 128 + ch);
+  };
+  auto commit1 = [&](int buf, int i) {
+    const f32x4 v = hr[i] + hq[i];
+    st4(&Hs[buf][rs + 8 * i][ch], f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)});
+  };
+  float pm[G], cm[G];                                    // per-point maxima: x2 (MFMA rows) and x1 (this thread's channel)
+  auto fold1 = [&](const f32x16& a, int t, int r) {      // accumulator register r of tile t -> the per-point maxima
+    const int row0 = 32 * t + acc_row(r, 0), row1 = row0 + 4;
+    const int p0 = row0 / KE, p1 = row1 / KE;
+    if (p0 == p1) {
+      pm[p0] = fmaxf(pm[p0], a[r]);
+    } else {
+      pm[p0] = fmaxf(pm[p0], half ? VCR_NEG_INF : a[r]);
+      pm[p1] = fmaxf(pm[p1], half ? a[r] : VCR_NEG_INF);
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_idx1(sl.first, 0, i, nb);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_row1(sl.first, 0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_idx1(sl.first, 1, i, nbn);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) commit1(0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) nb[i] = nbn[i];
+  lds_barrier();
+  int cur = 0;
+  for (int gi = 0; gi < my_groups; ++gi) {
+    const int grp = sl.first + gi * sl.stride;
+    const int grp_n = min(grp + sl.stride, grp_last);    // (the block's last group is re-read instead of branching)
+#pragma unroll
+    for (int q = 0; q < G; ++q) { pm[q] = VCR_NEG_INF; cm[q] = 0.f; }
+    f32x16 accp = {0};                                   // the previous tile's accumulator (folded during this tile)
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const float* hcol = &Hs[cur][rowp][colc];
+      const float* hrow = &Hs[cur][l31][4 * half];
+      f32x16 acc = {0};
+      f32x4 af[3];                                       // fragments are requested FRAG_AHEAD k-groups ahead
+      float xv[3];
+#pragma unroll
+      for (int g = 0; g < FRAG_AHEAD; ++g) { af[g] = ld4(hrow + 8 * g); xv[g] = hcol[2 * g * HP]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        if (g + FRAG_AHEAD < 16) {
+          af[(g + FRAG_AHEAD) % 3] = ld4(hrow + 8 * (g + FRAG_AHEAD));
+          xv[(g + FRAG_AHEAD) % 3] = hcol[2 * (g + FRAG_AHEAD) * HP];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(af[g % 3][e], wf[g][e], acc);
+        cm[(32 * t + 2 * g) / KE] = fmaxf(cm[(32 * t + 2 * g) / KE], xv[g % 3]);     // x1 pass, row 2g + parity
+        if (t > 0) fold1(accp, t - 1, g);                                           // previous tile, register g
+        if (g < 4) load_row1(t < 4 ? grp : grp_n, (t + 1) % 5, g);                  // tile s+1: rows (indices: tile s-1)
+        else if (g < 8) load_idx1(t < 3 ? grp : grp_n, (t + 2) % 5, g - 4, nbn);    // tile s+2: indices
+        else if (g >= 10 && g < 14) commit1(cur ^ 1, g - 10);                       // tile s+1 -> the other LDS buffer
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nb[i] = nbn[i];
+      if (t == 4) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fold1(acc, 4, r);   // (the group's last tile: nothing left to hide it under)
+        // group end: both maxima leave through LDS -- no cross-half shuffles, no per-point 4-B stores: one 16-B store of
+        // x1 and one of x2 per thread
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+          x2half[half][q][32 * w + l31] = pm[q];
+          x1half[rowp][q][colc] = cm[q];
+        }
+        lds_barrier();
+        for (int i = threadIdx.x; i < G * 32; i += 256) {
+          const int q = i >> 5, c4 = (i & 31) * 4, pt = grp * G + q;
+          if (pt < p.M) {
+            const f32x4 lo = ld4(&x1half[0][q][c4]), hi = ld4(&x1half[1][q][c4]);
+            st4(p.x1 + (size_t)pt * p.ldx1 + c4, f32x4{fmaxf(lo[0], hi[0]), fmaxf(lo[1], hi[1]), fmaxf(lo[2], hi[2]),
+                                                        fmaxf(lo[3], hi[3])});
+            const f32x4 a0 = ld4(&x2half[0][q][c4]), a1 = ld4(&x2half[1][q][c4]);
+            st4(p.x2 + (size_t)pt * p.ldx2 + c4,
+                f32x4{fmaxf(fmaxf(a0[0], a1[0]) + bias4[0], 0.f), fmaxf(fmaxf(a0[1], a1[1]) + bias4[1], 0.f),
+                      fmaxf(fmaxf(a0[2], a1[2]) + bias4[2], 0.f), fmaxf(fmaxf(a0[3], a1[3]) + bias4[3], 0.f)});
+          }
+        }
+      }
+      accp = acc;
+      lds_barrier();
+      cur ^= 1;
+    }
+  }
+}
+
+constexpr int EDGECONV_PIPE = 1;                         // 1: the kernel above; 0: edgeconv_dg_packed_kernel (A/B builds: probe_build.py --set)
+
 __global__ __launch_bounds__(256) void gathermax_kernel(vcr_gathermax_args p) {
   const int lane = threadIdx.x & 63;
   const int pt = xcd_chunk((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);
@@ -415,8 +565,16 @@ extern "C" int vcr_edgeconv_f32(const vcr_edgeconv_args* a, vcr_stream_t stream)
   if (a->ldpq < 256 || (a->ldpq & 3) || (a->ldx1 & 3) || a->ldx1 < 128 || a->ldx2 < 128) return VCR_EINVAL;
   if (a->k == 20 || a->k == 40) {                        // packed tiles: no padding rows
     const int G = 160 / a->k, ngroups = (a->M + G - 1) / G;
-    const int grid = ngroups < 1024 ? ngroups : 1024;
-    if (a->k == 20) hipLaunchKernelGGL(edgeconv_dg_packed_kernel<20>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    // one resident round: two workgroups per CU (each keeps a 32 x 128 slice of W2 in registers and pays one gather chain
+    // of two dependent round trips before its first tile; 1024 workgroups on 512 slots paid both twice)
+    const int slots = 2 * vcr_cu_count();
+    const int grid = ngroups < slots ? ngroups : slots;
+    // the hand-scheduled kernel stores x2 as 16-B pieces; rows that are not 16-B aligned keep the kernel above
+    const bool al16 = !(a->ldx2 & 3) && !(((uintptr_t)a->x1 | (uintptr_t)a->x2 | (uintptr_t)a->b2) & 15);
+    if (EDGECONV_PIPE && al16) {
+      if (a->k == 20) hipLaunchKernelGGL(edgeconv_dg_pipe_kernel<20>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+      else hipLaunchKernelGGL(edgeconv_dg_pipe_kernel<40>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
+    } else if (a->k == 20) hipLaunchKernelGGL(edgeconv_dg_packed_kernel<20>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL(edgeconv_dg_packed_kernel<40>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
     return VCR_LAUNCH_RC();
   }
