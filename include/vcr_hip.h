@@ -222,10 +222,13 @@ int vcr_edgeconv_bf16x3_f32(const vcr_edgeconv_args*, vcr_stream_t);
 typedef struct {
   const float* pq; int ldpq; int C; const int32_t* idx; int k; int M; int n_per_cloud;
   float* y; int ldy;
+  int variant;   /* tuning / tests, 0 = automatic: 1 = neighbour rows gathered through L2 (one wave per point); 32 / 16 / 8 =
+                    gathered out of LDS with that many channels per workgroup slice (VCR_EUNSUPPORTED when the slice of one
+                    cloud does not fit a workgroup's LDS, k is not 20 / 40, or pq / y / idx are not 16-B aligned) */
 } vcr_gathermax_args;
-/* (k = 20 / 40, n_per_cloud <= 1066, >= 192 (cloud, 32-channel slice) workgroups, 16-B aligned pq / y / idx: the neighbour
- * rows are gathered out of LDS -- a workgroup stages its slice of one cloud's P rows once -- instead of through L2;
- * same bits.  Environment VCR_GATHERMAX = lds | l2 forces one or the other: benchmarks.) */
+/* (automatic: k = 20 / 40, n_per_cloud <= 2048, >= 192 (cloud, 32-channel slice) workgroups, 16-B aligned pq / y / idx: the
+ * neighbour rows are gathered out of LDS -- a workgroup stages its slice of one cloud's P rows once (32 channels up to
+ * 1066 points, 16 beyond) -- instead of through L2; same bits either way.) */
 int vcr_gathermax_f32(const vcr_gathermax_args*, vcr_stream_t);
 
 /* ---- EdgeConv chains (DGCNN, vcrnet_model.py:104-118): per-edge rows h[(i,j)] = relu(P[nbr_ij] + Q[i])
@@ -309,7 +312,8 @@ int vcr_keymass_f32(const vcr_keymass_args*, vcr_stream_t);
 typedef struct {
   const float* q; int ldq; const float* k; int ldk; const float* qside4; const float* kside4;
   float* corr4; int nbatch, nq, nk, E; int mode; float scale;
-  float* split_work;                  /* optional: vcr_pairscore_args.split_work of the underlying op-0 launch */
+  float* split_work;                  /* optional: vcr_pairscore_args.split_work of the underlying op-0 launch ... */
+  long split_work_floats;             /* ... and its capacity in floats (see there) */
 } vcr_softcorr_args;
 int vcr_softcorr_f32(const vcr_softcorr_args*, vcr_stream_t);
 
@@ -336,8 +340,10 @@ typedef struct {
    * With it the launch may deal the streamed rows to up to that many workgroups per owner block when its grid would
    * otherwise leave a mostly empty last round on the chip (e.g. 288 or 320 workgroups on 256 CUs) or fill only part of it;
    * the partial (max, sum[, weighted xyz]) records are merged in a fixed order by a second small kernel.  Scores and
-   * arg-max are unaffected; the sums merge in a different order. */
-  float* split_work;
+   * arg-max are unaffected; the sums merge in a different order.  split_work_floats = the buffer's capacity in floats: a
+   * split whose records would not fit is not taken (the launch then runs unsplit), so an under-sized buffer costs speed,
+   * never an out-of-bounds write. */
+  float* split_work; long split_work_floats;
 } vcr_pairscore_args;
 #define VCR_PAIRSCORE_MAX_SPLIT 4
 int vcr_pairscore_f32(const vcr_pairscore_args*, vcr_stream_t);

@@ -430,6 +430,17 @@ def test_gathermax_lds_and_l2_paths_are_exact(nat, B, N, k, C):
         gathered = torch.stack([P[b][idx.view(B, N, k)[b].long()] for b in range(B)])
     ref = torch.relu(gathered.max(2).values + Q).view(B * N, C)
     assert torch.equal(y, ref)
+    # every form the args can force (vcr_gathermax_args.variant: 1 = L2, 32 / 16 / 8 = LDS slices) gives the same bits, or
+    # refuses when the slice of one cloud does not fit a workgroup's LDS
+    for variant in (1, 32, 16, 8):
+        fits = N * (variant + 4) * 4 <= 160 * 1024
+        if variant == 1 or fits:
+            assert torch.equal(nat.gathermax(pq, C, idx, N, variant=variant), ref), variant
+        else:
+            with pytest.raises(nat.VcrHipError):
+                nat.gathermax(pq, C, idx, N, variant=variant)
+    with pytest.raises(nat.VcrHipError):
+        nat.gathermax(pq, C, idx, N, variant=5)
 
 
 @pytest.mark.parametrize("B,N,k", [(2, 300, 20), (3, 101, 20), (2, 130, 40), (16, 1024, 20), (1, 203, 7)])

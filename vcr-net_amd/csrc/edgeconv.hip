@@ -591,13 +591,22 @@ extern "C" int vcr_gathermax_f32(const vcr_gathermax_args* a, vcr_stream_t strea
   // most of the chip (one workgroup per CU: >= 192 of them) and the 16-B accesses are aligned.  Measured on MI355X
   // (profiles/experiments/bench_gathermax.py): 32 clouds x 1024, k = 20, C = 256: 35.4 -> 23.0 us; 48 x 768: 39.5 -> 31.6;
   // 4 clouds x 1024 x 128 channels (16 workgroups): 11.1 -> 14.9, and 8-channel slices at N = 2048: 69 -> 121 -- those
-  // keep the L2 gathers.
+  // keep the L2 gathers.  a->variant forces a form (1 = L2; 32 / 16 / 8 = LDS with that slice), or refuses.
   const int N = a->n_per_cloud;
   const bool aligned = !(((uintptr_t)a->pq | (uintptr_t)a->y | (uintptr_t)a->idx) & 15) && (a->k == 20 || a->k == 40);
   const size_t budget = 150 * 1024;
-  int cs = aligned && (size_t)N * 36 * 4 <= budget && (long)(a->M / N) * ((a->C + 31) / 32) >= 192 ? 32 : 0;
-  static const char* const e = getenv("VCR_GATHERMAX");   // (read once)
-  if (e) cs = (e[0] == 'l' && e[1] == 'd') ? (aligned && (size_t)N * 36 * 4 <= budget ? 32 : 0) : 0;   // "lds" / "l2": benchmarks
+  int cs = 0;
+  if (a->variant == 0) {
+    // 32-channel slices up to N = 1066; 16-channel slices up to N = 2048 (a whole CU's LDS per workgroup; measured at 32
+    // clouds x 2048: 62.8 -> 57.2 us, profiles/r4j_bench_gathermax.txt; 8-channel slices lose everywhere: 121 us there)
+    if (aligned && (long)(a->M / N) * ((a->C + 31) / 32) >= 192)
+      cs = (size_t)N * 36 * 4 <= budget ? 32 : (size_t)N * 20 * 4 <= 160 * 1024 ? 16 : 0;
+  } else if (a->variant == 32 || a->variant == 16 || a->variant == 8) {
+    if (!aligned || (size_t)N * (a->variant + 4) * 4 > 160 * 1024) return VCR_EUNSUPPORTED;
+    cs = a->variant;
+  } else if (a->variant != 1) {
+    return VCR_EINVAL;
+  }
   if (cs) {
     const int slices = (a->C + cs - 1) / cs, clouds = a->M / N;
     const size_t lds = (size_t)N * (cs + 4) * 4;

@@ -133,7 +133,8 @@ struct Runner {
 
   // ln_stats + ln_colsum: LayerNorm folded into this linear (w, b are the folded weight / bias; the row statistics
   // come from the producer's epilogue);
-  // stats_out: this launch's epilogue writes the (sum, sum^2) partials of its output rows for a later LayerNorm.
+  // stats_out: this launch's epilogue writes the per-64-column (sum, second moment about the segment mean) partials of its
+  // output rows for a later LayerNorm (common.h: ln_row_moments).
   bool linear(const char* nm, const float* x, int ldx, const float* w, const void* wsplit, const float* b, float* y,
               int ldy, int M, int N, int K, int relu, const float* res = nullptr, int ldr = 0,
               const float* ln_stats = nullptr, const float* ln_colsum = nullptr, float* stats_out = nullptr) {
@@ -291,8 +292,8 @@ struct Runner {
       // free until the FFN and holds it when F >= 2E), else the masked form
       if (!io->force_keys) rank("select:dec.cross.keys", w.keymass, 1, nb, N, nkeep, w.xorder, w.keep, 1);
       if (io->out_keys) copy_idx("select:dec.cross.keys.out", io->out_keys, w.xorder, (size_t)nb * nkeep);
-      if (!sdpa_split) {
-        if (rc) return;
+      if (!sdpa_split && nkeep <= 16384) {               // (vcr_sdpa_f32 holds the index list in LDS: <= 16 384 kept keys;
+        if (rc) return;                                  //  longer lists take the dense copy / the masked form below)
         mark("sdpa:dec.cross");
         vcr_sdpa_args a{w.qc, E, w.kvc, 2 * E, w.kvc + E, 2 * E, w.att, E, nb, H, N, nkeep, 1.0f / sqrtf(128.f), B};
         a.key_index = w.xorder; a.nk_src = N;
@@ -323,6 +324,7 @@ struct Runner {
       a.nbatch = B; a.n_own = no; a.n_str = ns; a.E = E; a.score = 0; a.scale = 1.f; a.op = 1;
       a.stat2 = stat2; a.argmax = amax; a.score_out = score_out; a.ld_score = ld_score;
       a.split_work = amax ? nullptr : w.rsplit;
+      a.split_work_floats = amax ? 0 : (long)VCR_PAIRSCORE_MAX_SPLIT * B * N * 2;     // (sized in plan(): B1 * N * 2 per split)
       pairscore(nm, a);
     };
     // score_ij = (-|s_i|^2 + 2 s_i.t_j) - |t_j|^2 (:211-216), computed and stored once with the row soft-max
@@ -602,7 +604,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     if (R.rc) return;
     R.mark(nm);
     vcr_softcorr_args a{head_emb + q0 * E, E, head_emb + k0 * E, E, side + q0 * 4, side + k0 * 4,
-                        corr, B, N, N, E, W->head_mode == 1 ? 1 : 0, 1.0f / sqrtf((float)E), w.csplit};
+                        corr, B, N, N, E, W->head_mode == 1 ? 1 : 0, 1.0f / sqrtf((float)E), w.csplit,
+                        (long)VCR_PAIRSCORE_MAX_SPLIT * B * N * 8};
     R.ok(vcr_softcorr_f32(&a, R.stream));
   };
   if (hard_pairs) {
@@ -774,7 +777,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 23; }
+extern "C" int vcr_abi_version(void) { return 24; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

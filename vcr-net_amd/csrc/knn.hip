@@ -777,15 +777,17 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   finish<G, KS, 1>(sel, a, b, q0 + col, wave, 0, smem, blk_ties);
   if (blk_ties) replay_block_ties(a, blk_ties, smem);
 }
+// (k > 20: the logs of a workgroup take 51 KB, so three workgroups share a CU whatever the registers allow -- the bound
+//  says so and the lists of 42 keep their registers: at four waves per SIMD, 128 VGPRs, two spilled to scratch)
 template <int KS, int W, bool XT>
-__global__ __launch_bounds__(64 * W, 4) void knn64c_kernel(vcr_knn_args a) {
+__global__ __launch_bounds__(64 * W, (KS > 22 ? 3 : 4)) void knn64c_kernel(vcr_knn_args a) {
   int bx, b;
   xcd_chunk2(bx, b);
   knn64c_body<KS, W, 64, XT>(a, bx, b);
 }
 // the Cartesian search on the same body (distances = one MFMA per tile): the unsplit (S = 1) kernel of C == 4
 template <int KS, int W>
-__global__ __launch_bounds__(64 * W, 4) void knn3c_kernel(vcr_knn_args a) {
+__global__ __launch_bounds__(64 * W, (KS > 22 ? 3 : 4)) void knn3c_kernel(vcr_knn_args a) {
   int bx, b;
   xcd_chunk2(bx, b);
   knn64c_body<KS, W, 4>(a, bx, b);
@@ -900,7 +902,7 @@ __global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
 // alone is latency-bound at one wave per SIMD (1024 waves on 1024 SIMDs); launched together the second fills the
 // first one's idle issue slots, and the pair costs little more than the longer of the two.
 template <int KS, bool COL16, bool XT = false>
-__global__ __launch_bounds__(256, (COL16 ? 4 : 2)) void knn_pair_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
+__global__ __launch_bounds__(256, (COL16 ? (KS > 22 ? 3 : 4) : 2)) void knn_pair_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
   const int bid = (int)blockIdx.x;
   if (bid < n64) {
     const int lin = xcd_chunk(bid, n64);

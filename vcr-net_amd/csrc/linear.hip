@@ -479,8 +479,9 @@ int small_grid_rows(const long* tiles_by_h) {
   static const int hs[4] = {128, 96, 64, 32};
   int best = 128;
   double bc = 1e30;
+  const int cus = vcr_cu_count();
   for (int i = 0; i < 4; ++i) {
-    const long per_cu = (tiles_by_h[i] + 255) / 256;
+    const long per_cu = (tiles_by_h[i] + cus - 1) / cus;
     const double c = ((double)(per_cu / 2) * 1.75 + (double)(per_cu & 1)) * (hs[i] + 24);
     if (c < bc - 1e-9) { bc = c; best = hs[i]; }
   }
@@ -541,14 +542,14 @@ int linear_plan(const vcr_linear_args* a, LinearPlan* pl, int bm_override = 0, b
   // stores; two rounds of the BK 32 kernel's 512 slots drift apart instead.  Measured inside the forward on one box
   // (profiles/r3r_ab_conv3_bk32.txt): conv3 0.148 -> 0.1425 ms.  K >= 512 only (sn1_pq, K = 128: 0.047 -> 0.049 with BK 32).
   const bool one_round16 = !in_pair && variant == 0 && a->M >= 16384 && a->K >= 512 &&
-                           (long)((a->M + 127) / 128) * pl->tiles_n <= 1024;
+                           (long)((a->M + 127) / 128) * pl->tiles_n <= 4L * vcr_cu_count();
   pl->bk16 = ((!a->residual && !one_round16) || (variant & 64)) && !(variant & 8);
   pl->ms16 = (variant & 16) ? true : (variant & 1024) ? false : (LINEAR_MS_DEFAULT == 16 || (LINEAR_MS_DEFAULT == 0 && !pl->bk16));
   // Tile rows: bit 11 (2048) forces 96, bit 12 (4096) forces 128.  Automatic: 96 when the launch cost model above
   // prefers it by > 2 %, on the BK 32 kernels only (two workgroups per CU; measured at BASELINE configs[2], M = 36 864:
   // ffn2 0.335 -> 0.309 ms, cross.wo 0.184 -> 0.170, the wo pair 0.357 -> 0.340.  The BK 16 kernels run four
   // workgroups per CU, their last round costs little, and 96-row tiles measured 0-6 % SLOWER there).
-  const int slots = 256 * (pl->bk16 ? 4 : 2);            // MI355X: 256 CUs x resident workgroups per CU
+  const int slots = vcr_cu_count() * (pl->bk16 ? 4 : 2); // CUs (MI355X: 256) x resident workgroups per CU
   const long t128 = (long)((a->M + 127) / 128) * pl->tiles_n, t96 = (long)((a->M + 95) / 96) * pl->tiles_n;
   pl->t96 = t96; pl->t128 = t128;
   pl->bm_free = pl->glds && !(variant & (4096 | 2048 | 1024 | 8192 | 16384));   // nothing forces the tile rows or the 32x32x2 shape
@@ -567,7 +568,7 @@ int linear_plan(const vcr_linear_args* a, LinearPlan* pl, int bm_override = 0, b
     bm = (variant & 8192) ? 64 : 32;
   } else if (bm_override && pl->bm_free && (bm_override >= 96 || pl->small_free)) {
     bm = bm_override;
-  } else if (!bm_override && pl->small_free && t128 < 512) {
+  } else if (!bm_override && pl->small_free && t128 < 2L * vcr_cu_count()) {
     const long th[4] = {t128, t96, (long)((a->M + 63) / 64) * pl->tiles_n, (long)((a->M + 31) / 32) * pl->tiles_n};
     bm = small_grid_rows(th);
     if (bm >= 96) bm = bm96 ? 96 : 128;                  // (>= 96 rows: the regular choice above, with its k-slab and shape)
@@ -645,7 +646,7 @@ extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_ar
   if (rc == VCR_OK) rc = linear_plan(b, &pb, 0, true);
   if (rc != VCR_OK) return rc;
   int joint = 0;                                         // tile rows from the COMBINED grid (the two halves share the rounds)
-  if (pa.small_free && pb.small_free && pa.t128 + pb.t128 < 512) {     // a small grid even together
+  if (pa.small_free && pb.small_free && pa.t128 + pb.t128 < 2L * vcr_cu_count()) {     // a small grid even together
     const long th[4] = {pa.t128 + pb.t128, pa.t96 + pb.t96,
                         (long)((a->M + 63) / 64) * pa.tiles_n + (long)((b->M + 63) / 64) * pb.tiles_n,
                         (long)((a->M + 31) / 32) * pa.tiles_n + (long)((b->M + 31) / 32) * pb.tiles_n};
@@ -655,7 +656,7 @@ extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_ar
     const bool r = a->residual != nullptr, rb = b->residual != nullptr;     // (the regular k-slab: BK 32 iff a residual)
     joint = 0;
     if (r == rb) {
-      const int slots = 256 * (r ? 2 : 4);
+      const int slots = vcr_cu_count() * (r ? 2 : 4);
       joint = r && 1.02 * launch_cost(pa.t96 + pb.t96, slots, 96) < launch_cost(pa.t128 + pb.t128, slots, 128) ? 96 : 128;
     }
   }

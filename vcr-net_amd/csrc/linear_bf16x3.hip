@@ -229,8 +229,9 @@ extern "C" int vcr_split_bf16x3_f32(const float* x, void* planes, size_t n, vcr_
 
 extern "C" int vcr_linear_bf16x3_f32(const vcr_linear_args* a, const void* w_planes, vcr_stream_t stream) {
   if (!a || !a->x || !w_planes || !a->y) return VCR_EINVAL;
-  if (a->ln_stats_in && (!a->ln_colsum || !a->bias || a->ln_nseg <= 0 || a->K < 2 || ((uintptr_t)a->ln_colsum & 15)))
-    return VCR_EINVAL;
+  if (a->ln_stats_in && (!a->ln_colsum || !a->bias || a->ln_nseg <= 0 || a->K < 2 || (a->K % a->ln_nseg) ||
+                         ((uintptr_t)a->ln_colsum & 15)))
+    return VCR_EINVAL;                                   // (K % ln_nseg: ln_row_moments needs equal segments, as linear_plan checks)
   if (a->stats_out && (a->N % 64)) return VCR_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K % TK) != 0) return VCR_EINVAL;
   if ((a->ldx & 3) || a->ldx < a->K || a->ldy < a->N || (a->residual && a->ldr < a->N)) return VCR_EINVAL;

@@ -359,6 +359,8 @@ int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
     for (int sp = 2; sp <= VCR_PAIRSCORE_MAX_SPLIT; ++sp) {
       if (ntiles / sp < 4 * ot || (sp - 1) * ((ntiles + sp - 1) / sp) >= ntiles) break;   // a tile per wave, no empty run
       const double c = (double)((blocks * sp + slots - 1) / slots) / sp;
+      const long need = (long)sp * a->nbatch * a->n_own * (a->op == 0 ? 8 : 2);      // floats of partial records
+      if (need > a->split_work_floats) break;            // the caller's scratch decides how far the split may go
       if (c < 0.8 * base && c < best - 1e-9) { best = c; nsplit = sp; }
     }
   }
@@ -402,6 +404,6 @@ extern "C" int vcr_softcorr_f32(const vcr_softcorr_args* a, vcr_stream_t stream)
   p.own_side4 = a->qside4; p.str_side4 = a->kside4;
   p.nbatch = a->nbatch; p.n_own = a->nq; p.n_str = a->nk; p.E = a->E;
   p.score = a->mode; p.scale = a->scale; p.str_batch_shift = 0; p.op = 0; p.corr4 = a->corr4;
-  p.split_work = a->split_work;
+  p.split_work = a->split_work; p.split_work_floats = a->split_work_floats;
   return launch(&p, stream);
 }

@@ -21,6 +21,23 @@ from .weights import strip_module_prefix
 LINEAR_MODES = {"fp32": 0, "bf16x3": 1, "bf16x3+sdpa": 2}   # vcr_vcrnet_weights.linear_mode
 
 
+class _Shared:
+    """State that a module and its nn.DataParallel replicas share (replicas are shallow copies: ``__dict__.copy()``, so
+    they all point at THIS object): the packed weights per device and the pool of forward workspaces.  ``nn.DataParallel``
+    re-creates its replicas on every forward with freshly broadcast parameters (util/initPara.py:260 wraps the net in one),
+    and calls them from one host thread per replica: the packed form is therefore keyed by (device, the MASTER's parameter
+    versions), owns its memory, and every access goes through the lock."""
+
+    def __init__(self, master):
+        import threading
+        import weakref
+        self.lock = threading.RLock()
+        self.master = weakref.ref(master)
+        self.packed: Dict[torch.device, Tuple] = {}         # device -> (key, P, cw): the latest packing per device
+        self.pool: Dict[Tuple, list] = {}                   # workspace key -> idle workspaces (dicts: "ws", "stream")
+        self.packs = 0                                      # how many times weights were packed (tests)
+
+
 # ---- parameter containers with the reference's module tree (names are API) -------------------------------
 
 class _LPDNetParams(nn.Module):
@@ -220,30 +237,74 @@ class VCRNet(nn.Module):
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
         self._cw: Optional[native.VcrnetWeights] = None
-        self._bufs: Dict[Tuple, Dict[str, torch.Tensor]] = {}
+        self._shared = _Shared(self)
         # profiling hook: a native.Trace that the next forward() / vcrnetIter() call records its per-launch HIP events
         # into (bench.py sets it on the steps it traces; None = no events)
         self.launch_trace: Optional[native.Trace] = None
-        self._aux: Dict[torch.device, native.AuxStream] = {}
 
     # -- checkpoints saved through nn.DataParallel carry a "module." prefix --
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         return super().load_state_dict(strip_module_prefix(state_dict), strict=strict, **kw)
 
+    def __getstate__(self):
+        # pickling / copy.deepcopy: the packed weights (raw device pointers) and the shared cache stay behind; the copy
+        # packs for itself on its first call
+        d = self.__dict__.copy()
+        d.pop("_shared", None)
+        d["_packed"], d["_packed_key"], d["_cw"] = None, None, None
+        return d
+
     # -- weight packing: once per (device, parameter versions) --------------------------------------------------
+    def _tensors(self) -> Dict[str, torch.Tensor]:
+        """{state_dict key: tensor} of this module -- or of this nn.DataParallel REPLICA, whose parameters() is empty by
+        design (torch/nn/parallel/replicate.py: the broadcast copies are plain attributes, listed in _former_parameters)."""
+        out: Dict[str, torch.Tensor] = {}
+        for prefix, mod in self.named_modules():
+            former = mod.__dict__.get("_former_parameters") if getattr(mod, "_is_replica", False) else None
+            src = former if former is not None else mod._parameters
+            for k, v in list(src.items()) + list(mod._buffers.items()):
+                if v is not None:
+                    out[(prefix + "." if prefix else "") + k] = v
+        return out
+
+    def _device(self) -> torch.device:
+        return next(iter(self._tensors().values())).device
+
+    def _master(self):
+        """The module whose parameters define the weights: self, or -- for an nn.DataParallel replica -- the wrapped module."""
+        sh = self.__dict__.get("_shared")
+        m = sh.master() if sh is not None else None
+        if m is None or (m is not self and not getattr(self, "_is_replica", False)):
+            # a deep copy (copy.deepcopy keeps weak references as they are) or a module unpickled without its state
+            self._shared = sh = _Shared(self)
+            m = self
+        return m, sh
+
     def _fingerprint(self):
-        ps = list(self.parameters()) + list(self.buffers())
-        return (ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]), self.emb_nn.k,
+        m, _ = self._master()
+        ps = list(m.parameters()) + list(m.buffers())
+        dev = self._device()
+        return (dev, ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]), self.emb_nn.k,
                 self.linear_mode, self.linear_mfma, self.linear_bk, self.linear_bm, self.knn_waves, self.xscore_limit_mb,
                 self.merge_encdec)
 
     def _pack(self):
-        key = self._fingerprint()
-        if self._packed is not None and key == self._packed_key:
-            return
-        sd = {k: v.detach().float() for k, v in self.state_dict().items()}
+        m, sh = self._master()
+        with sh.lock:
+            key = self._fingerprint()
+            hit = sh.packed.get(key[0])
+            if hit is not None and hit[0] == key:
+                self._packed_key, self._packed, self._cw = hit
+                return
+            self._pack_locked(key, own=m is not self)
+            sh.packed[key[0]] = (self._packed_key, self._packed, self._cw)
+            sh.packs += 1
+
+    def _pack_locked(self, key, own):
+        sd = {k: v.detach().float() for k, v in self._tensors().items()}
         P: Dict[str, torch.Tensor] = {}
-        g = lambda k: sd[k].contiguous()
+        # a replica's parameters are freed when its forward returns: what the cache keeps must own its memory
+        g = (lambda k: sd[k].contiguous().clone()) if own else (lambda k: sd[k].contiguous())
         cw = native.VcrnetWeights()
         if self._emb_kind == "lpdnet":
             P["c1_w"] = g("emb_nn.conv1_lpd.weight").view(64, 3).contiguous(); P["c1_b"] = g("emb_nn.conv1_lpd.bias")
@@ -376,14 +437,24 @@ class VCRNet(nn.Module):
         self._packed, self._packed_key = P, key
         self._cw = cw
 
-    def _buffers_for(self, B: int, N: int, device) -> Dict[str, torch.Tensor]:
-        key = (B, N, device, int(self.emb_nn.k), int(self.xscore_limit_mb), bool(self.merge_encdec), self.linear_mode)
-        bufs = self._bufs.get(key)
-        if bufs is None:
-            nbytes = native.lib().vcr_vcrnet_workspace_bytes(C.byref(self._cw), B, N)
-            bufs = {"ws": torch.empty(nbytes + 256, dtype=torch.uint8, device=device)}
-            self._bufs = {key: bufs}                                       # keep one shape resident
-        return bufs
+    def _take_buffers(self, B: int, N: int, device) -> Tuple[Tuple, Dict[str, torch.Tensor]]:
+        """A forward workspace for this shape from the shared pool (an idle one, or a new one): concurrent calls -- two host
+        threads, DataParallel replicas -- never share one; _give_buffers returns it with the stream it was used on."""
+        sh = self._shared
+        key = (B, N, device, int(self.emb_nn.k), int(self.xscore_limit_mb), bool(self.merge_encdec), self.linear_mode,
+               self._emb_kind, self._vcp, self._partial, self._overlap2)
+        with sh.lock:
+            idle = sh.pool.get(key)
+            if idle:
+                return key, idle.pop()
+            for k_ in [k_ for k_ in sh.pool if k_[2] == device and k_ != key]:     # keep one shape resident per device
+                del sh.pool[k_]
+        nbytes = native.lib().vcr_vcrnet_workspace_bytes(C.byref(self._cw), B, N)
+        return key, {"ws": torch.empty(nbytes + 256, dtype=torch.uint8, device=device)}
+
+    def _give_buffers(self, key, bufs):
+        with self._shared.lock:
+            self._shared.pool.setdefault(key, []).append(bufs)
 
     def fused_supported(self) -> bool:
         """True when one vcr_vcrnet_forward_f32 / vcr_vcrnet_iter_f32 call covers this configuration: every
@@ -402,9 +473,9 @@ class VCRNet(nn.Module):
         if not (src.is_cuda and tgt.is_cuda):
             raise native.VcrHipError("vcrnet_amd.VCRNet runs on the MI355X HIP path only; move inputs to cuda "
                                      "(there is no CPU fallback by design)")
-        p0 = next(self.parameters())
-        if not (src.device == tgt.device == p0.device):
-            raise native.VcrHipError(f"src ({src.device}), tgt ({tgt.device}) and the parameters ({p0.device}) must "
+        pdev = self._device()
+        if not (src.device == tgt.device == pdev):
+            raise native.VcrHipError(f"src ({src.device}), tgt ({tgt.device}) and the parameters ({pdev}) must "
                                      "live on one device")
         if self.training or torch.is_grad_enabled():
             raise native.VcrHipError("inference only: call .eval() and wrap in torch.no_grad() "
@@ -446,11 +517,18 @@ class VCRNet(nn.Module):
     def _forward_fused_on(self, src, tgt, trace, want_emb, iters, force, want_selections, iter_api):
         self._pack()
         B, _, N = src.shape
-        dev = native.same_device(src, tgt, next(self.parameters()))
+        dev = native.same_device(src, tgt, next(iter(self._tensors().values())))
         srcc, tgtc = src.contiguous().float(), tgt.contiguous().float()
-        bufs = self._buffers_for(B, N, dev)
+        bkey, bufs = self._take_buffers(B, N, dev)
+        try:
+            return self._forward_with(bufs, srcc, tgtc, src, B, N, dev, trace, want_emb, iters, force, want_selections,
+                                      iter_api)
+        finally:
+            self._give_buffers(bkey, bufs)          # (enqueued: the next user on another stream waits for this one)
+
+    def _forward_with(self, bufs, srcc, tgtc, src, B, N, dev, trace, want_emb, iters, force, want_selections, iter_api):
         ws = bufs["ws"]
-        # the workspace is shared by consecutive calls: a call on ANOTHER stream first waits for the previous user
+        # a workspace is reused by later calls: one on ANOTHER stream first waits for the previous user's stream
         cur = torch.cuda.current_stream(dev)
         prev = bufs.get("stream")
         if prev is not None and prev != cur:

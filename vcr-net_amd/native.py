@@ -60,7 +60,7 @@ class EdgeconvArgs(C.Structure):
 
 class GathermaxArgs(C.Structure):
     _fields_ = [("pq", f32p), ("ldpq", C.c_int), ("C", C.c_int), ("idx", f32p), ("k", C.c_int), ("M", C.c_int),
-                ("n_per_cloud", C.c_int), ("y", f32p), ("ldy", C.c_int)]
+                ("n_per_cloud", C.c_int), ("y", f32p), ("ldy", C.c_int), ("variant", C.c_int)]
 
 
 class SdpaArgs(C.Structure):
@@ -81,7 +81,7 @@ class KeymassArgs(C.Structure):
 class SoftcorrArgs(C.Structure):
     _fields_ = [("q", f32p), ("ldq", C.c_int), ("k", f32p), ("ldk", C.c_int), ("qside4", f32p), ("kside4", f32p),
                 ("corr4", f32p), ("nbatch", C.c_int), ("nq", C.c_int), ("nk", C.c_int), ("E", C.c_int),
-                ("mode", C.c_int), ("scale", C.c_float), ("split_work", f32p)]
+                ("mode", C.c_int), ("scale", C.c_float), ("split_work", f32p), ("split_work_floats", C.c_long)]
 
 
 class PairscoreArgs(C.Structure):
@@ -90,7 +90,8 @@ class PairscoreArgs(C.Structure):
                 ("score", C.c_int), ("scale", C.c_float), ("str_batch_shift", C.c_int), ("op", C.c_int),
                 ("corr4", f32p), ("stat2", f32p), ("argmax", f32p), ("str_stat2", f32p),
                 ("str_stat_batch_stride", C.c_long), ("mass", f32p), ("accumulate", C.c_int),
-                ("score_out", f32p), ("ld_score", C.c_int), ("variant", C.c_int), ("split_work", f32p)]
+                ("score_out", f32p), ("ld_score", C.c_int), ("variant", C.c_int), ("split_work", f32p),
+                ("split_work_floats", C.c_long)]
 
 
 class MakePairsArgs(C.Structure):
@@ -216,7 +217,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 23         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 24         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -389,6 +390,17 @@ def knn(x, sq, k, exact_ties=True, waves=0, tie_work=True, xt=None):
     return idx
 
 
+def _tie_work(a, N, device, keep):
+    """Long rows (vcr_knn_tie_work_bytes(N) > 0, N > ~10 100): the replay's global scratch, as knn() provides it."""
+    L = lib()
+    L.vcr_knn_tie_work_bytes.restype, L.vcr_knn_tie_work_bytes.argtypes = C.c_size_t, [C.c_int]
+    need = L.vcr_knn_tie_work_bytes(N)
+    if need:
+        work = torch.empty(need, dtype=torch.uint8, device=device)
+        a.tie_work, a.tie_work_bytes = ptr(work), need
+        keep.append(work)
+
+
 @_guarded
 def knn_pair(feat, sq, xyz4, k, xt=None):
     """vcr_knn_pair_f32: the feature-space (feat [B,N,64], sq [B,N]) and the Cartesian (xyz4 [B,N,4]) kNN in one launch
@@ -400,6 +412,7 @@ def knn_pair(feat, sq, xyz4, k, xt=None):
         idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
         ties = torch.empty(1 + B * N, dtype=torch.int32, device=x.device)
         args.append(KnnArgs(ptr(x), x.stride(1), ptr(s_), B, N, Cc, k, ptr(idx), ptr(ties), B * N, 0))
+        _tie_work(args[-1], N, x.device, keep)
         out.append(idx); keep.append(ties)
     args[0].xt = ptr(xt)
     L.vcr_knn_pair_f32.argtypes = [C.POINTER(KnnArgs), C.POINTER(KnnArgs), C.c_void_p]
@@ -419,8 +432,10 @@ def knn_pair_deferred(xa, sqa, xb, sqb, k):
         ties = torch.zeros(1 + B * N, dtype=torch.int32, device=x.device)
         a = KnnArgs(ptr(x), x.stride(1), ptr(sq), B, N, Cc, k, ptr(idx), ptr(ties), B * N, 0)
         a.tie_zeroed, a.tie_defer = 1, 1
+        work = []
+        _tie_work(a, N, x.device, work)
         call("vcr_knn_f32", a)
-        args.append(a); keep.append((idx, ties))
+        args.append(a); keep.append((idx, ties, work))
     L.vcr_knn_ties_f32.argtypes = [C.POINTER(KnnArgs), C.POINTER(KnnArgs), C.c_void_p]
     L.vcr_knn_ties_f32.restype = C.c_int
     check(L.vcr_knn_ties_f32(C.byref(args[0]), C.byref(args[1]), C.c_void_p(stream_ptr())), "vcr_knn_ties_f32")
@@ -524,11 +539,12 @@ def edgeconv(pq, idx, n_per_cloud, w2, b2, bf16x3=False):
 
 
 @_guarded
-def gathermax(pq, Cc, idx, n_per_cloud):
+def gathermax(pq, Cc, idx, n_per_cloud, variant=0):
+    """variant: 0 automatic, 1 = gathers through L2, 32 / 16 / 8 = out of LDS with that channel slice (vcr_gathermax_args)."""
     M = pq.shape[0]
     k = idx.shape[-1]
     y = _f32(M, Cc, device=pq.device)
-    call("vcr_gathermax_f32", GathermaxArgs(ptr(pq), pq.stride(0), Cc, ptr(idx), k, M, n_per_cloud, ptr(y), Cc))
+    call("vcr_gathermax_f32", GathermaxArgs(ptr(pq), pq.stride(0), Cc, ptr(idx), k, M, n_per_cloud, ptr(y), Cc, variant))
     return y
 
 
@@ -573,7 +589,8 @@ def softcorr(q, k, qside4, kside4, nbatch, nq, nk, mode=0, scale=1.0, split=Fals
     corr4 = _f32(nbatch * nq, 4, device=q.device)
     work = _f32(4 * nbatch * nq * 8, device=q.device) if split else None
     call("vcr_softcorr_f32", SoftcorrArgs(ptr(q), q.stride(0), ptr(k), k.stride(0), ptr(qside4), ptr(kside4),
-                                          ptr(corr4), nbatch, nq, nk, q.shape[1], mode, scale, ptr(work)))
+                                          ptr(corr4), nbatch, nq, nk, q.shape[1], mode, scale, ptr(work),
+                                          work.numel() if split else 0))
     return corr4
 
 
@@ -607,7 +624,8 @@ def pairscore(own, strm, nbatch, n_own, n_str, op, score=0, scale=1.0, own_side4
         ptr(own), own.stride(0), ptr(strm), strm.stride(0), ptr(own_side4), ptr(str_side4), nbatch, n_own, n_str,
         own.shape[1], score, scale, shift, op, ptr(corr4), ptr(stat2), ptr(amax), ptr(str_stat2),
         int(str_stat_stride if str_stat_stride is not None else n_str * 2), ptr(mass), int(accumulate),
-        ptr(score_out), score_out.stride(1) if score_out is not None else 0, variant, ptr(work)))
+        ptr(score_out), score_out.stride(1) if score_out is not None else 0, variant, ptr(work),
+        work.numel() if split else 0))
     if op == 0:
         return corr4
     if op == 1:
