@@ -460,7 +460,7 @@ def measure(a, ctx, min_seconds):
         pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
         if pmcs and (B, N, a.k, a.partial, a.iters, a.emb_nn) == (16, 1024, 20, False, 1, "lpdnet"):
             kname = {"linear": "linear_glds", "sdpa": "sdpa_kernel<false, true>",
-                     "edgeconv": "edgeconv_dg_packed_kernel<20>", "softcorr": "pairscore_kernel<0>"}.get(dom)
+                     "edgeconv": "edgeconv_dg_pipe_kernel<20>", "softcorr": "pairscore_kernel<0>"}.get(dom)
             # a family can be several template instantiations (linear: plain / statistics-out / LayerNorm-in):
             # launch-weighted mean over the entries whose name starts with the family's kernel name
             ents = [e for k_, e in json.load(open(pmcs[-1])).items()

@@ -20,7 +20,7 @@ def short(name):
     for key in ("linear_glds_pair_kernel", "linear_kernel", "sdpa_kernel", "edgeconv_dg_kernel", "softcorr_kernel", "layernorm512_kernel",
                 "knn3_kernel", "knn64_kernel", "gathermax_kernel", "pointwise12_kernel", "rigid_svd_kernel",
                 "rowside_kernel", "linear_glds16_kernel", "linear_glds_kernel", "linear_persist_kernel",
-                "edgeconv_dg_packed_kernel", "pairscore_kernel", "rankselect_kernel", "knn_tiebreak_kernel",
+                "edgeconv_dg_packed_kernel", "edgeconv_dg_pipe_kernel", "pairscore_kernel", "rankselect_kernel", "knn_tiebreak_kernel",
                 "knn_pair_kernel", "knn64c_kernel", "sdpa16_kernel", "knn_tiebreak2_kernel", "edgechain_kernel",
                 "vcr_copy_words_kernel", "zero_i32_kernel", "pose_step_kernel", "edgeconv_dg_packed_bf16x3_kernel",
                 "keymass4_kernel", "keymass_kernel", "statmerge_kernel", "rowstat_merge_kernel", "score_colpass_kernel",

@@ -195,8 +195,11 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 //         k group: k = 16g + 4q + s).  Same flops per cycle; the chip sustains a higher clock on the 16x16 shape under
 //         the matrix pipe's power limit (profiles/r2e_mfma_sustained_rates.txt: 132-140 vs 127-136 TFLOP/s).  The two
 //         shapes sum k in different orders: results agree to fp32 rounding, not bitwise.
-template <int BK, bool LN_IN, bool STATS_OUT, int MS, int BMV = BM>
+// (LN_IN = p.ln_stats_in != NULL and STATS_OUT = p.stats_out != NULL are run-time properties of the launch -- a uniform
+//  branch in the prologue and two in the epilogue -- not template parameters: a quarter of the instantiations)
+template <int BK, int MS, int BMV = BM>
 __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int tiles_m, int tiles_n, int blk) {
+  const bool LN_IN = p.ln_stats_in != nullptr, STATS_OUT = p.stats_out != nullptr;
   static_assert(BMV == 128 || ((BMV == 96 || BMV == 64 || BMV == 32) && MS == 16), "the lower tiles are built from 16 x 16 MFMA tiles");
   using Tile = TileGT<BK, BMV>;
   constexpr int WR = BMV / 2;                            // rows per wave tile
@@ -451,19 +454,19 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
   //@probe __builtin_amdgcn_s_waitcnt(0); VCR_PROBE_STAMP(3);     // (stores acknowledged)
 }
 
-template <int BK, bool LN_IN, bool STATS_OUT, int MS, int BMV>
+template <int BK, int MS, int BMV>
 __global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_kernel(vcr_linear_args p, int tiles_m, int tiles_n) {
-  linear_glds_body<BK, LN_IN, STATS_OUT, MS, BMV>(p, tiles_m, tiles_n, (int)blockIdx.x);
+  linear_glds_body<BK, MS, BMV>(p, tiles_m, tiles_n, (int)blockIdx.x);
 }
 // Two independent linears of the same kernel configuration as ONE launch (the first n0 workgroups work on p0, the rest
 // on p1): the encoder's and the decoder's output projections, or enc.ffn1 beside dec.cross.q -- fewer, fuller rounds of
 // workgroups; each tile is computed exactly as in its own launch.
-template <int BK, bool LN_IN, bool STATS_OUT, int MS, int BMV>
+template <int BK, int MS, int BMV>
 __global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_pair_kernel(vcr_linear_args p0, vcr_linear_args p1, int tm0,
                                                                                  int tn0, int tm1, int tn1) {
   const int n0 = tm0 * tn0;
-  if ((int)blockIdx.x < n0) linear_glds_body<BK, LN_IN, STATS_OUT, MS, BMV>(p0, tm0, tn0, (int)blockIdx.x);
-  else linear_glds_body<BK, LN_IN, STATS_OUT, MS, BMV>(p1, tm1, tn1, (int)blockIdx.x - n0);
+  if ((int)blockIdx.x < n0) linear_glds_body<BK, MS, BMV>(p0, tm0, tn0, (int)blockIdx.x);
+  else linear_glds_body<BK, MS, BMV>(p1, tm1, tn1, (int)blockIdx.x - n0);
 }
 
 }  // namespace
@@ -584,25 +587,19 @@ int linear_plan(const vcr_linear_args* a, LinearPlan* pl, int bm_override = 0, b
   return VCR_OK;
 }
 
-// dispatch over the template grid (BK, LN_IN, STATS_OUT, MS, BMV): F is a generic lambda taking five integral_constants
+// dispatch over the template grid (BK, MS, BMV): F is a generic lambda taking three integral_constants
 template <class F>
 void linear_dispatch(const LinearPlan& pl, F&& f) {
-  auto d3 = [&](auto bk, auto ms, auto bm) {
-    if (pl.ln_in && pl.st_out) f(bk, std::true_type{}, std::true_type{}, ms, bm);
-    else if (pl.ln_in) f(bk, std::true_type{}, std::false_type{}, ms, bm);
-    else if (pl.st_out) f(bk, std::false_type{}, std::true_type{}, ms, bm);
-    else f(bk, std::false_type{}, std::false_type{}, ms, bm);
-  };
   using I16 = std::integral_constant<int, 16>;
   using I32 = std::integral_constant<int, 32>;
   using I96 = std::integral_constant<int, 96>;
   using I128 = std::integral_constant<int, 128>;
   using I64 = std::integral_constant<int, 64>;
-  if (pl.bm == 64) d3(I32{}, I16{}, I64{});
-  else if (pl.bm == 32) d3(I32{}, I16{}, I32{});
-  else if (pl.bm == 96) { if (pl.bk16) d3(I16{}, I16{}, I96{}); else d3(I32{}, I16{}, I96{}); }
-  else if (pl.bk16) { if (pl.ms16) d3(I16{}, I16{}, I128{}); else d3(I16{}, I32{}, I128{}); }
-  else { if (pl.ms16) d3(I32{}, I16{}, I128{}); else d3(I32{}, I32{}, I128{}); }
+  if (pl.bm == 64) f(I32{}, I16{}, I64{});
+  else if (pl.bm == 32) f(I32{}, I16{}, I32{});
+  else if (pl.bm == 96) { if (pl.bk16) f(I16{}, I16{}, I96{}); else f(I32{}, I16{}, I96{}); }
+  else if (pl.bk16) { if (pl.ms16) f(I16{}, I16{}, I128{}); else f(I16{}, I32{}, I128{}); }
+  else { if (pl.ms16) f(I32{}, I16{}, I128{}); else f(I32{}, I32{}, I128{}); }
 }
 }  // namespace
 
@@ -621,11 +618,10 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
   const int rc = linear_plan(a, &pl);
   if (rc != VCR_OK) return rc;
   if (pl.glds) {
-    linear_dispatch(pl, [&](auto bk, auto li, auto so, auto ms, auto bm) {
+    linear_dispatch(pl, [&](auto bk, auto ms, auto bm) {
       constexpr int BKV = decltype(bk)::value, MSV = decltype(ms)::value, BMV = decltype(bm)::value;
-      constexpr bool LI = decltype(li)::value, SO = decltype(so)::value;
-      VCR_DYN_LDS((linear_glds_kernel<BKV, LI, SO, MSV, BMV>), pl.lds);
-      hipLaunchKernelGGL((linear_glds_kernel<BKV, LI, SO, MSV, BMV>), dim3(pl.tiles_m * pl.tiles_n), dim3(256), pl.lds,
+      VCR_DYN_LDS((linear_glds_kernel<BKV, MSV, BMV>), pl.lds);
+      hipLaunchKernelGGL((linear_glds_kernel<BKV, MSV, BMV>), dim3(pl.tiles_m * pl.tiles_n), dim3(256), pl.lds,
                          (hipStream_t)stream, *a, pl.tiles_m, pl.tiles_n);
     });
   } else {
@@ -639,7 +635,7 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
 }
 
 // Two independent linears as one launch when they resolve to the same LDS-DMA kernel configuration (k-slab, MFMA shape,
-// LayerNorm-in, statistics-out; neither with a fused max); otherwise exactly the two vcr_linear_f32 calls.  Same results.
+// tile rows; neither with a fused max); otherwise exactly the two vcr_linear_f32 calls.  Same results.
 extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_args* b, vcr_stream_t stream) {
   LinearPlan pa{}, pb{};
   int rc = linear_plan(a, &pa, 0, true);
@@ -664,18 +660,17 @@ extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_ar
     linear_plan(a, &pa, joint, true);
     linear_plan(b, &pb, joint, true);
   }
-  const bool same = pa.glds && pb.glds && pa.bk16 == pb.bk16 && pa.ms16 == pb.ms16 && pa.bm == pb.bm && pa.ln_in == pb.ln_in &&
-                    pa.st_out == pb.st_out &&
-                    !a->segmax_out && !b->segmax_out;
+  const bool same = pa.glds && pb.glds && pa.bk16 == pb.bk16 && pa.ms16 == pb.ms16 && pa.bm == pb.bm &&
+                    !a->segmax_out && !b->segmax_out;  // (LayerNorm-in / statistics-out may differ: run-time flags of each half)
+  if (pb.lds > pa.lds) pa.lds = pb.lds;
   if (!same) {
     rc = vcr_linear_f32(a, stream);
     return rc ? rc : vcr_linear_f32(b, stream);
   }
-  linear_dispatch(pa, [&](auto bk, auto li, auto so, auto ms, auto bm) {
+  linear_dispatch(pa, [&](auto bk, auto ms, auto bm) {
     constexpr int BKV = decltype(bk)::value, MSV = decltype(ms)::value, BMV = decltype(bm)::value;
-    constexpr bool LI = decltype(li)::value, SO = decltype(so)::value;
-    VCR_DYN_LDS((linear_glds_pair_kernel<BKV, LI, SO, MSV, BMV>), pa.lds);
-    hipLaunchKernelGGL((linear_glds_pair_kernel<BKV, LI, SO, MSV, BMV>), dim3(pa.tiles_m * pa.tiles_n + pb.tiles_m * pb.tiles_n),
+    VCR_DYN_LDS((linear_glds_pair_kernel<BKV, MSV, BMV>), pa.lds);
+    hipLaunchKernelGGL((linear_glds_pair_kernel<BKV, MSV, BMV>), dim3(pa.tiles_m * pa.tiles_n + pb.tiles_m * pb.tiles_n),
                        dim3(256), pa.lds, (hipStream_t)stream, *a, *b, pa.tiles_m, pa.tiles_n, pb.tiles_m, pb.tiles_n);
   });
   return VCR_LAUNCH_RC();
