@@ -125,36 +125,65 @@ __global__ __launch_bounds__(512, 2) void linear_bf16x3_kernel(vcr_linear_args p
     brow_[i] = wn * 64 + i * 32 + l31; bsw[i] = (brow_[i] >> 2) & 3;
   }
 
+  // One slab = 2 k-steps of 16 x (2 x 2 output tiles) x 6 MFMAs.  The stream is laid out by hand (sched_barrier fences one
+  // CHUNK = one output tile's six MFMAs = 192 cycles of the matrix pipe): beside a wave that issues MFMAs back to back a
+  // SIMD lets the other wave's vector / LDS instructions through at one per 20-36 cycles, while a wave's own instructions
+  // issue in the shadow of its own MFMAs (profiles/r4f_mfma_valu_coissue.txt) -- and a slab carries ~150 of them per wave
+  // (24 fragment reads, the 3-way split of 16 activations = ~110 VALU, 12 LDS stores, the next slab's requests) against 48
+  // MFMAs.  hipcc grouped them in front of and behind the MFMA block, where both waves of a SIMD (one workgroup per CU: they
+  // run in phase) crawled through them together.  Here k-step 0's chunks carry the fragment reads of k-step 1 and the
+  // next slab's weight-plane requests, k-step 1's chunks the split + LDS stores of the next slab's activations, one
+  // quarter each.  Same MFMA order per output element: bit-identical results.
   const int nk = p.K / TK;
+  auto frag = [&](const Stage3& S, int sstep, bf16x8 (&fa)[2][3], bf16x8 (&fb)[2][3], int i) {   // row block i of both operands
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      fa[i][pl] = *reinterpret_cast<const bf16x8*>(&S.a[pl][arow[i]][((2 * sstep + half) ^ asw[i]) * 8]);
+      fb[i][pl] = *reinterpret_cast<const bf16x8*>(&S.b[pl][brow_[i]][((2 * sstep + half) ^ bsw[i]) * 8]);
+    }
+  };
+  auto store_a_row = [&](int buf, int i) {               // split + store the staged activations of row block i
+    const int row = ar0 + 64 * i;
+    unsigned short h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3(ra[i][e], h[e], m[e], l[e]);
+    const int off = ((ac >> 1) ^ ((row >> 2) & 3)) * 8 + (ac & 1) * 4;
+    *reinterpret_cast<s16x4*>(&st[buf].a[0][row][off]) = s16x4{(short)h[0], (short)h[1], (short)h[2], (short)h[3]};
+    *reinterpret_cast<s16x4*>(&st[buf].a[1][row][off]) = s16x4{(short)m[0], (short)m[1], (short)m[2], (short)m[3]};
+    *reinterpret_cast<s16x4*>(&st[buf].a[2][row][off]) = s16x4{(short)l[0], (short)l[1], (short)l[2], (short)l[3]};
+  };
+  auto tile6 = [&](const bf16x8 (&fa)[2][3], const bf16x8 (&fb)[2][3], int i, int j) {
+    f32x16 c = acc[i][j];
+    c = mfma_bf16(fa[i][1], fb[j][1], c);               // smallest terms first
+    c = mfma_bf16(fa[i][0], fb[j][2], c);
+    c = mfma_bf16(fa[i][2], fb[j][0], c);
+    c = mfma_bf16(fa[i][0], fb[j][1], c);
+    c = mfma_bf16(fa[i][1], fb[j][0], c);
+    c = mfma_bf16(fa[i][0], fb[j][0], c);
+    acc[i][j] = c;
+  };
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) { load_a((kt + 1) * TK); fill_b(cur ^ 1, (kt + 1) * TK); }
+    const bool more = kt + 1 < nk;
+    if (more) load_a((kt + 1) * TK);
     const Stage3& S = st[cur];
+    bf16x8 fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];
+    frag(S, 0, fa0, fb0, 0);
+    frag(S, 0, fa0, fb0, 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {                         // two 16-deep MFMA steps per 32-wide slab
-      bf16x8 fa[2][3], fb[2][3];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-          fa[i][pl] = *reinterpret_cast<const bf16x8*>(&S.a[pl][arow[i]][((2 * s + half) ^ asw[i]) * 8]);
-          fb[i][pl] = *reinterpret_cast<const bf16x8*>(&S.b[pl][brow_[i]][((2 * s + half) ^ bsw[i]) * 8]);
-        }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16 c = acc[i][j];
-          c = mfma_bf16(fa[i][1], fb[j][1], c);           // smallest terms first
-          c = mfma_bf16(fa[i][0], fb[j][2], c);
-          c = mfma_bf16(fa[i][2], fb[j][0], c);
-          c = mfma_bf16(fa[i][0], fb[j][1], c);
-          c = mfma_bf16(fa[i][1], fb[j][0], c);
-          c = mfma_bf16(fa[i][0], fb[j][0], c);
-          acc[i][j] = c;
-        }
+    for (int c = 0; c < 4; ++c) {                         // k-step 0: output tile (c >> 1, c & 1)
+      if (c < 2) frag(S, 1, fa1, fb1, c);                 // (six 16-B reads in each of the first two chunks)
+      tile6(fa0, fb0, c >> 1, c & 1);
+      if (more && c < 3) glds16b(wb + c * plane + (kt + 1) * TK, &st[cur ^ 1].b[c][wave * 16][0]);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (kt + 1 < nk) store_a(cur ^ 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                         // k-step 1
+      tile6(fa1, fb1, c >> 1, c & 1);
+      if (more) store_a_row(cur ^ 1, c);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
   }
 
