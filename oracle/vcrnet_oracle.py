@@ -321,6 +321,7 @@ def head_hard_pairs(src: Tensor, src_emb: Tensor, tgt: Tensor, tgt_emb: Tensor, 
     if cfg is not None:
         cfg.rec("pair_src", pick); cfg.rec("pair_tgt", torch.gather(idx.squeeze(-1), 1, pick))
         cfg.rec("argmax_tgt", idx.squeeze(-1))
+        cfg.rec("pair_val", val.squeeze(-1))                                 # the soft-max peaks that :312 ranks
     src_corr = _rows(cand * w.transpose(2, 1), pick)                        # :325 (weights are exactly 1)
     return _rows(src, pick), src_corr                                       # :328-330
 
@@ -364,7 +365,7 @@ def rigid_svd(src: Tensor, corr: Tensor, cfg: Optional[OracleConfig] = None) -> 
     H = torch.matmul(sc, cc.transpose(2, 1).contiguous())
     if cfg is not None:
         cfg.rec("H", H)
-    reflect = torch.eye(3)
+    reflect = torch.eye(3, dtype=H.dtype)                  # (dtype of the inputs: the tests run a float64 twin of the oracle too)
     reflect[2, 2] = -1
     rs = []
     for i in range(src.size(0)):

@@ -155,6 +155,27 @@ def case_c3(out, names):
 
 SMALL = {"it2_n256": (400, 2, 256, 2), "it2_eval": (810, 4, 256, 2), "n77": (200, 2, 77, 1), "n21": (200, 3, 21, 1),
          "pn_n256": (160, 2, 256, 1, "pointnet")}
+# round 4: the partial-overlap case of eval_harness.npz (items 830..835 as three batches of two, clouds cropped 256 -> 192,
+# one pass): which of its six pairs the reference itself does not reproduce
+PARTIAL_EVAL = ("partial_eval", 830, 2, 3, 256, 1)
+
+
+def case_partial_eval(out, names):
+    tag, first, B, nb, N, iters = PARTIAL_EVAL
+    print(tag)
+    Rs, ts = {n: [] for n in names}, {n: [] for n in names}
+    for b in range(nb):
+        res, _ = all_runs(first + b * B, B, N, iters, True)
+        for n in names:
+            Rs[n].append(res[n][0]); ts[n].append(res[n][1])
+    R = np.stack([np.concatenate(Rs[n]) for n in names]); t = np.stack([np.concatenate(ts[n]) for n in names])
+    P = B * nb
+    out[f"{tag}/first"], out[f"{tag}/B"], out[f"{tag}/nbatches"], out[f"{tag}/N"], out[f"{tag}/iters"] = map(np.int32, (first, B, nb, N, iters))
+    out[f"{tag}/R"], out[f"{tag}/t"] = R, t
+    pr = np.max([np.abs(R[i] - R[j]).reshape(P, -1).max(1) for i in range(4) for j in range(i)], 0)
+    pt = np.max([np.abs(t[i] - t[j]).reshape(P, -1).max(1) for i in range(4) for j in range(i)], 0)
+    out[f"{tag}/spread_R_pair"], out[f"{tag}/spread_t_pair"] = pr, pt
+    print(f"  spread over runs per pair: R {pr}  t {pt}")
 
 
 def case_small(out, names, tag):
@@ -173,7 +194,7 @@ def case_small(out, names, tag):
 
 if __name__ == "__main__":
     path = os.path.join(HERE, "selfdiv.npz")
-    todo = sys.argv[1:] or ["c3"] + list(SMALL)
+    todo = sys.argv[1:] or ["c3"] + list(SMALL) + ["partial_eval"]
     out = {}
     if sys.argv[1:] and os.path.exists(path):
         z = np.load(path)
@@ -183,6 +204,8 @@ if __name__ == "__main__":
     for tag in todo:
         if tag == "c3":
             case_c3(out, names)
+        elif tag == "partial_eval":
+            case_partial_eval(out, names)
         else:
             case_small(out, names, tag)
     np.savez_compressed(path, **out)

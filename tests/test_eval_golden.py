@@ -90,10 +90,37 @@ def test_evaluate_main_vs_the_reference_harness(name):
     mine = _floats(evalmetrics.EvalAccumulator.format_final(res["ab"]))
     ref = _floats(str(c["lines"][2]))
     assert mine.shape == ref.shape == (12,)
-    if c["partial"] or c["iters"] == 0:
-        ok = (dR <= 1e-4) & (dt <= 1e-5)
-        assert ok.sum() >= len(ok) - 1, (dR, dt)
-        np.testing.assert_allclose(mine, ref, rtol=2e-2, atol=2e-6)
+    if c["iters"] == 0:
+        # ICP refinement (--iter 0): nearest neighbours + an iteration count are discrete, and agree on every recorded pair
+        assert (dR <= 1e-4).all() and (dt <= 1e-5).all(), (dR, dt)
+        np.testing.assert_allclose(mine, ref, rtol=1e-3, atol=2e-6)
+    elif c["partial"]:
+        # The reference reproduces these six pairs against itself to 4e-7 (tests/golden/selfdiv.npz, partial_eval: 8 / 2 / 1
+        # threads and its float64 twin) -- but one of them hangs on a near-tie: the hard pairs are the K' sources with the
+        # largest soft-max peak (vcrnet_model.py:312), a 512-d negative-distance soft-max turns 1e-6 of embedding rounding
+        # into ~1e-4 of peak value (test_hip_forward.assert_mostly_close), and pair 831 ranks its last-in / first-out
+        # candidates 8.7e-5 apart.  The oracle (pinned to the reference) gives every pair's margin at that boundary:
+        # pairs decided by more than 5e-4 must match the reference's pose, the others may flip one hard pair.
+        import oracle
+        from vcrnet_amd import synth
+        from helpers import cfg_weights
+        w = cfg_weights()
+        margin = []
+        for b in range(c["nbatches"]):
+            src, tgt, _, _, _ = synth.make_batch(c["first"] + b * c["batch"], c["batch"], c["N"], partial=True)
+            rec = {}
+            oracle.vcrnet_forward(w, torch.from_numpy(src), torch.from_numpy(tgt),
+                                  oracle.OracleConfig(partial=True, overlap2=synth.OVERLAP2_0575, record=rec))
+            kp = rec["pair_src"].shape[1]
+            sv = torch.sort(rec["pair_val"], dim=1, descending=True)[0]
+            margin += ((sv[:, kp - 1] - sv[:, kp]) / sv[:, kp]).tolist()
+        margin = np.array(margin)
+        sd = golden("selfdiv")
+        assert int(sd["partial_eval/first"]) == c["first"] and len(sd["partial_eval/spread_R_pair"]) == len(dR)
+        ok = (dR <= 1e-4 + sd["partial_eval/spread_R_pair"]) & (dt <= 1e-5 + sd["partial_eval/spread_t_pair"])
+        print(f"{name}: hard-pair boundary margins {np.array2string(margin, precision=2)}; pairs off the reference: {np.flatnonzero(~ok)}")
+        assert (ok | (margin < 5e-4)).all(), (dR, dt, margin)
+        np.testing.assert_allclose(mine, ref, rtol=1e-3 if ok.all() else 2e-2, atol=2e-6)
     else:
         tol_R, tol_t = np.full(len(dR), 1e-4), np.full(len(dt), 1e-5 * max(1, c["iters"]))   # per pass; composed passes add up
         rtol = 1e-3

@@ -105,11 +105,10 @@ def test_hip_vcrnet_icp_and_eval():
 @pytest.mark.parametrize("partial,iters", [(False, 1), (False, 3), (True, 1)])
 def test_aggregate_metrics_match_oracle(partial, iters):
     """over a small test set the reference-style aggregates (rot_MSE in degrees^2, trans_MSE,
-    correspondence MSE) of the HIP path agree with the CPU oracle's: whole mode (1 and 3 refinement passes) to the
-    BASELINE pose tolerance, one partial-overlap pass within 2 %.  (SURVEY asks 1 % for 3 partial passes of the TRAINED
-    network.  With the seeded, untrained Transformer the refinement does not converge -- rot_MSE ~ 3000 deg^2 -- so a
-    single near-tie flip in a discrete selection moves that sample's final pose by degrees; the per-iteration,
-    teacher-forced comparison in test_hip_partial.py is the meaningful check for that path.)"""
+    correspondence MSE) of the HIP path agree with the CPU oracle's to 1e-3 -- whole mode with 1 and 3 refinement passes,
+    and one partial-overlap pass --, or to three times what the oracle's own float64 twin moves them by, computed here
+    on the same items.  (Three free-running partial passes of the untrained network are chaotic: that case is bounded by
+    the reference's recorded twin in test_selfdiv.py.)"""
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import evalmetrics, synth
     from vcrnet_amd.module import vcrnetIter
@@ -117,7 +116,8 @@ def test_aggregate_metrics_match_oracle(partial, iters):
     import oracle
     o2 = synth.OVERLAP2_0575
     net, w = build_net(partial=True, overlap2=o2) if partial else build_net()
-    acc, ref = evalmetrics.EvalAccumulator(), evalmetrics.EvalAccumulator()
+    acc, ref, twin = evalmetrics.EvalAccumulator(), evalmetrics.EvalAccumulator(), evalmetrics.EvalAccumulator()
+    w64 = {k: v.double() for k, v in w.items()}
     for first in (700, 704, 708):
         src, tgt, R, t, eul = synth.make_batch(first, 4, 256, partial=partial)
         s, tt, Rg, tg = (torch.from_numpy(x) for x in (src, tgt, R, t))
@@ -126,13 +126,15 @@ def test_aggregate_metrics_match_oracle(partial, iters):
         acc.add_batch(s.cuda(), tt.cuda(), Rg.cuda(), tg.cuda(), eul, out)
         cfg = oracle.OracleConfig(partial=partial, overlap2=o2 if partial else 0.75)
         ref.add_batch(s, tt, Rg, tg, eul, oracle.vcrnet_iter(w, s, tt, cfg, iters=iters))
-    m, r = acc.final(), ref.final()
-    # whole mode, one pass: every pose within 1e-4 / 1e-5 -> aggregates to 1e-3.  Refinement passes after the first and
-    # the partial path are discretely sensitive (tests/golden/selfdiv.npz): the aggregates agree to a few per cent; the
-    # harness ARITHMETIC is pinned elsewhere, against the reference's own output (tests/test_eval_golden.py)
-    tol = 1e-3 if (not partial and iters == 1) else 3e-2
+        # the oracle's float64 twin on the same items: what the reference arithmetic differs from itself by
+        twin.add_batch(s, tt, Rg, tg, eul, tuple(x.float() for x in oracle.vcrnet_iter(w64, s.double(), tt.double(), cfg, iters=iters)))
+    m, r, r64 = acc.final(), ref.final(), twin.final()
+    # every pose within 1e-4 / 1e-5 -> aggregates to 1e-3, or three times what the oracle's own float64 twin moves them by
     for key in ("rot_mse", "trans_mse", "mse", "rot_mae", "trans_mae"):
-        assert abs(m[key] - r[key]) <= tol * abs(r[key]) + 1e-9, (key, m[key], r[key])
+        spread = abs(r64[key] - r[key]) / abs(r[key])
+        dev = abs(m[key] - r[key]) / abs(r[key])
+        print(f"partial={partial} iters={iters} {key}: HIP vs oracle {dev:.2e} (oracle vs its float64 twin {spread:.2e})")
+        assert dev <= max(1e-3, 3 * spread) + 1e-9, (key, m[key], r[key], r64[key])
     line = evalmetrics.EvalAccumulator.format_final(m)
     assert line.startswith("EPOCH:: -1, Loss:") and "rot_MSE" in line and "trans_MAE" in line
 
