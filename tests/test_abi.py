@@ -122,7 +122,7 @@ def test_host_side_dispatch_logic_without_a_gpu(lib):
     assert lib.vcr_knn_tie_work_bytes(12000) == 64 * 16 * 12000
     a = knn_args(1, 12000, 4, 20)                          # long rows, replay owed, no scratch: refused, not skipped
     assert lib.vcr_knn_f32(ctypes.byref(a), None) == -3
-    assert lib.vcr_knn_f32(ctypes.byref(knn_args(4, 1024, 4, 41)), None) == -3 # library limit k <= 40
+    assert lib.vcr_knn_f32(ctypes.byref(knn_args(4, 1024, 4, 63)), None) == -3 # library limit k <= 62
     assert lib.vcr_knn_f32(ctypes.byref(knn_args(4, 1024, 4, 20, waves=3)), None) == -1
     lib.vcr_linear_pair_f32.argtypes = [ctypes.POINTER(native.LinearArgs), ctypes.POINTER(native.LinearArgs), ctypes.c_void_p]
     lib.vcr_linear_pair_f32.restype = ctypes.c_int

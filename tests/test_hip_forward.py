@@ -122,6 +122,28 @@ def test_config5_shape_vs_oracle():
     assert dR <= R_TOL and dt <= T_TOL
 
 
+@pytest.mark.parametrize("k,N", [(50, 512), (62, 300), (33, 200)])
+def test_other_neighbourhood_sizes_vs_oracle(k, N):
+    """LPDNet.k is an attribute the reference's callers may set to anything (lpdnet_model.py:81, util.py:143-160 has no
+    limit): neighbourhoods other than the path's 20 / 40 -- up to the library's 62 -- through the generic EdgeConv / gather
+    kernels and the 64-entry kNN lists, against the oracle at the BASELINE tolerance; 63 is refused loudly."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native, synth
+    net, w = build_net()
+    net.emb_nn.k = k
+    src, tgt, _, _, _ = synth.make_batch(5100 + k, 2, N)
+    src_t, tgt_t = torch.from_numpy(src), torch.from_numpy(tgt)
+    ref = oracle.vcrnet_forward(w, src_t, tgt_t, oracle.OracleConfig(k=k))
+    with torch.no_grad():
+        out = net(src_t.cuda(), tgt_t.cuda())
+    dR, dt = np.abs(out[2].cpu().numpy() - ref[2].numpy()).max(), np.abs(out[3].cpu().numpy() - ref[3].numpy()).max()
+    print(f"k = {k}, N = {N}: max|dR| {dR:.2e} max|dt| {dt:.2e}")
+    assert dR <= R_TOL and dt <= T_TOL
+    net.emb_nn.k = 63
+    with torch.no_grad(), pytest.raises(native.VcrHipError, match="unsupported"):
+        net(src_t.cuda(), tgt_t.cuda())
+
+
 @pytest.mark.parametrize("name,kw", [("dist_n256_b2", dict(vcp_nn="dist")), ("identity_n256_b2", dict(pointer="identity"))])
 def test_fused_variants_vs_golden(name, kw):
     g = golden(name)

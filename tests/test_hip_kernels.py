@@ -110,7 +110,7 @@ def test_pointwise_matches_cpu_rounding_bit_for_bit(nat, W, N):
         assert torch.equal(i64, j64) and torch.equal(i3, j3)
 
 
-@pytest.mark.parametrize("N,k", [(256, 20), (1024, 20), (192, 20), (100, 20), (512, 40), (64, 5)])
+@pytest.mark.parametrize("N,k", [(256, 20), (1024, 20), (192, 20), (100, 20), (512, 40), (64, 5), (512, 50), (300, 62), (64, 62)])
 def test_knn_feature_space(nat, W, N, k):
     g = golden("whole_n1024_b2")
     rs = np.random.RandomState(N + k)
@@ -125,7 +125,7 @@ def test_knn_feature_space(nat, W, N, k):
 
 
 @pytest.mark.parametrize("N,k", [(256, 20), (1024, 20), (768, 20), (100, 20), (512, 40), (2048, 20), (4096, 40), (21, 20),
-                                 (45, 40), (1000, 5)])
+                                 (45, 40), (1000, 5), (1024, 50), (4096, 62), (63, 62)])
 def test_knn_cartesian(nat, N, k):
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import synth
@@ -745,7 +745,8 @@ def test_knn_deferred_tie_replay_for_two_launches(nat):
     assert not torch.equal(lazy, ref_b)                    # the replay did matter on this input
 
 
-@pytest.mark.parametrize("N,k", [(1024, 20), (2048, 20), (512, 40), (4096, 40), (333, 5), (1344, 20), (1343, 20)])
+@pytest.mark.parametrize("N,k", [(1024, 20), (2048, 20), (512, 40), (4096, 40), (333, 5), (1344, 20), (1343, 20), (4096, 62),
+                                 (1000, 50), (4031, 62), (4032, 62)])       # (k + 1) * 64 <= N switches Tensor.topk's algorithm
 def test_knn_exact_ties_follow_torch_topk(nat, N, k):
     """Exact distance ties at the k-th neighbour: Tensor.topk on the CPU is libstdc++'s nth_element (or partial_sort
     when (k+1)*64 <= N) with a value-only comparator; the kernels detect such rows and replay that algorithm, so the
@@ -778,7 +779,7 @@ def test_knn_exact_ties_follow_torch_topk(nat, N, k):
 def test_knn_long_rows_replay_ties_through_global_scratch(nat):
     """N = 12 000 (> 10 091: a row's distances no longer fit the replay's LDS image): with tie_work the replay runs out
     of global scratch and the neighbour sets still equal Tensor.topk's on every row of a tie-heavy cloud; WITHOUT
-    tie_work the call is refused (VCR_EUNSUPPORTED) instead of silently skipping the replay.  k > 40 is refused too."""
+    tie_work the call is refused (VCR_EUNSUPPORTED) instead of silently skipping the replay.  k > 62 is refused too."""
     N, k = 12000, 20
     rs = np.random.RandomState(5)
     side = int(np.ceil(N ** (1 / 3))) + 1
@@ -794,7 +795,7 @@ def test_knn_long_rows_replay_ties_through_global_scratch(nat):
     with pytest.raises(nat.VcrHipError, match="unsupported"):
         nat.knn(xyz4, None, k, tie_work=False)
     with pytest.raises(nat.VcrHipError, match="unsupported"):
-        nat.knn(xyz4, None, 41)
+        nat.knn(xyz4, None, 63)
 
 
 def test_linear_pair_equals_two_launches(nat):

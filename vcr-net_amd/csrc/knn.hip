@@ -1321,7 +1321,7 @@ extern "C" int vcr_knn_ties_f32(const vcr_knn_args* a, const vcr_knn_args* b, vc
 // Smaller grids keep the 32-query kernels, whose S = 2 / 4 waves split the candidates of a query group.  Results are
 // identical either way (same k-ascending fma chain, same selection).
 static bool use_col16(const vcr_knn_args* a) {
-  if (a->waves == 8) return true;
+  if (a->waves == 8 || a->k > 40) return true;           // (k = 41 .. 62: lists of 64, built for the 16-query bodies only)
   if (a->waves != 0) return false;
   return (long)((a->N + 15) / 16) * a->B >= 1024;
 }
@@ -1351,7 +1351,7 @@ static size_t knn_lds_bytes(const vcr_knn_args* a, bool inl) {
   return inl ? inline_tie_offset(knn_log_bytes(a), a->N) + (1 + BLK_TIES) * 4 : knn_log_bytes(a);
 }
 extern "C" int vcr_knn_ties_inline(const vcr_knn_args* a) {
-  return (a && a->x && a->idx && a->B > 0 && a->N > 0 && a->k > 0 && a->k <= 40 && (a->C == 64 || a->C == 4) && ties_inline(a)) ? 1 : 0;
+  return (a && a->x && a->idx && a->B > 0 && a->N > 0 && a->k > 0 && a->k <= 62 && (a->C == 64 || a->C == 4) && ties_inline(a)) ? 1 : 0;
 }
 
 // Feature-space (a64: C == 64) and Cartesian (a3: C == 4) kNN of the same pass as one launch (see knn_pair_kernel) when
@@ -1437,7 +1437,8 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
 extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->idx) return VCR_EINVAL;
   if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k + 1 > a->N) return VCR_EINVAL;
-  if (a->k > 40 || a->N > 65535) return VCR_EUNSUPPORTED;   // limits of this library, not of the operation (see vcr_hip.h)
+  if (a->k > 62 || a->N > 65535) return VCR_EUNSUPPORTED;   // limits of this library, not of the operation (see vcr_hip.h):
+                                                            // the tie replay keeps topk(k + 1)'s heap in the 64 lanes of a wave
   if (a->waves != 0 && a->waves != 1 && a->waves != 2 && a->waves != 4 && a->waves != 8) return VCR_EINVAL;
   if (a->C != 64 && a->C != 4) return VCR_EUNSUPPORTED;
   if (a->C == 64 ? (!a->sq || a->ldx < 64 || (a->ldx & 3)) : (a->ldx < 4 || (a->ldx & 3))) return VCR_EINVAL;
@@ -1465,8 +1466,13 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
     const dim3 grid((a->N + 63) / 64, a->B);
     const size_t lds = knn_lds_bytes(a, inl);
-    if (a->xt) rc = k20 ? launch<knn64c_kernel<22, 4, true>>(grid, dim3(256), lds, s, ka) : launch<knn64c_kernel<42, 4, true>>(grid, dim3(256), lds, s, ka);
-    else rc = k20 ? launch<knn64c_kernel<22, 4, false>>(grid, dim3(256), lds, s, ka) : launch<knn64c_kernel<42, 4, false>>(grid, dim3(256), lds, s, ka);
+    const bool k40 = a->k <= 40;                         // lists of k + 2: 22 / 42 / 64 entries
+    if (a->xt) rc = k20 ? launch<knn64c_kernel<22, 4, true>>(grid, dim3(256), lds, s, ka)
+                  : k40 ? launch<knn64c_kernel<42, 4, true>>(grid, dim3(256), lds, s, ka)
+                        : launch<knn64c_kernel<64, 4, true>>(grid, dim3(256), lds, s, ka);
+    else rc = k20 ? launch<knn64c_kernel<22, 4, false>>(grid, dim3(256), lds, s, ka)
+              : k40 ? launch<knn64c_kernel<42, 4, false>>(grid, dim3(256), lds, s, ka)
+                    : launch<knn64c_kernel<64, 4, false>>(grid, dim3(256), lds, s, ka);
   } else if (a->C == 64) {
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;
     const int S = pick_s((long)((a->N + 31) / 32) * a->B), W = k20 ? 4 : 2;
@@ -1481,7 +1487,8 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
     const int S = pick_s((long)((a->N + 15) / 16) * a->B);
     const dim3 grid((a->N + 16 * (4 / S) - 1) / (16 * (4 / S)), a->B);
     const size_t lds = knn_lds_bytes(a, inl);
-    rc = !k20 ? launch<knn3c_kernel<42, 4>>(grid, dim3(256), lds, s, ka)
+    rc = a->k > 40 ? launch<knn3c_kernel<64, 4>>(grid, dim3(256), lds, s, ka)
+         : !k20 ? launch<knn3c_kernel<42, 4>>(grid, dim3(256), lds, s, ka)
          : S == 1 ? launch<knn3c_kernel<22, 4>>(grid, dim3(256), lds, s, ka)
          : S == 2 ? launch<knn3_kernel<22, 2>>(grid, dim3(256), lds, s, *a)
                   : launch<knn3_kernel<22, 4>>(grid, dim3(256), lds, s, *a);
