@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p, int nspli
   const int q = qb * 128 + w * 32 + l31;
   const int qc = min(q, p.nq - 1);
 
+  //@probe VCR_PROBE_STAMP(0);
   f32x4 qf[16];
   {
     const float* qp = p.q + ((size_t)b * p.nq + qc) * p.ldq + head * 128 + 4 * half;
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p, int nspli
   stage_load(t0);
   stage_write(0);
   __syncthreads();
+  //@probe VCR_PROBE_STAMP(1);
   int cur = 0;
   for (int tile = t0; tile < ntiles; ++tile) {
     if (tile + 1 < ntiles) stage_load(tile + 1);
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p, int nspli
     __syncthreads();
     cur ^= 1;
   }
+  //@probe VCR_PROBE_STAMP(2);
   const float lt = l + xhalf(l);
   if (p.rowstat && half == 0 && q < p.nq) {
     float* rs = (nsplit > 1 ? p.split_work + (size_t)sp * p.nbatch * p.heads * p.nq * 2 : p.rowstat) +
@@ -231,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p, int nspli
       }
     }
   }
+  //@probe __builtin_amdgcn_s_waitcnt(0); VCR_PROBE_STAMP(3);
 }
 
 // rowstat[row] = merge over the nsplit partial (max, sum) pairs of a row, in split order
