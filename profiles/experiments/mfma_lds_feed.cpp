@@ -10,7 +10,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int READS, bool DEP, int THREADS>
+// AGPR: the accumulators are forced into the accumulator half of the register file (inline assembly, "a" constraint)
+template <int READS, bool DEP, int THREADS, bool AGPR = false>
 __global__ __launch_bounds__(THREADS, 1) void k(const float* in, float* out, unsigned long long* st, int iters) {
   __shared__ __attribute__((aligned(16))) float lds[8192];
   for (int i = threadIdx.x; i < 8192; i += THREADS) lds[i] = in[i & 4095];
@@ -33,7 +34,8 @@ __global__ __launch_bounds__(THREADS, 1) void k(const float* in, float* out, uns
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float a = DEP ? cur[0][e] : b[e];
-        c[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[(e + g) & 3], c[e], 0, 0, 0);
+        if (AGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c[e]) : "v"(a), "v"(b[(e + g) & 3]));
+        else c[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[(e + g) & 3], c[e], 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < READS; ++r) { if (!DEP || r > 0) sink += cur[r]; cur[r] = nxt[r]; }
@@ -47,13 +49,13 @@ __global__ __launch_bounds__(THREADS, 1) void k(const float* in, float* out, uns
   if (lane == 0) st[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <int READS, bool DEP, int THREADS> void run(const float* in, float* out, unsigned long long* st) {
+template <int READS, bool DEP, int THREADS, bool AGPR = false> void run(const float* in, float* out, unsigned long long* st) {
   const int blocks = 256, iters = 2000, waves = THREADS / 64;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 300; ++i) k<READS, DEP, THREADS><<<blocks, THREADS>>>(in, out, st, iters);
+  for (int i = 0; i < 300; ++i) k<READS, DEP, THREADS, AGPR><<<blocks, THREADS>>>(in, out, st, iters);
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
-  for (int i = 0; i < 10; ++i) k<READS, DEP, THREADS><<<blocks, THREADS>>>(in, out, st, iters);
+  for (int i = 0; i < 10; ++i) k<READS, DEP, THREADS, AGPR><<<blocks, THREADS>>>(in, out, st, iters);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
   std::vector<unsigned long long> h(blocks * 16);
@@ -64,8 +66,8 @@ template <int READS, bool DEP, int THREADS> void run(const float* in, float* out
   const double mfmas = (double)iters * 32;                       // per wave
   const double per_simd = cyc[cyc.size() / 2] / (mfmas * (waves / 4.0));
   const double tf = (double)blocks * waves * mfmas * 4096.0 / (ms * 1e-3) / 1e12;
-  printf("%d ds_read_b128 per 4 MFMAs (%s), %d wave(s) per SIMD: %5.1f shader cycles per MFMA per SIMD (64 = pipe rate)  %6.1f TFLOP/s (%.3f)\n",
-         READS, READS == 0 ? "none" : DEP ? "operands from the reads" : "reads beside", waves / 4, per_simd, tf, tf / 157.3);
+  printf("%s%d ds_read_b128 per 4 MFMAs (%s), %d wave(s) per SIMD: %5.1f shader cycles per MFMA per SIMD (64 = pipe rate)  %6.1f TFLOP/s (%.3f)\n",
+         AGPR ? "[acc in AGPRs] " : "", READS, READS == 0 ? "none" : DEP ? "operands from the reads" : "reads beside", waves / 4, per_simd, tf, tf / 157.3);
 }
 
 int main() {
@@ -79,5 +81,7 @@ int main() {
   run<2, false, 512>(in, out, st); run<4, false, 512>(in, out, st); run<4, true, 512>(in, out, st);
   run<1, true, 256>(in, out, st); run<4, true, 256>(in, out, st);
   run<1, true, 1024>(in, out, st); run<4, true, 1024>(in, out, st);
+  run<0, false, 512, true>(in, out, st); run<1, true, 512, true>(in, out, st); run<1, false, 512, true>(in, out, st);
+  run<2, false, 512, true>(in, out, st); run<4, true, 512, true>(in, out, st);
   return 0;
 }

@@ -143,3 +143,42 @@ def test_dataparallel_with_two_replicas_on_the_one_gpu():
         halves = [net(s[i:i + 2], t[i:i + 2]) for i in (0, 2)]
     assert torch.equal(out[2], torch.cat((halves[0][2], halves[1][2]))) and torch.equal(out[3], torch.cat((halves[0][3], halves[1][3])))
     assert net._shared.packs - packs0 <= 1, net._shared.packs - packs0       # replicas do not re-pack per forward
+
+
+def test_module_copies_pickles_and_weight_updates():
+    """The shared cache must not leak between modules or survive a weight change: a deep copy and a pickled copy compute the
+    same results from their own packing; an in-place parameter update (optimizer step, load_state_dict) is picked up on the
+    next call (the cache is keyed by the parameters' version counters); the master and its replicas are unaffected by a copy."""
+    import copy
+    import io
+    from helpers import cfg_weights
+    net, _ = build_net()
+    s, t = _inputs(9300, 2, 256)
+    with torch.no_grad():
+        ref = net(s, t)
+        twin = copy.deepcopy(net)
+        assert twin._master()[0] is twin and twin._shared is not net._shared
+        out = twin(s, t)
+        assert all(torch.equal(a, b) for a, b in zip(ref[1:], out[1:])) and twin._shared.packs == 1
+        buf = io.BytesIO()
+        torch.save(net, buf)
+        buf.seek(0)
+        loaded = torch.load(buf, weights_only=False)
+        out = loaded(s, t)
+        assert all(torch.equal(a, b) for a, b in zip(ref[1:], out[1:]))
+        # in-place update of one weight: the next call re-packs and the result changes ...
+        packs = net._shared.packs
+        net.emb_nn.conv3_lpd.weight.mul_(1.01)
+        moved = net(s, t)
+        assert net._shared.packs == packs + 1 and not torch.equal(moved[2], ref[2])
+        # ... exactly as a fresh module with those weights computes it; the copy made before the update is untouched
+        fresh, _ = build_net()
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        fresh.load_state_dict(sd)
+        again = fresh.cuda()(s, t)
+        assert torch.equal(moved[2], again[2]) and torch.equal(moved[3], again[3])
+        assert torch.equal(twin(s, t)[2], ref[2])
+        # load_state_dict back to the seeded weights: picked up too
+        net.load_state_dict(cfg_weights())
+        back = net(s, t)
+        assert torch.equal(back[2], ref[2]) and torch.equal(back[3], ref[3])
