@@ -296,6 +296,12 @@ for _r, _base in (("seed4321", 600), ("trained", 700), ("randemb", 800)):
                                                                              partial=True, iters=3, regime=r)
 
 
+# ... and the other constructor branches under the trained-like regime (small clouds): DGCNN, the VcpAtt head, cycle
+CASES["trained_dgcnn_n256_b2"] = lambda n: run_vcrnet(n, B=2, N=256, first_item=900, cstride=32, emb_nn="dgcnn", regime="trained")
+CASES["trained_att_n256_b2"] = lambda n: run_vcrnet(n, B=2, N=256, first_item=910, cstride=32, vcp_nn="att", regime="trained")
+CASES["trained_cycle_n256_b2"] = lambda n: run_vcrnet(n, B=2, N=256, first_item=920, cstride=32, cycle=True, regime="trained")
+
+
 if __name__ == "__main__":
     # usage: gen_golden.py [case ...]   (no arguments = every case)
     sd = torch.load(os.path.join(REF, "pretrained", "lpd-pretrained.t7"), map_location="cpu")

@@ -102,3 +102,23 @@ def test_iter_loop_forced_under_regime(regime):
     dR, dt = np.abs(out[2].cpu().numpy() - g["R_final"]).max(), np.abs(out[3].cpu().numpy() - g["t_final"]).max()
     print(f"{regime}: forced {iters}-pass loop max|dR| {dR:.2e} max|dt| {dt:.2e}")
     assert dR <= R_TOL and dt <= T_TOL, (dR, dt)
+
+
+@pytest.mark.parametrize("name,kw", [("trained_dgcnn_n256_b2", dict(emb_nn="dgcnn")), ("trained_att_n256_b2", dict(vcp_nn="att")),
+                                     ("trained_cycle_n256_b2", dict(cycle=True))])
+def test_other_branches_under_the_trained_regime(name, kw):
+    """DGCNN / VcpAtt / cycle under the trained-like weights, against the reference's recording (+ its float64 twin's distance)."""
+    g = golden(name)
+    net, _ = build_net(regime="trained", **kw)
+    src, tgt = torch.from_numpy(g["src"]).cuda(), torch.from_numpy(g["tgt"]).cuda()
+    with torch.no_grad():
+        out = net(src, tgt)
+    sR = float(np.abs(g["it0_R"] - g["it0_R_f64"]).max())
+    st = float(np.abs(g["it0_t"] - g["it0_t_f64"]).max())
+    dR = float(np.abs(out[2].cpu().numpy() - g["it0_R"]).max())
+    dt = float(np.abs(out[3].cpu().numpy() - g["it0_t"]).max())
+    print(f"{name}: max|dR| {dR:.2e} max|dt| {dt:.2e} (reference vs its float64 twin {sR:.2e} / {st:.2e})")
+    assert dR <= R_TOL + sR and dt <= T_TOL + st, (dR, dt, sR, st)
+    if kw.get("cycle"):                                  # the second head's own solve (vcrnet_model.py:511-513)
+        np.testing.assert_allclose(out[4].cpu().numpy(), g["it0_R_ba"], atol=R_TOL + sR)
+        np.testing.assert_allclose(out[5].cpu().numpy(), g["it0_t_ba"], atol=T_TOL + st + 1e-5)

@@ -60,3 +60,17 @@ def test_the_trained_regime_is_peaky_and_offset():
     assert all(torch.equal(d[k], w[k]) for k in d if k.startswith("emb_nn.") and "conv3" not in k)   # LPD fixture kept
     r = cfg_weights("randemb")
     assert not torch.equal(r["emb_nn.convDG1.0.weight"], d["emb_nn.convDG1.0.weight"])
+
+
+@pytest.mark.parametrize("name,kw", [("trained_dgcnn_n256_b2", dict(emb_nn="dgcnn")), ("trained_att_n256_b2", dict(vcp_nn="att")),
+                                     ("trained_cycle_n256_b2", dict(cycle=True))])
+def test_other_branches_under_the_trained_regime(name, kw):
+    """The trained-like regime through the constructor's other branches: DGCNN embedding (BatchNorm folded), the VcpAtt head,
+    cycle (second head with the roles swapped)."""
+    g = golden(name)
+    wkw = {k: kw[k] for k in ("emb_nn", "vcp_nn") if k in kw}
+    w = cfg_weights("trained", **wkw)
+    rec = {}
+    cfg = oracle.OracleConfig(k=int(g["k"]), overlap2=float(g["overlap2"]), record=rec, **kw)
+    out = oracle.vcrnet_forward(w, torch.from_numpy(g["src"]), torch.from_numpy(g["tgt"]), cfg)
+    check_common(g, rec, out, lpd=kw.get("emb_nn", "lpdnet") == "lpdnet")
