@@ -20,6 +20,9 @@
 #if defined(VCR_PROBE_TU_linear)
 #define VCR_PROBE_BUF vcr_probe_buf_linear
 #define VCR_PROBE_READER vcr_dbg_probe_linear
+#elif defined(VCR_PROBE_TU_linear_bf16x3)
+#define VCR_PROBE_BUF vcr_probe_buf_linear_bf16x3
+#define VCR_PROBE_READER vcr_dbg_probe_linear_bf16x3
 #elif defined(VCR_PROBE_TU_knn)
 #define VCR_PROBE_BUF vcr_probe_buf_knn
 #define VCR_PROBE_READER vcr_dbg_probe_knn

@@ -846,3 +846,34 @@ def test_sdpa_indexed_keys_equal_the_gathered_rows(nat):
     ref = nat.sdpa(q, dense[:, :512], dense[:, 512:], nb, h, NQ, NK, 1 / math.sqrt(128), kv_batch_shift=1)
     out = nat.sdpa(q, kv[:, :512], kv[:, 512:], nb, h, NQ, NK, 1 / math.sqrt(128), kv_batch_shift=1, key_index=dev(idx), nk_src=NS)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("k", [20, 40])
+def test_knn_beyond_65535_points(nat, W, k):
+    """util.py:143-160 has no size limit; the kNN entry points take clouds of more than 65 535 points (N = 70 001 here: the
+    reference would materialise a 19.6 GB distance matrix).  Neighbour sets of 192 sampled queries -- Cartesian and
+    feature-space -- against the reference formula evaluated for those rows on the CPU; ties replayed through global scratch."""
+    N = 70001
+    rs = np.random.RandomState(k)
+    pts = torch.from_numpy(rs.uniform(-0.5, 0.5, size=(1, 3, N)).astype(np.float32))
+    h = F.relu(F.conv1d(pts, W["emb_nn.conv1_lpd.weight"], W["emb_nn.conv1_lpd.bias"]))
+    h = F.relu(F.conv1d(h, W["emb_nn.conv2_lpd.weight"], W["emb_nn.conv2_lpd.bias"]))          # [1, 64, N]
+    rows = torch.from_numpy(rs.choice(N, 192, replace=False))
+
+    def ref_sets(x):                                       # x [1, C, N]: rows of -xx - inner - xx^T (util.py:153-158)
+        xt = x[0].t().contiguous()                         # [N, C]
+        inner = -2 * torch.matmul(xt[rows], x[0])          # [192, N]
+        xx = torch.sum(x[0] ** 2, dim=0, keepdim=True)     # [1, N]
+        d = -xx - inner - xx[0, rows].unsqueeze(1)
+        return np.sort(d.topk(k + 1, dim=-1)[1][:, 1:].numpy(), -1), d
+
+    xyz4 = torch.cat((pts.transpose(1, 2), (pts ** 2).sum(1).unsqueeze(-1)), -1)
+    got3 = np.sort(nat.knn(dev(xyz4), None, k).cpu().numpy()[0][rows.numpy()], -1)
+    ref3, d3 = ref_sets(pts)
+    bad3 = int((got3 != ref3).any(-1).sum())
+    got64 = np.sort(nat.knn(dev(h.transpose(1, 2)), dev((h ** 2).sum(1)), k).cpu().numpy()[0][rows.numpy()], -1)
+    ref64, d64 = ref_sets(h)
+    bad64 = int((got64 != ref64).any(-1).sum())
+    print(f"N = {N}, k = {k}: rows differing xyz {bad3} / 192, features {bad64} / 192")
+    # (the row-subset matmul of this reference may round a distance differently from the full N x N one: allow a near-tie or two)
+    assert bad3 <= 2 and bad64 <= 2

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16x3_kernel(vcr_linear_args p
     for (int pl = 0; pl < 3; ++pl) glds16b(wb + pl * plane + k0, &st[buf].b[pl][wave * 16][0]);
   };
 
+  //@probe VCR_PROBE_STAMP(0);
   load_a(0);
   fill_b(0, 0);
   store_a(0);
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16x3_kernel(vcr_linear_args p
     rowst[2 * t + 1] = 1.f / (sqrtf(var) + p.ln_eps);
   }
   __syncthreads();
+  //@probe VCR_PROBE_STAMP(1);
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16x3_kernel(vcr_linear_args p
     __syncthreads();
   }
 
+  //@probe VCR_PROBE_STAMP(2);
   // epilogue: identical to linear.hip (the 32x32 accumulator layout does not depend on the input dtype)
   constexpr int EP = 68;
   float* ot = reinterpret_cast<float*>(smem) + wave * 32 * EP;
@@ -237,6 +240,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16x3_kernel(vcr_linear_args p
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
   }
+  //@probe __builtin_amdgcn_s_waitcnt(0); VCR_PROBE_STAMP(3);     // (stores acknowledged)
 }
 
 __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* x, short* out, size_t n) {
