@@ -10,6 +10,7 @@ built to scratch/bx3/lib_<name>.so and timed through its own ctypes binding.
 """
 import ctypes as C
 import os
+import re
 import subprocess
 import sys
 
@@ -18,97 +19,66 @@ SRC = os.path.join(ROOT, "vcr-net_amd", "csrc", "linear_bf16x3.hip")
 OUT = os.path.join(ROOT, "scratch", "bx3")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-STORE = "      if (more) store_a_row(cur ^ 1, c);\n"
-GLDS = "      if (more && c < 3) glds16b(wb + c * plane + (kt + 1) * TK, &st[cur ^ 1].b[c][wave * 16][0]);\n"
-FRAG0 = "    frag(S, 0, fa0, fb0, 0);\n    frag(S, 0, fa0, fb0, 1);\n"
-FRAG1 = "      if (c < 2) frag(S, 1, fa1, fb1, c);                 // (six 16-B reads in each of the first two chunks)\n"
-SYNC = "      __builtin_amdgcn_sched_barrier(0);\n    }\n    __syncthreads();\n  }\n"
-LOADA = "    if (more) load_a((kt + 1) * TK);\n"
-# fragments once, before the loop (they stay in registers: the loop body has no LDS reads)
-HOIST = ("  bf16x8 fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];\n  frag(st[0], 0, fa0, fb0, 0);\n  frag(st[0], 0, fa0, fb0, 1);\n"
-         "  frag(st[0], 1, fa1, fb1, 0);\n  frag(st[0], 1, fa1, fb1, 1);\n  for (int kt = 0; kt < nk; ++kt) {\n")
-LOOP = "  for (int kt = 0; kt < nk; ++kt) {\n"
-DECL = "    bf16x8 fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];\n"
+A_PART = """          split_half(c >> 1, c & 1);
+          if (c & 1) {
+            store_a(c >> 1);
+            if constexpr (more2) load_a((kt + 2) * TK, c >> 1);
+          }
+"""
+B_PART = """          store_b(c - 8);
+          if constexpr (more2) load_b((kt + 2) * TK, c - 8);
+"""
+BAR2 = "    lds_barrier();                                       // barrier 2: every wave holds its fragments, the image is free\n"
+BAR1 = "    lds_barrier();                                       // barrier 1: slab kt is in LDS\n"
+SPLIT = "    for (int e = 0; e < 2; ++e) split3(ra[i][2 * e2 + e], h[e], m[e], l[e]);\n"
+FRAGS = """        fa[i][pl] = *reinterpret_cast<const bf16x8*>(fap[i] + pl * TM * TK);
+        fb[i][pl] = *reinterpret_cast<const bf16x8*>(fbp[i] + pl * TN * TK);
+"""
+# fragments that do not come from LDS (the loop keeps its barriers; registers seeded from the staged loads so that nothing folds)
+FAKE = """        fa[i][pl] = rb[(i + pl) % 6];
+        fb[i][pl] = rb[(i + 2 * pl + 1) % 6];
+"""
 
 VARIANTS = {
     "base": [],
-    "no_a": [(STORE, ""), (LOADA, "")],                                  # no activation loads, split or LDS stores
-    "no_a_split": [(STORE, "      if (more && c == 0) *reinterpret_cast<f32x4*>(&st[cur ^ 1].a[0][ar0][ac * 4 * 2]) = "
-                           "(ra[0] + ra[1]) + (ra[2] + ra[3]);\n")],     # loads kept (one 16-B store consumes them), no split
-    "no_b": [(GLDS, "")],
-    "no_frag": [(LOOP, HOIST), (DECL, ""), (FRAG0, ""), (FRAG1, "")],
-    "no_sync": [(STORE, ""), (LOADA, ""), (GLDS, ""), (SYNC, "      __builtin_amdgcn_sched_barrier(0);\n    }\n  }\n")],
-    "mfma_only": [(STORE, ""), (LOADA, ""), (GLDS, ""), (LOOP, HOIST), (DECL, ""), (FRAG0, ""), (FRAG1, ""),
-                  (SYNC, "      __builtin_amdgcn_sched_barrier(0);\n    }\n  }\n")],
-    "no_a_no_b": [(STORE, ""), (LOADA, ""), (GLDS, "")],
+    "no_a": [(A_PART, "")],       # no activation loads, split or LDS stores
+    "no_split": [(SPLIT, "    for (int e = 0; e < 2; ++e) { h[e] = __float_as_uint(ra[i][2 * e2 + e]) >> 16; m[e] = __float_as_uint(ra[i][2 * e2 + e]) & 0xffff; l[e] = h[e] ^ m[e]; }\n")],
+    "no_b": [(B_PART, "")],
+    "no_a_no_b": [(A_PART, ""), (B_PART, "")],
+    "no_bar2": [(A_PART, ""), (B_PART, ""), (BAR2, "")],
+    "no_bars": [(A_PART, ""), (B_PART, ""), (BAR2, ""), (BAR1, "")],
+    "no_frag": [(FRAGS, FAKE)],
+    "mfma_only": [(A_PART, ""), (B_PART, ""), (BAR2, ""), (BAR1, ""), (FRAGS, FAKE)],
 }
-
-
-# the same MFMA-only loop on v_mfma_f32_16x16x32_bf16 (24 per output tile and slab instead of 12 of the 32x32x16 form: equal
-# flops and cycles; MI355X_MICROARCH.md reports the 16x16 form ~1.15x faster in bare loops, i.e. at a higher clock)
-LOOP16 = """  f32x4 acc4[2][2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc4[i][j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];
-  frag(st[0], 0, fa0, fb0, 0);
-  frag(st[0], 0, fa0, fb0, 1);
-  frag(st[0], 1, fa1, fb1, 0);
-  frag(st[0], 1, fa1, fb1, 1);
-  for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int i = c >> 1, j = c & 1;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bf16x8* a = (q >> 1) ? fa1[i] : fa0[i];
-        const bf16x8* b = (q & 1) ? fb1[j] : fb0[j];
-        f32x4 cc = acc4[i][j][q];
-        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], cc, 0, 0, 0);
-        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], cc, 0, 0, 0);
-        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], cc, 0, 0, 0);
-        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], cc, 0, 0, 0);
-        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], cc, 0, 0, 0);
-        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], cc, 0, 0, 0);
-        acc4[i][j][q] = cc;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = acc4[i][j][r >> 2][r & 3];
-"""
 
 
 def build():
     os.makedirs(OUT, exist_ok=True)
+    for f in os.listdir(OUT):
+        if f.startswith("lib_") and f != "lib_probe.so":
+            os.remove(os.path.join(OUT, f))
     src = open(SRC).read()
-    lo, hi = src.index(LOOP), src.index("  //@probe VCR_PROBE_STAMP(2);")
-    VARIANTS["mfma_only_16x16"] = [(src[lo:hi], LOOP16)]
     for name, patches in VARIANTS.items():
         txt = src
+        # (every variant is held at two workgroups per CU, as the product kernel's registers do: pad the dynamic LDS request)
+        patches = patches + [("  const int lds = sizeof(Stage3) + TM * 2 * sizeof(float);", "  const int lds = sizeof(Stage3) + TM * 2 * sizeof(float) + 24576;")]
         for old, new in patches:
             if txt.count(old) != 1:
                 sys.exit(f"{name}: patch anchor not found exactly once:\n{old}")
             txt = txt.replace(old, new)
+        txt = re.sub(r"^(\s*)//@probe ", r"\1", txt, flags=re.M)     # phase stamps on: main() reports the k loop's shader clock
         p = os.path.join(OUT, f"{name}.hip")
         open(p, "w").write(txt)
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                             "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I",
-                            os.path.join(ROOT, "vcr-net_amd", "csrc"), "-shared", "-Rpass-analysis=kernel-resource-usage",
+                            os.path.join(ROOT, "vcr-net_amd", "csrc"), "-include", os.path.join(ROOT, "profiles", "experiments", "probes.h"),
+                            "-DVCR_PROBE_TU_linear_bf16x3", "-shared", "-Rpass-analysis=kernel-resource-usage",
                             "-o", os.path.join(OUT, f"lib_{name}.so"), p], capture_output=True, text=True)
         if r.returncode:
             sys.exit(f"{name}:\n{r.stderr}")
-        use = [l.split("remark: ")[-1].strip() for l in r.stderr.splitlines()
-               if "linear_bf16x3_kernel" in l or "VGPRs:" in l or "Spill" in l or "Occupancy" in l]
-        print(name, "|", " ; ".join(use[:8]))
+        use = [l.split("remark: ")[-1].split(" [")[0].strip() for l in r.stderr.splitlines() if "linear_bf16x3_kernel" in l.split("remark:")[0] or True]
+        k = [i for i, l in enumerate(use) if "linear_bf16x3_kernel" in l]
+        print(name, "|", " ; ".join(x for x in use[k[0]:k[0] + 12] if x.startswith(("VGPRs:", "VGPRs Spill", "Occupancy"))) if k else "")
 
 
 def main():
@@ -125,6 +95,8 @@ def main():
         x = torch.randn(M, K, generator=g).cuda()
         w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
         data[name] = (x, native.split_bf16x3(w), torch.randn(N, generator=g).cuda(), torch.empty(M, N, device="cuda"))
+    import numpy as np
+    full = np.zeros((4096, 32), np.uint64)
     names = sorted(f[4:-3] for f in os.listdir(OUT) if f.startswith("lib_") and f.endswith(".so") and f != "lib_probe.so")
     for rnd in range(2):
         for vn in names:
@@ -149,7 +121,16 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) / 30 * 1e3
-                line += f"   {name} {us:7.1f} us {2.0 * M * N * K / us / 1e6:6.1f} TF/s-eq"
+                L.vcr_dbg_probe_linear_bf16x3.argtypes = [C.c_void_p, C.c_int]
+                L.vcr_dbg_probe_linear_bf16x3(None, 1)
+                fn()
+                torch.cuda.synchronize()
+                L.vcr_dbg_probe_linear_bf16x3(full.ctypes.data, 0)
+                ok = full[:, 0] > 0
+                wall = (full[ok, 2] - full[ok, 1]).astype(np.float64) * 0.01            # us in the k loop (100 MHz stamps)
+                cyc = (full[ok, 18] - full[ok, 17]).astype(np.float64)
+                line += (f"   {name} {us:7.1f} us {2.0 * M * N * K / us / 1e6:6.1f} TF/s-eq  k loop {np.median(wall):6.2f} us at "
+                         f"{np.median(cyc / wall) / 1e3:.2f} GHz = {np.median(cyc) / (K // 32):5.0f} cyc/slab")
             print(line, flush=True)
 
 

@@ -69,7 +69,7 @@ def main():
             print(f"    {what:9s} median {np.median(d):6.2f}  p10 {np.percentile(d, 10):6.2f}  p90 {np.percentile(d, 90):6.2f} us"
                   f"   shader clock {np.median(ghz):.2f} GHz")
         d = tt[:, 2] - tt[:, 1]
-        print(f"    per slab {np.median(d) / (K // 32):.2f} us (the 96 MFMAs of a SIMD's two waves need 1.28 us at 2.4 GHz)")
+        print(f"    per slab {np.median(d) / (K // 32):.2f} us (128-row tiles: a SIMD with two workgroups' waves needs 0.64 us per slab and workgroup at 2.4 GHz)")
 
 
 if __name__ == "__main__":
