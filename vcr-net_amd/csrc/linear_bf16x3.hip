@@ -67,6 +67,7 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+template <bool RES>   // RES: the launch has a residual operand (its tile is requested during the last slab's MFMAs)
 __global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(vcr_linear_args p, const short* wsplit, int tiles_m,
                                                                int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(vcr_linear_args p
   // stores.  Same MFMA order per output element in every build: bit-identical results.
   // (the body is instantiated three times -- steady state, last but one, last slab -- so that it stays ONE basic block: behind
   // a branch hipcc waits for every outstanding load, the one issued a chunk earlier included)
+  f32x4 res[16];                                         // (RES) residual[row 32 ps + 4 q + quad of the wave tile][4 columns], index 8 ps + q
   auto slab = [&](auto more_t, auto more2_t, int kt) {
     constexpr bool more = decltype(more_t)::value, more2 = decltype(more2_t)::value;
     lds_barrier();                                       // barrier 1: slab kt is in LDS
@@ -194,6 +196,10 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(vcr_linear_args p
       d = mfma_bf16(fa[i][1], fb[j][0], d);
       d = mfma_bf16(fa[i][0], fb[j][0], d);
       acc[i][j] = d;
+      if constexpr (RES && !more) {                      // last slab: the staging registers are free -- the residual tile, 16 B per chunk
+        const int row = min(m0 + wm * 64 + (c >> 3) * 32 + (c & 7) * 4 + quad, p.M - 1);
+        res[c] = ld4(p.residual + (size_t)row * p.ldr + min(n0 + wn * 64 + l15 * 4, p.N - 4));
+      }
       if constexpr (more) {
         if (c < 8) {                                     // chunks 0-7: half a staged float4 each (registers only)
           split_half(c >> 1, c & 1);
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(vcr_linear_args p
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     if (col < p.N) {
-#pragma unroll 4
+#pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int rl = q * 4 + quad;
         const int row = m0 + wm * 64 + ps * 32 + rl;
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(vcr_linear_args p
             v = v + bias;
           }
           if (p.relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-          if (p.residual) v = v + ld4(p.residual + (size_t)row * p.ldr + col);
+          if constexpr (RES) v = v + res[8 * ps + q];
           st4(p.y + (size_t)row * p.ldy + col, v);
           if (p.stats_out) {                             // the 16 lanes of a row group hold this wave's 64 columns of the row
             float s1 = (v[0] + v[1]) + (v[2] + v[3]);
@@ -302,8 +308,14 @@ extern "C" int vcr_linear_bf16x3_f32(const vcr_linear_args* a, const void* w_pla
   const int tiles_m = (a->M + TM - 1) / TM, tiles_n = (a->N + TN - 1) / TN;
   const int lds = sizeof(Stage3) + TM * 2 * sizeof(float);
   static_assert(sizeof(Stage3) >= 4 * 32 * 68 * 4, "epilogue slices fit");
-  VCR_DYN_LDS(linear_bf16x3_kernel, lds);
-  hipLaunchKernelGGL(linear_bf16x3_kernel, dim3(tiles_m * tiles_n), dim3(256), lds, (hipStream_t)stream, *a,
-                     reinterpret_cast<const short*>(w_planes), tiles_m, tiles_n);
+  if (a->residual) {
+    VCR_DYN_LDS(linear_bf16x3_kernel<true>, lds);
+    hipLaunchKernelGGL(linear_bf16x3_kernel<true>, dim3(tiles_m * tiles_n), dim3(256), lds, (hipStream_t)stream, *a,
+                       reinterpret_cast<const short*>(w_planes), tiles_m, tiles_n);
+  } else {
+    VCR_DYN_LDS(linear_bf16x3_kernel<false>, lds);
+    hipLaunchKernelGGL(linear_bf16x3_kernel<false>, dim3(tiles_m * tiles_n), dim3(256), lds, (hipStream_t)stream, *a,
+                       reinterpret_cast<const short*>(w_planes), tiles_m, tiles_n);
+  }
   return VCR_LAUNCH_RC();
 }
