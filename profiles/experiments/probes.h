@@ -23,6 +23,9 @@
 #elif defined(VCR_PROBE_TU_linear_bf16x3)
 #define VCR_PROBE_BUF vcr_probe_buf_linear_bf16x3
 #define VCR_PROBE_READER vcr_dbg_probe_linear_bf16x3
+#elif defined(VCR_PROBE_TU_attention_bf16x3)
+#define VCR_PROBE_BUF vcr_probe_buf_attention_bf16x3
+#define VCR_PROBE_READER vcr_dbg_probe_attention_bf16x3
 #elif defined(VCR_PROBE_TU_knn)
 #define VCR_PROBE_BUF vcr_probe_buf_knn
 #define VCR_PROBE_READER vcr_dbg_probe_knn

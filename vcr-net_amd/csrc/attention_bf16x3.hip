@@ -58,6 +58,7 @@ __global__ __launch_bounds__(512, 1) void sdpa_bf16x3_kernel(vcr_sdpa_args p) {
   const int q = qb * 256 + w * 32 + l31;
   const int qc = min(q, p.nq - 1);
 
+  //@probe VCR_PROBE_STAMP(0);
   bf16x8 qh[8], qm[8], ql[8];                            // Q[query l31][16 step + 8 half + 0..7], three planes
   {
     const float* qp = p.q + ((size_t)b * p.nq + qc) * p.ldq + head * 128 + 8 * half;
@@ -77,34 +78,34 @@ __global__ __launch_bounds__(512, 1) void sdpa_bf16x3_kernel(vcr_sdpa_args p) {
 
   f32x4 rk[2];
   float rv[4][2];
-  auto stage_load = [&](int tile) {
+  auto load_k = [&](int tile, int i) {
     const int key = min(tile * 32 + skey, p.nk - 1);
-    rk[0] = ld4(kbase + (size_t)key * p.ldk + sc);
-    rk[1] = ld4(kbase + (size_t)key * p.ldk + 64 + sc);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float* vr = vbase + (size_t)min(tile * 32 + 4 * w + c, p.nk - 1) * p.ldv + lane;
-      rv[c][0] = vr[0]; rv[c][1] = vr[64];
-    }
+    rk[i] = ld4(kbase + (size_t)key * p.ldk + 64 * i + sc);
   };
-  auto stage_write = [&](int buf) {
+  auto load_v = [&](int tile, int e) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      unsigned h0, m0, l0, h1, m1, l1;
-      split3x2(rk[i][0], rk[i][1], h0, m0, l0);
-      split3x2(rk[i][2], rk[i][3], h1, m1, l1);
-      *reinterpret_cast<u32x2*>(&st[buf].k[0][skey][sc + 64 * i]) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(&st[buf].k[1][skey][sc + 64 * i]) = u32x2{m0, m1};
-      *reinterpret_cast<u32x2*>(&st[buf].k[2][skey][sc + 64 * i]) = u32x2{l0, l1};
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      unsigned h0, m0, l0, h1, m1, l1;
-      split3x2(rv[0][e], rv[1][e], h0, m0, l0);
-      split3x2(rv[2][e], rv[3][e], h1, m1, l1);
-      *reinterpret_cast<u32x2*>(&st[buf].vt[0][lane + 64 * e][vpos]) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(&st[buf].vt[1][lane + 64 * e][vpos]) = u32x2{m0, m1};
-      *reinterpret_cast<u32x2*>(&st[buf].vt[2][lane + 64 * e][vpos]) = u32x2{l0, l1};
+    for (int c = 0; c < 4; ++c) rv[c][e] = vbase[(size_t)min(tile * 32 + 4 * w + c, p.nk - 1) * p.ldv + lane + 64 * e];
+  };
+  // Staging of the NEXT tile in eight pieces (one per 16-deep step of the score MFMAs, in whose shadow they issue): piece
+  // 2 i / 2 i + 1 = the two halves of K chunk i (split, then the three 8-B plane stores and the request for the tile after
+  // next), pieces 4 + 2 e / 5 + 2 e likewise for head dims lane + 64 e of V^T.
+  unsigned hp[2], mp[2], lp[2];
+  auto stage_piece = [&](int buf, int tile2, int piece) {
+    const int x = (piece >> 1) & 1, second = piece & 1;
+    if (piece < 4) split3x2(rk[x][2 * second], rk[x][2 * second + 1], hp[second], mp[second], lp[second]);
+    else split3x2(rv[2 * second][x], rv[2 * second + 1][x], hp[second], mp[second], lp[second]);
+    if (second) {
+      if (piece < 4) {
+        *reinterpret_cast<u32x2*>(&st[buf].k[0][skey][sc + 64 * x]) = u32x2{hp[0], hp[1]};
+        *reinterpret_cast<u32x2*>(&st[buf].k[1][skey][sc + 64 * x]) = u32x2{mp[0], mp[1]};
+        *reinterpret_cast<u32x2*>(&st[buf].k[2][skey][sc + 64 * x]) = u32x2{lp[0], lp[1]};
+        load_k(tile2, x);
+      } else {
+        *reinterpret_cast<u32x2*>(&st[buf].vt[0][lane + 64 * x][vpos]) = u32x2{hp[0], hp[1]};
+        *reinterpret_cast<u32x2*>(&st[buf].vt[1][lane + 64 * x][vpos]) = u32x2{mp[0], mp[1]};
+        *reinterpret_cast<u32x2*>(&st[buf].vt[2][lane + 64 * x][vpos]) = u32x2{lp[0], lp[1]};
+        load_v(tile2, x);
+      }
     }
   };
 
@@ -114,20 +115,30 @@ __global__ __launch_bounds__(512, 1) void sdpa_bf16x3_kernel(vcr_sdpa_args p) {
   float m = VCR_NEG_INF, l = 0.f;
   const float c2 = p.scale * LOG2E;
 
-  stage_load(0);
-  stage_write(0);
+  load_k(0, 0); load_k(0, 1); load_v(0, 0); load_v(0, 1);
+#pragma unroll
+  for (int piece = 0; piece < 8; ++piece) stage_piece(0, 1, piece);   // tile 0 -> LDS, tile 1 requested (rows clamped: always valid)
   __syncthreads();
+  //@probe VCR_PROBE_STAMP(1);
   int cur = 0;
+  // One tile.  The vector work that does not depend on this tile's scores -- the 3-way split and LDS stores of the NEXT
+  // tile's K and V (its loads were issued a tile ago) -- rides in the shadow of the 48 score MFMAs, a piece per step; the
+  // split of the second 16 keys' probabilities rides in the P V MFMAs of the first 16.  Before round 4 both sat between
+  // the MFMA phases, where the two waves of a SIMD (one workgroup per CU: in phase) went through them together with the
+  // matrix pipe idle (~1500 of a tile's ~9500 cycles).  sched_barrier fences keep hipcc from regrouping.  Past the last
+  // tile the pieces stage clamped rows into the buffer nobody reads: no branch in the loop body.
   for (int tile = 0; tile < ntiles; ++tile) {
-    if (tile + 1 < ntiles) stage_load(tile + 1);
     const Stage3& S = st[cur];
     f32x16 s = {0};
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s8 = 0; s8 < 8; ++s8) {
       bf16x8 kf[3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) kf[pl] = *reinterpret_cast<const bf16x8*>(&S.k[pl][l31][16 * s8 + 8 * half]);
       s = mfma6(kf, qh[s8], qm[s8], ql[s8], s);
+      stage_piece(cur ^ 1, tile + 2, s8);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // soft-max of attention.hip's fast path: running maximum kept in log2 units, one fma + exp2 per score
     float mt = VCR_NEG_INF, ls = 0.f;
@@ -159,12 +170,16 @@ __global__ __launch_bounds__(512, 1) void sdpa_bf16x3_kernel(vcr_sdpa_args p) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) o[d] = o[d] * alpha;
     }
+    // two 16-key steps; registers 8 sp .. 8 sp + 7 are this step's keys
+    unsigned PH[2][4], PM[2][4], PL[2][4];
 #pragma unroll
-    for (int sp = 0; sp < 2; ++sp) {                     // two 16-key steps; registers 8 sp .. 8 sp + 7 are this step's keys
-      const float x[8] = {s[8 * sp], s[8 * sp + 1], s[8 * sp + 2], s[8 * sp + 3],
-                          s[8 * sp + 4], s[8 * sp + 5], s[8 * sp + 6], s[8 * sp + 7]};
-      bf16x8 ph, pm, pl3;
-      split3x8(x, ph, pm, pl3);
+    for (int i = 0; i < 4; ++i) split3x2(s[2 * i], s[2 * i + 1], PH[0][i], PM[0][i], PL[0][i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+      const bf16x8 ph = __builtin_bit_cast(bf16x8, u32x4{PH[sp][0], PH[sp][1], PH[sp][2], PH[sp][3]}),
+                   pm = __builtin_bit_cast(bf16x8, u32x4{PM[sp][0], PM[sp][1], PM[sp][2], PM[sp][3]}),
+                   pl3 = __builtin_bit_cast(bf16x8, u32x4{PL[sp][0], PL[sp][1], PL[sp][2], PL[sp][3]});
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         bf16x8 vf[3];
@@ -172,13 +187,15 @@ __global__ __launch_bounds__(512, 1) void sdpa_bf16x3_kernel(vcr_sdpa_args p) {
         for (int pl = 0; pl < 3; ++pl)
           vf[pl] = *reinterpret_cast<const bf16x8*>(&S.vt[pl][32 * dt + l31][16 * sp + 8 * half]);
         o[dt] = mfma6(vf, ph, pm, pl3, o[dt]);
+        if (sp == 0) split3x2(s[8 + 2 * dt], s[9 + 2 * dt], PH[1][dt], PM[1][dt], PL[1][dt]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (tile + 1 < ntiles) stage_write(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
 
+  //@probe VCR_PROBE_STAMP(2);
   // O^T (d rows in registers, query on the lane) -> [query][d] rows through this wave's LDS slice, 64 head dims per
   // round, then 256-B contiguous row stores.  The stage buffers are free (all waves passed the last barrier).
   const float inv = 1.f / (l + xhalf(l));
