@@ -651,10 +651,13 @@ def test_feature_space_knn_is_bit_exact_vs_reference(nat, W, name):
 
 
 @pytest.mark.parametrize("M,N,K,relu,res", [(300, 200, 64, True, False), (1024, 512, 512, False, True),
-                                            (257, 1536, 128, False, False), (128, 64, 1024, True, True)])
+                                            (257, 1536, 128, False, False), (128, 64, 1024, True, True),
+                                            (130, 36, 32, False, True), (300, 200, 96, True, True), (1, 4, 32, False, True)])
 def test_linear_bf16x3(nat, M, N, K, relu, res):
     """The bf16-pipe linear splits every operand exactly into three bf16 pieces and keeps the six leading
-    partial products: same fp32-GEMM error bound as the fp32-MFMA kernel."""
+    partial products: same fp32-GEMM error bound as the fp32-MFMA kernel.  (Ragged M / N with a residual: its tile is
+    requested with clamped rows / columns during the last slab; K = 32, 64, 96: one, two, three slabs = the three
+    instantiations of the slab body.)"""
     g = torch.Generator().manual_seed(M + N + K + 7)
     xw = torch.randn(M, K + 32, generator=g)
     x = xw[:, :K]
