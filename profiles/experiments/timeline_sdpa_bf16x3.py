@@ -41,7 +41,8 @@ def main():
     nb, h, N = 32, 4, 1024
     full = np.zeros((4096, 32), np.uint64)
     for kind in (sys.argv[1:] or ["randn", "forward"]):
-        if kind == "randn":
+        planes = kind == "planes"                             # K | V as bf16x3 planes (vcr_sdpa_bf16x3_planes_f32), N(0,1) operands
+        if kind in ("randn", "planes"):
             qkv = torch.randn(nb * N, 1536, generator=g).cuda()
         else:
             x = torch.randn(nb * N, 512, generator=g)
@@ -53,6 +54,17 @@ def main():
         a.q, a.ldq, a.k, a.ldk, a.v, a.ldv = ptr(q), 1536, ptr(k), 1536, ptr(v), 1536
         a.out, a.ldo, a.nbatch, a.heads, a.nq, a.nk, a.scale = ptr(out), 512, nb, h, N, N, 1 / math.sqrt(128)
         fn = lambda: L.vcr_sdpa_bf16x3_f32(C.byref(a), C.c_void_p(stream_ptr()))
+        if planes:                                            # (only in a build with profiles/experiments/kv_planes_dataflow.patch applied)
+            if not hasattr(L, "vcr_sdpa_bf16x3_planes_f32"):
+                print("planes   : this build has no vcr_sdpa_bf16x3_planes_f32 (apply kv_planes_dataflow.patch)")
+                continue
+            from vcrnet_amd import native
+            from vcrnet_amd.native import SdpaPlanes
+            kv = qkv[:, 512:].contiguous()
+            pl = native.split_bf16x3(kv).view(3, nb * N, 1024)
+            pp = SdpaPlanes(ptr(pl), ptr(pl[:, :, 512:]), 1024, nb * N * 1024)
+            L.vcr_sdpa_bf16x3_planes_f32.argtypes = [C.POINTER(SdpaArgs), C.POINTER(SdpaPlanes), C.c_void_p]
+            fn = lambda: L.vcr_sdpa_bf16x3_planes_f32(C.byref(a), C.byref(pp), C.c_void_p(stream_ptr()))
         assert fn() == 0
         for _ in range(3):
             fn()
