@@ -172,12 +172,25 @@ __global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_ker
     }
   };
 
-  if (nflat > 0) load_chunk(0, bufA);
-  for (int f = 0; f < nflat; f += 2) {                   // nflat is even: chunks = E/64 is even (E % 128 == 0)
-    if (f + 1 < nflat) load_chunk(f + 1, bufB);
+  // nflat is even (chunks = E/64 is even: E % 128 == 0).  The requests of the NEXT chunk are fenced in front of the current
+  // chunk's MFMAs, and the steady-state body issues them unconditionally: left alone hipcc sinks the eight loads to the end of
+  // the chunk before their use (a register double buffer that hides nothing: vmcnt(7) right after the requests), and behind a
+  // branch it cannot count how many loads are in flight and waits for the newest possible one
+  if (nflat > 0) {
+    load_chunk(0, bufA);
+    int f = 0;
+    for (; f + 2 < nflat; f += 2) {
+      load_chunk(f + 1, bufB);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(f, bufA);
+      load_chunk(f + 2, bufA);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(f + 1, bufB);
+    }
+    load_chunk(f + 1, bufB);
+    __builtin_amdgcn_sched_barrier(0);
     compute(f, bufA);
-    if (f + 2 < nflat) load_chunk(f + 2, bufA);
-    if (f + 1 < nflat) compute(f + 1, bufB);
+    compute(f + 1, bufB);
   }
 
   // the two halves of a wave hold disjoint streamed rows of the same owner (same running max)
