@@ -457,7 +457,12 @@ def measure(a, ctx, min_seconds):
         # HBM traffic per launch of that kernel comes from SEPARATE rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
         # of this same command, condensed by profiles/summarize.py; null when no summary is committed.
         import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+        from vcrnet_amd import build as vb
+
+        def _pmc_rank(path):                               # the summary taken on THIS build's kernel sources, else the latest one
+            meta = json.load(open(path)).get("_meta", {})
+            return (meta.get("kernel_sources_sha16") == vb.sources_sha16(), meta.get("date_utc", ""), path)
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), key=_pmc_rank)
         if pmcs and (B, N, a.k, a.partial, a.iters, a.emb_nn) == (16, 1024, 20, False, 1, "lpdnet"):
             kname = {"linear": "linear_glds", "sdpa": "sdpa_kernel<false, true>",
                      "edgeconv": "edgeconv_dg_pipe_kernel<20>", "softcorr": "pairscore_kernel<0>"}.get(dom)
@@ -470,7 +475,6 @@ def measure(a, ctx, min_seconds):
                 roof["traffic"] = sum(e["hbm_bytes_per_launch"] * n for e, n in zip(ents, nd)) / sum(nd)
                 roof["traffic_source"] = os.path.relpath(pmcs[-1], ROOT)
                 # were those counters taken on this code?  (the summary records a hash of csrc/ + include/; no .git on the box)
-                from vcrnet_amd import build as vb
                 meta = json.load(open(pmcs[-1])).get("_meta", {})
                 roof["traffic_source_kernel_sources"] = (
                     "identical to this build" if meta.get("kernel_sources_sha16") == vb.sources_sha16() else
