@@ -444,10 +444,10 @@ def measure(a, ctx, min_seconds):
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak,
                     "unit": "TFLOP/s", "frac": ach / peak, "traffic": None}
             if not split:
-                # register-only MFMA loops on all 256 CUs, random operands (profiles/r2e_mfma_sustained_rates.txt): the
-                # fp32 matrix pipe is power-limited chip-wide below its nominal rate
-                roof["sustained_peak_measured"] = {"four_accumulators": 127.2, "one_accumulator": 135.6, "unit": "TFLOP/s",
-                                                   "frac_of_four_accumulator_rate": ach / 127.2}
+                # what a register-only fp32 MFMA loop holds on all 256 CUs after 2 s of load, with the shader clock read inside the
+                # kernel (round 4, three boxes): the pipe is NOT power-limited -- `frac` above is priced against the nominal peak
+                roof["peak_measured"] = {"register_only_mfma_loop": 153.5, "unit": "TFLOP/s", "shader_clock_ghz": 2.39,
+                                         "source": "profiles/r4c_mfma_f32_clock.txt"}
             if split:
                 roof["note"] = "fp32-equivalent FLOPs; peak = 2500 TFLOP/s dense bf16 / 6 MFMAs per split product"
         else:
