@@ -182,3 +182,33 @@ def test_module_copies_pickles_and_weight_updates():
         net.load_state_dict(cfg_weights())
         back = net(s, t)
         assert torch.equal(back[2], ref[2]) and torch.equal(back[3], ref[3])
+
+
+def test_first_call_inside_the_threads_and_repack_between_rounds():
+    """the packed-weight cache must be safe across STREAMS, not only threads.  Nothing is packed before the
+    threads start: one of four threads packs on its own non-blocking stream, the other three hit the published entry and
+    must wait for the packing kernels (the entry's event) before their forwards read the packed pointers.  Then the
+    weights change and the same four streams call again (a re-pack while the others still hold the old entry)."""
+    from vcrnet_amd.module import vcrnetIter
+    net, _ = build_net()
+    ref_net, _ = build_net()
+    xs = [_inputs(9400 + 10 * i, 2, 384) for i in range(4)]
+    with torch.no_grad():
+        serial = [vcrnetIter(ref_net, s, t, iter=1) for s, t in xs]
+    torch.cuda.synchronize()
+    assert net._shared.packs == 0
+    got = _run_threads([lambda s=s, t=t: vcrnetIter(net, s, t, iter=1) for s, t in xs])
+    assert net._shared.packs == 1
+    for ref, out in zip(serial, got):
+        for a, b in zip(ref, out):
+            assert torch.equal(a, b)
+    with torch.no_grad():
+        for n in (net, ref_net):
+            n.emb_nn.conv3_lpd.weight.mul_(1.01)
+        serial = [vcrnetIter(ref_net, s, t, iter=1) for s, t in xs]
+    torch.cuda.synchronize()
+    got = _run_threads([lambda s=s, t=t: vcrnetIter(net, s, t, iter=1) for s, t in xs])
+    assert net._shared.packs == 2
+    for ref, out in zip(serial, got):
+        for a, b in zip(ref, out):
+            assert torch.equal(a, b)

@@ -244,6 +244,7 @@ class VCRNet(nn.Module):
 
     # -- checkpoints saved through nn.DataParallel carry a "module." prefix --
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self.__dict__.pop("_tcache", None)                 # (assign=True replaces the parameter objects)
         return super().load_state_dict(strip_module_prefix(state_dict), strict=strict, **kw)
 
     def __getstate__(self):
@@ -251,13 +252,19 @@ class VCRNet(nn.Module):
         # packs for itself on its first call
         d = self.__dict__.copy()
         d.pop("_shared", None)
+        d.pop("_tcache", None)
         d["_packed"], d["_packed_key"], d["_cw"] = None, None, None
         return d
 
     # -- weight packing: once per (device, parameter versions) --------------------------------------------------
     def _tensors(self) -> Dict[str, torch.Tensor]:
         """{state_dict key: tensor} of this module -- or of this nn.DataParallel REPLICA, whose parameters() is empty by
-        design (torch/nn/parallel/replicate.py: the broadcast copies are plain attributes, listed in _former_parameters)."""
+        design (torch/nn/parallel/replicate.py: the broadcast copies are plain attributes, listed in _former_parameters).
+        Walked once per object (a replica is a shallow copy that inherits its master's __dict__: the cache is tagged with
+        the object it was built for); _apply / load_state_dict drop it."""
+        hit = self.__dict__.get("_tcache")
+        if hit is not None and hit[0] == id(self):
+            return hit[1]
         out: Dict[str, torch.Tensor] = {}
         for prefix, mod in self.named_modules():
             former = mod.__dict__.get("_former_parameters") if getattr(mod, "_is_replica", False) else None
@@ -265,7 +272,12 @@ class VCRNet(nn.Module):
             for k, v in list(src.items()) + list(mod._buffers.items()):
                 if v is not None:
                     out[(prefix + "." if prefix else "") + k] = v
+        self.__dict__["_tcache"] = (id(self), out)
         return out
+
+    def _apply(self, fn, *a, **kw):
+        self.__dict__.pop("_tcache", None)                 # .to() / .cuda() / .float() may replace parameter objects
+        return super()._apply(fn, *a, **kw)
 
     def _device(self) -> torch.device:
         return next(iter(self._tensors().values())).device
@@ -289,15 +301,30 @@ class VCRNet(nn.Module):
                 self.merge_encdec)
 
     def _pack(self):
+        """Packed weights for this device and these parameter versions, shared with every replica / thread.  The packing
+        kernels (clones, fold_layernorm, split_bf16x3) are enqueued on the PACKING thread's current stream; the entry
+        carries an event recorded behind them, and a caller on any other stream waits for it (once per stream) before its
+        forward reads the packed pointers.  Replacing an entry (the weights changed) first drains the device: forwards on
+        other streams may still be reading the old packing, whose memory the caching allocator would otherwise hand to
+        the new one."""
         m, sh = self._master()
+        key = self._fingerprint()                          # (outside the lock: a walk over ~60 tensors per call)
+        dev = key[0]
+        cur = torch.cuda.current_stream(dev)
         with sh.lock:
-            key = self._fingerprint()
-            hit = sh.packed.get(key[0])
+            hit = sh.packed.get(dev)
             if hit is not None and hit[0] == key:
-                self._packed_key, self._packed, self._cw = hit
+                self._packed_key, self._packed, self._cw, ev, waited = hit
+                if cur.cuda_stream not in waited:
+                    cur.wait_event(ev)
+                    waited.add(cur.cuda_stream)
                 return
+            if hit is not None:
+                torch.cuda.synchronize(dev)
             self._pack_locked(key, own=m is not self)
-            sh.packed[key[0]] = (self._packed_key, self._packed, self._cw)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            sh.packed[dev] = (self._packed_key, self._packed, self._cw, ev, {cur.cuda_stream})
             sh.packs += 1
 
     def _pack_locked(self, key, own):
@@ -448,13 +475,28 @@ class VCRNet(nn.Module):
             if idle:
                 return key, idle.pop()
             for k_ in [k_ for k_ in sh.pool if k_[2] == device and k_ != key]:     # keep one shape resident per device
-                del sh.pool[k_]
+                for b_ in sh.pool.pop(k_):
+                    self._retire(b_)
         nbytes = native.lib().vcr_vcrnet_workspace_bytes(C.byref(self._cw), B, N)
         return key, {"ws": torch.empty(nbytes + 256, dtype=torch.uint8, device=device)}
 
+    MAX_IDLE_WORKSPACES = 4                                # per shape: more concurrent calls than this allocate and free
+
+    @staticmethod
+    def _retire(bufs):
+        """Drop a pooled workspace whose last user may still be running on ANOTHER stream than the one it was allocated on:
+        tell the caching allocator, or it could hand the memory to a new allocation while those kernels run."""
+        st = bufs.get("stream")
+        if st is not None:
+            bufs["ws"].record_stream(st)
+
     def _give_buffers(self, key, bufs):
         with self._shared.lock:
-            self._shared.pool.setdefault(key, []).append(bufs)
+            idle = self._shared.pool.setdefault(key, [])
+            if len(idle) < self.MAX_IDLE_WORKSPACES:
+                idle.append(bufs)
+            else:
+                self._retire(bufs)
 
     def fused_supported(self) -> bool:
         """True when one vcr_vcrnet_forward_f32 / vcr_vcrnet_iter_f32 call covers this configuration: every
