@@ -276,6 +276,21 @@ def setup_rank(a):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
+    rccl_log = None
+    if world > 1 and rank == 0 and a.backend == "nccl":
+        # "RCCL over xGMI only" must be shown, not assumed: rank 0's RCCL writes its INIT / GRAPH debug lines to a file
+        # (set before the library initialises) and measure() parses the transports of its channels into multi_gpu.transport
+        from vcrnet_amd import shard
+        logdir = os.environ.get("VCR_BENCH_LOGDIR", os.path.join(ROOT, "gpurun_out"))
+        os.makedirs(logdir, exist_ok=True)
+        rccl_log = os.path.join(logdir, "rank0.rccl.log")
+        try:
+            os.remove(rccl_log)
+        except OSError:
+            pass
+        for k_, v_ in shard.rccl_debug_env(rccl_log).items():
+            os.environ.setdefault(k_, v_)
+        rccl_log = os.environ["NCCL_DEBUG_FILE"]
     if world > 1:
         import datetime
         import torch.distributed as dist
@@ -288,7 +303,9 @@ def setup_rank(a):
         print(f"rank {rank}: injected failure", file=sys.stderr, flush=True)
         os._exit(3)
 
-    return SimpleNamespace(json_fd=json_fd, world=world, rank=rank, dev=dev, dist=dist, ndev=ndev)
+    # (tests: a canned RCCL log stands in for the one a multi-GPU box would write)
+    rccl_log = os.environ.get("VCR_BENCH_RCCL_LOG", rccl_log) if rank == 0 else None
+    return SimpleNamespace(json_fd=json_fd, world=world, rank=rank, dev=dev, dist=dist, ndev=ndev, rccl_log=rccl_log)
 
 
 def rccl_version():
@@ -417,6 +434,19 @@ def measure(a, ctx, min_seconds):
                                            + ("" if a.backend == "nccl" else
                                               f"; backend {a.backend}: the poses are staged through the host, so this is a "
                                               "device-to-host copy + a CPU collective, not RCCL"))}
+        # which transport carried the collective (rank 0's RCCL debug log, see setup_rank): xgmi_only is True only when
+        # every channel is P2P and the topology RCCL detected lists XGMI links; False as soon as a NET/ or SHM/ transport
+        # appears; None when there is no log to read (gloo, or RCCL wrote nothing)
+        if ctx.rccl_log:
+            from vcrnet_amd import shard
+            try:
+                with open(ctx.rccl_log, errors="replace") as f:
+                    multi["transport"] = dict(shard.parse_rccl_log(f.read()), log=os.path.relpath(ctx.rccl_log, ROOT))
+            except OSError as e:
+                multi["transport"] = {"xgmi_only": None, "error": f"{type(e).__name__}: {e}"}
+        else:
+            multi["transport"] = {"xgmi_only": None, "note": "no RCCL log (backend %s)" % a.backend}
+        multi["xgmi_only"] = multi["transport"].get("xgmi_only")
 
     # per-launch durations from the HIP events recorded inside the (last) timed block
     fam_ms, fam_flops, fam_bytes, fam_gather, rows = {}, {}, {}, {}, {}
@@ -446,8 +476,10 @@ def measure(a, ctx, min_seconds):
             if not split:
                 # what a register-only fp32 MFMA loop holds on all 256 CUs after 2 s of load, with the shader clock read inside the
                 # kernel (round 4, three boxes): the pipe is NOT power-limited -- `frac` above is priced against the nominal peak
-                roof["peak_measured"] = {"register_only_mfma_loop": 153.5, "unit": "TFLOP/s", "shader_clock_ghz": 2.39,
-                                         "source": "profiles/r4c_mfma_f32_clock.txt"}
+                roof["peak_recorded"] = {"register_only_mfma_loop": 153.5, "unit": "TFLOP/s", "shader_clock_ghz": 2.39,
+                                         "source": "profiles/r4c_mfma_f32_clock.txt",
+                                         "note": "a RECORDED constant (round 4, two boxes, 2 s of load), not measured in this run: "
+                                                 "the same kernels ran at 2.15-2.38 GHz from run to run on one box"}
             if split:
                 roof["note"] = "fp32-equivalent FLOPs; peak = 2500 TFLOP/s dense bf16 / 6 MFMAs per split product"
         else:

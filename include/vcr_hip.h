@@ -71,7 +71,7 @@ int vcr_rows4_pq_f32(const float* x_cf, float* xyz4, int B, int N, const float* 
  * D_ij = (-sq_j + 2 x_i.x_j) - sq_i ; idx = indices of the k largest D per row after dropping
  * rank 0 ("topk(k+1)[:, :, 1:]").  C == 64 (feature space, fp32 MFMA) or C == 4 (xyz4 rows; Cartesian, VALU).
  * Limits of this library (the reference's knn has none): k <= 62 (lists of k + 2 <= 64 values per query; the tie replay keeps
- * topk(k + 1)'s heap in the 64 lanes of a wave) and N <= 2^20 (validated to N = 70 001), VCR_EUNSUPPORTED beyond; the whole forward
+ * topk(k + 1)'s heap in the 64 lanes of a wave) and N <= 131 072 with B * N < 2^31 (the largest size validated: sampled rows at N = 70 001 and 131 072), VCR_EUNSUPPORTED beyond; the whole forward
  * (vcr_forward_f32) keeps N <= 65535: its other stages were never validated beyond.
  * Exact ties at the (k+1)-th value: with tie_scratch the kept SET equals what Tensor.topk (libstdc++ nth_element /
  * partial_sort on the CPU) keeps; without it one of the tied candidates is kept (deterministically, but not by a

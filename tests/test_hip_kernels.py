@@ -851,12 +851,12 @@ def test_sdpa_indexed_keys_equal_the_gathered_rows(nat):
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("k", [20, 40])
-def test_knn_beyond_65535_points(nat, W, k):
-    """util.py:143-160 has no size limit; the kNN entry points take clouds of more than 65 535 points (N = 70 001 here: the
-    reference would materialise a 19.6 GB distance matrix).  Neighbour sets of 192 sampled queries -- Cartesian and
-    feature-space -- against the reference formula evaluated for those rows on the CPU; ties replayed through global scratch."""
-    N = 70001
+@pytest.mark.parametrize("N,k", [(70001, 20), (70001, 40), (131072, 20)])
+def test_knn_beyond_65535_points(nat, W, N, k):
+    """util.py:143-160 has no size limit; the kNN entry points take clouds of more than 65 535 points, up to the library's
+    limit of 131 072 (the reference would materialise a 19.6 / 68.7 GB distance matrix).  Neighbour sets of 192 sampled queries
+    -- Cartesian and feature-space -- against the reference formula evaluated for those rows on the CPU; ties replayed
+    through global scratch.  One point more is refused (VCR_EUNSUPPORTED), not computed unvalidated."""
     rs = np.random.RandomState(k)
     pts = torch.from_numpy(rs.uniform(-0.5, 0.5, size=(1, 3, N)).astype(np.float32))
     h = F.relu(F.conv1d(pts, W["emb_nn.conv1_lpd.weight"], W["emb_nn.conv1_lpd.bias"]))
@@ -880,3 +880,7 @@ def test_knn_beyond_65535_points(nat, W, k):
     print(f"N = {N}, k = {k}: rows differing xyz {bad3} / 192, features {bad64} / 192")
     # (the row-subset matmul of this reference may round a distance differently from the full N x N one: allow a near-tie or two)
     assert bad3 <= 2 and bad64 <= 2
+    if N == 131072:
+        big = torch.zeros(1, N + 1, 4, device="cuda")
+        with pytest.raises(nat.VcrHipError, match="unsupported"):
+            nat.knn(big, None, k)

@@ -114,10 +114,14 @@ def test_bench_eight_ranks_on_the_one_gpu_explains_itself():
     a first real 8-GPU run needs to be read -- world size, backend, every rank's own step time, the collective's time,
     the devices visible -- and per-rank logs."""
     import tempfile
+    from test_shard_gloo import RCCL_LOG_XGMI
     logdir = tempfile.mkdtemp(prefix="vcr_bench_logs_")
+    canned = os.path.join(tempfile.mkdtemp(prefix="vcr_rccl_log_"), "rank0.rccl.log")      # what an 8-GPU box's RCCL would write
+    with open(canned, "w") as f:
+        f.write(RCCL_LOG_XGMI)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--batch", "1",
                         "--points", "64", "--steps", "3", "--warmup", "1", "--min-seconds", "0.2", "--deadline-s", "500"],
-                       capture_output=True, text=True, timeout=900, env=_bench_env(VCR_BENCH_LOGDIR=logdir))
+                       capture_output=True, text=True, timeout=900, env=_bench_env(VCR_BENCH_LOGDIR=logdir, VCR_BENCH_RCCL_LOG=canned))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = r.stdout.strip().splitlines()
     assert len(lines) == 1, r.stdout
@@ -130,6 +134,8 @@ def test_bench_eight_ranks_on_the_one_gpu_explains_itself():
     assert m["all_gather_ms"] > 0 and m["n_devices_visible"] >= 1
     assert sorted(os.listdir(logdir)) == [f"rank{i}.err" for i in range(8)]
     assert "other_configs" not in j and "cpu_baseline" not in j
+    # the transport evidence (here from the canned log: gloo writes none): parsed into the line
+    assert m["xgmi_only"] is True and m["transport"]["transports"] == {"P2P/IPC": 2, "P2P/direct pointer": 1}
 
 
 def test_bench_eight_ranks_rank_five_dies():

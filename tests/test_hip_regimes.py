@@ -4,11 +4,12 @@ peaky soft-maxes, large LayerNorm offsets; random feature extractor), in fp32 AN
 whole N = 1024, k = 40 at N = 512, and the partial-overlap path at N = 768 with the reference's discrete selections of
 all three passes forced.
 
-Tolerance = BASELINE (1e-4 on R, 1e-5 on t) + the distance the reference shows from its OWN float64 twin on the same
-inputs and weights, recorded next to each pose (it*_R_f64 / it*_t_f64): for 7 of the 9 fixtures that spread is below a
-tenth of the tolerance and changes nothing; where the reference itself is not stable at 1e-5 (seed4321 / k = 40:
-7.6e-5 on t) no other implementation can be held tighter than that.  Forced passes have no twin term: with identical
-selections the path is continuous."""
+Tolerance = BASELINE (1e-4 on R, 1e-5 on t), flat.  Round 4 added the distance the reference shows from its OWN
+float64 twin (it*_R_f64 / it*_t_f64, printed below); round 5's accuracy ledger (tests/test_hip_ledger.py,
+profiles/accuracy_ledger.txt) measured both implementations against that twin and, with the head's scores accumulated in
+blocks like ATen's sgemm, the HIP path stays within 1.5e-5 / 2e-6 of the fp32 reference in every regime: the allowance
+is gone.  Free-running selection flips against the fp32 reference are bounded by 1.5x (+2) what the reference's own twin
+flips against it (round 4: 3x)."""
 import numpy as np
 import pytest
 import torch
@@ -46,8 +47,8 @@ def test_whole_under_regime(regime, shape, mode):
     dt = float(np.abs(t.cpu().numpy() - g["it0_t"]).max())
     print(f"{regime}/{shape}/{mode}: max|dR| {dR:.2e} max|dt| {dt:.2e}  (reference vs its float64 twin {sR:.2e} / {st:.2e}; "
           f"peak cross-attention probability {float(g['it0_peak_cross_attn']):.4f})")
-    assert dR <= R_TOL + sR and dt <= T_TOL + st, (dR, dt, sR, st)
-    np.testing.assert_allclose(R_ba.cpu().numpy(), g["it0_R_ba"], atol=R_TOL + sR)
+    assert dR <= R_TOL and dt <= T_TOL, (dR, dt, sR, st)
+    np.testing.assert_allclose(R_ba.cpu().numpy(), g["it0_R_ba"], atol=R_TOL)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -75,15 +76,15 @@ def test_partial_forced_under_regime(regime, mode):
               f"max|dR| {np.abs(g[p + 'R'] - g[p + 'R_f64']).max():.2e})")
         assert dR <= R_TOL and dt <= T_TOL, (it, dR, dt)
         B, N = cur.shape[0], cur.shape[2]
-        # free-running flips: the bounds of tests/test_hip_forced.py, or three times (+2) what the reference's own float64 twin
+        # free-running flips: the bounds of tests/test_hip_forced.py, or 1.5 times (+2) what the reference's own float64 twin
         # flips against it on this very input (it*_twin_flips; a random feature extractor leaves the hard-pair scores
-        # nearly tied: the twin moves 22-37 of the 392 pairs there, 0 under the second seed)
-        # (the twin differs from the fp32 run by ONE fp32 evaluation's rounding, two fp32 implementations differ by two:
-        # three times the twin's worst pass, +2)
+        # nearly tied: the twin moves 22-37 of the 392 pairs there, 0 under the second seed).  The fp32 reference's own
+        # rounding is in that count whatever the other side does; the HIP path adds less than half of it again (the
+        # ledger: 7-23 flips against the twin where the reference has 22-37) -- round 4 needed 3x here (54-56 observed).
         tw = np.max([g[f"it{j}_twin_flips"] for j in range(int(g["iters"]))], axis=0)
-        assert fl["keys"] <= max(2, 2 * B * N // 100, 3 * int(tw[0]) + 2), (fl, tw)
-        assert fl["overlap"] <= max(4, B * N // 50, 3 * int(tw[1]) + 2), (fl, tw)
-        assert fl["pairs"] <= max(2, fl["n_pairs"] // 20, 3 * int(tw[2]) + 2), (fl, tw)
+        assert fl["keys"] <= max(2, 2 * B * N // 100, (3 * int(tw[0]) + 1) // 2 + 2), (fl, tw)
+        assert fl["overlap"] <= max(4, B * N // 50, (3 * int(tw[1]) + 1) // 2 + 2), (fl, tw)
+        assert fl["pairs"] <= max(2, fl["n_pairs"] // 20, (3 * int(tw[2]) + 1) // 2 + 2), (fl, tw)
         if fl["keys"] == fl["overlap"] == fl["pairs"] == 0:
             assert fR <= R_TOL and ft <= T_TOL, (it, fR, ft)
 
@@ -118,7 +119,7 @@ def test_other_branches_under_the_trained_regime(name, kw):
     dR = float(np.abs(out[2].cpu().numpy() - g["it0_R"]).max())
     dt = float(np.abs(out[3].cpu().numpy() - g["it0_t"]).max())
     print(f"{name}: max|dR| {dR:.2e} max|dt| {dt:.2e} (reference vs its float64 twin {sR:.2e} / {st:.2e})")
-    assert dR <= R_TOL + sR and dt <= T_TOL + st, (dR, dt, sR, st)
+    assert dR <= R_TOL and dt <= T_TOL, (dR, dt, sR, st)
     if kw.get("cycle"):                                  # the second head's own solve (vcrnet_model.py:511-513)
-        np.testing.assert_allclose(out[4].cpu().numpy(), g["it0_R_ba"], atol=R_TOL + sR)
-        np.testing.assert_allclose(out[5].cpu().numpy(), g["it0_t_ba"], atol=T_TOL + st + 1e-5)
+        np.testing.assert_allclose(out[4].cpu().numpy(), g["it0_R_ba"], atol=R_TOL)
+        np.testing.assert_allclose(out[5].cpu().numpy(), g["it0_t_ba"], atol=T_TOL + 1e-5)

@@ -170,3 +170,34 @@ def test_bench_multi_rank_run_honours_its_deadline():
                               {"VCR_BENCH_HANG_RANK": "all"})
     assert r.returncode != 0 and el < 60
     assert j is not None and "deadline" in j["error"] and j["value"] is None
+
+
+RCCL_LOG_XGMI = """runc:123:456 [0] NCCL INFO NCCL version 2.26.6+hip7.0
+runc:123:456 [0] NCCL INFO === System : maxBw 48.0 totalBw 336.0 ===
+runc:123:456 [0] NCCL INFO + XGMI[48.0] - GPU/3D000
+runc:123:456 [0] NCCL INFO + XGMI[48.0] - GPU/4E000
+runc:123:789 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC
+runc:123:789 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC comm 0x1234 nRanks 08
+runc:123:789 [0] NCCL INFO Channel 02/0 : 7[7] -> 0[0] via P2P/direct pointer
+"""
+
+
+def test_rccl_log_parse_says_which_transport_carried_the_collective():
+    """BASELINE north_star: "RCCL all-gather of per-rank metrics over xGMI only".  bench.py's rank 0 runs RCCL with
+    NCCL_DEBUG=INFO / INIT,GRAPH into a file and shard.parse_rccl_log turns the channel lines into multi_gpu.transport:
+    xgmi_only needs every channel on a P2P transport AND XGMI links in the detected topology; any NET/ or SHM/ channel
+    fails it; an empty log says nothing (None)."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import shard
+    ok = shard.parse_rccl_log(RCCL_LOG_XGMI)
+    assert ok["channels"] == 3 and ok["transports"] == {"P2P/IPC": 2, "P2P/direct pointer": 1}
+    assert ok["xgmi_links_in_topology"] == 2 and ok["net_or_shm"] == [] and ok["xgmi_only"] is True
+    net = shard.parse_rccl_log(RCCL_LOG_XGMI + "runc:1:2 [0] NCCL INFO Channel 00/0 : 0[1b000] -> 1[3d000] [send] via NET/Socket/0\n")
+    assert net["xgmi_only"] is False and net["net_or_shm"] == ["NET/Socket/0"]
+    shm = shard.parse_rccl_log(RCCL_LOG_XGMI.replace("P2P/IPC", "SHM/direct/direct"))
+    assert shm["xgmi_only"] is False and shm["net_or_shm"] == ["SHM/direct/direct"]
+    pcie = shard.parse_rccl_log(RCCL_LOG_XGMI.replace("XGMI[", "PCI["))          # P2P, but over PCIe
+    assert pcie["xgmi_only"] is False and pcie["xgmi_links_in_topology"] == 0
+    assert shard.parse_rccl_log("no channel line")["xgmi_only"] is None
+    env = shard.rccl_debug_env("/tmp/x.log")
+    assert env["NCCL_DEBUG"] == "INFO" and env["NCCL_DEBUG_FILE"] == "/tmp/x.log" and "GRAPH" in env["NCCL_DEBUG_SUBSYS"]

@@ -362,6 +362,7 @@ extern "C" int vcr_keymass_f32(const vcr_keymass_args* a, vcr_stream_t stream) {
 }
 
 extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
+  vcr_stream_scope bound(stream);
   if (!a || !a->q || !a->k) return VCR_EINVAL;
   const bool pv = a->out != nullptr;
   if (pv && !a->v) return VCR_EINVAL;

@@ -90,11 +90,24 @@ __device__ __forceinline__ void ln_row_moments(const float* sp, int nseg, int K,
   var = m2 / (float)(K - 1);
 }
 
-// CUs of the current device (cached per device: the attribute query is cheap but not free)
+// CUs of the device the launch goes to: the STREAM's device when an entry point bound one (vcr_stream_scope: a caller may
+// pass a stream of a device that is not the thread's current one), else the current device.  Cached per device.
+inline int& vcr_bound_device() {
+  static thread_local int dev = -1;
+  return dev;
+}
+struct vcr_stream_scope {                                 // first statement of every entry point that sizes a grid by the CU count
+  int saved;
+  explicit vcr_stream_scope(vcr_stream_t s) : saved(vcr_bound_device()) {
+    int dev = -1;
+    if (s && hipStreamGetDevice((hipStream_t)s, &dev) == hipSuccess && dev >= 0) vcr_bound_device() = dev;
+  }
+  ~vcr_stream_scope() { vcr_bound_device() = saved; }
+};
 inline int vcr_cu_count() {
   static std::atomic<int> cache[16];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
+  int dev = vcr_bound_device();
+  if (dev < 0) (void)hipGetDevice(&dev);
   const bool ok = dev >= 0 && dev < 16;
   int n = ok ? cache[dev].load(std::memory_order_relaxed) : 0;
   if (n <= 0) {

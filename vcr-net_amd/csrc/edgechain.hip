@@ -235,6 +235,7 @@ __global__ __launch_bounds__(512, 1) void edgechain_kernel(vcr_edgechain_args p,
 }  // namespace
 
 extern "C" int vcr_edgechain_f32(const vcr_edgechain_args* a, vcr_stream_t stream) {
+  vcr_stream_scope bound(stream);
   if (!a || !a->pq || !a->idx || !a->w2 || !a->b2 || !a->w3 || !a->b3 || !a->w4 || !a->b4 || !a->out) return VCR_EINVAL;
   if (a->M <= 0 || a->n_per_cloud <= 0 || a->ldpq < 128 || (a->ldpq & 3) || a->ldo < 512) return VCR_EINVAL;
   if (((uintptr_t)a->pq | (uintptr_t)a->w2 | (uintptr_t)a->w3 | (uintptr_t)a->w4) & 15) return VCR_EINVAL;

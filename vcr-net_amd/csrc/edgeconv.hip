@@ -560,6 +560,7 @@ extern "C" int vcr_segmax_f32(const vcr_segmax_args* a, vcr_stream_t stream) {
 }
 
 extern "C" int vcr_edgeconv_f32(const vcr_edgeconv_args* a, vcr_stream_t stream) {
+  vcr_stream_scope bound(stream);
   if (!a || !a->pq || !a->idx || !a->w2 || !a->b2 || !a->x1 || !a->x2) return VCR_EINVAL;
   if (a->M <= 0 || a->k <= 0 || a->k > 64 || a->n_per_cloud <= 0 || (a->M % a->n_per_cloud)) return VCR_EINVAL;
   if (a->ldpq < 256 || (a->ldpq & 3) || (a->ldx1 & 3) || a->ldx1 < 128 || a->ldx2 < 128) return VCR_EINVAL;

@@ -374,7 +374,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     return VCR_EINVAL;
   const int B = io->B, N = io->N, E = W->E, F = W->F, k = W->k;
   if (B <= 0 || N <= 0 || E != 512 || W->heads * 128 != E || k <= 0 || k + 1 > N) return VCR_EINVAL;
-  if (k > 62 || N > 65535) return VCR_EUNSUPPORTED;     // k: vcr_knn_f32's limit; N: the forward's own (the kNN kernels alone take N <= 2^20)
+  if (k > 62 || N > 65535) return VCR_EUNSUPPORTED;     // k: vcr_knn_f32's limit; N: the forward's own (the kNN kernels alone take N <= 131 072)
   if (W->emb_kind < 0 || W->emb_kind > 2) return VCR_EINVAL;
   if (W->emb_kind == 2 && !(W->c1_w && W->c1_b && W->c2_w && W->c2_b && W->pointnet.c3_w && W->pointnet.c3_b && W->pointnet.c4_w &&
                             W->pointnet.c4_b && W->pointnet.c5_w && W->pointnet.c5_b))

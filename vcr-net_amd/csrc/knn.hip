@@ -44,8 +44,10 @@ constexpr int TILE = 32;            // candidates per MFMA tile
 // Log capacity per query.  Measured for the MFMA kernel at k = 20 (MI355X, 32 clouds): 96 / 128 entries make the kernel
 // alone 7 % faster at N = 1024 (fewer compactions) but cost the second workgroup per CU at N = 2048 (+20 %) and the
 // co-residency of the one-launch kNN pair (+20 %): 64 stays.
-constexpr int KNN_MAX_N = 1 << 20;                      // points per cloud the kNN entry points accept (validated at N = 70 001, tests/test_hip_kernels.py;
-                                                         // the whole forward keeps its own, lower limit: forward.hip)
+constexpr int KNN_MAX_N = 131072;                       // points per cloud the kNN entry points accept: the largest size that is validated
+                                                         // (sampled rows at N = 70 001 and 131 072, tests/test_hip_kernels.py; beyond: VCR_EUNSUPPORTED
+                                                         // rather than an unvalidated result).  The whole forward keeps its own, lower limit: forward.hip
+static bool knn_rows_overflow(const vcr_knn_args* a) { return (long long)a->B * a->N >= (1ll << 31); }   // row = b * N + q is an int
 constexpr int KNN_PEND_MFMA = 64;
 struct GeomMfma;
 struct GeomCol16;
@@ -1371,7 +1373,7 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
   const bool small = !fusable && a64->k == a3->k && a64->k <= 20 && a64->waves == 0 && a3->waves == 0 && !col16 &&
                      (a64->tie_scratch != nullptr) == (a3->tie_scratch != nullptr) && a64->tie_defer == a3->tie_defer &&
                      a64->B > 0 && a3->B > 0 && a64->N > 0 && a3->N > 0 && a64->k > 0 && a64->k + 1 <= a64->N && a3->k + 1 <= a3->N &&
-                     a64->N <= KNN_MAX_N && a3->N <= KNN_MAX_N && a64->sq && a64->ldx >= 64 && !(a64->ldx & 3) && a3->ldx >= 4 && !(a3->ldx & 3) &&
+                     a64->N <= KNN_MAX_N && a3->N <= KNN_MAX_N && !knn_rows_overflow(a64) && !knn_rows_overflow(a3) && a64->sq && a64->ldx >= 64 && !(a64->ldx & 3) && a3->ldx >= 4 && !(a3->ldx & 3) &&
                      !(a64->tie_scratch && (a64->tie_cap < 1 || a3->tie_cap < 1)) && !tie_work_missing(a64) && !tie_work_missing(a3) &&
                      knn_s(a64) != 1;                     // (an unsplit feature-space search on a small grid: the separate launches)
   if (small) {
@@ -1403,7 +1405,7 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
   }
   for (const vcr_knn_args* a : {a64, a3}) {
     if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k + 1 > a->N || a->ldx < a->C || (a->ldx & 3)) return VCR_EINVAL;
-    if (a->N > KNN_MAX_N) return VCR_EUNSUPPORTED;
+    if (a->N > KNN_MAX_N || knn_rows_overflow(a)) return VCR_EUNSUPPORTED;
     if (a->tie_scratch && a->tie_cap < 1) return VCR_EINVAL;
     if (tie_work_missing(a)) return VCR_EUNSUPPORTED;
   }
@@ -1439,7 +1441,7 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
 extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
   if (!a || !a->x || !a->idx) return VCR_EINVAL;
   if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k + 1 > a->N) return VCR_EINVAL;
-  if (a->k > 62 || a->N > KNN_MAX_N) return VCR_EUNSUPPORTED;   // limits of this library, not of the operation (see vcr_hip.h):
+  if (a->k > 62 || a->N > KNN_MAX_N || knn_rows_overflow(a)) return VCR_EUNSUPPORTED;   // limits of this library, not of the operation (see vcr_hip.h):
                                                             // the tie replay keeps topk(k + 1)'s heap in the 64 lanes of a wave
   if (a->waves != 0 && a->waves != 1 && a->waves != 2 && a->waves != 4 && a->waves != 8) return VCR_EINVAL;
   if (a->C != 64 && a->C != 4) return VCR_EUNSUPPORTED;

@@ -614,6 +614,7 @@ extern "C" int vcr_linear_config(const vcr_linear_args* a) {
 }
 
 extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
+  vcr_stream_scope bound(stream);
   LinearPlan pl{};
   const int rc = linear_plan(a, &pl);
   if (rc != VCR_OK) return rc;
@@ -637,6 +638,7 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
 // Two independent linears as one launch when they resolve to the same LDS-DMA kernel configuration (k-slab, MFMA shape,
 // tile rows; neither with a fused max); otherwise exactly the two vcr_linear_f32 calls.  Same results.
 extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_args* b, vcr_stream_t stream) {
+  vcr_stream_scope bound(stream);
   LinearPlan pa{}, pb{};
   int rc = linear_plan(a, &pa, 0, true);
   if (rc == VCR_OK) rc = linear_plan(b, &pb, 0, true);

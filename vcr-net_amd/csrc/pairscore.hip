@@ -94,12 +94,17 @@ __global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_ker
     m[ot] = VCR_NEG_INF; l[ot] = ox[ot] = oy[ot] = oz[ot] = 0.f; best[ot] = VCR_NEG_INF; bidx[ot] = 0x7fffffff;
     mass[ot] = 0.f; s[ot] = f32x16{0};
   }
+  // The 512-d dot products are accumulated in BLOCKS: every 64-channel chunk is its own k-ascending MFMA chain from zero,
+  // and the chunk sums are added up in fp32 -- what a blocked CPU sgemm does (ATen's matmul, vcrnet_model.py:213,289,339),
+  // and ~3-5x closer to the exact dot product than ONE 512-step chain, whose late additions each round at the full
+  // magnitude of the sum.  Measured against the reference's float64 twin (profiles/accuracy_ledger.txt, round 5): with the
+  // single chain the hard-pair selections of the random-feature regime flipped 49-57 of 392 against the twin where the
+  // fp32 reference flips 22-37.
+  f32x16 tot[OT];
   auto compute = [&](int flat, const f32x4* kf) {
     const int tile = t0 + w + NW * (flat / chunks), c = flat % chunks;
-    if (c == 0) {
 #pragma unroll
-      for (int ot = 0; ot < OT; ++ot) s[ot] = f32x16{0};
-    }
+    for (int ot = 0; ot < OT; ++ot) s[ot] = f32x16{0};
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
 #pragma unroll
@@ -108,6 +113,11 @@ __global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_ker
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[ot] = mfma32(kf[g][e], qv[e], s[ot]);
       }
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      if (c == 0) tot[ot] = s[ot];
+      else tot[ot] += s[ot];
     }
     if (c != chunks - 1) return;
     float rn = 0.f;
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(128 * OT * 2, (OT == 1 ? 2 : 1)) void pairscore_ker
     }
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) {
-      f32x16& sc16 = s[ot];
+      f32x16& sc16 = tot[ot];
       if (p.score == 0) sc16 = mfma32(half == 0 ? 1.f : 0.f, half == 0 ? -0.5f * own_norm[ot] : 0.f, sc16);
       else if (p.score == 2) sc16 = mfma32(half == 0 ? -0.5f * rn : 0.f, half == 0 ? 1.f : 0.f, sc16);
       float mt = VCR_NEG_INF;
@@ -344,6 +354,7 @@ __global__ __launch_bounds__(256) void score_rowpass_kernel(vcr_scoremass_args p
 }
 
 int launch(const vcr_pairscore_args* a, vcr_stream_t stream) {
+  vcr_stream_scope bound(stream);
   if (!a || !a->own || !a->str) return VCR_EINVAL;
   if (a->nbatch <= 0 || a->n_own <= 0 || a->n_str <= 0 || a->E <= 0 || (a->E % 128) || a->E > 1024) return VCR_EINVAL;
   if ((a->ld_own & 3) || (a->ld_str & 3) || a->ld_own < a->E || a->ld_str < a->E) return VCR_EINVAL;

@@ -361,6 +361,7 @@ extern "C" int vcr_rows4_f32(const float* x_cf, float* xyz4, int B, int N, vcr_s
 }
 
 extern "C" int vcr_pointwise_f32(const vcr_pointwise_args* a, vcr_stream_t stream) {
+  vcr_stream_scope bound(stream);
   if (!a || !a->x_cf || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->xyz4 || !a->feat64 || !a->sq64) return VCR_EINVAL;
   if (((uintptr_t)a->w2 | (uintptr_t)a->pq_w) & 15) return VCR_EINVAL;   // the weights are fetched as 16-B chunks
   if (a->B <= 0 || a->N <= 0 || a->B2 < 0 || (a->B2 > 0 && !a->x_cf2)) return VCR_EINVAL;

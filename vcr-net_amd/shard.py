@@ -54,3 +54,32 @@ def all_gather_ragged(pose: torch.Tensor, total: int, world: int) -> torch.Tenso
         lo, hi = shard_range(total, r, world)
         parts.append(g[r, : hi - lo])
     return torch.cat(parts, 0)
+
+
+# ---- which transport did RCCL choose?  (BASELINE north_star: "RCCL all-gather ... over xGMI only") ----------------------
+# rank 0 runs with NCCL_DEBUG=INFO, NCCL_DEBUG_SUBSYS=INIT,GRAPH and NCCL_DEBUG_FILE=<log> (bench.py sets them before the
+# process group exists); after the first collective the log holds one line per channel and peer,
+#     "... NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC"      (or P2P/direct pointer, P2P/CUMEM, SHM/direct/direct,
+#                                                                    NET/Socket/0, NET/IB/0/GDRDMA ...)
+# and the topology RCCL detected ("... + XGMI[48.0] - GPU/..." per link on an xGMI box, "PCI[..]" otherwise).
+
+def rccl_debug_env(log_path: str) -> dict:
+    """Environment of the rank whose RCCL log is parsed (set BEFORE torch.distributed.init_process_group)."""
+    return {"NCCL_DEBUG": "INFO", "NCCL_DEBUG_SUBSYS": "INIT,GRAPH", "NCCL_DEBUG_FILE": log_path}
+
+
+def parse_rccl_log(text: str) -> dict:
+    """{"channels": n, "transports": {"P2P/IPC": n, ...}, "xgmi_links_in_topology": n, "net_or_shm": [...], "xgmi_only": bool|None}.
+    xgmi_only: every channel of every peer is a P2P transport (no NET/..., no SHM/...) AND the detected topology lists
+    XGMI links; None when the log holds no channel line at all (nothing can be said)."""
+    import re
+    transports: dict = {}
+    for m in re.finditer(r"Channel\s+\d+(?:/\d+)?\s*:\s*\d+\[[0-9a-fA-F]+\]\s*->\s*\d+\[[0-9a-fA-F]+\]\s*(?:\[(?:send|receive)\]\s*)?via\s+([A-Za-z0-9_]+(?:/[A-Za-z0-9_ ]+?)*)\s*(?:$|\n|comm|,)",
+                         text):
+        key = m.group(1).strip()
+        transports[key] = transports.get(key, 0) + 1
+    n = sum(transports.values())
+    bad = sorted(k for k in transports if not k.upper().startswith("P2P"))
+    xgmi = len(re.findall(r"XGMI\[", text))
+    return {"channels": n, "transports": transports, "xgmi_links_in_topology": xgmi, "net_or_shm": bad,
+            "xgmi_only": None if n == 0 else (not bad and xgmi > 0)}
