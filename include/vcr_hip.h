@@ -455,12 +455,13 @@ typedef struct {
   struct {
     const void *dg1_pq, *sn1_pq, *c3, *enc_qkv, *enc_wo, *enc_ffn1, *enc_ffn2, *dec_qkv, *dec_self_wo, *dec_cross_q,
                *dec_cross_kv, *dec_cross_wo, *dec_ffn1, *dec_ffn2;
+    const void* encdec_qkv;                          /* optional: the split of fold_encdec_qkv.w [6E,E] (the merged first sublayers, below) */
   } split;
   /* has_pointer 1 (every linear_mode): the six Linears that consume a LayerNorm, folded with it by
    * vcr_fold_layernorm_f32 (w [N,E], colsum [N], bias [N]).  dec_cross_kv is folded with the ENCODER's final norm. */
   struct vcr_folded { const float *w, *colsum, *bias; } fold_enc_qkv, fold_enc_ffn1, fold_dec_qkv, fold_dec_cross_q,
       fold_dec_cross_kv, fold_dec_ffn1;
-  /* optional (linear_mode 0): fold_enc_qkv and fold_dec_qkv stacked, w [6E,E], colsum [6E], bias [6E] -- both consume the
+  /* optional (linear_mode 0; 1 / 2 with split.encdec_qkv): fold_enc_qkv and fold_dec_qkv stacked, w [6E,E], colsum [6E], bias [6E] -- both consume the
    * embedding rows with the same row statistics, so the two projections run as ONE GEMM and the encoder's and the
    * decoder's self-attention as ONE grouped launch (fewer, fuller rounds of workgroups).  w == NULL: two launches each. */
   struct vcr_folded fold_encdec_qkv;

@@ -33,7 +33,7 @@ def test_header_symbols_exported(lib):
 
 def test_version_and_strerror(lib):
     from vcrnet_amd import native
-    assert lib.vcr_abi_version() == native.ABI_VERSION == 24
+    assert lib.vcr_abi_version() == native.ABI_VERSION == 25
     assert lib.vcr_strerror(0) == b"ok"
     assert b"invalid" in lib.vcr_strerror(-1)
     assert b"workspace" in lib.vcr_strerror(-2)

@@ -407,15 +407,18 @@ def test_forward_captures_into_a_hip_graph():
                 _ = torch.randn(1 << 16, device="cuda").sum().item()       # unrelated allocation + kernels + sync
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16x3+sdpa"])
 @pytest.mark.parametrize("partial", [False, True])
-def test_merged_encoder_decoder_launches_change_nothing(partial):
+def test_merged_encoder_decoder_launches_change_nothing(partial, mode):
     """enc.qkv + dec.qkv as ONE stacked GEMM and the encoder's / decoder's self-attention as ONE grouped launch
-    (vcr_vcrnet_weights.fold_encdec_qkv, vcr_sdpa_args.ngroups) against the four separate launches: the same tiles with
-    the same arithmetic, so every output is bit-identical."""
+    (vcr_vcrnet_weights.fold_encdec_qkv / split.encdec_qkv, vcr_sdpa_args.ngroups) against the four separate launches:
+    the same tiles with the same arithmetic, so every output is bit-identical -- in fp32 and (round 5) in both
+    exact-split modes, whose attention kernel takes groups since."""
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import synth
     kw = dict(partial=True, overlap2=synth.OVERLAP2_0575) if partial else {}
     net, _ = build_net(**kw)
+    net.linear_mode = mode
     src, tgt, _, _, _ = synth.make_batch(7100, 3, 320, partial=partial)
     s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
     outs = []

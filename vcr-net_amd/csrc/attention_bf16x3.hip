@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512, 1) void sdpa_bf16x3_kernel(vcr_sdpa_args p) {
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   // XCD-aware block order (as attention.hip): all query blocks of a (batch, head) pair stream K/V through one L2
-  const int nqb = (p.nq + 255) / 256, nbh = p.nbatch * p.heads;
+  const int nqb = (p.nq + 255) / 256, nbh = p.nbatch * p.heads * (p.ngroups > 1 ? p.ngroups : 1);
   int qb, bh;
   if ((nbh & 7) == 0) {
     const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
@@ -53,7 +53,9 @@ __global__ __launch_bounds__(512, 1) void sdpa_bf16x3_kernel(vcr_sdpa_args p) {
   } else {
     qb = blockIdx.x % nqb; bh = blockIdx.x / nqb;
   }
-  const int head = bh % p.heads, b = bh / p.heads;
+  const int head = bh % p.heads, grp = (bh / p.heads) / p.nbatch, b = (bh / p.heads) % p.nbatch;   // (grp == 0 unless p.ngroups > 1)
+  p.q += (size_t)grp * p.q_group_stride; p.k += (size_t)grp * p.k_group_stride;
+  p.v += (size_t)grp * p.v_group_stride; p.out += (size_t)grp * p.out_group_stride;
   const int kvb = (b + p.kv_batch_shift) % p.nbatch;
   const int q = qb * 256 + w * 32 + l31;
   const int qc = min(q, p.nq - 1);
@@ -230,13 +232,13 @@ __global__ __launch_bounds__(512, 1) void sdpa_bf16x3_kernel(vcr_sdpa_args p) {
 // the statistics-only passes of the partial-overlap path stay on vcr_sdpa_f32.
 extern "C" int vcr_sdpa_bf16x3_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   if (!a || !a->q || !a->k || !a->v || !a->out) return VCR_EINVAL;
-  if (a->ngroups > 1 || a->key_index) return VCR_EUNSUPPORTED;   // grouped / indexed-key launches: vcr_sdpa_f32 only
+  if (a->key_index) return VCR_EUNSUPPORTED;             // indexed-key launches: vcr_sdpa_f32 only
   if (a->rowstat || a->score_out || !(a->scale > 0.f)) return VCR_EUNSUPPORTED;
   if (a->nbatch <= 0 || a->heads <= 0 || a->nq <= 0 || a->nk <= 0) return VCR_EINVAL;
   if ((a->ldq & 3) || (a->ldk & 3) || (a->ldo & 3)) return VCR_EINVAL;
   if (a->ldq < a->heads * 128 || a->ldk < a->heads * 128 || a->ldv < a->heads * 128) return VCR_EINVAL;
   if (((uintptr_t)a->q & 15) || ((uintptr_t)a->k & 15) || ((uintptr_t)a->out & 15)) return VCR_EINVAL;
-  dim3 grid(((a->nq + 255) / 256) * a->heads * a->nbatch);
+  dim3 grid(((a->nq + 255) / 256) * a->heads * a->nbatch * (a->ngroups > 1 ? a->ngroups : 1));
   const int lds = 2 * sizeof(Stage3);
   static_assert(2 * sizeof(Stage3) >= 8 * 32 * EP * 4, "epilogue slices fit");
   hipStream_t s = (hipStream_t)stream;

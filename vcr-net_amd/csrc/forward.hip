@@ -111,7 +111,8 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
 
 // enc.qkv + dec.qkv as one GEMM, the two self-attentions as one grouped launch: needs the stacked folded weight (fp32 mode)
 inline int merged_encdec(const vcr_vcrnet_weights* W) {
-  return W->has_pointer == 1 && W->linear_mode == 0 && W->fold_encdec_qkv.w && W->fold_encdec_qkv.colsum && W->fold_encdec_qkv.bias;
+  return W->has_pointer == 1 && (W->linear_mode == 0 || W->split.encdec_qkv) && W->fold_encdec_qkv.w && W->fold_encdec_qkv.colsum &&
+         W->fold_encdec_qkv.bias;
 }
 
 __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* p, long n) {
@@ -527,7 +528,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     if (merged) {
       // both first sublayers read the embedding rows with the same row statistics: one [M, 6E] projection, and the two
       // independent self-attentions as one grouped launch (group 0 = encoder, 1 = decoder)
-      R.linear("linear:encdec.qkv", w.emb, E, W->fold_encdec_qkv.w, nullptr, W->fold_encdec_qkv.bias, w.qkv, 6 * E, M2, 6 * E, E, 0,
+      R.linear("linear:encdec.qkv", w.emb, E, W->fold_encdec_qkv.w, SP(encdec_qkv), W->fold_encdec_qkv.bias, w.qkv, 6 * E, M2, 6 * E, E, 0,
                nullptr, 0, w.st_emb, W->fold_encdec_qkv.colsum);
       R.sdpa("sdpa:encdec.self", w.qkv, 6 * E, w.qkv + E, 6 * E, w.qkv + 2 * E, 6 * E, w.att, E, 2 * B, H, N, N, 0, nullptr, nullptr,
              nullptr, 0, 2, 3 * E, (long)M2 * E);
@@ -537,7 +538,19 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
              nullptr, 0, w.st_emb, W->fold_enc_qkv.colsum);
     R.sdpa("sdpa:enc.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
     }
-    if (merged) {
+    if (merged && W->linear_mode != 0) {
+      // the split-arithmetic linears have no paired launcher: the same sequence, one launch each
+      R.linear("linear:enc.wo", w.att, E, W->enc_self.wo, SP(enc_wo), W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E,
+               nullptr, nullptr, w.st_e1);
+      R.linear("linear:dec.self.wo", att_dec, E, W->dec_self.wo, SP(dec_self_wo), W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E,
+               nullptr, nullptr, w.st_d1);
+      R.linear("linear:enc.ffn1", w.e1, E, W->fold_enc_ffn1.w, SP(enc_ffn1), W->fold_enc_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
+               w.st_e1, W->fold_enc_ffn1.colsum);
+      R.linear("linear:dec.cross.q", w.d1, E, W->fold_dec_cross_q.w, SP(dec_cross_q), W->fold_dec_cross_q.bias, w.qc, E, M2, E, E, 0, nullptr, 0,
+               w.st_d1, W->fold_dec_cross_q.colsum);
+      R.linear("linear:enc.ffn2", w.hid, F, W->enc_ffn.w2, SP(enc_ffn2), W->enc_ffn.b2, w.e2, E, M2, E, F, 0, w.e1, E,
+               nullptr, nullptr, w.st_e2);
+    } else if (merged) {
       // independent launches of one kernel configuration run as pairs: the two output projections (inputs = the two
       // attention outputs, residual = the embedding), then the encoder's FFN-in beside the decoder's cross-attention query
       R.linear2("linear:enc.wo+dec.self.wo",
@@ -777,7 +790,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 24; }
+extern "C" int vcr_abi_version(void) { return 25; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

@@ -432,6 +432,7 @@ class VCRNet(nn.Module):
                 # the encoder's and the decoder's first sublayers both read the embedding rows: one stacked projection
                 f = tuple(torch.cat((a_, b_), 0).contiguous() for a_, b_ in zip(P["fold.enc_qkv"], P["fold.dec_qkv"]))
                 P["fold.encdec_qkv"] = f
+                P["fold.encdec_qkv.w"] = f[0]
                 cw.fold_encdec_qkv = native.FoldedW(*(native.ptr(t) for t in f))
         else:
             cw.has_pointer = 2 if isinstance(self.pointer, _Identity) else 0
@@ -445,7 +446,7 @@ class VCRNet(nn.Module):
                    "enc_wo": "enc_self.wo", "enc_ffn1": "fold.enc_ffn1.w", "enc_ffn2": "enc_ffn.w_2.weight",
                    "dec_qkv": "fold.dec_qkv.w", "dec_self_wo": "dec_self.wo", "dec_cross_q": "fold.dec_cross_q.w",
                    "dec_cross_kv": "fold.dec_cross_kv.w", "dec_cross_wo": "dec_cross.wo", "dec_ffn1": "fold.dec_ffn1.w",
-                   "dec_ffn2": "dec_ffn.w_2.weight"}
+                   "dec_ffn2": "dec_ffn.w_2.weight", "encdec_qkv": "fold.encdec_qkv.w"}
             for site, key in src.items():
                 if key in P:
                     P["split." + site] = native.split_bf16x3(P[key])

@@ -151,7 +151,7 @@ class FfnW(C.Structure):
 
 
 SPLIT_SITES = ("dg1_pq", "sn1_pq", "c3", "enc_qkv", "enc_wo", "enc_ffn1", "enc_ffn2", "dec_qkv", "dec_self_wo",
-               "dec_cross_q", "dec_cross_kv", "dec_cross_wo", "dec_ffn1", "dec_ffn2")
+               "dec_cross_q", "dec_cross_kv", "dec_cross_wo", "dec_ffn1", "dec_ffn2", "encdec_qkv")
 
 
 class SplitW(C.Structure):
@@ -217,7 +217,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 24         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 25         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
