@@ -10,13 +10,53 @@
 
 namespace {
 
-struct Bump {
-  unsigned char* base; size_t off, cap;
-  template <class T> T* take(size_t n) {
-    off = (off + 255) & ~(size_t)255;
-    T* p = reinterpret_cast<T*>(base + off);
-    off += n * sizeof(T);
-    return p;
+// Workspace plan (round 5): every buffer of the forward with the launches between which it is LIVE, laid out by a static
+// interval allocator -- buffers whose lifetimes do not overlap share memory.  Rounds 1-4 carved the workspace with a bump
+// allocator (every buffer its own memory: 1.5 GB at BASELINE configs[1], 12 GB at configs[4]); the plan needs what the
+// busiest launch has live (the grouped self-attention: embeddings + enc | dec Q | K | V + both outputs = 9 x [2BN, 512]
+// floats).  Times are positions in the launch sequence of forward_impl (the merged and the unmerged first sublayers have
+// their own numbering up to 15; from the cross-attention's K | V projection on they agree):
+//   0 stem  1 kNN (+ dg1_pq)  2 tie replay  3 EdgeConv / DGCNN chain  4 sn1_pq  5 gathermax  6 conv3
+//   merged:   7 encdec.qkv  8 self-attention  9 wo pair  10 enc.ffn1 + dec.cross.q  11 enc.ffn2
+//   unmerged: 7 enc.qkv  8 enc.self  9 enc.wo  10 enc.ffn1  11 enc.ffn2  12 dec.qkv  13 dec.self  14 dec.self.wo  15 dec.cross.q
+//   16 dec.cross.kv  17 cross-attention  18 dec.cross.wo  19 dec.ffn1  20 dec.ffn2  21 dec.norm / rowside  22 head  23 second head
+struct Plan {
+  struct Req { void** slot; size_t bytes; int birth, death; size_t off; };
+  static constexpr int MAXR = 96;
+  Req r[MAXR];
+  int n = 0;
+  template <class T> void want(T*& field, size_t count, int birth, int death) {
+    field = nullptr;
+    if (count == 0 || n >= MAXR) return;
+    r[n++] = Req{reinterpret_cast<void**>(&field), (count * sizeof(T) + 255) & ~(size_t)255, birth, death, 0};
+  }
+  // largest first, each at the lowest offset where it collides with no placed buffer that is live at the same time
+  size_t solve(unsigned char* base) {
+    int order[MAXR];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i) {                        // insertion sort by size, descending (n ~ 60)
+      const int x = order[i];
+      int j = i - 1;
+      while (j >= 0 && r[order[j]].bytes < r[x].bytes) { order[j + 1] = order[j]; --j; }
+      order[j + 1] = x;
+    }
+    size_t total = 0;
+    for (int oi = 0; oi < n; ++oi) {
+      Req& q = r[order[oi]];
+      size_t off = 0;
+      for (bool moved = true; moved;) {
+        moved = false;
+        for (int pj = 0; pj < oi; ++pj) {
+          const Req& p = r[order[pj]];
+          if (p.death < q.birth || q.death < p.birth) continue;          // never live together
+          if (off < p.off + p.bytes && p.off < off + q.bytes) { off = p.off + p.bytes; moved = true; }
+        }
+      }
+      q.off = off;
+      if (off + q.bytes > total) total = off + q.bytes;
+    }
+    for (int i = 0; i < n; ++i) *r[i].slot = base + r[i].off;
+    return total;
   }
 };
 
@@ -24,7 +64,8 @@ struct Ws {
   float *xyz4, *feat64, *sq64, *pq1, *cat, *pq3, *emb;
   int32_t *idx1, *idx3, *ties;                         // ties: 2 x (count + one slot per row) for the kNN tie replay
   unsigned char* tie_work; size_t tie_work_each;       // 2 x vcr_knn_tie_work_bytes(N): replay scratch of long rows (else NULL)
-  float *qkv, *att, *e1, *e2, *hid, *d1, *d2, *d3, *qc, *kvc, *embf, *side4, *csplit, *asplit;
+  float *qkv, *att, *attx, *e1, *e2, *hid, *d1, *d2, *d3, *qc, *kvc, *embf, *side4, *csplit, *asplit;   // att: self-attention output(s), attx: cross
+  float* corr_ba;                                      // cycle: the second head's correspondences [B, N, 4]
   long asplit_floats;
   float *st_emb, *st_e1, *st_e2, *st_d1, *st_d2;       // [M, E/64, 2] LayerNorm partial sums
   // partial-overlap mode
@@ -49,63 +90,79 @@ inline int overlap_k2(int N, double o2) { return (int)((double)overlap_k1(N, o2)
 
 Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, double o2, int emb_kind, int xscore_limit_mb,
          int merged) {
-  Bump bp{reinterpret_cast<unsigned char*>(base), 0, 0};
+  Plan pl;
   const size_t M = (size_t)2 * B * N;
+  constexpr int END = 23;                                // (the last launch of a forward; vcrnetIter's state lives across forwards)
   Ws w{};
-  w.xyz4 = bp.take<float>(M * 4);   w.feat64 = bp.take<float>(M * 64); w.sq64 = bp.take<float>(M);
-  w.idx1 = bp.take<int32_t>(M * k); w.idx3 = bp.take<int32_t>(M * k); w.ties = bp.take<int32_t>(2 * (1 + M));   // a slot for every row
+  pl.want(w.xyz4, M * 4, 0, END);   pl.want(w.feat64, M * 64, 0, 3);   pl.want(w.sq64, M, 0, 2);   // (PointNet: conv3 reads feat64 at 3)
+  pl.want(w.idx1, M * k, 1, 3);     pl.want(w.idx3, M * k, 1, 5);      pl.want(w.ties, 2 * (1 + M), 0, 2);   // a slot for every row
   w.tie_work_each = vcr_knn_tie_work_bytes(N);
-  w.tie_work = w.tie_work_each ? bp.take<unsigned char>(2 * w.tie_work_each) : nullptr;
-  w.pq1 = bp.take<float>(M * 256);  w.cat = bp.take<float>(M * 512);   w.pq3 = bp.take<float>(M * 512);
-  w.emb = bp.take<float>(M * E);
+  pl.want(w.tie_work, w.tie_work_each ? 2 * w.tie_work_each : 0, 1, 2);
+  pl.want(w.pq1, M * 256, 0, 4);    pl.want(w.cat, M * 512, 3, 6);     pl.want(w.pq3, M * 512, 4, 5);   // (PointNet: conv4 reads pq1 at 4)
+  pl.want(w.emb, M * E, 0, 21);                          // (0 .. 2: the transposed feat64 rows of the 16-query kNN waves; 6 ..: the embeddings)
   // merged: the encoder's and the decoder's Q|K|V side by side ([M, 6E]) and their attention outputs one after the other
-  w.qkv = bp.take<float>(M * 3 * E * (merged ? 2 : 1)); w.att = bp.take<float>(M * E * (merged ? 2 : 1));
-  w.e1 = bp.take<float>(M * E);     w.e2 = bp.take<float>(M * E);
-  w.hid = bp.take<float>(M * F);
-  w.d1 = bp.take<float>(M * E);     w.d2 = bp.take<float>(M * E);      w.d3 = bp.take<float>(M * E);
-  w.qc = bp.take<float>(M * E);     w.kvc = bp.take<float>(M * 2 * E);
-  w.embf = bp.take<float>(M * E);   w.side4 = bp.take<float>(M * 4);
-  w.csplit = bp.take<float>(VCR_PAIRSCORE_MAX_SPLIT * (M / 2) * 8);   // vcr_softcorr_args.split_work of the soft heads
+  pl.want(w.qkv, M * 3 * E * (merged ? 2 : 1), 7, merged ? 8 : 13);
+  pl.want(w.att, M * E * (merged ? 2 : 1), 8, merged ? 9 : 14);
+  pl.want(w.e1, M * E, 9, 11);      pl.want(w.e2, M * E, 11, 16);
+  pl.want(w.hid, M * F, 10, 20);                         // (FFN hidden rows of both layers; 17: the dense K | V copy of the exact-split cross-attention)
+  pl.want(w.d1, M * E, merged ? 9 : 14, 18);
+  pl.want(w.qc, M * E, merged ? 10 : 15, 17);            pl.want(w.kvc, M * 2 * E, 16, 17);
+  pl.want(w.attx, M * E, 17, 18);
+  pl.want(w.d2, M * E, 18, END);                         // (23: the VcpAtt projections of the second head)
+  pl.want(w.d3, M * E, 20, END);                         // (22: the VcpAtt projections of the head)
+  pl.want(w.embf, M * E, 21, END);  pl.want(w.side4, M * 4, 21, END);
+  pl.want(w.csplit, VCR_PAIRSCORE_MAX_SPLIT * (M / 2) * 8, 22, END);   // vcr_softcorr_args.split_work of the soft heads
+  pl.want(w.corr_ba, (size_t)B * N * 4, 23, END);
   {
     // planes of a key-split attention-output launch (vcr_sdpa_args.split_work; the grouped self-attention has 2 M rows):
     // the library only splits while the planes stay below 64 MB, i.e. at small batches -- no more than that is set aside
     const size_t rows = 2 * M, ml = (size_t)VCR_SDPA_MAX_SPLIT * rows * heads * 2;
     const size_t want = (size_t)VCR_SDPA_MAX_SPLIT * rows * E, cap = ((size_t)64 << 20) / 4;
     w.asplit_floats = (long)((want < cap ? want : cap) + ml);
-    w.asplit = bp.take<float>((size_t)w.asplit_floats);
+    // ... and only for grids of at most half a round: vcr_sdpa_f32 splits the keys when blocks x split <= 2 x CUs (512 on
+    // MI355X); the smallest attention-output launch of the forward is the cross-attention (ceil(N / 128) x 2B x heads blocks)
+    if ((long)((N + 127) / 128) * 2 * B * heads > 256) w.asplit_floats = 0;
+    pl.want(w.asplit, (size_t)w.asplit_floats, 8, 17);
   }
   const size_t sn = M * (E / 64) * 2;
-  w.st_emb = bp.take<float>(sn); w.st_e1 = bp.take<float>(sn); w.st_e2 = bp.take<float>(sn);
-  w.st_d1 = bp.take<float>(sn);  w.st_d2 = bp.take<float>(sn);
+  pl.want(w.st_emb, sn, 6, 12);
+  pl.want(w.st_e1, sn, 9, 10);      pl.want(w.st_e2, sn, 11, 16);
+  pl.want(w.st_d1, sn, merged ? 9 : 14, merged ? 10 : 15);             pl.want(w.st_d2, sn, 18, 19);
+  const size_t K1 = (size_t)overlap_k1(N, o2), K2 = (size_t)overlap_k2(N, o2), B1 = (size_t)B;
   if (partial) {
-    const size_t K1 = (size_t)overlap_k1(N, o2), K2 = (size_t)overlap_k2(N, o2), B1 = (size_t)B;
-    w.rowstat = bp.take<float>(M * heads * 2); w.keymass = bp.take<float>(M); w.keep = bp.take<uint8_t>(M);
-    w.xsplit = bp.take<float>(VCR_SDPA_MAX_SPLIT * M * heads * 2);
+    pl.want(w.rowstat, M * heads * 2, 17, 17); pl.want(w.keymass, M, 17, 17); pl.want(w.keep, M, 17, 17);
+    pl.want(w.xsplit, VCR_SDPA_MAX_SPLIT * M * heads * 2, 17, 17);
     const size_t xs = M * heads * ((N + 31) & ~31);       // keep the cross-attention scores if they fit 4 GB
     const size_t xlimit = xscore_limit_mb > 0 ? (size_t)xscore_limit_mb << 20 : xscore_limit_mb < 0 ? 0 : (size_t)4 << 30;
-    w.xscore = xs * 4 <= xlimit ? bp.take<float>(xs) : nullptr;
-    w.xorder = bp.take<int32_t>(M);
-    w.rstat = bp.take<float>(B1 * N * 2); w.cstat = bp.take<float>(B1 * N * 2);
-    w.rsplit = bp.take<float>(VCR_PAIRSCORE_MAX_SPLIT * B1 * N * 2);
+    pl.want(w.xscore, xs * 4 <= xlimit ? xs : 0, 17, 17);
+    pl.want(w.xorder, M, 17, 17);
+    pl.want(w.rstat, B1 * N * 2, 22, END); pl.want(w.cstat, B1 * N * 2, 22, END);
+    pl.want(w.rsplit, VCR_PAIRSCORE_MAX_SPLIT * B1 * N * 2, 22, END);
     // source-side block first, target-side block right behind it ([2B, ...] like the embeddings): one rank-select and
     // one gather launch then serve both clouds
-    w.rowsum = bp.take<float>(2 * B1 * N); w.colsum = w.rowsum + B1 * N;
-    w.score = bp.take<float>(B1 * N * ((N + 31) & ~31));
-    w.sel_s = bp.take<int32_t>(2 * B1 * K1); w.sel_t = w.sel_s + B1 * K1;
-    w.amax = bp.take<int32_t>(B1 * K1);   w.pick = bp.take<int32_t>(B1 * (K2 ? K2 : 1));
-    w.so_e = bp.take<float>(2 * B1 * K1 * E); w.to_e = w.so_e + B1 * K1 * E;
-    w.so_s = bp.take<float>(2 * B1 * K1 * 4); w.to_s = w.so_s + B1 * K1 * 4;
-    w.peak = bp.take<float>(B1 * K1 * 2);
+    pl.want(w.rowsum, 2 * B1 * N, 22, END);
+    pl.want(w.score, B1 * N * ((N + 31) & ~31), 22, END);
+    pl.want(w.sel_s, 2 * B1 * K1, 22, END);
+    pl.want(w.amax, B1 * K1, 22, END);     pl.want(w.pick, B1 * (K2 ? K2 : 1), 22, END);
+    pl.want(w.so_e, 2 * B1 * K1 * E, 22, END);
+    pl.want(w.so_s, 2 * B1 * K1 * 4, 22, END);
+    pl.want(w.peak, B1 * K1 * 2, 22, END);
   }
   if (emb_kind == 1 && k != 20 && k != 40) {              // (k = 20 / 40 run the chain in one kernel: no per-edge tensor at all)
     const size_t Mk = M * k;
-    w.eh1 = bp.take<float>(Mk * 64); w.eh2 = bp.take<float>(Mk * 64);
-    w.eh3 = bp.take<float>(Mk * 128);                      // (conv4's [M*k, 256] output is only ever max-reduced: never stored)
+    pl.want(w.eh1, Mk * 64, 3, 5); pl.want(w.eh2, Mk * 64, 3, 5);
+    pl.want(w.eh3, Mk * 128, 3, 5);                        // (conv4's [M*k, 256] output is only ever max-reduced: never stored)
   }
-  w.cur_cf = bp.take<float>((size_t)B * 3 * N);
-  w.Ri = bp.take<float>((size_t)B * 9); w.ti = bp.take<float>((size_t)B * 3);
-  w.Rb = bp.take<float>((size_t)B * 9); w.tb = bp.take<float>((size_t)B * 3);
-  w.bytes = bp.off + 256;
+  pl.want(w.cur_cf, (size_t)B * 3 * N, 0, END);
+  pl.want(w.Ri, (size_t)B * 9, 0, END); pl.want(w.ti, (size_t)B * 3, 0, END);
+  pl.want(w.Rb, (size_t)B * 9, 0, END); pl.want(w.tb, (size_t)B * 3, 0, END);
+  w.bytes = pl.solve(reinterpret_cast<unsigned char*>(base)) + 256;
+  if (partial) {
+    w.colsum = w.rowsum + B1 * N;
+    w.sel_t = w.sel_s + B1 * K1;
+    w.to_e = w.so_e + B1 * K1 * E;
+    w.to_s = w.so_s + B1 * K1 * 4;
+  }
   return w;
 }
 
@@ -296,19 +353,19 @@ struct Runner {
       if (!sdpa_split && nkeep <= 16384) {               // (vcr_sdpa_f32 holds the index list in LDS: <= 16 384 kept keys;
         if (rc) return;                                  //  longer lists take the dense copy / the masked form below)
         mark("sdpa:dec.cross");
-        vcr_sdpa_args a{w.qc, E, w.kvc, 2 * E, w.kvc + E, 2 * E, w.att, E, nb, H, N, nkeep, 1.0f / sqrtf(128.f), B};
+        vcr_sdpa_args a{w.qc, E, w.kvc, 2 * E, w.kvc + E, 2 * E, w.attx, E, nb, H, N, nkeep, 1.0f / sqrtf(128.f), B};
         a.key_index = w.xorder; a.nk_src = N;
         ok(vcr_sdpa_f32(&a, stream));
         return;
       }
       if (W->F >= 2 * E) {
         gather("select:gather.kv", w.kvc, 2 * E, N, w.xorder, nb, nkeep, 2 * E, w.hid);
-        sdpa("sdpa:dec.cross", w.qc, E, w.hid, 2 * E, w.hid + E, 2 * E, w.att, E, nb, H, N, nkeep, B);
+        sdpa("sdpa:dec.cross", w.qc, E, w.hid, 2 * E, w.hid + E, 2 * E, w.attx, E, nb, H, N, nkeep, B);
         return;
       }
       keep = w.keep;
     }
-    sdpa("sdpa:dec.cross", w.qc, E, w.kvc, 2 * E, w.kvc + E, 2 * E, w.att, E, nb, H, N, N, B, keep);
+    sdpa("sdpa:dec.cross", w.qc, E, w.kvc, 2 * E, w.kvc + E, 2 * E, w.attx, E, nb, H, N, N, B, keep);
   }
 
   // VcpTopK partial mode: selectCom (vcrnet_model.py:190-262) + getCopair (:264-332) + SVD.  The N x N score
@@ -584,7 +641,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     R.linear("linear:dec.cross.kv", w.e2, E, W->fold_dec_cross_kv.w, SP(dec_cross_kv), W->fold_dec_cross_kv.bias, w.kvc, 2 * E, M2, 2 * E, E, 0,
              nullptr, 0, w.st_e2, W->fold_dec_cross_kv.colsum);
     R.cross_attention(W, io, w, B, N);
-    R.linear("linear:dec.cross.wo", w.att, E, W->dec_cross.wo, SP(dec_cross_wo), W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E,
+    R.linear("linear:dec.cross.wo", w.attx, E, W->dec_cross.wo, SP(dec_cross_wo), W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E,
              nullptr, nullptr, w.st_d2);
     R.linear("linear:dec.ffn1", w.d2, E, W->fold_dec_ffn1.w, SP(dec_ffn1), W->fold_dec_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
              w.st_d2, W->fold_dec_ffn1.colsum);
@@ -633,7 +690,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     }
     if (W->cycle) {
       // cycle consistency (vcrnet_model.py:511-513): a second head + solve with the roles swapped gives (R_ba, t_ba)
-      // instead of the inverse of (R_ab, t_ab); the qkv buffer is free and takes the second correspondence set
+      // instead of the inverse of (R_ab, t_ab)
       if (!io->R_ba || !io->t_ba) return VCR_EINVAL;
       if (W->head_mode == 2) {
         // VcpAtt with the roles swapped, head(tgt_emb, src_emb, tgt, src) (vcrnet_model.py:511-513 -> :444-445):
@@ -649,10 +706,10 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
         }
         head_emb = w.d2;
       }
-      soft_head("softcorr:head.ba", (size_t)M1, 0, w.qkv);
+      soft_head("softcorr:head.ba", (size_t)M1, 0, w.corr_ba);
       if (R.rc == 0) {
         R.mark("rigid_svd:ba");
-        vcr_rigid_svd_args a{w.xyz4 + (size_t)M1 * 4, 4, w.qkv, 4, B, N, io->R_ba, io->t_ba, nullptr, nullptr, nullptr};
+        vcr_rigid_svd_args a{w.xyz4 + (size_t)M1 * 4, 4, w.corr_ba, 4, B, N, io->R_ba, io->t_ba, nullptr, nullptr, nullptr};
         R.ok(vcr_rigid_svd_f32(&a, R.stream));
       }
     }
