@@ -12,6 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vcrnet_amd  # noqa: E402,F401
 from vcrnet_amd import native  # noqa: E402
 
+if os.environ.get("VCR_LIB"):                              # a variant build (profiles/experiments/probe_build.py --out ...)
+    native.LIB_PATH = os.path.abspath(os.environ["VCR_LIB"])
+
 
 def bench(fn, reps=30):
     for _ in range(5):
