@@ -14,8 +14,9 @@ sys.path.insert(0, ROOT)
 import vcrnet_amd  # noqa: E402,F401
 from vcrnet_amd import native  # noqa: E402
 
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] != "-":
     native.LIB_PATH = os.path.abspath(sys.argv[1])
+BX3 = "bf16x3" in sys.argv                                  # vcr_edgeconv_bf16x3_f32 instead (x2 agrees to fp32-GEMM rounding)
 g = torch.Generator().manual_seed(0)
 
 
@@ -34,12 +35,14 @@ def bench(fn, reps=50):
 
 print("library", native.LIB_PATH)
 for B, N, k in ((32, 1024, 20), (48, 768, 20), (32, 2048, 20), (64, 4096, 40), (3, 77, 20), (5, 333, 40)):
+    if BX3 and k not in (20, 40):
+        continue
     M = B * N
     pq = torch.randn(M, 256, generator=g).cuda()
     w2 = (torch.randn(128, 128, generator=g) / 11).cuda()
     b2 = torch.randn(128, generator=g).cuda()
     idx = torch.randint(0, N, (M, k), generator=g, dtype=torch.int32).cuda()
-    x1, x2 = native.edgeconv(pq, idx, N, w2, b2)
+    x1, x2 = native.edgeconv(pq, idx, N, w2, b2, bf16x3=BX3)
     # reference: the definition, in torch (max is exact; the GEMM agrees to fp32 rounding)
     sel = slice(0, min(M, 4096))
     base = (torch.arange(M, device="cuda") // N * N)[sel, None]
@@ -48,7 +51,7 @@ for B, N, k in ((32, 1024, 20), (48, 768, 20), (32, 2048, 20), (64, 4096, 40), (
     r2 = torch.relu((H @ w2.t()).max(1).values + b2)
     ok1 = torch.equal(x1[sel], r1)
     d2 = (x2[sel] - r2).abs().max().item()
-    us = bench(lambda: native.edgeconv(pq, idx, N, w2, b2))
+    us = bench(lambda: native.edgeconv(pq, idx, N, w2, b2, bf16x3=BX3))
     tf = 2.0 * M * k * 128 * 128 / (us * 1e-6) / 1e12
     print(f"B={B:3d} N={N:5d} k={k}: {us:8.1f} us  {tf:6.1f} TF/s   x1 exact {ok1}  max|x2 - ref| {d2:.1e}   checksum "
           f"{x1.double().sum().item():.10e} {x2.double().sum().item():.10e}", flush=True)
