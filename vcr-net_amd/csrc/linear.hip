@@ -197,6 +197,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 //         shapes sum k in different orders: results agree to fp32 rounding, not bitwise.
 // (LN_IN = p.ln_stats_in != NULL and STATS_OUT = p.stats_out != NULL are run-time properties of the launch -- a uniform
 //  branch in the prologue and two in the epilogue -- not template parameters: a quarter of the instantiations)
+constexpr int LINEAR_BLOCKED_ACC = 1;                     // 1: the BK 32 kernels accumulate in blocks of 128 k (below); 0: one chain (A/B builds)
 template <int BK, int MS, int BMV = BM>
 __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int tiles_m, int tiles_n, int blk) {
   const bool LN_IN = p.ln_stats_in != nullptr, STATS_OUT = p.stats_out != nullptr;
@@ -300,6 +301,38 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
             (p.residual && row < p.M && colr < p.N) ? ld4(p.residual + (size_t)row * p.ldr + colr) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
   }
+  // BK 32 (two workgroups per CU: the registers are there): the k loop accumulates in BLOCKS of 128 -- every four slabs the
+  // MFMA accumulators are added into a second set and start again from zero -- like a blocked CPU sgemm and ~2-3x closer to
+  // the exact dot product than ONE k-ascending chain of 512 / 1024 steps (round 5's accuracy ledger: profiles/NOTES.md).
+  // The BK 16 launches (four workgroups per CU, ~100 of 128 VGPRs) keep the single chain.
+  constexpr bool BLOCKED = LINEAR_BLOCKED_ACC && BK == 32;
+  f32x16 tot[BLOCKED ? 2 : 1][BLOCKED ? 2 : 1];
+  f32x4 tot4[BLOCKED ? (MS == 16 ? NTM : 4) : 1][BLOCKED ? 4 : 1];
+  if constexpr (BLOCKED) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) tot[i][j] = f32x16{0};
+#pragma unroll
+    for (int i = 0; i < (MS == 16 ? NTM : 4); ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tot4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto bank = [&]() {                                     // accumulators -> block totals
+    if constexpr (BLOCKED) {
+      if constexpr (MS == 32) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = f32x16{0}; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NTM; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { tot4[i][j] += acc4[i][j]; acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
+    }
+  };
   const int nk = p.K / BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -336,7 +369,22 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
             for (int j = 0; j < 4; ++j) acc4[i][j] = mfma16(fa[i][s], fb[j][s], acc4[i][j]);
       }
     }
+    if (BLOCKED && (kt & 3) == 3 && kt + 1 < nk) bank();
     __syncthreads();                                     // drains the LDS-DMA (vmcnt(0)) and orders the buffers
+  }
+  if constexpr (BLOCKED) {                               // the last block, and the totals back into the epilogue's registers
+    bank();
+    if constexpr (MS == 32) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = tot[i][j];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NTM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc4[i][j] = tot4[i][j];
+    }
   }
   //@probe VCR_PROBE_STAMP(2);
 
