@@ -22,6 +22,17 @@ constexpr int LINEAR_MS_DEFAULT = 0;   // 0 = per launch (see vcr_linear_f32), 1
 // Lines that start with "//@probe " are inert here: profiles/experiments/probe_build.py uncomments them in a scratch copy
 // built against profiles/experiments/probes.h (in-kernel clock stamps; DESIGN.md, measurement protocol).
 
+// OPTIONAL block accumulation (compile-time, off in the product build).  1: every linear kernel adds its MFMA accumulators into
+// a second register set at each multiple of 128 k and starts again from zero -- what a blocked CPU sgemm does (ATen's, i.e. the
+// reference's), 3-5x closer to the exact dot product than ONE k-ascending chain of 512 / 1024 steps; the block boundaries are the
+// same for every k-slab, MFMA shape, tile height and staging variant, so a shape's results still do not depend on the kernel
+// configuration.  2: only the BK 32 kernels (a shape's bits then depend on the configuration).  0: one chain (rounds 1-4).
+// Measured on one box (round 5, profiles/NOTES.md): final embeddings vs the reference's float64 twin, rms relative to the fp32
+// reference's own: 0 -> 1.35x, 2 -> 1.10x, 1 -> 1.0x; pairs/s at BASELINE configs[1]: 3174-3179 / 3144-3150 / 3122-3127 -- the
+// second accumulator set costs the BK 16 kernels their fourth workgroup per CU.  The head's scores, where a discrete decision
+// hangs on the last bits, are block-accumulated unconditionally (pairscore.hip); here speed wins: 0.
+constexpr int LINEAR_BLOCKED_ACC = 0;
+
 template <int BK> struct TileT { float a[BM][BK + 4]; float b[BN][BK + 4]; };
 
 // Register-staged kernel: the ALIGNMENT-FREE fallback of vcr_linear_f32 (any N, any row pitch of y / residual; the
@@ -69,6 +80,11 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 3)) void linear_kernel(vcr_lin
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
 
+  f32x16 tot[2][2];                                      // block accumulation (head of this file)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) tot[i][j] = f32x16{0};
   const int nk = p.K / BK;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -91,12 +107,24 @@ __global__ __launch_bounds__(256, (BK == 32 ? 2 : 3)) void linear_kernel(vcr_lin
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i][s], fb[j][s], acc[i][j]);
     }
+    if (LINEAR_BLOCKED_ACC && (((kt + 1) * BK) % 128 == 0 || kt + 1 == nk)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = f32x16{0}; }
+    }
     if (kt + 1 < nk) {
       Tile& Nx = tile[cur ^ 1];
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) { st4(&Nx.a[r0 + RPP * i][c4], ra[i]); st4(&Nx.b[r0 + RPP * i][c4], rb[i]); }
     }
     __syncthreads();
+  }
+  if (LINEAR_BLOCKED_ACC) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = tot[i][j];
   }
 
   // epilogue.  Fast path: transpose the wave's 64x64 tile through its slice of the (now free) LDS so that
@@ -197,7 +225,6 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 //         shapes sum k in different orders: results agree to fp32 rounding, not bitwise.
 // (LN_IN = p.ln_stats_in != NULL and STATS_OUT = p.stats_out != NULL are run-time properties of the launch -- a uniform
 //  branch in the prologue and two in the epilogue -- not template parameters: a quarter of the instantiations)
-constexpr int LINEAR_BLOCKED_ACC = 1;                     // 1: the BK 32 kernels accumulate in blocks of 128 k (below); 0: one chain (A/B builds)
 template <int BK, int MS, int BMV = BM>
 __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int tiles_m, int tiles_n, int blk) {
   const bool LN_IN = p.ln_stats_in != nullptr, STATS_OUT = p.stats_out != nullptr;
@@ -301,11 +328,8 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
             (p.residual && row < p.M && colr < p.N) ? ld4(p.residual + (size_t)row * p.ldr + colr) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
   }
-  // BK 32 (two workgroups per CU: the registers are there): the k loop accumulates in BLOCKS of 128 -- every four slabs the
-  // MFMA accumulators are added into a second set and start again from zero -- like a blocked CPU sgemm and ~2-3x closer to
-  // the exact dot product than ONE k-ascending chain of 512 / 1024 steps (round 5's accuracy ledger: profiles/NOTES.md).
-  // The BK 16 launches (four workgroups per CU, ~100 of 128 VGPRs) keep the single chain.
-  constexpr bool BLOCKED = LINEAR_BLOCKED_ACC && BK == 32;
+  // optional block accumulation (head of this file)
+  constexpr bool BLOCKED = LINEAR_BLOCKED_ACC == 1 || (LINEAR_BLOCKED_ACC == 2 && BK == 32);
   f32x16 tot[BLOCKED ? 2 : 1][BLOCKED ? 2 : 1];
   f32x4 tot4[BLOCKED ? (MS == 16 ? NTM : 4) : 1][BLOCKED ? 4 : 1];
   if constexpr (BLOCKED) {
@@ -369,7 +393,7 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
             for (int j = 0; j < 4; ++j) acc4[i][j] = mfma16(fa[i][s], fb[j][s], acc4[i][j]);
       }
     }
-    if (BLOCKED && (kt & 3) == 3 && kt + 1 < nk) bank();
+    if (BLOCKED && ((kt + 1) * BK) % 128 == 0 && kt + 1 < nk) bank();
     __syncthreads();                                     // drains the LDS-DMA (vmcnt(0)) and orders the buffers
   }
   if constexpr (BLOCKED) {                               // the last block, and the totals back into the epilogue's registers
@@ -503,14 +527,14 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
 }
 
 template <int BK, int MS, int BMV>
-__global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_kernel(vcr_linear_args p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, (BK == 32 ? 2 : LINEAR_BLOCKED_ACC == 1 ? 3 : 4)) void linear_glds_kernel(vcr_linear_args p, int tiles_m, int tiles_n) {
   linear_glds_body<BK, MS, BMV>(p, tiles_m, tiles_n, (int)blockIdx.x);
 }
 // Two independent linears of the same kernel configuration as ONE launch (the first n0 workgroups work on p0, the rest
 // on p1): the encoder's and the decoder's output projections, or enc.ffn1 beside dec.cross.q -- fewer, fuller rounds of
 // workgroups; each tile is computed exactly as in its own launch.
 template <int BK, int MS, int BMV>
-__global__ __launch_bounds__(256, (BK == 32 ? 2 : 4)) void linear_glds_pair_kernel(vcr_linear_args p0, vcr_linear_args p1, int tm0,
+__global__ __launch_bounds__(256, (BK == 32 ? 2 : LINEAR_BLOCKED_ACC == 1 ? 3 : 4)) void linear_glds_pair_kernel(vcr_linear_args p0, vcr_linear_args p1, int tm0,
                                                                                  int tn0, int tm1, int tn1) {
   const int n0 = tm0 * tn0;
   if ((int)blockIdx.x < n0) linear_glds_body<BK, MS, BMV>(p0, tm0, tn0, (int)blockIdx.x);

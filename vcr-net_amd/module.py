@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -19,6 +20,23 @@ from . import native
 from .weights import strip_module_prefix
 
 LINEAR_MODES = {"fp32": 0, "bf16x3": 1, "bf16x3+sdpa": 2}   # vcr_vcrnet_weights.linear_mode
+
+
+_CALL = threading.local()
+
+
+class _call_scope:
+    """One parameter walk per call (VCRNet._tensors): nested scopes share the outermost one."""
+
+    def __enter__(self):
+        self.owner = getattr(_CALL, "tensors", None) is None
+        if self.owner:
+            _CALL.tensors = {}
+        return self
+
+    def __exit__(self, *exc):
+        if self.owner:
+            _CALL.tensors = None
 
 
 class _Shared:
@@ -244,7 +262,6 @@ class VCRNet(nn.Module):
 
     # -- checkpoints saved through nn.DataParallel carry a "module." prefix --
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        self.__dict__.pop("_tcache", None)                 # (assign=True replaces the parameter objects)
         return super().load_state_dict(strip_module_prefix(state_dict), strict=strict, **kw)
 
     def __getstate__(self):
@@ -252,7 +269,6 @@ class VCRNet(nn.Module):
         # packs for itself on its first call
         d = self.__dict__.copy()
         d.pop("_shared", None)
-        d.pop("_tcache", None)
         d["_packed"], d["_packed_key"], d["_cw"] = None, None, None
         return d
 
@@ -260,11 +276,12 @@ class VCRNet(nn.Module):
     def _tensors(self) -> Dict[str, torch.Tensor]:
         """{state_dict key: tensor} of this module -- or of this nn.DataParallel REPLICA, whose parameters() is empty by
         design (torch/nn/parallel/replicate.py: the broadcast copies are plain attributes, listed in _former_parameters).
-        Walked once per object (a replica is a shallow copy that inherits its master's __dict__: the cache is tagged with
-        the object it was built for); _apply / load_state_dict drop it."""
-        hit = self.__dict__.get("_tcache")
-        if hit is not None and hit[0] == id(self):
-            return hit[1]
+        Walked ONCE PER CALL: forward() / _forward_fused() open a thread-local scope (_call_scope) in which the walk is
+        reused by the device check, the fingerprint and the launch; nothing outlives the call, so a Parameter object
+        replaced between calls is seen."""
+        scope = getattr(_CALL, "tensors", None)
+        if scope is not None and id(self) in scope:
+            return scope[id(self)]
         out: Dict[str, torch.Tensor] = {}
         for prefix, mod in self.named_modules():
             former = mod.__dict__.get("_former_parameters") if getattr(mod, "_is_replica", False) else None
@@ -272,12 +289,9 @@ class VCRNet(nn.Module):
             for k, v in list(src.items()) + list(mod._buffers.items()):
                 if v is not None:
                     out[(prefix + "." if prefix else "") + k] = v
-        self.__dict__["_tcache"] = (id(self), out)
+        if scope is not None:
+            scope[id(self)] = out
         return out
-
-    def _apply(self, fn, *a, **kw):
-        self.__dict__.pop("_tcache", None)                 # .to() / .cuda() / .float() may replace parameter objects
-        return super()._apply(fn, *a, **kw)
 
     def _device(self) -> torch.device:
         return next(iter(self._tensors().values())).device
@@ -294,7 +308,7 @@ class VCRNet(nn.Module):
 
     def _fingerprint(self):
         m, _ = self._master()
-        ps = list(m.parameters()) + list(m.buffers())
+        ps = list(m._tensors().values())                   # the MASTER's parameters + buffers (this call's walk, see _tensors)
         dev = self._device()
         return (dev, ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]), self.emb_nn.k,
                 self.linear_mode, self.linear_mfma, self.linear_bk, self.linear_bm, self.knn_waves, self.xscore_limit_mb,
@@ -526,6 +540,10 @@ class VCRNet(nn.Module):
 
     # -- forward ------------------------------------------------------------------------------------------------
     def forward(self, *input):
+        with _call_scope():
+            return self._forward(*input)
+
+    def _forward(self, *input):
         src, tgt = input[0], input[1]
         self._check_call(src, tgt)
         # HIP launches go to the CURRENT device's stream: make the tensors' device current for the whole call (a module
@@ -554,7 +572,7 @@ class VCRNet(nn.Module):
         ``want_selections`` appends a dict of the selections that were used, one block per iteration.
         ``iter_api``: use vcr_vcrnet_iter_f32 also for iters == 1 (vcrnetIter's contract: (R_ba, t_ba) is ALWAYS the
         inverse of the composed pose, vcrnet_model.py:40-41, even when args.cycle gives forward() a second head)."""
-        with torch.cuda.device(src.device):
+        with _call_scope(), torch.cuda.device(src.device):
             return self._forward_fused_on(src, tgt, trace, want_emb, iters, force, want_selections, iter_api)
 
     def _forward_fused_on(self, src, tgt, trace, want_emb, iters, force, want_selections, iter_api):
