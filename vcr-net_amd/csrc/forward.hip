@@ -25,9 +25,11 @@ struct Plan {
   static constexpr int MAXR = 96;
   Req r[MAXR];
   int n = 0;
+  bool overflow = false;                                 // more requests than MAXR: carve() reports an impossible size
   template <class T> void want(T*& field, size_t count, int birth, int death) {
     field = nullptr;
-    if (count == 0 || n >= MAXR) return;
+    if (count == 0) return;
+    if (n >= MAXR) { overflow = true; return; }
     r[n++] = Req{reinterpret_cast<void**>(&field), (count * sizeof(T) + 255) & ~(size_t)255, birth, death, 0};
   }
   // largest first, each at the lowest offset where it collides with no placed buffer that is live at the same time
@@ -157,6 +159,7 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   pl.want(w.Ri, (size_t)B * 9, 0, END); pl.want(w.ti, (size_t)B * 3, 0, END);
   pl.want(w.Rb, (size_t)B * 9, 0, END); pl.want(w.tb, (size_t)B * 3, 0, END);
   w.bytes = pl.solve(reinterpret_cast<unsigned char*>(base)) + 256;
+  if (pl.overflow) w.bytes = ~(size_t)0;                 // (never with the ~60 buffers above: forward_impl then returns VCR_EWORKSPACE)
   if (partial) {
     w.colsum = w.rowsum + B1 * N;
     w.sel_t = w.sel_s + B1 * K1;
