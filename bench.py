@@ -281,16 +281,20 @@ def setup_rank(a):
         # "RCCL over xGMI only" must be shown, not assumed: rank 0's RCCL writes its INIT / GRAPH debug lines to a file
         # (set before the library initialises) and measure() parses the transports of its channels into multi_gpu.transport
         from vcrnet_amd import shard
-        logdir = os.environ.get("VCR_BENCH_LOGDIR", os.path.join(ROOT, "gpurun_out"))
-        os.makedirs(logdir, exist_ok=True)
-        rccl_log = os.path.join(logdir, "rank0.rccl.log")
-        try:
-            os.remove(rccl_log)
-        except OSError:
-            pass
-        for k_, v_ in shard.rccl_debug_env(rccl_log).items():
-            os.environ.setdefault(k_, v_)
-        rccl_log = os.environ["NCCL_DEBUG_FILE"]
+        import tempfile
+        for logdir in (os.environ.get("VCR_BENCH_LOGDIR", os.path.join(ROOT, "gpurun_out")), tempfile.gettempdir()):
+            try:                                                     # (a read-only checkout must not cost the run: the log moves)
+                os.makedirs(logdir, exist_ok=True)
+                rccl_log = os.path.join(logdir, "rank0.rccl.log")
+                with open(rccl_log, "w"):
+                    pass
+                break
+            except OSError:
+                rccl_log = None
+        if rccl_log:
+            for k_, v_ in shard.rccl_debug_env(rccl_log).items():
+                os.environ.setdefault(k_, v_)
+            rccl_log = os.environ["NCCL_DEBUG_FILE"]
     if world > 1:
         import datetime
         import torch.distributed as dist
