@@ -95,6 +95,32 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 0, 1024) == 0
 
 
+def test_workspace_plan_sizes_of_the_baseline_configs(lib):
+    """The forward's workspace is laid out by buffer liveness (forward.hip: Plan): pure host arithmetic, so the
+    sizes of the BASELINE configs are pinned here -- a buffer registered with too long a life, or the bump allocator coming
+    back, shows up as a size regression without a GPU.  (Round 4's bump layout: 1.5 GB at configs[1], ~12 GB at configs[4].)"""
+    from vcrnet_amd import native
+    lib.vcr_vcrnet_workspace_bytes.restype = ctypes.c_size_t
+
+    def gib(B, N, k=20, merged=True, **kw):
+        w = native.VcrnetWeights()
+        w.E, w.F, w.heads, w.k, w.has_pointer = 512, 1024, 4, k, 1
+        if merged:                                           # (the merged enc + dec first sublayers: never dereferenced here)
+            w.fold_encdec_qkv.w = w.fold_encdec_qkv.colsum = w.fold_encdec_qkv.bias = 0x1000
+        for f, v in kw.items():
+            setattr(w, f, v)
+        return lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), B, N) / 2.0 ** 30
+
+    c1, c1u = gib(16, 1024), gib(16, 1024, merged=False)
+    assert 0.5 < c1 < 0.6 and 0.5 < c1u < 0.6, (c1, c1u)     # GiB: nine [M, 512] buffers live at the peak (+ the small ones)
+    assert 0.9 < gib(24, 768, partial=1, overlap2=0.75) < 1.25
+    assert 1.0 < gib(16, 2048) < 1.35                        # twice configs[1]'s rows
+    assert 4.0 < gib(32, 4096, k=40) < 5.3
+    sizes = [gib(B, 1024) for B in (1, 2, 4, 8, 16)]
+    assert all(a < b for a, b in zip(sizes, sizes[1:]))
+    assert sizes[-1] / sizes[0] < 16.5                       # linear in the batch, no per-call constant of note
+
+
 def test_host_side_dispatch_logic_without_a_gpu(lib):
     """Pure host logic of the round-3 entry points: which kNN calls replay their ties inside the launch, how much
     scratch the replay of long rows needs, the limits that are refused rather than degraded, argument errors of the
