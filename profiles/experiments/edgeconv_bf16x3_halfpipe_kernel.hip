@@ -43,26 +43,26 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_bf16x3_kernel(vcr_e
   if (sl.count == 0) return;
   const int my_groups = sl.count;
 
-  f32x4 hr[4];
-  int nb[4];                                             // neighbour indices, requested ONE TILE AHEAD of the rows they address:
-  auto indices = [&](int grp, int t) {                   // the gather is then one memory round trip per tile, not two
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = 32 * t + rs + 8 * i;                 // edge row inside the group, 0..159
-      const int pl = e / KE, j = e - pl * KE;
-      const int pt = min(grp * G + pl, p.M - 1);
-      nb[i] = p.idx[(size_t)pt * KE + j];
-    }
+  // Gathers run AHEAD of the tile being multiplied, slab by slab (a slab = the 8 rows rs + 8 i of a tile): at the start of tile
+  // t the rows of tile t + 1 are in flight (hp / hq) and the indices of tile t + 2 have been requested (nb).  In k-step 2 i + 1 of
+  // tile t, slab i of tile t + 1 is split and committed to the other LDS buffer IN THE SHADOW of this wave's own MFMAs (beside the
+  // partner wave's MFMAs the same ~40 vector instructions per slab crawl at one per ~20 cycles: profiles/r4f_mfma_valu_coissue.txt),
+  // and its registers are re-used at once for slab i of tile t + 2, whose indices came in a tile ago; the indices of tile t + 3
+  // follow.  Every request is unconditional (past the block's last group it re-reads that group: never committed).
+  f32x4 hp[4], hq[4];                                    // neighbour P rows / centre Q rows of the tile after the current one
+  int nb[4];
+  auto idx_slab = [&](int grp, int t, int i) {
+    const int e = 32 * t + rs + 8 * i;                   // edge row inside the group, 0..159
+    const int pl = e / KE, j = e - pl * KE;
+    const int pt = min(grp * G + pl, p.M - 1);
+    nb[i] = p.idx[(size_t)pt * KE + j];
   };
-  auto gather = [&](int grp, int t) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = 32 * t + rs + 8 * i;
-      const int pt = min(grp * G + e / KE, p.M - 1);
-      const int base = (pt / p.n_per_cloud) * p.n_per_cloud;
-      const f32x4 v = ld4(p.pq + (size_t)(base + nb[i]) * p.ldpq + ch) + ld4(p.pq + (size_t)pt * p.ldpq + 128 + ch);
-      hr[i] = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-    }
+  auto row_slab = [&](int grp, int t, int i) {
+    const int e = 32 * t + rs + 8 * i;
+    const int pt = min(grp * G + e / KE, p.M - 1);
+    const int base = (pt / p.n_per_cloud) * p.n_per_cloud;
+    hp[i] = ld4(p.pq + (size_t)(base + nb[i]) * p.ldpq + ch);
+    hq[i] = ld4(p.pq + (size_t)pt * p.ldpq + 128 + ch);
   };
   float cm[G][4];                                        // x1: running max of this thread's rows, per point (H >= 0)
 #pragma unroll
@@ -70,30 +70,32 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_bf16x3_kernel(vcr_e
 #pragma unroll
     for (int c = 0; c < 4; ++c) cm[q][c] = 0.f;
   // registers -> three bf16 planes in LDS, and the x1 maxima: the 8 rows rs + 8i (rs = 0..7) of slab i of tile t belong
-  // to at most two points, split at a compile-time row (t, i are constants after unrolling); a point whose last row lies
-  // in this tile is reduced over the 8 row residues (lanes with the same cg: three exchanges) and written
-  auto commit = [&](int buf, int t, int grp) {
+  // to at most two points, split at a compile-time row (t, i are constants after unrolling)
+  auto commit_slab = [&](int buf, int t, int i) {
+    const f32x4 v = hp[i] + hq[i];
+    const f32x4 h = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3x2(h[0], h[1], h0, m0, l0);
+    split3x2(h[2], h[3], h1, m1, l1);
+    *reinterpret_cast<u32x2*>(&Hs[buf][0][rs + 8 * i][ch]) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(&Hs[buf][1][rs + 8 * i][ch]) = u32x2{m0, m1};
+    *reinterpret_cast<u32x2*>(&Hs[buf][2][rs + 8 * i][ch]) = u32x2{l0, l1};
+    const int e0 = 32 * t + 8 * i, p0 = e0 / KE, p1 = (e0 + 7) / KE;
+    if (p0 == p1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      unsigned h0, m0, l0, h1, m1, l1;
-      split3x2(hr[i][0], hr[i][1], h0, m0, l0);
-      split3x2(hr[i][2], hr[i][3], h1, m1, l1);
-      *reinterpret_cast<u32x2*>(&Hs[buf][0][rs + 8 * i][ch]) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(&Hs[buf][1][rs + 8 * i][ch]) = u32x2{m0, m1};
-      *reinterpret_cast<u32x2*>(&Hs[buf][2][rs + 8 * i][ch]) = u32x2{l0, l1};
-      const int e0 = 32 * t + 8 * i, p0 = e0 / KE, p1 = (e0 + 7) / KE;
-      if (p0 == p1) {
+      for (int c = 0; c < 4; ++c) cm[p0][c] = fmaxf(cm[p0][c], h[c]);
+    } else {
+      const bool second = rs >= p1 * KE - e0;            // this lane's row belongs to point p1
 #pragma unroll
-        for (int c = 0; c < 4; ++c) cm[p0][c] = fmaxf(cm[p0][c], hr[i][c]);
-      } else {
-        const bool second = rs >= p1 * KE - e0;          // this lane's row belongs to point p1
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          cm[p0][c] = fmaxf(cm[p0][c], second ? 0.f : hr[i][c]);
-          cm[p1][c] = fmaxf(cm[p1][c], second ? hr[i][c] : 0.f);
-        }
+      for (int c = 0; c < 4; ++c) {
+        cm[p0][c] = fmaxf(cm[p0][c], second ? 0.f : h[c]);
+        cm[p1][c] = fmaxf(cm[p1][c], second ? h[c] : 0.f);
       }
     }
+  };
+  // a point whose last row lies in tile t: its maxima reduced over the 8 row residues (lanes with the same cg: three
+  // exchanges) and written
+  auto finish_points = [&](int t, int grp) {
 #pragma unroll
     for (int q = 0; q < G; ++q) {
       if (KE * q + KE - 1 < 32 * t || KE * q + KE - 1 > 32 * t + 31) continue;     // (compile-time)
@@ -112,33 +114,48 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_bf16x3_kernel(vcr_e
     }
   };
 
-  indices(sl.first, 0);
-  gather(sl.first, 0);
-  indices(sl.first, 1);
-  commit(0, 0, sl.first);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) idx_slab(sl.first, 0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) row_slab(sl.first, 0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) idx_slab(sl.first, 1, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) commit_slab(0, 0, i);
+  finish_points(0, sl.first);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) row_slab(sl.first, 1, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) idx_slab(sl.first, 2, i);
   __syncthreads();
   int cur = 0;
   for (int gi = 0; gi < my_groups; ++gi) {
     const int grp = sl.first + gi * sl.stride;
     const bool more = gi + 1 < my_groups;
+    const int grp_after = more ? grp + sl.stride : grp;  // (no group after the last: its rows again, never committed)
     float pm[G];                                         // x2: per-point maxima of the MFMA rows
 #pragma unroll
     for (int q = 0; q < G; ++q) pm[q] = VCR_NEG_INF;
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       const bool has_next = t < 4 || more;
-      if (has_next) {
-        gather(t < 4 ? grp : grp + sl.stride, t < 4 ? t + 1 : 0);      // (with the indices that came in during the last tile)
-        // the indices of the tile after that one (past the block's last group: the last group's again, never used)
-        indices(t < 3 || !more ? grp : grp + sl.stride, t < 3 ? t + 2 : t - 3);
-      }
+      const int tn = (t + 1) % 5, t2 = (t + 2) % 5, t3 = (t + 3) % 5;
+      const int grp2 = t + 2 < 5 ? grp : grp_after, grp3 = t + 3 < 5 ? grp : grp_after;
       f32x16 acc = {0};
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         bf16x8 fa[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) fa[pl] = *reinterpret_cast<const bf16x8*>(&Hs[cur][pl][l31][16 * s + 8 * half]);
         acc = mfma6(fa, wh[s], wm[s], wl[s], acc);
+        if (s & 1) {
+          const int i = s >> 1;
+          if (has_next) commit_slab(cur ^ 1, tn, i);
+          row_slab(grp2, t2, i);
+          idx_slab(grp3, t3, i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {                     // fold the tile into the per-point maxima (static map)
@@ -160,8 +177,8 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_bf16x3_kernel(vcr_e
           if (half == 0 && pt < p.M) p.x2[(size_t)pt * p.ldx2 + 32 * w + l31] = fmaxf(v + bias2, 0.f);
         }
       }
-      if (has_next) commit(cur ^ 1, t < 4 ? t + 1 : 0, t < 4 ? grp : grp + sl.stride);
-      __syncthreads();
+      if (has_next) finish_points(tn, t < 4 ? grp : grp + sl.stride);
+      lds_barrier();                                     // (LDS only: the rows / indices requested ahead stay in flight across it)
       cur ^= 1;
     }
   }
