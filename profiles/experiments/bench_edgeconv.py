@@ -34,7 +34,10 @@ def bench(fn, reps=50):
 
 
 print("library", native.LIB_PATH)
-for B, N, k in ((32, 1024, 20), (48, 768, 20), (32, 2048, 20), (64, 4096, 40), (3, 77, 20), (5, 333, 40)):
+SHAPES = ((32, 1024, 20), (48, 768, 20), (32, 2048, 20), (64, 4096, 40), (3, 77, 20), (5, 333, 40))
+if "sizes" in sys.argv:                                     # k and launch size separated: both k at both sizes
+    SHAPES = ((32, 1024, 20), (32, 1024, 40), (64, 4096, 20), (64, 4096, 40), (128, 1024, 20), (8, 4096, 20))
+for B, N, k in SHAPES:
     if BX3 and k not in (20, 40):
         continue
     M = B * N
