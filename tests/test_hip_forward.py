@@ -353,6 +353,46 @@ def test_c_abi_error_codes():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("kw,mode", [({}, "fp32"), ({}, "bf16x3+sdpa"), (dict(partial=True), "fp32"),
+                                     (dict(emb_nn="dgcnn"), "fp32"), (dict(vcp_nn="dist", cycle=True), "fp32"),
+                                     (dict(emb_nn="pointnet"), "fp32"), (dict(vcp_nn="att"), "bf16x3"),
+                                     (dict(pointer="identity"), "fp32")])
+def test_workspace_contents_do_not_matter(kw, mode):
+    """The workspace is laid out by buffer liveness (forward.hip: Plan): a buffer's bytes are whatever an earlier, dead buffer of
+    the same call -- or the previous call -- left there.  Nothing may be read before it is written: the pooled workspace is
+    filled with zeros / NaN bit patterns / a ramp between calls and every output must come out bit-identical."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    net, _ = build_net(**kw)
+    net.linear_mode = mode
+    partial = bool(kw.get("partial"))
+    src, tgt, _, _, _ = synth.make_batch(77, 3, 384, partial=partial)
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+
+    def run(fill):
+        pooled = [b["ws"] for idle in net._shared.pool.values() for b in idle]
+        assert pooled, "the first call leaves its workspace in the pool"
+        for ws in pooled:
+            if fill == "ramp":
+                ws.copy_((torch.arange(ws.numel(), device=ws.device) * 37 % 251).to(torch.uint8))
+            else:
+                ws.fill_(fill)
+        with torch.no_grad():
+            out = net._forward_fused(s, t, want_emb=True)
+        torch.cuda.synchronize()
+        return [o.clone() for o in out if torch.is_tensor(o)]
+
+    with torch.no_grad():
+        net._forward_fused(s, t, want_emb=True)
+    torch.cuda.synchronize()
+    ref = run(0)
+    for fill in (0xFF, 0x7F, "ramp"):                      # 0xFFFFFFFF / 0x7F7F7F7F: NaN and 3.4e38 as floats, huge indices as ints
+        got = run(fill)
+        assert len(got) == len(ref)
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert torch.equal(a, b), (fill, i, (a.float() - b.float()).abs().max().item())
+
+
 def test_runs_on_the_callers_stream():
     """Every launch goes to the stream the caller is on (torch.cuda.current_stream()): the same results on a side
     stream, and nothing leaks onto the default stream (the output is only valid after the SIDE stream is waited on)."""
