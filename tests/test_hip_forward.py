@@ -356,13 +356,15 @@ def test_c_abi_error_codes():
 @pytest.mark.parametrize("kw,mode", [({}, "fp32"), ({}, "bf16x3+sdpa"), (dict(partial=True), "fp32"),
                                      (dict(emb_nn="dgcnn"), "fp32"), (dict(vcp_nn="dist", cycle=True), "fp32"),
                                      (dict(emb_nn="pointnet"), "fp32"), (dict(vcp_nn="att"), "bf16x3"),
-                                     (dict(pointer="identity"), "fp32")])
+                                     (dict(pointer="identity"), "fp32"), (dict(partial=True, _iters=3), "fp32")])
 def test_workspace_contents_do_not_matter(kw, mode):
     """The workspace is laid out by buffer liveness (forward.hip: Plan): a buffer's bytes are whatever an earlier, dead buffer of
     the same call -- or the previous call -- left there.  Nothing may be read before it is written: the pooled workspace is
     filled with zeros / NaN bit patterns / a ramp between calls and every output must come out bit-identical."""
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import synth
+    kw = dict(kw)
+    iters = kw.pop("_iters", 1)                            # > 1: the device-side vcrnetIter loop (vcr_vcrnet_iter_f32)
     net, _ = build_net(**kw)
     net.linear_mode = mode
     partial = bool(kw.get("partial"))
@@ -378,12 +380,12 @@ def test_workspace_contents_do_not_matter(kw, mode):
             else:
                 ws.fill_(fill)
         with torch.no_grad():
-            out = net._forward_fused(s, t, want_emb=True)
+            out = net._forward_fused(s, t, want_emb=iters == 1, iters=iters)
         torch.cuda.synchronize()
         return [o.clone() for o in out if torch.is_tensor(o)]
 
     with torch.no_grad():
-        net._forward_fused(s, t, want_emb=True)
+        net._forward_fused(s, t, want_emb=iters == 1, iters=iters)
     torch.cuda.synchronize()
     ref = run(0)
     for fill in (0xFF, 0x7F, "ramp"):                      # 0xFFFFFFFF / 0x7F7F7F7F: NaN and 3.4e38 as floats, huge indices as ints
