@@ -102,7 +102,30 @@ typedef struct {
    * Same operands, same k order: the result does not depend on whether xt is given.  x is still required (tie replay,
    * the 32-query kernel). */
   const float* xt;
+  /* Optional: the ORDERED search (all seven set, by vcr_knn_order_f32; vcr_knn_pair_f32 with 16-query waves only -- any other
+   * launch ignores them).  The points of a cloud are ranked along a Morton curve of their coordinates: perm[b][r] = the point at
+   * rank r; xp / sqp = the rows of xt (C == 64; of x for C == 4) and of sq in rank order (pitch ldx); per tile of 16 consecutive
+   * ranks: cen = the centroid row (same layout; C == 4: (x, y, z, |c|^2)), cen_sq its squared norm (C == 64), cen_rad an upper
+   * bound of the distance of the tile's rows to it, cen_sqmax their largest squared norm.  A wave of 16 queries scans the 9 tiles
+   * around its own rank, then only the tiles whose ball (centroid, radius) can still hold a neighbour of one of its queries --
+   * decided with the fp32 rounding of the scores priced in, so the neighbour SETS are those of the plain search (rank-0 and
+   * boundary-tie rules included: indices are translated back before they are applied).  Ranked clouds up to 4096 points. */
+  const int32_t* perm; const float* xp; const float* sqp;
+  const float* cen; const float* cen_sq; const float* cen_rad; const float* cen_sqmax;
 } vcr_knn_args;
+
+/* Ranks the points of every cloud along a Morton curve of their coordinates and writes what the ordered search reads
+ * (vcr_knn_args.perm ...): perm [B,N]; xyz4_p [B,N,4]; cen4 [B,T,4], cen4_rad / cen4_sqmax [B,T] with T = (N + 15) / 16; and,
+ * when feat_t is given ([B,N,64] rows in vcr_knn_args.xt's layout, pitch ldf, with sq [B,N]): feat_p [B,N,64] (pitch 64),
+ * sq_p [B,N], cen64 [B,T,64], cen64_sq / cen64_rad / cen64_sqmax [B,T].  N <= 4096 (VCR_EUNSUPPORTED beyond). */
+typedef struct {
+  const float* xyz4;                  /* [B,N,4] rows (x, y, z, |p|^2) */
+  const float* feat_t; int ldf; const float* sq;
+  int B, N;
+  int32_t* perm; float* xyz4_p; float* cen4; float* cen4_rad; float* cen4_sqmax;
+  float* feat_p; float* sq_p; float* cen64; float* cen64_sq; float* cen64_rad; float* cen64_sqmax;
+} vcr_knn_order_args;
+int vcr_knn_order_f32(const vcr_knn_order_args*, vcr_stream_t);
 int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
 size_t vcr_knn_tie_work_bytes(int N);
 /* 1 when vcr_knn_f32 / vcr_knn_pair_f32 with these args replays the tied rows INSIDE the kNN launch (workgroups of 4 x 16

@@ -33,7 +33,7 @@ def test_header_symbols_exported(lib):
 
 def test_version_and_strerror(lib):
     from vcrnet_amd import native
-    assert lib.vcr_abi_version() == native.ABI_VERSION == 25
+    assert lib.vcr_abi_version() == native.ABI_VERSION == 26
     assert lib.vcr_strerror(0) == b"ok"
     assert b"invalid" in lib.vcr_strerror(-1)
     assert b"workspace" in lib.vcr_strerror(-2)
@@ -46,6 +46,7 @@ def test_ctypes_structs_match_the_c_layout(tmp_path):
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import native
     pairs = {"vcr_pointwise_args": native.PointwiseArgs, "vcr_knn_args": native.KnnArgs,
+             "vcr_knn_order_args": native.KnnOrderArgs,
              "vcr_linear_args": native.LinearArgs, "vcr_layernorm_args": native.LayerNormArgs,
              "vcr_rowside_args": native.RowsideArgs, "vcr_edgeconv_args": native.EdgeconvArgs,
              "vcr_gathermax_args": native.GathermaxArgs, "vcr_edgerows_args": native.EdgerowsArgs,

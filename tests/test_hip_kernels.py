@@ -730,6 +730,40 @@ def test_knn_pair_equals_the_two_launches(nat, B, N, k):
     assert torch.equal(a, nat.knn(feat, sq, k)) and torch.equal(b, nat.knn(x4, None, k))
 
 
+@pytest.mark.parametrize("B,N,k,kind", [(8, 2048, 20, "smooth"), (4, 4096, 40, "smooth"), (8, 2048, 20, "random"), (16, 1024, 20, "smooth"),
+                                        (8, 2040, 20, "dup"), (8, 2048, 20, "lattice"), (6, 3000, 40, "lattice"), (4, 4096, 20, "equal")])
+def test_knn_ordered_search_keeps_the_sets(nat, B, N, k, kind):
+    """The ordered search (vcr_knn_order_f32 + vcr_knn_args.perm: Morton ranking, tiles skipped by their balls) against the plain
+    pair launch: the same neighbour SET on every row -- smooth features (a function of the coordinates, as the stem's are),
+    features unrelated to the coordinates (nothing can be skipped), every point twice (the rank-0 rule picks by point index),
+    lattices (thousands of exact ties: the replay) and a cloud of one repeated point."""
+    rs = np.random.RandomState(B * N + k)
+    if kind == "lattice":
+        xyz = rs.randint(0, 9, (B, N, 3)).astype(np.float32) / 8
+    elif kind == "equal":
+        xyz = np.zeros((B, N, 3), np.float32) + 0.25
+    else:
+        xyz = rs.rand(B, N, 3).astype(np.float32) - 0.5
+    if kind == "dup":
+        xyz[:, N // 2:] = xyz[:, : N - N // 2]
+    w1, w2 = rs.randn(3, 64).astype(np.float32) * 0.8, rs.randn(64, 64).astype(np.float32) * 0.2
+    feat = np.maximum(np.maximum(xyz @ w1 + 0.1, 0) @ w2 + 0.05, 0)
+    if kind == "random":
+        feat = rs.randn(B, N, 64).astype(np.float32)
+    feat = dev(torch.from_numpy(np.ascontiguousarray(feat)))
+    x4 = dev(torch.from_numpy(np.concatenate((xyz, (xyz ** 2).sum(-1, keepdims=True)), -1).astype(np.float32)))
+    sq = (feat ** 2).sum(-1).contiguous()
+    ft = feat.view(B, N, 4, 4, 4).transpose(3, 4).reshape(B, N, 64).contiguous()
+    order = nat.knn_order(x4, ft, sq)
+    perm = order["perm"].long().cpu()
+    assert all(torch.equal(torch.sort(perm[b]).values, torch.arange(N)) for b in range(B))
+    assert torch.equal(torch.gather(x4, 1, order["perm"].long()[..., None].expand(-1, -1, 4)), order["xyz4_p"])
+    a0, b0 = nat.knn_pair(feat, sq, x4, k, xt=ft)
+    a1, b1 = nat.knn_pair(feat, sq, x4, k, xt=ft, order=order)
+    for plain, ordered in ((a0, a1), (b0, b1)):
+        assert torch.equal(torch.sort(plain, -1).values, torch.sort(ordered, -1).values)
+
+
 def test_knn_deferred_tie_replay_for_two_launches(nat):
     """vcr_knn_args.tie_defer + vcr_knn_ties_f32: the Cartesian and the feature-space launch list their tied rows, one
     replay launch serves both -- the same indices as two self-contained calls, on inputs built to tie massively."""

@@ -170,6 +170,7 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
 }
 
 // enc.qkv + dec.qkv as one GEMM, the two self-attentions as one grouped launch: needs the stacked folded weight (fp32 mode)
+constexpr int KNN_ORDERED_MIN_N = 2048;                 // clouds from this size on take the ordered kNN search (see the LPDNet stage)
 inline int merged_encdec(const vcr_vcrnet_weights* W) {
   return W->has_pointer == 1 && (W->linear_mode == 0 || W->split.encdec_qkv) && W->fold_encdec_qkv.w && W->fold_encdec_qkv.colsum &&
          W->fold_encdec_qkv.bias;
@@ -554,6 +555,30 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     a64.tie_work = w.tie_work; a3.tie_work = w.tie_work ? w.tie_work + w.tie_work_each : nullptr;
     a64.tie_work_bytes = a3.tie_work_bytes = w.tie_work_each;
     a64.xt = W->E >= 64 ? w.emb : nullptr;
+    // The ORDERED search (vcr_knn_args.perm) for the larger clouds: ranking the points along a Morton curve lets a 16-query
+    // wave skip the tiles whose balls cannot hold a neighbour -- measured (profiles/r5o_knn_ordered.txt) 416 -> 295 + 45 us
+    // (ranking) at 32 x 2048, 2970 -> 1850 + 93 at 64 x 4096, k = 40; at 1024 points the plain scan is faster (120 vs 143 + 30).
+    // Its arrays live in the unused part of w.emb (free until conv3; feat64t is its first M2 x 64 floats).
+    if (R.rc == 0 && W->E >= 256 && N >= KNN_ORDERED_MIN_N && N <= 4096 && (k == 20 || k == 40) && W->knn_waves == 0 &&
+        (long)2 * B * ((N + 15) / 16) >= 1024) {         // (fewer query groups: vcr_knn_pair_f32 takes its small-grid kernels)
+      const size_t m = (size_t)M2, mt = (size_t)2 * B * ((N + 15) / 16);
+      float* base = w.emb + m * 64;
+      float* feat_p = base;                 base += m * 64;
+      float* xyz4_p = base;                 base += m * 4;
+      float* cen64 = base;                  base += mt * 64;
+      float* cen4 = base;                   base += mt * 4;
+      float* sq_p = base;                   base += m;
+      int32_t* perm = reinterpret_cast<int32_t*>(base);   base += m;
+      float* c64_sq = base;  base += mt;  float* c64_rad = base;  base += mt;  float* c64_max = base;  base += mt;
+      float* c4_rad = base;  base += mt;  float* c4_max = base;
+      R.mark("knn:rank");
+      vcr_knn_order_args o{w.xyz4, w.emb, 64, w.sq64, 2 * B, N, perm, xyz4_p, cen4, c4_rad, c4_max, feat_p, sq_p, cen64, c64_sq,
+                           c64_rad, c64_max};
+      R.ok(vcr_knn_order_f32(&o, R.stream));
+      a64.perm = a3.perm = perm;
+      a64.xp = feat_p; a64.sqp = sq_p; a64.cen = cen64; a64.cen_sq = c64_sq; a64.cen_rad = c64_rad; a64.cen_sqmax = c64_max;
+      a3.xp = xyz4_p; a3.cen = cen4; a3.cen_rad = c4_rad; a3.cen_sqmax = c4_max;
+    }
     R.knn_pair("knn:feat64+xyz", a64, a3);
   }
   if (!pq_fused) R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
@@ -850,7 +875,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 25; }
+extern "C" int vcr_abi_version(void) { return 26; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

@@ -54,6 +54,8 @@ struct GeomCol16;
 // 16-query kernels (k <= 20): 72 -- the most that keeps four workgroups per CU (4 x (76 rows x 16 queries x 8 B x 4 waves
 // + the tie list) = 157 KB of the 160): a compaction then frees 35 slots instead of 27.  Measured against 64: the pair
 // launch 151.4 -> 147.7 us at BASELINE configs[1], 147.5 -> 136.7 at N = 768 (configs[2]), 439 -> 432 at N = 2048.
+constexpr int KNN_ORD_NEAR = 4;                          // tiles on either side of the own one scanned first
+constexpr int KNN_ORD_MODE = 0;                          // timing ablations of the ordered search: 1 = its loop over ALL tiles, 2 = the plain loop over the ranked rows
 constexpr int KNN_PEND_K40 = 96;                         // k = 21 .. 40 (lists of 42)
 constexpr int KNN_PEND_COL16 = 72;                       // (the sweeps: profiles/experiments/probe_build.py --set NAME=VALUE)
 template <class G, int KS> constexpr int pend_of() {
@@ -351,9 +353,11 @@ template <class G> __device__ __forceinline__ float col_min(float x, int sg) {  
 
 // Final stage shared by both kernels: the log holds every candidate above the (k+2)-th best value; fold the lists /
 // logs of the S waves of a query group into wave part 0, reduce the log to the k+1 best, drop rank 0, write the set.
+// perm (ordered search): q and the logged indices are RANKS of the cloud's Morton order; the kept entries are translated to
+// point indices before the rank-0 rule and the output, which goes to the row of the point at rank q
 template <class G, int KS, int S>
 __device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args& a, int b, int q, int wave, int part,
-                                       unsigned char* smem, int* blk_ties = nullptr) {
+                                       unsigned char* smem, int* blk_ties = nullptr, const int32_t* perm = nullptr) {
   constexpr int T = Selector<G, KS>::T;
   constexpr int PEND = Selector<G, KS>::PEND;
   constexpr int AREA = 2 * (PEND + 1) * G::COLS;         // floats per wave
@@ -399,11 +403,24 @@ __device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args&
   // rank 0 = the largest value (the point itself; the first logged on an exact tie, e.g. duplicate points): dropped
   int imax = 0;
   float vmax = VCR_NEG_INF;
+  if (perm) {
+    // (the plain scan logs in index order, so "the first logged" is the LOWEST point index among the largest values)
+    for (int i = sel.sg; i < sel.cnt; i += G::LPQ) sel.li[i * G::COLS + sel.col] = perm[sel.li[i * G::COLS + sel.col]];
+    int jmax = 0x7fffffff;
+    for (int i = 0; __any(i < sel.cnt); ++i) {
+      const int ic = min(i, PEND - 1);
+      const float d = i < sel.cnt ? sel.lv[ic * G::COLS + sel.col] : VCR_NEG_INF;
+      const int j = sel.li[ic * G::COLS + sel.col];
+      if (d > vmax || (d == vmax && i < sel.cnt && j < jmax)) { vmax = d; imax = i; jmax = j; }
+    }
+  } else {
   for (int i = 0; __any(i < sel.cnt); ++i) {
     const float d = i < sel.cnt ? sel.lv[min(i, PEND - 1) * G::COLS + sel.col] : VCR_NEG_INF;
     if (d > vmax) { vmax = d; imax = i; }
   }
+  }
   if (q < a.N) {
+    if (perm) q = perm[q];
     int32_t* o = a.idx + ((size_t)b * a.N + q) * a.k;
     for (int i = sel.sg; i < sel.cnt && i <= a.k; i += G::LPQ)
       if (i != imax) o[i - (i > imax ? 1 : 0)] = sel.li[i * G::COLS + sel.col];
@@ -583,10 +600,11 @@ __global__ __launch_bounds__(64 * W, 2) void knn64_kernel(vcr_knn_args a) {
 // k-ascending chain is ((x x' + y y') + z z') - |c|^2 / 2, exactly the fma chain + norm step of the C = 64 case and of the
 // VALU kernel knn3_body (whose (2 dot - |c|^2) - |q|^2 is the same rounding: doubling is exact).  The Cartesian
 // search's distances then cost the idle matrix pipe one instruction per 16 x 16 tile instead of 16 VALU FMAs per wave.
-template <int KS, int W, int C = 64, bool XT = false>
+template <int KS, int W, int C = 64, bool XT = false, bool ORD = false>
 __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b) {
   using G = GeomCol16;
   static_assert(C == 64 || C == 4, "feature rows of 64 floats or xyz4 rows");
+  static_assert(!ORD || C == 4 || XT, "the ranked rows are stored in xt's layout");
   constexpr int NST = C == 64 ? 16 : 1;                  // MFMA steps of the dot product
   constexpr int PEND = pend_of<G, KS>();
   constexpr int CT = 16;                                 // candidates per tile
@@ -599,12 +617,14 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   constexpr int LROWS = PEND + 4;
   float* lv = reinterpret_cast<float*>(smem) + wave * (2 * LROWS * 16);
   Selector<G, KS> sel;
-  const float* xb = a.x + (size_t)b * a.N * a.ldx;
+  // (ORD: the rows in rank order -- vcr_knn_args.xp / sqp; everything below then counts ranks, finish() translates)
+  const bool ord = ORD && a.perm != nullptr;             // (an ORD launch may still run ONE of its two searches the plain way)
+  const float* xb = (ord ? a.xp : a.x) + (size_t)b * a.N * a.ldx;
   // (C == 64) rows whose 16-channel groups are stored transposed (vcr_knn_args.xt): lane row q4's chunks 4 g + q4 are its
   // operands of steps 4 g .. 4 g + 3 as they lie -- same addresses, no shuffles
   constexpr bool pre = C == 64 && XT;                  // (a compile-time variant: the launcher picks it when a.xt is set)
-  const float* xl = pre ? a.xt + (size_t)b * a.N * a.ldx : xb;
-  const float* sqb = C == 64 ? a.sq + (size_t)b * a.N : nullptr;
+  const float* xl = ord ? xb : pre ? a.xt + (size_t)b * a.N * a.ldx : xb;
+  const float* sqb = C == 64 ? (ord ? a.sqp : a.sq) + (size_t)b * a.N : nullptr;
   const int q = min(q0 + col, a.N - 1);
   // Operand fetch (C == 64).  MFMA step s needs x[row][4 s + q4] in lane row q4: every fourth float of the row.  Fetched as such
   // (16 x global_load_dword) the texture path sees 4-byte requests -- 8x the requests of knn64_body per byte, and the
@@ -752,12 +772,152 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
     //@probe VCR_PROBE_ACC(3);                                              // wait for the prefetched rows + transpose
   }
   };
+  // ---- ORD: the ordered search.  Tiles = 16 consecutive RANKS of the cloud's Morton order (compact in coordinate AND feature
+  // space).  (1) the 2 NEAR + 1 tiles around the wave's own rank are scanned: the list then holds a valid lower bound thr of every
+  // query's final (k + 2)-th value.  (2) the tiles' centroids go through the same MFMA chain as candidates: s = -|q - c|^2; with
+  // the tile's radius rho, no row of the tile can score above -(max(0, |q - c| - rho))^2 -- evaluated with the fp32 rounding of
+  // the scores priced in (m: 3e-5 of the norms involved, ~4x the worst case of a 64-term fp32 dot product), so a tile is dropped
+  // only when every one of its rows would fail the filter `score > thr` for every query of the wave.  (3) the remaining tiles
+  // are scanned like any others.  Visiting order and omissions of entries below the final threshold do not change the kept set.
+  [[maybe_unused]] auto ordered_scan_impl = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    constexpr int NEAR = KNN_ORD_NEAR;
+    const int T = ntiles, g = q0 / CT;
+    int lo = max(0, g - NEAR), hi = min(T, g + NEAR + 1);
+    if (hi - lo < 2 * NEAR + 1) { if (lo == 0) hi = min(T, 2 * NEAR + 1); else lo = max(0, T - (2 * NEAR + 1)); }
+    // the two-tile step of scan_all over an arbitrary tile sequence (next() = the next tile, -1 at the end; wave-uniform)
+    auto scan_seq = [&](auto&& next) {
+      int tA = next(), tB = tA >= 0 ? next() : -1;
+      if (tA < 0) return;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = min((u ? max(tB, 0) : tA) * CT + col, a.N - 1);
+        load_raw(c, nraw[u]);
+        if constexpr (C == 64) csq[u] = sqb[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        transpose(nraw[u], cf[u]);
+        asm volatile("" : "+v"(csq[u]));
+      }
+      while (tA >= 0) {
+        const int nA = next(), nB = nA >= 0 ? next() : -1;
+        if (nA >= 0) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int c = min((u ? max(nB, 0) : nA) * CT + col, a.N - 1);
+            load_raw(c, nraw[u]);
+            if constexpr (C == 64) nsq[u] = sqb[c];
+          }
+        }
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+          acc[0] = mfma16(cf[0][st], qf[st], acc[0]);
+          acc[1] = mfma16(cf[1][st], qf[st], acc[1]);
+        }
+        if constexpr (C == 64) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) acc[u] = mfma16(q4 == 0 ? -0.5f * csq[u] : 0.f, q4 == 0 ? 1.f : 0.f, acc[u]);
+        }
+        select_tile(tA, acc[0]);
+        if (tB >= 0) select_tile(tB, acc[1]);
+        if (nA >= 0) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            transpose(nraw[u], cf[u]);
+            csq[u] = nsq[u];
+            asm volatile("" : "+v"(csq[u]));
+          }
+        }
+        tA = nA; tB = nB;
+      }
+    };
+    if constexpr (FULL) { lo = 0; hi = T; }
+    if constexpr (FULL) {
+      int t = lo;
+      scan_seq([&]() { return t < hi ? t++ : -1; });
+    } else {
+      // own tile first, then outwards (g + 1, g - 1, g + 2, ...): along the curve the tiles get closer as the scan approaches
+      // the wave's rank -- in rank order every candidate would beat the threshold the previous ones left (a streaming top-k's
+      // worst case: the plain loop over ranked rows takes 1.9x its time over unranked ones)
+      int i = 0;
+      const int gc = min(max(g, lo), hi - 1);
+      scan_seq([&]() {
+        while (i < 2 * (2 * NEAR + 1) + 2) {
+          const int d = (i + 1) >> 1, t = (i & 1) ? gc + d : gc - d;
+          ++i;
+          if (t >= lo && t < hi && !(d == 0 && (i & 1) == 0)) return t;
+        }
+        return -1;
+      });
+    }
+    if (FULL || hi - lo >= T) return;
+    sel.drain();                                         // thr = the (k + 2)-th best of the near candidates, exactly
+    unsigned long long need[4] = {0ull, 0ull, 0ull, 0ull};                 // tiles still to visit (T <= 256)
+    const float* cen = a.cen + (size_t)b * T * a.ldx;
+    const float* crad = a.cen_rad + (size_t)b * T;
+    const float* cmax = a.cen_sqmax + (size_t)b * T;
+    for (int ct = 0; ct * CT < T; ++ct) {
+      const int crow = min(ct * CT + col, T - 1);
+      float ccf[NST];
+      float cs = 0.f;
+      {
+        f32x4 raw[C == 64 ? 4 : 1];
+        if constexpr (C == 64) {
+          const float* rp = cen + (size_t)crow * a.ldx + 4 * q4;
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) raw[gq] = ld4(rp + 16 * gq);
+          cs = a.cen_sq[(size_t)b * T + crow];
+        } else {
+          raw[0][0] = cen[(size_t)crow * a.ldx + q4];
+        }
+        transpose(raw, ccf);
+      }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < NST; ++st) acc = mfma16(ccf[st], qf[st], acc);
+      if constexpr (C == 64) acc = mfma16(q4 == 0 ? -0.5f * cs : 0.f, q4 == 0 ? 1.f : 0.f, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = ct * CT + 4 * q4 + r, tc = min(t, T - 1);
+        const float sc = fmaf(2.f, acc[r], -sq_q);       // -|q - centroid|^2 as the kernel computes scores
+        const float m = 3e-5f * (sq_q + cmax[tc]) + 1e-30f;
+        const float dl = __builtin_sqrtf(fmaxf(0.f, -sc - m)) * 0.999999f;
+        const float lbd = fmaxf(0.f, dl - crad[tc]);
+        const float ub = m - lbd * lbd;                  // no row of tile t scores above ub for this query
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(t < T && !(ub < sel.thr));
+#pragma unroll
+        for (int qg = 0; qg < 4; ++qg)
+          if ((bal >> (16 * qg)) & 0xffffull) {
+            const int tt = ct * CT + 4 * qg + r;
+            need[tt >> 6] |= 1ull << (tt & 63);
+          }
+      }
+    }
+    for (int t = lo; t < hi; ++t) need[t >> 6] &= ~(1ull << (t & 63));
+    {
+      // (ascending rank order; nearest-first on either side of the near range measured 10-14 % slower: the two tiles of a step
+      // then lie far apart and the scalar bookkeeping per step grows)
+      int w = 0;
+      unsigned long long cur = need[0];
+      scan_seq([&]() {
+        while (cur == 0ull && w < 3) cur = need[++w];
+        if (cur == 0ull) return -1;
+        const int bit = __builtin_ctzll(cur);
+        cur &= cur - 1ull;
+        return w * 64 + bit;
+      });
+    }
+  };
+  [[maybe_unused]] auto ordered_scan = [&]() { ordered_scan_impl(std::false_type{}); };
+  [[maybe_unused]] auto ordered_scan_full = [&]() { ordered_scan_impl(std::true_type{}); };
   // C == 4: filter floor from a sample (see SampleNet): the first 256 candidates' values only -- 16 MFMAs -- give a
   // threshold the scan proper starts with (the VALU kernel: 75 -> 65 us; distances are one MFMA per tile here, so the
   // pre-pass costs next to nothing.  C == 64 recomputes 17 MFMAs per sampled tile: measured a wash, off).
   if constexpr (C == 4) {
     constexpr int T0 = SAMPLE / CT, R0 = (KS + 1 + G::LPQ - 1) / G::LPQ;     // LPQ * R0 - 1 >= KS
-    if (ntiles >= 2 * T0 + 1) {
+    if (!ord && ntiles >= 2 * T0 + 1) {
       SampleNet<R0> net;
       net.init();
       for (int t = 0; t < T0; ++t) {                     // (full tiles: 16 T0 <= N)
@@ -769,16 +929,23 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
       sel.init(lv, reinterpret_cast<int*>(lv + LROWS * 16), lane, col_min<G>(net.s[R0 - 1], sel.sg));
     }
   }
-  scan_all();
+  if constexpr (ORD) {
+    if (!ord) scan_all();
+    else if constexpr (KNN_ORD_MODE == 0) ordered_scan();
+    else if constexpr (KNN_ORD_MODE == 1) ordered_scan_full();
+    else scan_all();
+  } else {
+    scan_all();
+  }
   if constexpr (C == 4) {
     sel.drain();
-    if (__any(!sel.floor_held())) {                      // the sample misjudged some query of this wave: scan without a floor
+    if (!ord && __any(!sel.floor_held())) {                      // the sample misjudged some query of this wave: scan without a floor
       sel.init(lv, reinterpret_cast<int*>(lv + LROWS * 16), lane);
       scan_all();
     }
   }
   //@probe VCR_PROBE_ACC_FLUSH(threadIdx.x == 0 && blockIdx.y == 0, blockIdx.x);
-  finish<G, KS, 1>(sel, a, b, q0 + col, wave, 0, smem, blk_ties);
+  finish<G, KS, 1>(sel, a, b, q0 + col, wave, 0, smem, blk_ties, ord ? a.perm + (size_t)b * a.N : nullptr);
   if (blk_ties) replay_block_ties(a, blk_ties, smem);
 }
 // (k > 20: the logs of a workgroup take 51 KB, so three workgroups share a CU whatever the registers allow -- the bound
@@ -905,16 +1072,16 @@ __global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
 // are independent): the first n64 workgroups run the MFMA kernel's body, the rest the Cartesian one.  Either kernel
 // alone is latency-bound at one wave per SIMD (1024 waves on 1024 SIMDs); launched together the second fills the
 // first one's idle issue slots, and the pair costs little more than the longer of the two.
-template <int KS, bool COL16, bool XT = false>
-__global__ __launch_bounds__(256, (COL16 ? (KS > 22 ? 3 : 4) : 2)) void knn_pair_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
+template <int KS, bool COL16, bool XT = false, bool ORD = false>
+__global__ __launch_bounds__(256, (COL16 ? (KS > 22 || ORD ? 3 : 4) : 2)) void knn_pair_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
   const int bid = (int)blockIdx.x;
   if (bid < n64) {
     const int lin = xcd_chunk(bid, n64);
-    if constexpr (COL16) knn64c_body<KS, 4, 64, XT>(a64, lin % gx64, lin / gx64);
+    if constexpr (COL16) knn64c_body<KS, 4, 64, XT, ORD>(a64, lin % gx64, lin / gx64);
     else knn64_body<KS, 1, 4>(a64, lin % gx64, lin / gx64);
   } else {
     const int lin = xcd_chunk(bid - n64, (int)gridDim.x - n64);
-    knn64c_body<KS, 4, 4>(a3, lin % gx3, lin / gx3);
+    knn64c_body<KS, 4, 4, false, ORD>(a3, lin % gx3, lin / gx3);
   }
 }
 
@@ -1362,6 +1529,11 @@ extern "C" int vcr_knn_ties_inline(const vcr_knn_args* a) {
 // both are in the one-list-per-query regime the path runs in (k <= 20, >= 1024 query groups each); any other shape
 // simply makes the two self-contained calls.  Tie handling as in vcr_knn_f32 (tie_defer honoured; a
 // replay that is not deferred serves both launches at once).
+// the ordered search's inputs are all there and the cloud is small enough for the wave's tile mask (256 tiles of 16 ranks)
+static bool knn_ordered(const vcr_knn_args* a) {
+  return a->perm && a->xp && a->cen && a->cen_rad && a->cen_sqmax && (a->C == 4 || (a->sqp && a->cen_sq)) && a->N <= 4096 &&
+         !(((uintptr_t)a->xp | (uintptr_t)a->cen) & 15);
+}
 extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3, vcr_stream_t stream) {
   if (!a64 || !a3 || !a64->x || !a3->x || !a64->idx || !a3->idx || a64->C != 64 || a3->C != 4) return VCR_EINVAL;
   const bool col16 = use_col16(a64);
@@ -1420,11 +1592,16 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
   const int n64 = gx64 * a64->B, n3 = gx3 * a3->B;
   vcr_knn_args k64 = *a64, k3 = *a3;                     // (tie_inline is the library's own field)
   k64.tie_inline = ties_inline(a64) ? 1 : 0; k3.tie_inline = ties_inline(a3) ? 1 : 0;
+  if (!knn_ordered(a64)) k64.perm = nullptr;             // (incomplete ordered inputs: that search runs the plain way)
+  if (!knn_ordered(a3)) k3.perm = nullptr;
   const size_t lds64 = col16 ? knn_lds_bytes(a64, k64.tie_inline != 0) : (size_t)4 * 2 * (pend_of<GeomMfma, 22>() + 1) * 32 * 4;
   const size_t lds3 = knn_lds_bytes(a3, k3.tie_inline != 0), lds = lds64 > lds3 ? lds64 : lds3;
   const dim3 grid(n64 + n3);
   int rc;
   if (!col16) rc = launch<knn_pair_kernel<22, false>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3);
+  else if ((knn_ordered(a64) || knn_ordered(a3)) && a64->xt)           // searches over the ranked rows (see vcr_knn_args.perm)
+    rc = a64->k <= 20 ? launch<knn_pair_kernel<22, true, true, true>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3)
+                      : launch<knn_pair_kernel<42, true, true, true>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3);
   else if (a64->k <= 20) rc = a64->xt ? launch<knn_pair_kernel<22, true, true>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3)
                                       : launch<knn_pair_kernel<22, true>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3);
   else rc = a64->xt ? launch<knn_pair_kernel<42, true, true>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3)

@@ -1,0 +1,180 @@
+// What the ORDERED kNN search reads (vcr_knn_args.perm ...; util/util.py:143-160 is order-free: any visiting order gives the same
+// neighbour sets): the points of every cloud ranked along a Morton curve of their coordinates, the rows in rank order, and per
+// tile of 16 consecutive ranks a ball (centroid, radius) that holds its rows -- in coordinate space and in feature space.  The
+// features are a smooth function of the coordinates (lpdnet_model.py:111-112: two pointwise convs), so a tile of Morton
+// neighbours is compact in BOTH spaces: with the tiles' balls a 16-query wave needs 0.4-0.5 of a 1024-point cloud's tiles and
+// 0.2-0.3 of a 4096-point cloud's (profiles/r5n_knn_feat_prune_potential.txt).
+#include "common.h"
+
+namespace {
+
+constexpr int ORDER_MAX_N = 4096;
+
+__device__ __forceinline__ unsigned spread10(unsigned v) {           // 10 bits -> every third bit
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+// one workgroup per cloud: bounding box, 30-bit Morton codes, bitonic sort of (code, index) in LDS
+__global__ __launch_bounds__(1024) void knn_morton_kernel(const float* xyz4, int N, int P, int32_t* perm) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char mo_smem[];
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(mo_smem);          // [P]
+  float* red = reinterpret_cast<float*>(key + P);                                     // [6][16]
+  const int t = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+  const float* rows = xyz4 + (size_t)b * N * 4;
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int i = t; i < N; i += nt) {
+    const f32x4 v = ld4(rows + (size_t)i * 4);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], v[d]); hi[d] = fmaxf(hi[d], v[d]); }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = -wave_max(-lo[d]); hi[d] = wave_max(hi[d]);
+    if ((t & 63) == 0) { red[d * 16 + (t >> 6)] = lo[d]; red[(3 + d) * 16 + (t >> 6)] = hi[d]; }
+  }
+  __syncthreads();
+  const int nw = nt >> 6;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float l = red[d * 16], h = red[(3 + d) * 16];
+    for (int w = 1; w < nw; ++w) { l = fminf(l, red[d * 16 + w]); h = fmaxf(h, red[(3 + d) * 16 + w]); }
+    lo[d] = l; hi[d] = h;
+  }
+  for (int i = t; i < P; i += nt) {
+    unsigned long long k = ~0ull;                         // padding sorts behind every point
+    if (i < N) {
+      const f32x4 v = ld4(rows + (size_t)i * 4);
+      unsigned code = 0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float ext = hi[d] - lo[d];
+        const float u = ext > 0.f ? (v[d] - lo[d]) / ext : 0.f;
+        const unsigned qd = (unsigned)fminf(fmaxf(u * 1024.f, 0.f), 1023.f);
+        code |= spread10(qd) << d;
+      }
+      k = ((unsigned long long)code << 32) | (unsigned)i;
+    }
+    key[i] = k;
+  }
+  __syncthreads();
+  for (int kk = 2; kk <= P; kk <<= 1)
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < P; i += nt) {
+        const int x = i ^ j;
+        if (x > i) {
+          const unsigned long long a = key[i], c = key[x];
+          const bool up = (i & kk) == 0;
+          if ((a > c) == up) { key[i] = c; key[x] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = t; i < N; i += nt) perm[(size_t)b * N + i] = (int32_t)(key[i] & 0xffffffffu);
+}
+
+// one wave per tile of 16 ranks: rows into rank order, the tile's ball.  lane = (row = lane >> 2, quarter = lane & 3)
+__global__ __launch_bounds__(256) void knn_rank_rows_kernel(vcr_knn_order_args a, int T) {
+  const int lane = threadIdx.x & 63;
+  const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= (long)a.B * T) return;
+  const int b = (int)(gw / T), t = (int)(gw % T);
+  const int row = lane >> 2, qd = lane & 3;
+  const int r = t * 16 + row;
+  const bool valid = r < a.N;
+  const int o = a.perm[(size_t)b * a.N + min(r, a.N - 1)];
+  const float inv = 1.f / (float)min(16, a.N - t * 16);
+  auto rows_sum = [](float x) {                           // over the 16 rows (lanes of one quarter)
+    x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64); x += __shfl_xor(x, 16, 64); x += __shfl_xor(x, 32, 64);
+    return x;
+  };
+  auto rows_max = [](float x) {
+    x = fmaxf(x, __shfl_xor(x, 4, 64)); x = fmaxf(x, __shfl_xor(x, 8, 64));
+    x = fmaxf(x, __shfl_xor(x, 16, 64)); x = fmaxf(x, __shfl_xor(x, 32, 64));
+    return x;
+  };
+  // ---- coordinates
+  {
+    const f32x4 v = ld4(a.xyz4 + ((size_t)b * a.N + o) * 4);
+    if (valid && qd == 0) st4(a.xyz4_p + ((size_t)b * a.N + r) * 4, v);
+    float c[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) c[d] = rows_sum(valid ? v[d] : 0.f) * inv;
+    const float dx = v[0] - c[0], dy = v[1] - c[1], dz = v[2] - c[2];
+    const float d2 = rows_max(valid ? dx * dx + dy * dy + dz * dz : 0.f);
+    const float nmax = rows_max(valid ? v[3] : 0.f);
+    if (lane == 0) {
+      st4(a.cen4 + ((size_t)b * T + t) * 4, f32x4{c[0], c[1], c[2], c[0] * c[0] + c[1] * c[1] + c[2] * c[2]});
+      a.cen4_rad[(size_t)b * T + t] = __builtin_sqrtf(d2 * 1.00002f) * 1.000002f + 1e-30f;      // rounded UP: a bound
+      a.cen4_sqmax[(size_t)b * T + t] = nmax;
+    }
+  }
+  if (!a.feat_t) return;
+  // ---- features: this lane's 16 floats of its row (any layout: the centroid is taken position by position)
+  f32x4 v[4];
+  const float* src = a.feat_t + ((size_t)b * a.N + o) * a.ldf + 16 * qd;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) v[g] = ld4(src + 4 * g);
+  if (valid) {
+    float* dst = a.feat_p + ((size_t)b * a.N + r) * 64 + 16 * qd;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) st4(dst + 4 * g, v[g]);
+  }
+  const float sqv = a.sq[(size_t)b * a.N + o];
+  if (valid && qd == 0) a.sq_p[(size_t)b * a.N + r] = sqv;
+  float d2 = 0.f, cn = 0.f;
+  f32x4 c[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float m = rows_sum(valid ? v[g][e] : 0.f) * inv;
+      c[g][e] = m;
+      const float df = v[g][e] - m;
+      d2 += df * df;
+      cn += m * m;
+    }
+  d2 += __shfl_xor(d2, 1, 64); d2 += __shfl_xor(d2, 2, 64);       // the row's four quarters
+  cn += __shfl_xor(cn, 1, 64); cn += __shfl_xor(cn, 2, 64);
+  d2 = rows_max(valid ? d2 : 0.f);
+  const float nmax = rows_max(valid ? sqv : 0.f);
+  if (row == 0) {
+    float* dst = a.cen64 + ((size_t)b * T + t) * 64 + 16 * qd;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) st4(dst + 4 * g, c[g]);
+  }
+  if (lane == 0) {
+    a.cen64_sq[(size_t)b * T + t] = cn;
+    a.cen64_rad[(size_t)b * T + t] = __builtin_sqrtf(d2 * 1.00002f) * 1.000002f + 1e-30f;
+    a.cen64_sqmax[(size_t)b * T + t] = nmax;
+  }
+}
+
+}  // namespace
+
+extern "C" int vcr_knn_order_f32(const vcr_knn_order_args* a, vcr_stream_t stream) {
+  vcr_stream_scope bound(stream);
+  if (!a || !a->xyz4 || !a->perm || !a->xyz4_p || !a->cen4 || !a->cen4_rad || !a->cen4_sqmax) return VCR_EINVAL;
+  if (a->B <= 0 || a->N <= 0) return VCR_EINVAL;
+  if (a->feat_t && (!a->sq || !a->feat_p || !a->sq_p || !a->cen64 || !a->cen64_sq || !a->cen64_rad || !a->cen64_sqmax ||
+                    a->ldf < 64 || (a->ldf & 3)))
+    return VCR_EINVAL;
+  if (((uintptr_t)a->xyz4 | (uintptr_t)a->xyz4_p | (uintptr_t)a->cen4 | (uintptr_t)a->feat_t | (uintptr_t)a->feat_p |
+       (uintptr_t)a->cen64) & 15)
+    return VCR_EINVAL;
+  if (a->N > ORDER_MAX_N) return VCR_EUNSUPPORTED;
+  int P = 16;
+  while (P < a->N) P <<= 1;
+  const int threads = P >= 2048 ? 1024 : P >= 512 ? 512 : 256;
+  const size_t lds = (size_t)P * 8 + 6 * 16 * 4;
+  hipLaunchKernelGGL(knn_morton_kernel, dim3(a->B), dim3(threads), lds, (hipStream_t)stream, a->xyz4, a->N, P, a->perm);
+  int rc = VCR_LAUNCH_RC();
+  if (rc != 0) return rc;
+  const int T = (a->N + 15) / 16;
+  const long waves = (long)a->B * T;
+  hipLaunchKernelGGL(knn_rank_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a, T);
+  return VCR_LAUNCH_RC();
+}

@@ -30,7 +30,16 @@ class KnnArgs(C.Structure):
                 ("k", C.c_int), ("idx", f32p), ("tie_scratch", f32p), ("tie_cap", C.c_int), ("waves", C.c_int),
                 ("tie_zeroed", C.c_int),
                 ("tie_defer", C.c_int), ("tie_work", C.c_void_p), ("tie_work_bytes", C.c_size_t), ("tie_inline", C.c_int),
-                ("xt", f32p)]
+                ("xt", f32p),
+                ("perm", f32p), ("xp", f32p), ("sqp", f32p), ("cen", f32p), ("cen_sq", f32p), ("cen_rad", f32p),
+                ("cen_sqmax", f32p)]
+
+
+class KnnOrderArgs(C.Structure):
+    _fields_ = [("xyz4", f32p), ("feat_t", f32p), ("ldf", C.c_int), ("sq", f32p), ("B", C.c_int), ("N", C.c_int),
+                ("perm", f32p), ("xyz4_p", f32p), ("cen4", f32p), ("cen4_rad", f32p), ("cen4_sqmax", f32p),
+                ("feat_p", f32p), ("sq_p", f32p), ("cen64", f32p), ("cen64_sq", f32p), ("cen64_rad", f32p),
+                ("cen64_sqmax", f32p)]
 
 
 class LinearArgs(C.Structure):
@@ -217,7 +226,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 25         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 26         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -402,9 +411,9 @@ def _tie_work(a, N, device, keep):
 
 
 @_guarded
-def knn_pair(feat, sq, xyz4, k, xt=None):
+def knn_pair(feat, sq, xyz4, k, xt=None, order=None):
     """vcr_knn_pair_f32: the feature-space (feat [B,N,64], sq [B,N]) and the Cartesian (xyz4 [B,N,4]) kNN in one launch
-    -> (idx_feat, idx_xyz), tie replay included."""
+    -> (idx_feat, idx_xyz), tie replay included.  order = knn_order()'s dict: the ordered search (vcr_knn_args.perm)."""
     L = lib()
     out, args, keep = [], [], []
     for x, s_ in ((feat, sq), (xyz4, None)):
@@ -415,6 +424,13 @@ def knn_pair(feat, sq, xyz4, k, xt=None):
         _tie_work(args[-1], N, x.device, keep)
         out.append(idx); keep.append(ties)
     args[0].xt = ptr(xt)
+    if order is not None:
+        o = lambda n: ptr(order[n])
+        args[0].perm = args[1].perm = o("perm")
+        a = args[0]
+        a.xp, a.sqp, a.cen, a.cen_sq, a.cen_rad, a.cen_sqmax = o("feat_p"), o("sq_p"), o("cen64"), o("cen64_sq"), o("cen64_rad"), o("cen64_sqmax")
+        a = args[1]
+        a.xp, a.cen, a.cen_rad, a.cen_sqmax = o("xyz4_p"), o("cen4"), o("cen4_rad"), o("cen4_sqmax")
     L.vcr_knn_pair_f32.argtypes = [C.POINTER(KnnArgs), C.POINTER(KnnArgs), C.c_void_p]
     L.vcr_knn_pair_f32.restype = C.c_int
     check(L.vcr_knn_pair_f32(C.byref(args[0]), C.byref(args[1]), C.c_void_p(stream_ptr())), "vcr_knn_pair_f32")
@@ -536,6 +552,22 @@ def edgeconv(pq, idx, n_per_cloud, w2, b2, bf16x3=False):
     call("vcr_edgeconv_bf16x3_f32" if bf16x3 else "vcr_edgeconv_f32", EdgeconvArgs(ptr(pq), pq.stride(0), ptr(idx), k, M, n_per_cloud, ptr(w2), ptr(b2),
                                           ptr(x1), 128, ptr(x2), 128))
     return x1, x2
+
+
+def knn_order(xyz4, feat_t=None, sq=None):
+    """vcr_knn_order_f32: the clouds' Morton ranking and what the ordered kNN search reads (vcr_knn_args.perm ...), as a dict."""
+    B, N, _ = xyz4.shape
+    T = (N + 15) // 16
+    e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=xyz4.device)
+    o = {"perm": e(B, N, dt=torch.int32), "xyz4_p": e(B, N, 4), "cen4": e(B, T, 4), "cen4_rad": e(B, T), "cen4_sqmax": e(B, T)}
+    if feat_t is not None:
+        o.update(feat_p=e(B, N, 64), sq_p=e(B, N), cen64=e(B, T, 64), cen64_sq=e(B, T), cen64_rad=e(B, T), cen64_sqmax=e(B, T))
+    g = lambda n: ptr(o.get(n))
+    a = KnnOrderArgs(ptr(xyz4), ptr(feat_t), feat_t.stride(1) if feat_t is not None else 0, ptr(sq), B, N, g("perm"), g("xyz4_p"),
+                     g("cen4"), g("cen4_rad"), g("cen4_sqmax"), g("feat_p"), g("sq_p"), g("cen64"), g("cen64_sq"), g("cen64_rad"),
+                     g("cen64_sqmax"))
+    call("vcr_knn_order_f32", a)
+    return o
 
 
 @_guarded

@@ -55,6 +55,8 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
             return 2.0 * (64 + 3) * N * N * 2 * B, 4.0 * M2 * (64 + 1 + 4 + 2 * k)
         if site == "ties":                                 # the replay of the few rows with a boundary tie: latency only
             return 0.0, 4.0 * M2
+        if site == "rank":                                 # Morton ranking + the rows in rank order + the tiles' balls (ordered search)
+            return 0.0, 4.0 * M2 * (4 + 2 * (64 + 1 + 4) + 1 + 6)
         C = 64 if site == "feat64" else 3
         return 2.0 * C * N * N * 2 * B, 4.0 * M2 * ((C if C == 64 else 4) + (1 if C == 64 else 0) + k)
     if fam == "linear":
