@@ -73,8 +73,8 @@ def test_whole_vs_reference_golden(name):
     print(f"{name}: max|dR|={np.abs(R.cpu().numpy() - g['it0_R']).max():.2e} max|dt|={np.abs(t.cpu().numpy() - g['it0_t']).max():.2e}")
 
 
-@pytest.mark.parametrize("B,N,kind", [(4, 1024, "object"), (3, 320, "object"), (2, 2048, "uniform"),
-                                      (5, 1000, "object"), (2, 77, "object"), (3, 21, "object")])   # ragged / minimal N
+@pytest.mark.parametrize("B,N,kind", [(4, 1024, "object"), (3, 320, "object"), (2, 2048, "uniform"), (4, 2048, "uniform"),
+                                      (5, 1000, "object"), (2, 77, "object"), (3, 21, "object")])   # ragged / minimal N; (4, 2048): the ordered kNN search
 def test_whole_vs_oracle(B, N, kind):
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import synth
@@ -101,6 +101,29 @@ def test_whole_vs_oracle(B, N, kind):
     dR, dt = np.abs(out[2].cpu().numpy() - ref[2].numpy()).max(), np.abs(out[3].cpu().numpy() - ref[3].numpy()).max()
     print(f"whole vs oracle B={B} N={N}: max|dR| {dR:.2e} max|dt| {dt:.2e} (tolerance {r_tol:.2e} / {t_tol:.2e})")
     assert dR <= r_tol and dt <= t_tol, (dR, dt)
+
+
+@pytest.mark.parametrize("B,N,k", [(4, 2048, 20), (2, 4096, 40), (5, 2500, 20)])
+def test_ordered_knn_search_changes_no_bit_of_the_forward(B, N, k):
+    """Clouds of 2048+ points take the ordered kNN search (Morton ranking, tiles skipped by their balls; forward.hip); a kNN
+    tuning value (knn_waves = 8: the same 16-query-wave kernels, asked for explicitly) keeps the plain scan.  The neighbour SETS
+    are equal and everything downstream is a max over a point's neighbours, so every output is bit-identical."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    net, _ = build_net()
+    net.emb_nn.k = k
+    src, tgt, _, _, _ = synth.make_batch(900, B, N, kind="uniform")
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    with torch.no_grad():
+        tr = vcrnet_amd.native.LaunchTrace()
+        ordered = net._forward_fused(s, t, want_emb=True, trace=tr.trace)
+        torch.cuda.synchronize()
+        assert any(n == "knn:rank" for n, _ in tr.launches()), "the ordered search did not run"
+        net.knn_waves = 8
+        plain = net._forward_fused(s, t, want_emb=True)
+    for a, b in zip(ordered, plain):
+        if torch.is_tensor(a):
+            assert torch.equal(a, b)
 
 
 def test_config5_shape_vs_oracle():
