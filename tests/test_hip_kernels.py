@@ -758,6 +758,17 @@ def test_knn_ordered_search_keeps_the_sets(nat, B, N, k, kind):
     perm = order["perm"].long().cpu()
     assert all(torch.equal(torch.sort(perm[b]).values, torch.arange(N)) for b in range(B))
     assert torch.equal(torch.gather(x4, 1, order["perm"].long()[..., None].expand(-1, -1, 4)), order["xyz4_p"])
+    # the ranking IS the sort by (30-bit Morton code of the bounding-box-normalised coordinates, point index)
+    lo, hi = xyz.min(1, keepdims=True), xyz.max(1, keepdims=True)
+    ext = (hi - lo).astype(np.float32)
+    u = np.where(ext > 0, (xyz - lo).astype(np.float32) / np.where(ext > 0, ext, 1).astype(np.float32), 0).astype(np.float32)
+    qd = np.minimum(np.maximum(u * np.float32(1024), 0), 1023).astype(np.int64)
+    code = np.zeros((B, N), np.int64)
+    for bit in range(10):
+        for d in range(3):
+            code |= ((qd[..., d] >> bit) & 1) << (3 * bit + d)
+    key = (code << 32) | np.arange(N)[None]
+    assert np.array_equal(perm.numpy(), np.argsort(key, 1, kind="stable"))
     a0, b0 = nat.knn_pair(feat, sq, x4, k, xt=ft)
     a1, b1 = nat.knn_pair(feat, sq, x4, k, xt=ft, order=order)
     for plain, ordered in ((a0, a1), (b0, b1)):
