@@ -18,11 +18,20 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {           // 10 bits 
   return v;
 }
 
-// one workgroup per cloud: bounding box, 30-bit Morton codes, bitonic sort of (code, index) in LDS
-__global__ __launch_bounds__(1024) void knn_morton_kernel(const float* xyz4, int N, int P, int32_t* perm) {
+// one workgroup per cloud: bounding box, 30-bit Morton codes, and the rank of every (code, index) key by BUCKETS of the code's
+// top 12 bits -- histogram (LDS atomics: the counts do not depend on their order), exclusive prefix, the keys dealt to their
+// bucket's segment (slot order arbitrary), and a key's rank = its bucket's start + the number of smaller keys in that segment
+// (keys are distinct: the ranking is the sort's, whatever order the slots were handed out in).  Four barriers instead of the
+// ~70 steps of a bitonic sort in LDS (32 x 2048: 49 -> ~12 us, 64 x 4096: 107 -> ~20); a cloud whose points share few buckets
+// (all points equal: one) degrades to the quadratic count of one segment, ~50 us at 4096 points.
+constexpr int ORDER_BUCKETS = 4096;
+__global__ __launch_bounds__(1024) void knn_morton_kernel(const float* xyz4, int N, int32_t* perm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char mo_smem[];
-  unsigned long long* key = reinterpret_cast<unsigned long long*>(mo_smem);          // [P]
-  float* red = reinterpret_cast<float*>(key + P);                                     // [6][16]
+  unsigned long long* seg = reinterpret_cast<unsigned long long*>(mo_smem);           // [N] keys, grouped by bucket
+  int* cnt = reinterpret_cast<int*>(seg + N);                                          // [BUCKETS] counts -> next free slot
+  int* start = cnt + ORDER_BUCKETS;                                                    // [BUCKETS] first slot of a bucket
+  float* red = reinterpret_cast<float*>(start + ORDER_BUCKETS);                        // [6][16]
+  int* wsum = reinterpret_cast<int*>(red + 96);                                        // [16] wave totals of the prefix
   const int t = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
   const float* rows = xyz4 + (size_t)b * N * 4;
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -36,6 +45,7 @@ __global__ __launch_bounds__(1024) void knn_morton_kernel(const float* xyz4, int
     lo[d] = -wave_max(-lo[d]); hi[d] = wave_max(hi[d]);
     if ((t & 63) == 0) { red[d * 16 + (t >> 6)] = lo[d]; red[(3 + d) * 16 + (t >> 6)] = hi[d]; }
   }
+  for (int i = t; i < ORDER_BUCKETS; i += nt) cnt[i] = 0;
   __syncthreads();
   const int nw = nt >> 6;
 #pragma unroll
@@ -44,36 +54,55 @@ __global__ __launch_bounds__(1024) void knn_morton_kernel(const float* xyz4, int
     for (int w = 1; w < nw; ++w) { l = fminf(l, red[d * 16 + w]); h = fmaxf(h, red[(3 + d) * 16 + w]); }
     lo[d] = l; hi[d] = h;
   }
-  for (int i = t; i < P; i += nt) {
-    unsigned long long k = ~0ull;                         // padding sorts behind every point
-    if (i < N) {
-      const f32x4 v = ld4(rows + (size_t)i * 4);
-      unsigned code = 0;
+  auto key_of = [&](int i) {
+    const f32x4 v = ld4(rows + (size_t)i * 4);
+    unsigned code = 0;
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const float ext = hi[d] - lo[d];
-        const float u = ext > 0.f ? (v[d] - lo[d]) / ext : 0.f;
-        const unsigned qd = (unsigned)fminf(fmaxf(u * 1024.f, 0.f), 1023.f);
-        code |= spread10(qd) << d;
-      }
-      k = ((unsigned long long)code << 32) | (unsigned)i;
+    for (int d = 0; d < 3; ++d) {
+      const float ext = hi[d] - lo[d];
+      const float u = ext > 0.f ? (v[d] - lo[d]) / ext : 0.f;
+      const unsigned qd = (unsigned)fminf(fmaxf(u * 1024.f, 0.f), 1023.f);
+      code |= spread10(qd) << d;
     }
-    key[i] = k;
+    return ((unsigned long long)code << 32) | (unsigned)i;
+  };
+  for (int i = t; i < N; i += nt) atomicAdd(&cnt[(int)(key_of(i) >> 50)], 1);          // bucket = the code's top 12 of 30 bits
+  __syncthreads();
+  // exclusive prefix of the ORDER_BUCKETS counts: ORDER_BUCKETS / nt consecutive buckets per thread, wave scan, wave totals
+  {
+    const int per = ORDER_BUCKETS / nt;                   // (nt divides ORDER_BUCKETS: 256 / 512 / 1024 threads)
+    int local = 0;
+    for (int u = 0; u < per; ++u) local += cnt[t * per + u];
+    int inc = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if ((t & 63) >= o) inc += up;
+    }
+    if ((t & 63) == 63) wsum[t >> 6] = inc;
+    __syncthreads();
+    int base = inc - local;
+    for (int w = 0; w < (t >> 6); ++w) base += wsum[w];
+    for (int u = 0; u < per; ++u) {
+      const int c = cnt[t * per + u];
+      start[t * per + u] = base;
+      cnt[t * per + u] = base;                            // becomes the bucket's next free slot
+      base += c;
+    }
   }
   __syncthreads();
-  for (int kk = 2; kk <= P; kk <<= 1)
-    for (int j = kk >> 1; j > 0; j >>= 1) {
-      for (int i = t; i < P; i += nt) {
-        const int x = i ^ j;
-        if (x > i) {
-          const unsigned long long a = key[i], c = key[x];
-          const bool up = (i & kk) == 0;
-          if ((a > c) == up) { key[i] = c; key[x] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  for (int i = t; i < N; i += nt) perm[(size_t)b * N + i] = (int32_t)(key[i] & 0xffffffffu);
+  for (int i = t; i < N; i += nt) {
+    const unsigned long long k = key_of(i);
+    seg[atomicAdd(&cnt[(int)(k >> 50)], 1)] = k;
+  }
+  __syncthreads();
+  for (int i = t; i < N; i += nt) {
+    const unsigned long long k = key_of(i);
+    const int bk = (int)(k >> 50), s0 = start[bk], s1 = cnt[bk];
+    int r = s0;
+    for (int j = s0; j < s1; ++j) r += seg[j] < k ? 1 : 0;
+    perm[(size_t)b * N + r] = i;
+  }
 }
 
 // one wave per tile of 16 ranks: rows into rank order, the tile's ball.  lane = (row = lane >> 2, quarter = lane & 3)
@@ -166,11 +195,10 @@ extern "C" int vcr_knn_order_f32(const vcr_knn_order_args* a, vcr_stream_t strea
        (uintptr_t)a->cen64) & 15)
     return VCR_EINVAL;
   if (a->N > ORDER_MAX_N) return VCR_EUNSUPPORTED;
-  int P = 16;
-  while (P < a->N) P <<= 1;
-  const int threads = P >= 2048 ? 1024 : P >= 512 ? 512 : 256;
-  const size_t lds = (size_t)P * 8 + 6 * 16 * 4;
-  hipLaunchKernelGGL(knn_morton_kernel, dim3(a->B), dim3(threads), lds, (hipStream_t)stream, a->xyz4, a->N, P, a->perm);
+  const int threads = a->N >= 2048 ? 1024 : a->N >= 512 ? 512 : 256;
+  const size_t lds = (size_t)a->N * 8 + 2 * ORDER_BUCKETS * 4 + 96 * 4 + 16 * 4;
+  VCR_DYN_LDS(knn_morton_kernel, (int)lds);               // (64.5 KB at 4096 points)
+  hipLaunchKernelGGL(knn_morton_kernel, dim3(a->B), dim3(threads), lds, (hipStream_t)stream, a->xyz4, a->N, a->perm);
   int rc = VCR_LAUNCH_RC();
   if (rc != 0) return rc;
   const int T = (a->N + 15) / 16;
