@@ -858,33 +858,41 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
     const float* cen = a.cen + (size_t)b * T * a.ldx;
     const float* crad = a.cen_rad + (size_t)b * T;
     const float* cmax = a.cen_sqmax + (size_t)b * T;
-    for (int ct = 0; ct * CT < T; ++ct) {
+    // (two centroid tiles in flight: fetched one iteration ahead, unconditionally -- past the last one the last again --, so that
+    //  the loop is not a chain of exposed memory round trips; 64 x 4096, k = 40: 1846 -> 1795 us)
+    struct CenTile { f32x4 raw[C == 64 ? 4 : 1]; float cs, rd[4], mx[4]; };
+    auto cfetch = [&](int ct, CenTile& f) {
       const int crow = min(ct * CT + col, T - 1);
-      float ccf[NST];
-      float cs = 0.f;
-      {
-        f32x4 raw[C == 64 ? 4 : 1];
-        if constexpr (C == 64) {
-          const float* rp = cen + (size_t)crow * a.ldx + 4 * q4;
+      if constexpr (C == 64) {
+        const float* rp = cen + (size_t)crow * a.ldx + 4 * q4;
 #pragma unroll
-          for (int gq = 0; gq < 4; ++gq) raw[gq] = ld4(rp + 16 * gq);
-          cs = a.cen_sq[(size_t)b * T + crow];
-        } else {
-          raw[0][0] = cen[(size_t)crow * a.ldx + q4];
-        }
-        transpose(raw, ccf);
+        for (int gq = 0; gq < 4; ++gq) f.raw[gq] = ld4(rp + 16 * gq);
+        f.cs = a.cen_sq[(size_t)b * T + crow];
+      } else {
+        f.raw[0][0] = cen[(size_t)crow * a.ldx + q4];
+        f.cs = 0.f;
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tc = min(ct * CT + 4 * q4 + r, T - 1);
+        f.rd[r] = crad[tc];
+        f.mx[r] = cmax[tc];
+      }
+    };
+    auto ceval = [&](int ct, const CenTile& f) {
+      float ccf[NST];
+      transpose(f.raw, ccf);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int st = 0; st < NST; ++st) acc = mfma16(ccf[st], qf[st], acc);
-      if constexpr (C == 64) acc = mfma16(q4 == 0 ? -0.5f * cs : 0.f, q4 == 0 ? 1.f : 0.f, acc);
+      if constexpr (C == 64) acc = mfma16(q4 == 0 ? -0.5f * f.cs : 0.f, q4 == 0 ? 1.f : 0.f, acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int t = ct * CT + 4 * q4 + r, tc = min(t, T - 1);
+        const int t = ct * CT + 4 * q4 + r;
         const float sc = fmaf(2.f, acc[r], -sq_q);       // -|q - centroid|^2 as the kernel computes scores
-        const float m = 3e-5f * (sq_q + cmax[tc]) + 1e-30f;
+        const float m = 3e-5f * (sq_q + f.mx[r]) + 1e-30f;
         const float dl = __builtin_sqrtf(fmaxf(0.f, -sc - m)) * 0.999999f;
-        const float lbd = fmaxf(0.f, dl - crad[tc]);
+        const float lbd = fmaxf(0.f, dl - f.rd[r]);
         const float ub = m - lbd * lbd;                  // no row of tile t scores above ub for this query
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(t < T && !(ub < sel.thr));
 #pragma unroll
@@ -893,6 +901,17 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
             const int tt = ct * CT + 4 * qg + r;
             need[tt >> 6] |= 1ull << (tt & 63);
           }
+      }
+    };
+    {
+      const int nct = (T + CT - 1) / CT;
+      CenTile fa, fb;
+      cfetch(0, fa);
+      for (int ct = 0; ct < nct; ct += 2) {
+        cfetch(min(ct + 1, nct - 1), fb);
+        ceval(ct, fa);
+        cfetch(min(ct + 2, nct - 1), fa);
+        if (ct + 1 < nct) ceval(ct + 1, fb);
       }
     }
     for (int t = lo; t < hi; ++t) need[t >> 6] &= ~(1ull << (t & 63));
