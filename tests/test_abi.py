@@ -94,6 +94,16 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     n16 = lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 16, 1024)
     assert 0 < n1 < n16 < (4 << 30)
     assert lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 0, 1024) == 0
+    # the ordered search's ranking entry point: NULL / missing outputs, then a cloud beyond its 4096 points
+    assert lib.vcr_knn_order_f32(None, None) == -1
+    o = native.KnnOrderArgs()
+    assert lib.vcr_knn_order_f32(ctypes.byref(o), None) == -1
+    for f in ("xyz4", "perm", "xyz4_p", "cen4", "cen4_rad", "cen4_sqmax"):
+        setattr(o, f, 0x1000)                                # (never dereferenced: the size check comes first)
+    o.B, o.N = 2, 5000
+    assert lib.vcr_knn_order_f32(ctypes.byref(o), None) == -3 and b"unsupported" in lib.vcr_strerror(-3)
+    o.feat_t = 0x2000                                        # features without their norms / outputs
+    assert lib.vcr_knn_order_f32(ctypes.byref(o), None) == -1
 
 
 def test_workspace_plan_sizes_of_the_baseline_configs(lib):
