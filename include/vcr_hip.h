@@ -37,7 +37,8 @@ extern "C" {
 typedef void* vcr_stream_t;  /* hipStream_t */
 
 const char* vcr_strerror(int code);
-int vcr_abi_version(void);   /* bumped on any signature change */
+#define VCR_ABI_VERSION 27
+int vcr_abi_version(void);   /* == VCR_ABI_VERSION of the header the library was built from; bumped on any signature / layout change */
 
 /* ---- K-a: conv1_lpd + conv2_lpd (model/lpdnet_model.py:111-112), ReLU == LeakyReLU(0.0) ----
  * x_cf  [B,3,N] channels-first input (the module's forward() argument layout)
@@ -79,6 +80,9 @@ int vcr_rows4_pq_f32(const float* x_cf, float* xyz4, int B, int N, const float* 
  * (vcr_knn_tie_work_bytes(N) bytes of 16-B aligned device scratch) -- with tie_scratch set and tie_work missing such a
  * call returns VCR_EUNSUPPORTED: the replay is never skipped silently. */
 typedef struct {
+  uint32_t struct_bytes;              /* sizeof(vcr_knn_args) as the CALLER was compiled (ABI 27): fewer bytes than this header's
+                                         = a caller built against an older header, the missing tail is read as zeros; 0, less than
+                                         the mandatory part (through tie_cap) or more than this library knows: VCR_EINVAL */
   const float* x; int ldx;            /* [B,N,C] rows                                  */
   const float* sq;                    /* [B,N] squared norms (C==64); ignored for C==4 */
   int B, N, C, k;
@@ -455,6 +459,9 @@ typedef struct {
   const float *w1, *b1, *w2, *b2;     /* [F,E],[F],[E,F],[E] */
 } vcr_ffn_w;
 typedef struct {
+  uint32_t struct_bytes;                           /* sizeof(vcr_vcrnet_weights) as the CALLER was compiled (ABI 27; see vcr_knn_args):
+                                                      the mandatory part ends before fold_encdec_qkv; a shorter, zero or longer
+                                                      value is VCR_EINVAL (vcr_vcrnet_workspace_bytes / vcr_vcrnet_pairs: 0) */
   /* LPDNet */
   const float *c1_w, *c1_b, *c2_w, *c2_b;          /* conv1_lpd, conv2_lpd                         */
   const float *dg1_wpq, *dg1_bpq;                  /* [256,64]: rows 0..127 = W[:, :64] (neighbour), 128.. = W[:, 64:] (centre); bias [256] = (0, b) */
@@ -524,6 +531,11 @@ typedef struct {
    * key-mass pass when they fit this many MiB of workspace (0 = 4096), and recomputed per head otherwise (< 0: never
    * kept).  Same kept-key set either way up to summation order. */
   int xscore_limit_mb;
+  /* tests: != 0 lays the forward's workspace out with EVERY buffer live from the first launch to the last (no two buffers
+   * share memory; vcr_vcrnet_workspace_bytes grows ~2.5x).  The default layout overlays buffers by their (first, last) launch;
+   * a lifetime registered too short would let one launch overwrite what a later one still reads -- comparing the two
+   * layouts bit for bit is the test for that.  Results never depend on it. */
+  int workspace_flat;
 } vcr_vcrnet_weights;
 
 typedef struct {
@@ -572,6 +584,23 @@ int vcr_vcrnet_forward_traced_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io
  * No host synchronisation between iterations.  trace may be NULL; launches of all iterations are appended. */
 int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io*, int iters, void* workspace,
                         size_t workspace_bytes, vcr_stream_t, vcr_trace* trace);
+
+/* One step of vcrnetIter's / vcrnetIcpNet's bookkeeping (vcrnet_model.py:32-38,52-59; transform_point_cloud, util/util.py:91-96)
+ * for hosts that drive the passes themselves (what vcr_vcrnet_iter_f32 does between its passes):
+ *   out_cf = R_i in_cf + t_i                       when out_cf != NULL ([B,3,N] channels-first; in place is allowed)
+ *   compose 1: R_f <- R_i R_f, t_f <- R_i t_f + t_i (in place), then (R_ba, t_ba) = (R_f^T, -R_f^T t_f)
+ *   compose 2: (R_ba, t_ba) = (R_i^T, -R_i^T t_i)   (the inverse of this pass's pose only; R_f / t_f unused)
+ *   compose 0: neither.
+ * Products are k-ascending fma chains, as the reference's CPU matmul computes 3 x 3 products. */
+typedef struct {
+  const float* R_i; const float* t_i;              /* [B,9], [B,3] */
+  int B, N;
+  const float* in_cf; float* out_cf;               /* optional pair */
+  int compose;
+  float* R_f; float* t_f;                          /* compose 1 */
+  float* R_ba; float* t_ba;                        /* compose 1 / 2 */
+} vcr_pose_step_args;
+int vcr_pose_step_f32(const vcr_pose_step_args*, vcr_stream_t);
 
 /* hipEvent helpers (create / destroy / record / elapsed) bound to the same HIP runtime as the
  * kernels, for hosts without HIP bindings.  Elapsed needs both events completed (synchronise first). */

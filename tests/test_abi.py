@@ -33,7 +33,7 @@ def test_header_symbols_exported(lib):
 
 def test_version_and_strerror(lib):
     from vcrnet_amd import native
-    assert lib.vcr_abi_version() == native.ABI_VERSION == 26
+    assert lib.vcr_abi_version() == native.ABI_VERSION == 27
     assert lib.vcr_strerror(0) == b"ok"
     assert b"invalid" in lib.vcr_strerror(-1)
     assert b"workspace" in lib.vcr_strerror(-2)
@@ -56,7 +56,7 @@ def test_ctypes_structs_match_the_c_layout(tmp_path):
              "vcr_pairscore_args": native.PairscoreArgs, "vcr_scoremass_args": native.ScoremassArgs,
              "vcr_rankselect_args": native.RankselectArgs, "vcr_gather_args": native.GatherArgs,
              "vcr_rigid_svd_args": native.RigidSvdArgs, "vcr_icp_args": native.IcpArgs,
-             "vcr_make_pairs_args": native.MakePairsArgs, "vcr_vcrnet_weights": native.VcrnetWeights,
+             "vcr_make_pairs_args": native.MakePairsArgs, "vcr_pose_step_args": native.PoseStepArgs, "vcr_vcrnet_weights": native.VcrnetWeights,
              "vcr_vcrnet_io": native.VcrnetIo, "vcr_trace": native.Trace}
     hdr = open(HEADER).read()
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
@@ -94,6 +94,18 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     n16 = lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 16, 1024)
     assert 0 < n1 < n16 < (4 << 30)
     assert lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 0, 1024) == 0
+    # vcrnetIter's bookkeeping step: NULL poses, a cloud without its output, a composition without its destination
+    assert lib.vcr_pose_step_f32(None, None) == -1
+    ps = native.PoseStepArgs()
+    assert lib.vcr_pose_step_f32(ctypes.byref(ps), None) == -1
+    ps.R_i, ps.t_i, ps.B, ps.N = 0x1000, 0x2000, 2, 64
+    assert lib.vcr_pose_step_f32(ctypes.byref(ps), None) == 0          # nothing asked for: no launch
+    ps.in_cf = 0x3000
+    assert lib.vcr_pose_step_f32(ctypes.byref(ps), None) == -1
+    ps.in_cf, ps.compose = None, 1
+    assert lib.vcr_pose_step_f32(ctypes.byref(ps), None) == -1
+    ps.compose = 3
+    assert lib.vcr_pose_step_f32(ctypes.byref(ps), None) == -1
     # the ordered search's ranking entry point: NULL / missing outputs, then a cloud beyond its 4096 points
     assert lib.vcr_knn_order_f32(None, None) == -1
     o = native.KnnOrderArgs()
@@ -104,6 +116,44 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.vcr_knn_order_f32(ctypes.byref(o), None) == -3 and b"unsupported" in lib.vcr_strerror(-3)
     o.feat_t = 0x2000                                        # features without their norms / outputs
     assert lib.vcr_knn_order_f32(ctypes.byref(o), None) == -1
+
+
+def test_sized_structs_refuse_what_they_cannot_read(lib):
+    """ABI 27: vcr_knn_args / vcr_vcrnet_weights state their size.  Zero (a caller that never heard of the field), less than
+    the mandatory part, or more than the library knows is an argument error; a SHORTER struct from an older header is served,
+    its missing tail read as zeros -- the library never reads past what the caller said it passed."""
+    from vcrnet_amd import native
+    lib.vcr_vcrnet_workspace_bytes.restype = ctypes.c_size_t
+    lib.vcr_knn_ties_inline.argtypes = [ctypes.POINTER(native.KnnArgs)]
+    w = native.VcrnetWeights()
+    assert w.struct_bytes == ctypes.sizeof(native.VcrnetWeights)
+    w.E, w.F, w.heads, w.k, w.has_pointer = 512, 1024, 4, 20, 1
+    full = lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 4, 1024)
+    assert full > 0 and lib.vcr_vcrnet_pairs(ctypes.byref(w), 1024) == 1024
+    mandatory = native.VcrnetWeights.fold_encdec_qkv.offset
+    w.partial = 1                                            # lives BEHIND the mandatory part ...
+    w.overlap2 = 0.75
+    assert lib.vcr_vcrnet_pairs(ctypes.byref(w), 1024) < 1024
+    w.struct_bytes = mandatory                               # ... so a struct that ends before it is a whole-mode request
+    assert lib.vcr_vcrnet_pairs(ctypes.byref(w), 1024) == 1024
+    assert lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 4, 1024) == full
+    for bad in (0, mandatory - 8, ctypes.sizeof(native.VcrnetWeights) + 8):
+        w.struct_bytes = bad
+        assert lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 4, 1024) == 0
+        assert lib.vcr_vcrnet_pairs(ctypes.byref(w), 1024) == 0
+        assert lib.vcr_vcrnet_forward_f32(ctypes.byref(w), None, None, 0, None) == -1
+        assert lib.vcr_vcrnet_iter_f32(ctypes.byref(w), None, 1, None, 0, None, None) == -1
+    a = native.KnnArgs(0x1000, 4, None, 64, 1024, 4, 20, 0x2000, 0x3000, 64 * 1024)
+    assert a.struct_bytes == ctypes.sizeof(native.KnnArgs) and a.N == 1024
+    assert lib.vcr_knn_ties_inline(ctypes.byref(a)) == 1
+    a.struct_bytes = native.KnnArgs.waves.offset             # the mandatory part alone
+    assert lib.vcr_knn_ties_inline(ctypes.byref(a)) == 1
+    for bad in (0, native.KnnArgs.waves.offset - 4, ctypes.sizeof(native.KnnArgs) + 8):
+        a.struct_bytes = bad
+        assert lib.vcr_knn_ties_inline(ctypes.byref(a)) == 0
+        assert lib.vcr_knn_f32(ctypes.byref(a), None) == -1
+        assert lib.vcr_knn_pair_f32(ctypes.byref(a), ctypes.byref(a), None) == -1
+        assert lib.vcr_knn_ties_f32(ctypes.byref(a), None, None) == -1
 
 
 def test_workspace_plan_sizes_of_the_baseline_configs(lib):

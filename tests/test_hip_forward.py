@@ -418,6 +418,41 @@ def test_workspace_contents_do_not_matter(kw, mode):
             assert torch.equal(a, b), (fill, i, (a.float() - b.float()).abs().max().item())
 
 
+@pytest.mark.parametrize("kw,mode,merge", [({}, "fp32", True), ({}, "fp32", False), ({}, "bf16x3", True), ({}, "bf16x3+sdpa", True),
+                                           ({}, "bf16x3+sdpa", False), (dict(partial=True), "fp32", True),
+                                           (dict(partial=True), "bf16x3+sdpa", True), (dict(emb_nn="dgcnn"), "fp32", True),
+                                           (dict(emb_nn="pointnet"), "fp32", True), (dict(vcp_nn="dist", cycle=True), "fp32", True),
+                                           (dict(vcp_nn="att", cycle=True), "bf16x3", True), (dict(pointer="identity"), "fp32", True),
+                                           (dict(partial=True, _iters=3), "fp32", True), (dict(_iters=2, _n=2048, _b=4), "fp32", True)])
+def test_planned_and_flat_workspace_layouts_agree(kw, mode, merge):
+    """forward.hip overlays workspace buffers by hand-registered (first, last) launch numbers.  A lifetime one launch too short
+    lets a launch overwrite rows a later one still reads -- and test_workspace_contents_do_not_matter cannot see that (both of
+    its runs share the layout).  vcr_vcrnet_weights.workspace_flat gives every buffer its own memory: every output of every
+    path must be bit-identical between the two layouts (the 2048-point case takes the ordered kNN search, whose arrays live
+    in the embedding buffer until conv3)."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    kw = dict(kw)
+    iters, n, b = kw.pop("_iters", 1), kw.pop("_n", 384), kw.pop("_b", 2)     # (4 x 2048: enough query groups for the ordered search)
+    partial = bool(kw.get("partial"))
+    src, tgt, _, _, _ = synth.make_batch(78, b, n, partial=partial, kind="object" if n < 2048 else "uniform")
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    outs, sizes = [], []
+    for flat in (False, True):
+        net, _ = build_net(**kw)
+        net.linear_mode, net.merge_encdec, net.workspace_flat = mode, merge, flat
+        with torch.no_grad():
+            out = net._forward_fused(s, t, want_emb=iters == 1, iters=iters, want_selections=partial)
+        torch.cuda.synchronize()
+        sel = out[-1] if partial else {}
+        outs.append([o.clone() for o in out if torch.is_tensor(o)] + [sel[k_].clone() for k_ in sorted(sel)])
+        sizes.append(sum(b["ws"].numel() for idle in net._shared.pool.values() for b in idle))
+    assert sizes[1] > 1.3 * sizes[0], sizes                 # the flat layout really is another layout
+    assert len(outs[0]) == len(outs[1])
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), (i, (a.float() - b.float()).abs().max().item())
+
+
 def test_runs_on_the_callers_stream():
     """Every launch goes to the stream the caller is on (torch.cuda.current_stream()): the same results on a side
     stream, and nothing leaks onto the default stream (the output is only valid after the SIDE stream is waited on)."""

@@ -158,3 +158,32 @@ def test_every_pair_of_a_larger_set_is_within_tolerance():
         worst_R = max(worst_R, float((out[2].cpu() - ref[2]).abs().max()))
         worst_t = max(worst_t, float((out[3].cpu() - ref[3]).abs().max()))
     assert worst_R <= R_TOL and worst_t <= T_TOL, (worst_R, worst_t)
+
+
+@pytest.mark.gpu
+def test_pose_step_entry_point():
+    """vcr_pose_step_f32 (vcrnet_model.py:32-41, util/util.py:91-96): what the host-driven loops (DataParallel over several
+    device ids, vcrnetIcpNet) call between passes.  Against the same products in float64; inputs are left untouched."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native, synth
+    src, _, R_gt, t_gt, _ = synth.make_batch(300, 3, 200)
+    _, _, R2, t2, _ = synth.make_batch(400, 3, 200)
+    P, R, t = (torch.from_numpy(x).cuda() for x in (src, R_gt, t_gt))
+    Rn, tn = torch.from_numpy(R2).cuda(), torch.from_numpy(t2).cuda()
+    R0, t0 = R.clone(), t.clone()
+    moved, Rf, tf, Rba, tba = native.pose_step(R, t, P)
+    d = lambda a, b: float((a.double().cpu() - b).abs().max())
+    P64, R64, t64 = P.double().cpu(), R.double().cpu(), t.double().cpu()
+    assert d(moved, R64 @ P64 + t64[:, :, None]) < 1e-6
+    assert torch.equal(Rf, R) and torch.equal(tf, t)
+    assert d(Rba, R64.transpose(1, 2)) == 0.0 and d(tba, -(R64.transpose(1, 2) @ t64[:, :, None])[:, :, 0]) < 1e-6
+    moved2, Rf2, tf2, Rba2, tba2 = native.pose_step(Rn, tn, moved, Rf, tf)
+    Rc = Rn.double().cpu() @ R64
+    tc = (Rn.double().cpu() @ t64[:, :, None])[:, :, 0] + tn.double().cpu()
+    assert d(Rf2, Rc) < 1e-6 and d(tf2, tc) < 1e-6
+    assert d(Rba2, Rc.transpose(1, 2)) < 1e-6 and d(tba2, -(Rc.transpose(1, 2) @ tc[:, :, None])[:, :, 0]) < 1e-6
+    assert d(moved2, Rn.double().cpu() @ moved.double().cpu() + tn.double().cpu()[:, :, None]) < 1e-6
+    assert torch.equal(R, R0) and torch.equal(t, t0) and torch.equal(Rf, R0)      # nothing modified in place
+    # composition only (vcrnetIcpNet's use): no cloud
+    none, Rf3, tf3, _, _ = native.pose_step(Rn, tn, None, R, t)
+    assert none is None and torch.equal(Rf3, Rf2) and torch.equal(tf3, tf2)

@@ -14,20 +14,47 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define VCR_LAUNCH_RC() ((int)hipGetLastError())
 
+// Args structs that grow with the ABI carry a leading `struct_bytes` (ABI 27): the entry point works on a zero-filled copy of
+// what the caller really passed, so a caller built against an older, shorter header is served (its missing tail = "not
+// given") and a struct that does not say its size, or says more than this build knows, is refused instead of over-read.
+#include <string.h>
+template <class T>
+static inline int vcr_take_args(const T* user, T* mine, size_t mandatory_bytes) {
+  if (!user) return VCR_EINVAL;
+  const size_t n = user->struct_bytes;
+  if (n < mandatory_bytes || n > sizeof(T)) return VCR_EINVAL;
+  memset((void*)mine, 0, sizeof(T));
+  memcpy((void*)mine, (const void*)user, n);
+  mine->struct_bytes = (uint32_t)sizeof(T);
+  return VCR_OK;
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is sticky per (kernel, device): raise it when a launch needs more than
 // any earlier launch on that device did, not on every launch.  The cache is a per-call-site static of atomics (a
 // monotone maximum), so the entry points stay re-entrant: two threads may both issue the same idempotent
 // hipFuncSetAttribute, neither can lower the limit.
 struct vcr_lds_cache { std::atomic<int> cur[16]; };
+// The device an entry point's stream belongs to (vcr_stream_scope below binds it for the duration of the call; -1 = none
+// bound: the thread's current device).
+inline int& vcr_bound_device() {
+  static thread_local int dev = -1;
+  return dev;
+}
+// The limit is raised ON THE DEVICE THE LAUNCH GOES TO: the stream's when the entry point bound one -- hipFuncSetAttribute
+// acts on the current device, so a stream of another device makes that device current for the one call.
 inline void vcr_raise_dyn_lds(const void* kernel, int bytes, vcr_lds_cache& c) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+  int cur = 0;
+  const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  const int dev = vcr_bound_device() >= 0 ? vcr_bound_device() : cur;
+  if (!have_cur || dev < 0 || dev >= 16) {
     (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     return;
   }
   int seen = c.cur[dev].load(std::memory_order_acquire);
   if (seen >= bytes) return;
+  if (dev != cur) (void)hipSetDevice(dev);
   (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (dev != cur) (void)hipSetDevice(cur);
   while (seen < bytes && !c.cur[dev].compare_exchange_weak(seen, bytes, std::memory_order_release)) {}
 }
 #define VCR_DYN_LDS(kernel, bytes)                                                   \
@@ -92,10 +119,6 @@ __device__ __forceinline__ void ln_row_moments(const float* sp, int nseg, int K,
 
 // CUs of the device the launch goes to: the STREAM's device when an entry point bound one (vcr_stream_scope: a caller may
 // pass a stream of a device that is not the thread's current one), else the current device.  Cached per device.
-inline int& vcr_bound_device() {
-  static thread_local int dev = -1;
-  return dev;
-}
 struct vcr_stream_scope {                                 // first statement of every entry point that sizes a grid by the CU count
   int saved;
   explicit vcr_stream_scope(vcr_stream_t s) : saved(vcr_bound_device()) {

@@ -26,9 +26,11 @@ struct Plan {
   Req r[MAXR];
   int n = 0;
   bool overflow = false;                                 // more requests than MAXR: carve() reports an impossible size
+  bool flat = false;                                     // vcr_vcrnet_weights.workspace_flat: nothing is overlaid
   template <class T> void want(T*& field, size_t count, int birth, int death) {
     field = nullptr;
     if (count == 0) return;
+    if (flat) { birth = 0; death = 1 << 30; }
     if (n >= MAXR) { overflow = true; return; }
     r[n++] = Req{reinterpret_cast<void**>(&field), (count * sizeof(T) + 255) & ~(size_t)255, birth, death, 0};
   }
@@ -91,8 +93,9 @@ inline int overlap_k1(int N, double o2) { return (int)((double)N * 0.84 * o2); }
 inline int overlap_k2(int N, double o2) { return (int)((double)overlap_k1(N, o2) * 0.52 * o2); }
 
 Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, double o2, int emb_kind, int xscore_limit_mb,
-         int merged) {
+         int merged, int flat) {
   Plan pl;
+  pl.flat = flat != 0;
   const size_t M = (size_t)2 * B * N;
   constexpr int END = 23;                                // (the last launch of a forward; vcrnetIter's state lives across forwards)
   Ws w{};
@@ -460,7 +463,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (!W->partial && (io->force_keys || io->force_sel_src || io->force_sel_tgt || io->force_argmax || io->force_pairs))
     return VCR_EINVAL;                                   // there is nothing discrete to force in whole mode
   if ((io->force_sel_src != nullptr) != (io->force_sel_tgt != nullptr)) return VCR_EINVAL;
-  Ws w = carve(workspace, B, N, k, E, F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W));
+  Ws w = carve(workspace, B, N, k, E, F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W), W->workspace_flat);
   if (ws_bytes < w.bytes) return VCR_EWORKSPACE;
   const int M1 = B * N, M2 = 2 * M1;
   Runner R{(hipStream_t)stream, tr};
@@ -487,7 +490,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
                             W->dgcnn.c1_bpq, 128, w.pq1 + (size_t)c * M1 * 128, 128, R.stream));
     }
     {
-      vcr_knn_args a3{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
+      vcr_knn_args a3{(uint32_t)sizeof(vcr_knn_args), w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
       a3.tie_work = w.tie_work; a3.tie_work_bytes = w.tie_work_each;
       R.knn("knn:xyz", a3, 1);
     }
@@ -550,8 +553,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   // The feature-space and the Cartesian kNN (lpdnet_model.py:113,129) are independent: one launch for both, and one
   // tie replay for both right before the first consumer of the indices.
   {
-    vcr_knn_args a64{w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2, W->knn_waves};
-    vcr_knn_args a3{w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
+    vcr_knn_args a64{(uint32_t)sizeof(vcr_knn_args), w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2, W->knn_waves};
+    vcr_knn_args a3{(uint32_t)sizeof(vcr_knn_args), w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
     a64.tie_work = w.tie_work; a3.tie_work = w.tie_work ? w.tie_work + w.tie_work_each : nullptr;
     a64.tie_work_bytes = a3.tie_work_bytes = w.tie_work_each;
     a64.xt = W->E >= 64 ? w.emb : nullptr;
@@ -793,29 +796,45 @@ __global__ __launch_bounds__(256) void pose_step_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights* W, int B, int N) {
-  if (!W || B <= 0 || N <= 0) return 0;
-  return carve(nullptr, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W)).bytes;
+// the part of vcr_vcrnet_weights every caller must pass: up to the first optional extension (fold_encdec_qkv)
+static int weights_take(const vcr_vcrnet_weights* user, vcr_vcrnet_weights* mine) {
+  return vcr_take_args(user, mine, offsetof(vcr_vcrnet_weights, fold_encdec_qkv));
 }
 
-extern "C" int vcr_vcrnet_pairs(const vcr_vcrnet_weights* W, int N) {
-  if (!W || N <= 0) return 0;
+extern "C" size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights* UW, int B, int N) {
+  vcr_vcrnet_weights Wn;
+  const vcr_vcrnet_weights* W = &Wn;
+  if (weights_take(UW, &Wn) || B <= 0 || N <= 0) return 0;
+  return carve(nullptr, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W), W->workspace_flat).bytes;
+}
+
+extern "C" int vcr_vcrnet_pairs(const vcr_vcrnet_weights* UW, int N) {
+  vcr_vcrnet_weights Wn;
+  const vcr_vcrnet_weights* W = &Wn;
+  if (weights_take(UW, &Wn) || N <= 0) return 0;
   return (W->partial && W->head_mode == 0) ? overlap_k2(N, W->overlap2) : N;
 }
 
-extern "C" int vcr_vcrnet_forward_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* ws, size_t bytes,
+extern "C" int vcr_vcrnet_forward_f32(const vcr_vcrnet_weights* UW, const vcr_vcrnet_io* io, void* ws, size_t bytes,
                                       vcr_stream_t stream) {
-  return forward_impl(W, io, ws, bytes, stream, nullptr);
+  vcr_vcrnet_weights Wn;
+  if (weights_take(UW, &Wn)) return VCR_EINVAL;
+  return forward_impl(&Wn, io, ws, bytes, stream, nullptr);
 }
 
-extern "C" int vcr_vcrnet_forward_traced_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* ws,
+extern "C" int vcr_vcrnet_forward_traced_f32(const vcr_vcrnet_weights* UW, const vcr_vcrnet_io* io, void* ws,
                                              size_t bytes, vcr_stream_t stream, vcr_trace* tr) {
+  vcr_vcrnet_weights Wn;
+  if (weights_take(UW, &Wn)) return VCR_EINVAL;
   if (tr) tr->count = 0;
-  return forward_impl(W, io, ws, bytes, stream, tr);
+  return forward_impl(&Wn, io, ws, bytes, stream, tr);
 }
 
-extern "C" int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, int iters, void* ws,
+extern "C" int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights* UW, const vcr_vcrnet_io* io, int iters, void* ws,
                                    size_t bytes, vcr_stream_t stream, vcr_trace* tr) {
+  vcr_vcrnet_weights Wn;
+  const vcr_vcrnet_weights* W = &Wn;
+  if (weights_take(UW, &Wn)) return VCR_EINVAL;
   if (!W || !io || iters < 1 || !io->R_ba || !io->t_ba) return VCR_EINVAL;
   if (tr) tr->count = 0;
   const int B = io->B, N = io->N;
@@ -833,7 +852,7 @@ extern "C" int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet
     R.finish();
     return lrc;
   }
-  const Ws w = carve(ws, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W));
+  const Ws w = carve(ws, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W), W->workspace_flat);
   if (bytes < w.bytes) return VCR_EWORKSPACE;
   const size_t nkeys = W->partial ? (size_t)2 * B * (int)((double)N * W->overlap2) : 0;
   const size_t nsel = W->partial ? (size_t)B * overlap_k1(N, W->overlap2) : 0;
@@ -865,6 +884,18 @@ extern "C" int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights* W, const vcr_vcrnet
   return VCR_OK;
 }
 
+extern "C" int vcr_pose_step_f32(const vcr_pose_step_args* a, vcr_stream_t stream) {
+  if (!a || !a->R_i || !a->t_i || a->B <= 0 || a->compose < 0 || a->compose > 2) return VCR_EINVAL;
+  if ((a->out_cf != nullptr) != (a->in_cf != nullptr) || (a->out_cf && a->N <= 0)) return VCR_EINVAL;
+  if (a->compose && (!a->R_ba || !a->t_ba)) return VCR_EINVAL;
+  if (a->compose == 1 && (!a->R_f || !a->t_f)) return VCR_EINVAL;
+  if (!a->compose && !a->out_cf) return VCR_OK;
+  const int gx = a->out_cf ? (a->N + 255) / 256 : 1;
+  hipLaunchKernelGGL(pose_step_kernel, dim3(gx, a->B), dim3(a->out_cf ? 256 : 64), 0, (hipStream_t)stream, a->R_i, a->t_i,
+                     a->in_cf, a->out_cf, a->N, a->compose, a->R_f, a->t_f, a->R_ba, a->t_ba);
+  return VCR_LAUNCH_RC();
+}
+
 extern "C" const char* vcr_strerror(int code) {
   switch (code) {
     case VCR_OK: return "ok";
@@ -875,7 +906,7 @@ extern "C" const char* vcr_strerror(int code) {
   }
 }
 
-extern "C" int vcr_abi_version(void) { return 26; }
+extern "C" int vcr_abi_version(void) { return VCR_ABI_VERSION; }
 
 // hipEvent helpers so a host language without HIP bindings can time launches on the SAME runtime
 // this library is bound to.

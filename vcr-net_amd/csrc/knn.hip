@@ -1494,8 +1494,16 @@ static bool tie_work_missing(const vcr_knn_args* a) {
   return a->tie_scratch && need && (!a->tie_work || a->tie_work_bytes < need || ((uintptr_t)a->tie_work & 15));
 }
 
-extern "C" int vcr_knn_ties_f32(const vcr_knn_args* a, const vcr_knn_args* b, vcr_stream_t stream) {
-  if (!a || !a->x || !a->idx || !a->tie_scratch || a->tie_cap < 1) return VCR_EINVAL;
+// the part of vcr_knn_args every caller must pass: through tie_cap (everything behind it is optional, zero = automatic)
+static int knn_take(const vcr_knn_args* user, vcr_knn_args* mine) {
+  return vcr_take_args(user, mine, offsetof(vcr_knn_args, waves));
+}
+
+extern "C" int vcr_knn_ties_f32(const vcr_knn_args* ua, const vcr_knn_args* ub, vcr_stream_t stream) {
+  vcr_knn_args na, nb;
+  if (knn_take(ua, &na) || (ub && knn_take(ub, &nb))) return VCR_EINVAL;
+  const vcr_knn_args *a = &na, *b = ub ? &nb : nullptr;
+  if (!a->x || !a->idx || !a->tie_scratch || a->tie_cap < 1) return VCR_EINVAL;
   if (b && (!b->x || !b->idx || !b->tie_scratch || b->tie_cap < 1)) return VCR_EINVAL;
   if (tie_work_missing(a) || (b && tie_work_missing(b))) return VCR_EUNSUPPORTED;
   const size_t la = tiebreak_launch_lds(a->N), lb = b ? tiebreak_launch_lds(b->N) : 0, lds = la > lb ? la : lb;
@@ -1540,8 +1548,10 @@ static bool ties_inline(const vcr_knn_args* a) {
 static size_t knn_lds_bytes(const vcr_knn_args* a, bool inl) {
   return inl ? inline_tie_offset(knn_log_bytes(a), a->N) + (1 + BLK_TIES) * 4 : knn_log_bytes(a);
 }
-extern "C" int vcr_knn_ties_inline(const vcr_knn_args* a) {
-  return (a && a->x && a->idx && a->B > 0 && a->N > 0 && a->k > 0 && a->k <= 62 && (a->C == 64 || a->C == 4) && ties_inline(a)) ? 1 : 0;
+extern "C" int vcr_knn_ties_inline(const vcr_knn_args* ua) {
+  vcr_knn_args na;
+  const vcr_knn_args* a = &na;
+  return (knn_take(ua, &na) == 0 && a->x && a->idx && a->B > 0 && a->N > 0 && a->k > 0 && a->k <= 62 && (a->C == 64 || a->C == 4) && ties_inline(a)) ? 1 : 0;
 }
 
 // Feature-space (a64: C == 64) and Cartesian (a3: C == 4) kNN of the same pass as one launch (see knn_pair_kernel) when
@@ -1549,12 +1559,18 @@ extern "C" int vcr_knn_ties_inline(const vcr_knn_args* a) {
 // simply makes the two self-contained calls.  Tie handling as in vcr_knn_f32 (tie_defer honoured; a
 // replay that is not deferred serves both launches at once).
 // the ordered search's inputs are all there and the cloud is small enough for the wave's tile mask (256 tiles of 16 ranks)
+// (vcr_knn_order_f32 writes the ranked rows and the centroids at pitch C: a padded x keeps the plain scan)
 static bool knn_ordered(const vcr_knn_args* a) {
   return a->perm && a->xp && a->cen && a->cen_rad && a->cen_sqmax && (a->C == 4 || (a->sqp && a->cen_sq)) && a->N <= 4096 &&
+         a->ldx == a->C &&
          !(((uintptr_t)a->xp | (uintptr_t)a->cen) & 15);
 }
-extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3, vcr_stream_t stream) {
-  if (!a64 || !a3 || !a64->x || !a3->x || !a64->idx || !a3->idx || a64->C != 64 || a3->C != 4) return VCR_EINVAL;
+extern "C" int vcr_knn_pair_f32(const vcr_knn_args* u64, const vcr_knn_args* u3, vcr_stream_t stream) {
+  vcr_knn_args n64_, n3_;
+  if (knn_take(u64, &n64_) || knn_take(u3, &n3_)) return VCR_EINVAL;
+  const vcr_knn_args *a64 = &n64_, *a3 = &n3_;
+  vcr_stream_scope scope_(stream);
+  if (!a64->x || !a3->x || !a64->idx || !a3->idx || a64->C != 64 || a3->C != 4) return VCR_EINVAL;
   const bool col16 = use_col16(a64);
   const bool fusable = a64->k == a3->k && (a64->k <= 20 || (col16 && a64->k <= 40)) &&      // (k > 20: the 16-query bodies only)
                        (a64->waves == 0 || a64->waves == 1 || a64->waves == 8) && a3->waves == 0 &&
@@ -1634,8 +1650,12 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* a64, const vcr_knn_args* a3,
   return rc;
 }
 
-extern "C" int vcr_knn_f32(const vcr_knn_args* a, vcr_stream_t stream) {
-  if (!a || !a->x || !a->idx) return VCR_EINVAL;
+extern "C" int vcr_knn_f32(const vcr_knn_args* ua, vcr_stream_t stream) {
+  vcr_knn_args na;
+  if (knn_take(ua, &na)) return VCR_EINVAL;
+  const vcr_knn_args* a = &na;
+  vcr_stream_scope scope_(stream);
+  if (!a->x || !a->idx) return VCR_EINVAL;
   if (a->B <= 0 || a->N <= 0 || a->k <= 0 || a->k + 1 > a->N) return VCR_EINVAL;
   if (a->k > 62 || a->N > KNN_MAX_N || knn_rows_overflow(a)) return VCR_EUNSUPPORTED;   // limits of this library, not of the operation (see vcr_hip.h):
                                                             // the tie replay keeps topk(k + 1)'s heap in the 64 lanes of a wave

@@ -252,6 +252,7 @@ class VCRNet(nn.Module):
         # enc.qkv + dec.qkv as one GEMM and the two self-attentions as one grouped launch (fp32 mode; same arithmetic)
         self.merge_encdec = os.environ.get("VCRNET_MERGE_ENCDEC", "1") == "1"
         self.xscore_limit_mb = 0            # partial mode: keep the cross-attention scores up to this many MiB (0 = 4096)
+        self.workspace_flat = False         # tests: no two workspace buffers share memory (vcr_vcrnet_weights.workspace_flat)
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
         self._cw: Optional[native.VcrnetWeights] = None
@@ -312,7 +313,7 @@ class VCRNet(nn.Module):
         dev = self._device()
         return (dev, ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]), self.emb_nn.k,
                 self.linear_mode, self.linear_mfma, self.linear_bk, self.linear_bm, self.knn_waves, self.xscore_limit_mb,
-                self.merge_encdec)
+                self.merge_encdec, bool(self.workspace_flat))
 
     def _pack(self):
         """Packed weights for this device and these parameter versions, shared with every replica / thread.  The packing
@@ -475,6 +476,7 @@ class VCRNet(nn.Module):
         cw.linear_mfma, cw.linear_bk, cw.linear_bm = int(self.linear_mfma), int(self.linear_bk), int(self.linear_bm)
         cw.knn_waves = int(self.knn_waves)
         cw.xscore_limit_mb = int(self.xscore_limit_mb)
+        cw.workspace_flat = int(bool(self.workspace_flat))
         cw.partial, cw.overlap2 = int(self._partial), self._overlap2
         self._packed, self._packed_key = P, key
         self._cw = cw
@@ -484,7 +486,7 @@ class VCRNet(nn.Module):
         threads, DataParallel replicas -- never share one; _give_buffers returns it with the stream it was used on."""
         sh = self._shared
         key = (B, N, device, int(self.emb_nn.k), int(self.xscore_limit_mb), bool(self.merge_encdec), self.linear_mode,
-               self._emb_kind, self._vcp, self._partial, self._overlap2)
+               self._emb_kind, self._vcp, self._partial, self._overlap2, bool(self.workspace_flat))
         with sh.lock:
             idle = sh.pool.get(key)
             if idle:
@@ -693,12 +695,9 @@ def vcrnetIcpNet(args, net, src, tgt):
     """model/vcrnet_model.py:46-62 (--iter 0): one network pass, ICP on the moved source, poses composed."""
     icp = ICP(max_iterations=args.max_iterations)
     _, _, R, t, _, _ = net(src, tgt)
-    moved = torch.matmul(R, src) + t.unsqueeze(2)
+    moved = native.pose_step(R, t, src)[0]                                 # transform_point_cloud, util/util.py:91-96
     _, _, Ri, ti, _, _ = icp(moved, tgt)
-    R2 = torch.matmul(Ri, R)                                               # :55
-    t2 = torch.matmul(Ri, t.unsqueeze(2)).squeeze(2) + ti                  # :56-57
-    R_ba = R2.transpose(2, 1).contiguous()
-    t_ba = -torch.matmul(R_ba, t2.unsqueeze(2)).squeeze(2)
+    _, R2, t2, R_ba, t_ba = native.pose_step(Ri, ti, None, R, t)           # :55-59: R_i R, R_i t + t_i and its inverse
     return moved, tgt, R2, t2, R_ba, t_ba
 
 
@@ -722,12 +721,6 @@ def vcrnetIter(net, src, tgt, iter=1):
     R_f = t_f = None
     for _ in range(iter):
         srcK, corrK, R, t, _, _ = net(cur, tgt)
-        cur = torch.matmul(R, cur) + t.unsqueeze(2)                        # util/util.py:91-96
-        if R_f is None:
-            R_f, t_f = R.detach(), t.detach()
-        else:
-            R_f = torch.matmul(R.detach(), R_f)                            # :35
-            t_f = torch.matmul(R.detach(), t_f.unsqueeze(2)).squeeze(2) + t.detach()   # :36-38
-    R_ba = R_f.transpose(2, 1).contiguous()
-    t_ba = -torch.matmul(R_ba, t_f.unsqueeze(2)).squeeze(2)
+        # util/util.py:91-96 and vcrnet_model.py:35-41 as one vcr_pose_step_f32 launch (the device loop's own kernel)
+        cur, R_f, t_f, R_ba, t_ba = native.pose_step(R.detach(), t.detach(), cur, R_f, t_f)
     return srcK, corrK, R_f, t_f, R_ba, t_ba

@@ -25,8 +25,16 @@ class PointwiseArgs(C.Structure):
                 ("pq_w", f32p), ("pq_b", f32p), ("pq", f32p), ("ldpq", C.c_int), ("feat64t", f32p)]
 
 
-class KnnArgs(C.Structure):
-    _fields_ = [("x", f32p), ("ldx", C.c_int), ("sq", f32p), ("B", C.c_int), ("N", C.c_int), ("C", C.c_int),
+class _Sized(C.Structure):
+    """Args structs with a leading `struct_bytes` (ABI 27): set on construction, positional arguments start at the field
+    behind it -- KnnArgs(x, ldx, ...) reads as before."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
+
+
+class KnnArgs(_Sized):
+    _fields_ = [("struct_bytes", C.c_uint32), ("x", f32p), ("ldx", C.c_int), ("sq", f32p), ("B", C.c_int), ("N", C.c_int), ("C", C.c_int),
                 ("k", C.c_int), ("idx", f32p), ("tie_scratch", f32p), ("tie_cap", C.c_int), ("waves", C.c_int),
                 ("tie_zeroed", C.c_int),
                 ("tie_defer", C.c_int), ("tie_work", C.c_void_p), ("tie_work_bytes", C.c_size_t), ("tie_inline", C.c_int),
@@ -179,8 +187,8 @@ class PointnetW(C.Structure):
     _fields_ = [(n, f32p) for n in ("c3_w", "c3_b", "c4_w", "c4_b", "c5_w", "c5_b")]
 
 
-class VcrnetWeights(C.Structure):
-    _fields_ = [("c1_w", f32p), ("c1_b", f32p), ("c2_w", f32p), ("c2_b", f32p),
+class VcrnetWeights(_Sized):
+    _fields_ = [("struct_bytes", C.c_uint32), ("c1_w", f32p), ("c1_b", f32p), ("c2_w", f32p), ("c2_b", f32p),
                 ("dg1_wpq", f32p), ("dg1_bpq", f32p), ("dg2_w", f32p), ("dg2_b", f32p),
                 ("sn1_wpq", f32p), ("sn1_bpq", f32p), ("c3_w", f32p), ("c3_b", f32p),
                 ("enc_ln0", NormW), ("enc_ln1", NormW), ("enc_norm", NormW), ("dec_ln0", NormW),
@@ -195,7 +203,7 @@ class VcrnetWeights(C.Structure):
                 ("partial", C.c_int), ("overlap2", C.c_double), ("emb_kind", C.c_int), ("dgcnn", DgcnnW), ("pointnet", PointnetW),
                 ("att_w0", f32p), ("att_b0", f32p), ("att_w1", f32p), ("att_b1", f32p), ("cycle", C.c_int),
                 ("linear_mfma", C.c_int), ("linear_bk", C.c_int), ("linear_bm", C.c_int), ("knn_waves", C.c_int),
-                ("xscore_limit_mb", C.c_int)]
+                ("xscore_limit_mb", C.c_int), ("workspace_flat", C.c_int)]
 
 
 class VcrnetIo(C.Structure):
@@ -226,7 +234,7 @@ _SIGS = {
 _lib: Optional[C.CDLL] = None
 
 
-ABI_VERSION = 26         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
+ABI_VERSION = 27         # include/vcr_hip.h vcr_abi_version(); the ctypes structs below mirror that header
 
 
 class VcrHipError(RuntimeError):
@@ -745,6 +753,34 @@ def icp(src_cf, dst_cf, max_iterations=10, tolerance=0.001):
                 ptr(tb), ptr(iters))
     check(L.vcr_icp_f32(C.byref(a), C.c_void_p(ws.data_ptr() + off), nbytes, C.c_void_p(stream_ptr())), "vcr_icp_f32")
     return final4[:, :, :3].transpose(1, 2).contiguous(), R, t, Rb, tb, iters
+
+
+class PoseStepArgs(C.Structure):
+    _fields_ = [("R_i", f32p), ("t_i", f32p), ("B", C.c_int), ("N", C.c_int), ("in_cf", f32p), ("out_cf", f32p),
+                ("compose", C.c_int), ("R_f", f32p), ("t_f", f32p), ("R_ba", f32p), ("t_ba", f32p)]
+
+
+@_guarded
+def pose_step(R_i, t_i, cloud=None, R_f=None, t_f=None):
+    """vcr_pose_step_f32: one step of vcrnetIter's bookkeeping (vcrnet_model.py:32-38).  cloud [B,3,N] -> the moved cloud
+    R_i cloud + t_i (util/util.py:91-96).  With (R_f, t_f) the composed pose so far: they are REPLACED by (R_i R_f,
+    R_i t_f + t_i) (new tensors; the inputs are not modified) and (R_ba, t_ba) is the inverse of the composition; without
+    them the composition is (R_i, t_i) itself.  Returns (moved or None, R_f, t_f, R_ba, t_ba)."""
+    B = R_i.shape[0]
+    dev = R_i.device
+    R_i, t_i = R_i.contiguous().float(), t_i.contiguous().float()
+    moved = None
+    if cloud is not None:
+        cloud = cloud.contiguous().float()
+        moved = torch.empty_like(cloud)
+    if R_f is not None:
+        R_f, t_f = R_f.contiguous().float().clone(), t_f.contiguous().float().clone()
+    R_ba, t_ba = _f32(B, 3, 3, device=dev), _f32(B, 3, device=dev)
+    call("vcr_pose_step_f32", PoseStepArgs(ptr(R_i), ptr(t_i), B, cloud.shape[2] if cloud is not None else 0, ptr(cloud),
+                                           ptr(moved), 1 if R_f is not None else 2, ptr(R_f), ptr(t_f), ptr(R_ba), ptr(t_ba)))
+    if R_f is None:
+        R_f, t_f = R_i, t_i
+    return moved, R_f, t_f, R_ba, t_ba
 
 
 @_guarded
