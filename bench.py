@@ -57,6 +57,10 @@ def parse(argv=None):
     ap.add_argument("--iters", type=int, default=1, help="vcrnetIter refinement passes per step (one C call)")
     ap.add_argument("--emb-nn", default="lpdnet", choices=["lpdnet", "dgcnn", "pointnet"],
                     help="feature extractor (--emb_nn of the reference; dgcnn / pointnet use seeded weights)")
+    ap.add_argument("--regime", default="default", choices=["default", "seed4321", "trained", "randemb"],
+                    help="point in weight space (vcrnet_amd.weights.regime_weights; lpdnet only): default = seed 1234 + the "
+                         "LPD-pretrained emb_nn (the headline), randemb = a random feature extractor -- what the ordered kNN "
+                         "search's per-cloud guard must cope with")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=100.0,
                     help="wall-clock budget of the CPU-baseline thread sweep (each thread count: one warm-up, then up "
@@ -230,6 +234,59 @@ def cpu_baseline(w, B, N, k, partial=False, iters=1, budget_s=100.0, full=False,
                       f"best = {best} threads of os.cpu_count()={ncpu}"}
 
 
+def parity_ledger(mode):
+    """The accuracy trade the throughput is bought with, next to it: profiles/accuracy_ledger.txt (written by
+    tests/test_hip_ledger.py on the GPU box) holds, per weight regime and fixture, the error of the HIP path AND of the
+    fp32 reference against the reference's float64 twin.  Condensed for this run's arithmetic mode: the ratio HIP error /
+    reference's own error of the final embeddings (rms) per whole-mode fixture, the worst pose errors, and the discrete
+    selections of the partial path that differ from the twin's (HIP vs the fp32 reference).  A ratio of 1 = as accurate as
+    ATen's fp32; the linears' single 512-step accumulation chain (LINEAR_BLOCKED_ACC = 0, csrc/linear.hip) is what
+    puts the embeddings above 1 -- the blocked variant measures 1.0x at -1.6 % of the headline."""
+    import hashlib
+    import re
+    path = os.path.join(ROOT, "profiles", "accuracy_ledger.txt")
+    try:
+        raw = open(path, "rb").read()
+    except OSError:
+        return None
+    from vcrnet_amd import build as vb
+    whole, flips = {}, {"hip": [0, 0, 0], "ref32": [0, 0, 0], "hip_vs_ref32": [0, 0, 0]}
+    taken_on = None
+    num = r"([0-9.eE+-]+)"
+    for ln in raw.decode(errors="replace").splitlines():
+        m = re.match(r"# kernel_sources_sha16=(\w+)", ln)
+        if m:
+            taken_on = m.group(1)
+            continue
+        f = ln.split("|")
+        head = f[0].split()
+        if len(head) >= 4 and head[0] == "whole" and head[3] == mode:
+            R = re.search(f"hip {num} ref32 {num}", f[1]); t = re.search(f"hip {num} ref32 {num}", f[2])
+            e = re.search(f"hip {num}/{num} ref32 {num}/{num}", f[3])
+            whole[f"{head[1]}/{head[2]}"] = {
+                "emb_rms_hip_over_ref32": round(float(e.group(2)) / float(e.group(4)), 3),
+                "R_err_hip": float(R.group(1)), "R_err_ref32": float(R.group(2)),
+                "t_err_hip": float(t.group(1)), "t_err_ref32": float(t.group(2))}
+        elif len(head) >= 5 and head[0] == "partial" and head[4] == mode:
+            m = re.search(r"hip (\d+)/(\d+)/(\d+)\s+ref32 (\d+)/(\d+)/(\d+)", f[1])
+            v = re.search(r"hip vs ref32 (\d+)/(\d+)/(\d+)", f[2])
+            for i in range(3):
+                flips["hip"][i] += int(m.group(1 + i)); flips["ref32"][i] += int(m.group(4 + i))
+                flips["hip_vs_ref32"][i] += int(v.group(1 + i))
+    if not whole:
+        return None
+    ratios = [v["emb_rms_hip_over_ref32"] for v in whole.values()]
+    return {"source": "profiles/accuracy_ledger.txt", "source_sha16": hashlib.sha256(raw).hexdigest()[:16],
+            "ledger_kernel_sources": taken_on or "(unrecorded: a ledger of round 5)",
+            "this_build_kernel_sources": vb.sources_sha16(), "arithmetic": mode,
+            "yardstick": "the reference model in float64 on the same weights and inputs (tests/golden/*_twin.npz)",
+            "emb_rms_hip_over_ref32": {"worst": max(ratios), "median": float(np.median(ratios)), "by_fixture": whole},
+            "worst_R_err": {"hip": max(v["R_err_hip"] for v in whole.values()), "ref32": max(v["R_err_ref32"] for v in whole.values())},
+            "worst_t_err": {"hip": max(v["t_err_hip"] for v in whole.values()), "ref32": max(v["t_err_ref32"] for v in whole.values())},
+            "partial_selection_flips_vs_twin_keys_overlap_pairs": flips,
+            "linear_accumulation": "one k-ascending chain per output (LINEAR_BLOCKED_ACC = 0); blocked: 1.0x at -1.6 %, BK 32 only: 1.10x at -0.9 %"}
+
+
 def workload_label(a, Nfull, N, B, kind, world=1):
     if a.partial:
         base = ("BASELINE configs[2]" if (Nfull, B, a.iters) == (1024, 24, 3) else "partial-overlap (configs[2] recipe)") + \
@@ -246,6 +303,8 @@ def workload_label(a, Nfull, N, B, kind, world=1):
         " with the reference's transform recipe"
     emb = {"lpdnet": "LPDNet", "dgcnn": "DGCNN", "pointnet": "PointNet"}[a.emb_nn]
     wts = "LPD-pretrained emb_nn + seeded Transformer weights" if a.emb_nn == "lpdnet" else "seeded weights"
+    if a.emb_nn == "lpdnet" and a.regime != "default":
+        wts = f"weight regime '{a.regime}' (vcrnet_amd.weights.regime_weights)"
     return base + "N=%d, batch=%d pairs per GPU, %s(k=%d)+Transformer+VcpTopK+SVD, iter=%d, fp32; %s; %s" % (
         N, B, emb, a.k, a.iters, clouds, wts)
 
@@ -328,7 +387,7 @@ def measure(a, ctx, min_seconds):
     from vcrnet_amd import native, shard, synth, weights, workmodel
     from vcrnet_amd.module import VCRNet, vcrnetIter
 
-    w = (weights.generate_weights(1234, lpd=weights.load_lpd_fixture()) if a.emb_nn == "lpdnet"
+    w = (weights.regime_weights(a.regime, lpd=weights.load_lpd_fixture()) if a.emb_nn == "lpdnet"
          else weights.generate_weights(1234, emb_nn=a.emb_nn))
     net = VCRNet(model_args(a.partial, a.emb_nn))
     net.load_state_dict(w)
@@ -376,7 +435,9 @@ def measure(a, ctx, min_seconds):
     torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
-    traced_steps = list(range(0, a.steps, max(1, a.trace_every)))      # steps of a block that carry per-launch events
+    # steps of a block that carry per-launch events -- never the first ones behind the fence (the queue is empty there and
+    # the device may have idled: a traced step must look like every other step of the block)
+    traced_steps = list(range(min(2, a.steps - 1), a.steps, max(1, a.trace_every)))
     traces = {i: native.LaunchTrace() for i in traced_steps}
     nt = len(traced_steps)
 
@@ -572,6 +633,10 @@ def measure(a, ctx, min_seconds):
                              "per_launch_events": f"steps {traced_steps} of every block (a step that carries the ~35 event "
                                                   "records runs ~2 % longer: the stage times sum to that step, not to ms_per_step)"},
             "roofline": roof,
+            # the traced launches' HIP-event durations, summed, over the timed block's ms_per_step: what share of a step the
+            # launch table explains.  Below ~0.97 the steps are not back-to-back kernels (host-bound enqueue, idle gaps) or
+            # traced steps run at another clock than untraced ones -- the per-launch rates then overstate the steady state
+            "accounted_frac": (total_ms / nt) / (elapsed / a.steps * 1e3),
             "stages": stages,
             "flops_per_pair_reference": workmodel.reference_flops_per_pair(N, a.k)["total"],
         }
@@ -595,7 +660,7 @@ OTHER_CONFIGS = [
 
 def is_headline(a):
     d = parse([])
-    return all(getattr(a, k) == getattr(d, k) for k in ("gpus", "batch", "points", "k", "partial", "iters", "emb_nn", "strong",
+    return all(getattr(a, k) == getattr(d, k) for k in ("gpus", "batch", "points", "k", "partial", "iters", "emb_nn", "strong", "regime",
                                                         "linear_mode", "linear_mfma", "linear_bk", "linear_bm", "knn_waves",
                                                         "no_merge_encdec"))
 
@@ -622,11 +687,13 @@ def run_rank(a):
                                "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
                                "timed_blocks": o["timed_blocks"]["count"], "dtype": o["dtype"],
                                "roofline": {k_: r[k_] for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac")},
+                               "accounted_frac": o["accounted_frac"],
                                "knn_edgeconv_stage": {k_: o["knn_edgeconv_stage"][k_] for k_ in
                                                       ("ms_per_step", "hbm_frac", "achieved_gbs", "knn_ms_per_step")},
                                "wall_s": round(time.perf_counter() - t0, 2)})
                 torch.cuda.empty_cache()
             line["other_configs"] = others
+        line["parity_ledger"] = parity_ledger(a.linear_mode)
         if ctx.world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, B, Nfull, a.k, a.partial, a.iters, a.cpu_budget_s, a.cpu_baseline_full)
         os.write(ctx.json_fd, (json.dumps(line) + "\n").encode())

@@ -116,6 +116,10 @@ typedef struct {
    * boundary-tie rules included: indices are translated back before they are applied).  Ranked clouds up to 4096 points. */
   const int32_t* perm; const float* xp; const float* sqp;
   const float* cen; const float* cen_sq; const float* cen_rad; const float* cen_sqmax;
+  /* Optional, with perm: ord_ok[b] == 0 sends cloud b's search over the plain scan although it is ranked (vcr_knn_order_args.ord_ok:
+   * the ranking's own verdict on whether this cloud's rows are compact enough along the curve for the pruning to pay).  Decided on
+   * the device, cloud by cloud; the neighbour sets do not depend on it. */
+  const int32_t* ord_ok;
 } vcr_knn_args;
 
 /* Ranks the points of every cloud along a Morton curve of their coordinates and writes what the ordered search reads
@@ -128,6 +132,12 @@ typedef struct {
   int B, N;
   int32_t* perm; float* xyz4_p; float* cen4; float* cen4_rad; float* cen4_sqmax;
   float* feat_p; float* sq_p; float* cen64; float* cen64_sq; float* cen64_rad; float* cen64_sqmax;
+  /* Optional guard of the FEATURE-space search (needs feat_t): the ordered search assumes that the features are a smooth function of
+   * the coordinates, so that 16 Morton neighbours are close in feature space too.  Per cloud, ord_stat[b] = mean squared tile radius /
+   * mean squared distance of the tile centroids from their mean (small: compact tiles far apart -- the pruning pays; unrelated
+   * features: ~30), and ord_ok[b] = ord_stat[b] < guard_ratio (0 = the library's threshold, from measurement: profiles/NOTES.md).
+   * Hand ord_ok to vcr_knn_args.ord_ok.  Costs one small launch; never changes a result. */
+  int32_t* ord_ok; float* ord_stat; float guard_ratio;
 } vcr_knn_order_args;
 int vcr_knn_order_f32(const vcr_knn_order_args*, vcr_stream_t);
 int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);

@@ -775,6 +775,49 @@ def test_knn_ordered_search_keeps_the_sets(nat, B, N, k, kind):
         assert torch.equal(torch.sort(plain, -1).values, torch.sort(ordered, -1).values)
 
 
+def _smooth_and_unrelated(B, N, seed, mix=None):
+    rs = np.random.RandomState(seed)
+    xyz = rs.rand(B, N, 3).astype(np.float32) - 0.5
+    w1, w2 = rs.randn(3, 64).astype(np.float32) * 0.8, rs.randn(64, 64).astype(np.float32) * 0.2
+    feat = np.maximum(np.maximum(xyz @ w1 + 0.1, 0) @ w2 + 0.05, 0)
+    rnd = np.maximum(rs.randn(B, N, 64).astype(np.float32), 0)
+    if mix is not None:                                    # clouds listed in `mix` get features unrelated to their coordinates
+        for b in mix:
+            feat[b] = rnd[b]
+    feat = dev(torch.from_numpy(np.ascontiguousarray(feat)))
+    x4 = dev(torch.from_numpy(np.concatenate((xyz, (xyz ** 2).sum(-1, keepdims=True)), -1).astype(np.float32)))
+    sq = (feat ** 2).sum(-1).contiguous()
+    ft = feat.view(B, N, 4, 4, 4).transpose(3, 4).reshape(B, N, 64).contiguous()
+    return feat, sq, x4, ft
+
+
+@pytest.mark.parametrize("N,k", [(2048, 20), (4096, 40)])
+def test_ordered_knn_guard_fires_on_unrelated_features_and_changes_no_bit(nat, N, k):
+    """vcr_knn_order_args.ord_ok: the ranking judges, cloud by cloud, whether 16 Morton neighbours are compact in FEATURE space
+    (mean squared tile radius against the spread of the tile centroids).  Smooth features (a function of the coordinates, as the
+    stem's are) pass; features unrelated to the coordinates fail and those clouds take the plain scan inside the same launch
+    -- a batch may mix both.  Whatever the verdict, every row's neighbour set is the plain search's."""
+    B = 16
+    bad = [1, 2, 7, 15]
+    feat, sq, x4, ft = _smooth_and_unrelated(B, N, 5 * N + k, mix=bad)
+    order = nat.knn_order(x4, ft, sq, guard=True)
+    ok, stat = order["ord_ok"].cpu().numpy(), order["ord_stat"].cpu().numpy()
+    print(f"N={N}: ord_stat smooth {stat[[b for b in range(B) if b not in bad]].max():.3g} (max), unrelated {stat[bad].min():.3g} (min)")
+    assert [b for b in range(B) if not ok[b]] == bad, (ok, stat)
+    assert stat[bad].min() > 10 * stat[[b for b in range(B) if b not in bad]].max()       # the two populations are far apart
+    a0, b0 = nat.knn_pair(feat, sq, x4, k, xt=ft)
+    a1, b1 = nat.knn_pair(feat, sq, x4, k, xt=ft, order=order)                             # guarded
+    ung = dict(order); ung.pop("ord_ok")
+    a2, b2 = nat.knn_pair(feat, sq, x4, k, xt=ft, order=ung)                               # every cloud ordered
+    for plain, other in ((a0, a1), (b0, b1), (a0, a2), (b0, b2)):
+        assert torch.equal(torch.sort(plain, -1).values, torch.sort(other, -1).values)
+    # a forced verdict (all clouds refused / all accepted) is honoured and changes nothing either
+    for v in (0, 1):
+        forced = dict(order); forced["ord_ok"] = torch.full_like(order["ord_ok"], v)
+        a3, b3 = nat.knn_pair(feat, sq, x4, k, xt=ft, order=forced)
+        assert torch.equal(torch.sort(a0, -1).values, torch.sort(a3, -1).values) and torch.equal(torch.sort(b0, -1).values, torch.sort(b3, -1).values)
+
+
 def test_knn_deferred_tie_replay_for_two_launches(nat):
     """vcr_knn_args.tie_defer + vcr_knn_ties_f32: the Cartesian and the feature-space launch list their tied rows, one
     replay launch serves both -- the same indices as two self-contained calls, on inputs built to tie massively."""

@@ -35,7 +35,13 @@ def _emit(line):
     LEDGER.append(line)
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
-        with open(os.path.join(out, "accuracy_ledger.txt"), "a") as f:
+        path = os.path.join(out, "accuracy_ledger.txt")
+        if len(LEDGER) == 1:                                 # a new table: which kernel sources it measures (bench.py's
+            import vcrnet_amd  # noqa: F401                  # `parity_ledger` quotes this hash next to the ratios)
+            from vcrnet_amd import build as vb
+            with open(path, "w") as f:
+                f.write(f"# kernel_sources_sha16={vb.sources_sha16()}\n")
+        with open(path, "a") as f:
             f.write(line + "\n")
 
 

@@ -573,12 +573,14 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       float* sq_p = base;                   base += m;
       int32_t* perm = reinterpret_cast<int32_t*>(base);   base += m;
       float* c64_sq = base;  base += mt;  float* c64_rad = base;  base += mt;  float* c64_max = base;  base += mt;
-      float* c4_rad = base;  base += mt;  float* c4_max = base;
+      float* c4_rad = base;  base += mt;  float* c4_max = base;  base += mt;
+      int32_t* ord_ok = reinterpret_cast<int32_t*>(base);                  // the ranking's per-cloud verdict on the feature tiles
       R.mark("knn:rank");
       vcr_knn_order_args o{w.xyz4, w.emb, 64, w.sq64, 2 * B, N, perm, xyz4_p, cen4, c4_rad, c4_max, feat_p, sq_p, cen64, c64_sq,
-                           c64_rad, c64_max};
+                           c64_rad, c64_max, ord_ok, nullptr, 0.f};
       R.ok(vcr_knn_order_f32(&o, R.stream));
       a64.perm = a3.perm = perm;
+      a64.ord_ok = ord_ok;
       a64.xp = feat_p; a64.sqp = sq_p; a64.cen = cen64; a64.cen_sq = c64_sq; a64.cen_rad = c64_rad; a64.cen_sqmax = c64_max;
       a3.xp = xyz4_p; a3.cen = cen4; a3.cen_rad = c4_rad; a3.cen_sqmax = c4_max;
     }

@@ -618,7 +618,8 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   float* lv = reinterpret_cast<float*>(smem) + wave * (2 * LROWS * 16);
   Selector<G, KS> sel;
   // (ORD: the rows in rank order -- vcr_knn_args.xp / sqp; everything below then counts ranks, finish() translates)
-  const bool ord = ORD && a.perm != nullptr;             // (an ORD launch may still run ONE of its two searches the plain way)
+  // (an ORD launch may still run ONE of its two searches the plain way -- or single clouds of one: vcr_knn_args.ord_ok)
+  const bool ord = ORD && a.perm != nullptr && (C != 64 || !a.ord_ok || a.ord_ok[b] != 0);
   const float* xb = (ord ? a.xp : a.x) + (size_t)b * a.N * a.ldx;
   // (C == 64) rows whose 16-channel groups are stored transposed (vcr_knn_args.xt): lane row q4's chunks 4 g + q4 are its
   // operands of steps 4 g .. 4 g + 3 as they lie -- same addresses, no shuffles

@@ -182,6 +182,37 @@ __global__ __launch_bounds__(256) void knn_rank_rows_kernel(vcr_knn_order_args a
   }
 }
 
+// The guard of the feature-space search (vcr_knn_order_args.ord_ok): one workgroup per cloud over the T tile balls.  lane = position
+// in the 64-float centroid row (any layout: only distances between centroids are taken), waves take every fourth tile.  Two passes
+// (mean, then squared deviations): post-ReLU features have |mean| >> spread.
+constexpr float ORDER_GUARD_RATIO = 1.0f;
+__global__ __launch_bounds__(256) void knn_order_guard_kernel(const float* cen64, const float* rad, int T, float ratio,
+                                                              int32_t* ok, float* stat) {
+  __shared__ float part[4][64];
+  __shared__ float red[8];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const float* c = cen64 + (size_t)b * T * 64;
+  float s = 0.f;
+  for (int i = w; i < T; i += 4) s += c[(size_t)i * 64 + lane];
+  part[w][lane] = s;
+  __syncthreads();
+  const float mean = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (float)T;
+  float d2 = 0.f;
+  for (int i = w; i < T; i += 4) { const float d = c[(size_t)i * 64 + lane] - mean; d2 += d * d; }
+  float r2 = 0.f;
+  for (int i = t; i < T; i += 256) { const float r = rad[(size_t)b * T + i]; r2 += r * r; }
+  d2 = wave_sum(d2); r2 = wave_sum(r2);
+  if (lane == 0) { red[w] = d2; red[4 + w] = r2; }
+  __syncthreads();
+  if (t == 0) {
+    const float between = (((red[0] + red[1]) + red[2]) + red[3]) / (float)T;
+    const float within = (((red[4] + red[5]) + red[6]) + red[7]) / (float)T;
+    const float q = within / fmaxf(between, 1e-37f);
+    ok[b] = q < ratio ? 1 : 0;
+    if (stat) stat[b] = q;
+  }
+}
+
 }  // namespace
 
 extern "C" int vcr_knn_order_f32(const vcr_knn_order_args* a, vcr_stream_t stream) {
@@ -191,6 +222,7 @@ extern "C" int vcr_knn_order_f32(const vcr_knn_order_args* a, vcr_stream_t strea
   if (a->feat_t && (!a->sq || !a->feat_p || !a->sq_p || !a->cen64 || !a->cen64_sq || !a->cen64_rad || !a->cen64_sqmax ||
                     a->ldf < 64 || (a->ldf & 3)))
     return VCR_EINVAL;
+  if (a->ord_ok && !a->feat_t) return VCR_EINVAL;         // (the guard judges the feature-space tiles)
   if (((uintptr_t)a->xyz4 | (uintptr_t)a->xyz4_p | (uintptr_t)a->cen4 | (uintptr_t)a->feat_t | (uintptr_t)a->feat_p |
        (uintptr_t)a->cen64) & 15)
     return VCR_EINVAL;
@@ -204,5 +236,9 @@ extern "C" int vcr_knn_order_f32(const vcr_knn_order_args* a, vcr_stream_t strea
   const int T = (a->N + 15) / 16;
   const long waves = (long)a->B * T;
   hipLaunchKernelGGL(knn_rank_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a, T);
+  rc = VCR_LAUNCH_RC();
+  if (rc != 0 || !a->ord_ok) return rc;
+  hipLaunchKernelGGL(knn_order_guard_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, a->cen64, a->cen64_rad, T,
+                     a->guard_ratio > 0.f ? a->guard_ratio : ORDER_GUARD_RATIO, a->ord_ok, a->ord_stat);
   return VCR_LAUNCH_RC();
 }

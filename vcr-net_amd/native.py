@@ -40,14 +40,14 @@ class KnnArgs(_Sized):
                 ("tie_defer", C.c_int), ("tie_work", C.c_void_p), ("tie_work_bytes", C.c_size_t), ("tie_inline", C.c_int),
                 ("xt", f32p),
                 ("perm", f32p), ("xp", f32p), ("sqp", f32p), ("cen", f32p), ("cen_sq", f32p), ("cen_rad", f32p),
-                ("cen_sqmax", f32p)]
+                ("cen_sqmax", f32p), ("ord_ok", f32p)]
 
 
 class KnnOrderArgs(C.Structure):
     _fields_ = [("xyz4", f32p), ("feat_t", f32p), ("ldf", C.c_int), ("sq", f32p), ("B", C.c_int), ("N", C.c_int),
                 ("perm", f32p), ("xyz4_p", f32p), ("cen4", f32p), ("cen4_rad", f32p), ("cen4_sqmax", f32p),
                 ("feat_p", f32p), ("sq_p", f32p), ("cen64", f32p), ("cen64_sq", f32p), ("cen64_rad", f32p),
-                ("cen64_sqmax", f32p)]
+                ("cen64_sqmax", f32p), ("ord_ok", f32p), ("ord_stat", f32p), ("guard_ratio", C.c_float)]
 
 
 class LinearArgs(C.Structure):
@@ -437,6 +437,7 @@ def knn_pair(feat, sq, xyz4, k, xt=None, order=None):
         args[0].perm = args[1].perm = o("perm")
         a = args[0]
         a.xp, a.sqp, a.cen, a.cen_sq, a.cen_rad, a.cen_sqmax = o("feat_p"), o("sq_p"), o("cen64"), o("cen64_sq"), o("cen64_rad"), o("cen64_sqmax")
+        a.ord_ok = ptr(order.get("ord_ok"))
         a = args[1]
         a.xp, a.cen, a.cen_rad, a.cen_sqmax = o("xyz4_p"), o("cen4"), o("cen4_rad"), o("cen4_sqmax")
     L.vcr_knn_pair_f32.argtypes = [C.POINTER(KnnArgs), C.POINTER(KnnArgs), C.c_void_p]
@@ -562,18 +563,22 @@ def edgeconv(pq, idx, n_per_cloud, w2, b2, bf16x3=False):
     return x1, x2
 
 
-def knn_order(xyz4, feat_t=None, sq=None):
-    """vcr_knn_order_f32: the clouds' Morton ranking and what the ordered kNN search reads (vcr_knn_args.perm ...), as a dict."""
+def knn_order(xyz4, feat_t=None, sq=None, guard=False, guard_ratio=0.0):
+    """vcr_knn_order_f32: the clouds' Morton ranking and what the ordered kNN search reads (vcr_knn_args.perm ...), as a dict.
+    guard: also the per-cloud verdict ord_ok [B] / statistic ord_stat [B] on whether the FEATURE tiles are compact enough for the
+    ordered search to pay (knn_pair(order=) hands ord_ok on; results never depend on it)."""
     B, N, _ = xyz4.shape
     T = (N + 15) // 16
     e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=xyz4.device)
     o = {"perm": e(B, N, dt=torch.int32), "xyz4_p": e(B, N, 4), "cen4": e(B, T, 4), "cen4_rad": e(B, T), "cen4_sqmax": e(B, T)}
     if feat_t is not None:
         o.update(feat_p=e(B, N, 64), sq_p=e(B, N), cen64=e(B, T, 64), cen64_sq=e(B, T), cen64_rad=e(B, T), cen64_sqmax=e(B, T))
+        if guard:
+            o.update(ord_ok=e(B, dt=torch.int32), ord_stat=e(B))
     g = lambda n: ptr(o.get(n))
     a = KnnOrderArgs(ptr(xyz4), ptr(feat_t), feat_t.stride(1) if feat_t is not None else 0, ptr(sq), B, N, g("perm"), g("xyz4_p"),
                      g("cen4"), g("cen4_rad"), g("cen4_sqmax"), g("feat_p"), g("sq_p"), g("cen64"), g("cen64_sq"), g("cen64_rad"),
-                     g("cen64_sqmax"))
+                     g("cen64_sqmax"), g("ord_ok"), g("ord_stat"), float(guard_ratio))
     call("vcr_knn_order_f32", a)
     return o
 
