@@ -145,6 +145,29 @@ def test_dataparallel_with_two_replicas_on_the_one_gpu():
     assert net._shared.packs - packs0 <= 1, net._shared.packs - packs0       # replicas do not re-pack per forward
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16x3+sdpa"])
+def test_weights_are_packed_once_in_every_arithmetic_mode(mode):
+    """Repeated forwards on unchanged parameters hit the packed-weights cache: ONE packing, whatever the arithmetic mode (the
+    split modes re-packed on every call until round 6 -- a loop variable shadowed the cache key -- which cost the exact-split
+    bench line 13 %: profiles/NOTES.md, round 6), and no stray launches between forwards."""
+    from vcrnet_amd.module import vcrnetIter
+    net, _ = build_net()
+    net.linear_mode = mode
+    s, t = _inputs(9300, 2, 256)
+    with torch.no_grad():
+        net(s, t)
+        packs0, key0 = net._shared.packs, net._packed_key
+        assert isinstance(key0, tuple) and key0[5] == mode       # the fingerprint, not a weight name
+        for _ in range(3):
+            net(s, t)
+            vcrnetIter(net, s, t, iter=2)
+    assert net._shared.packs == packs0 and net._packed_key == key0
+    net.linear_mode = "fp32" if mode != "fp32" else "bf16x3"     # a changed selector IS a new packing
+    with torch.no_grad():
+        net(s, t)
+    assert net._shared.packs == packs0 + 1
+
+
 def test_module_copies_pickles_and_weight_updates():
     """The shared cache must not leak between modules or survive a weight change: a deep copy and a pickled copy compute the
     same results from their own packing; an in-place parameter update (optimizer step, load_state_dict) is picked up on the

@@ -904,7 +904,7 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
           }
       }
     };
-    {
+    if constexpr (KS > 22) {
       const int nct = (T + CT - 1) / CT;
       CenTile fa, fb;
       cfetch(0, fa);
@@ -913,6 +913,15 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
         ceval(ct, fa);
         cfetch(min(ct + 2, nct - 1), fa);
         if (ct + 1 < nct) ceval(ct + 1, fb);
+      }
+    } else {
+      // (k <= 20: ONE centroid tile at a time -- the second one in flight costs 25 registers, and with them the fourth
+      //  workgroup per CU; the lists of 22 are what makes 128 registers possible at all)
+      const int nct = (T + CT - 1) / CT;
+      CenTile fa;
+      for (int ct = 0; ct < nct; ++ct) {
+        cfetch(ct, fa);
+        ceval(ct, fa);
       }
     }
     for (int t = lo; t < hi; ++t) need[t >> 6] &= ~(1ull << (t & 63));
@@ -1093,7 +1102,7 @@ __global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
 // alone is latency-bound at one wave per SIMD (1024 waves on 1024 SIMDs); launched together the second fills the
 // first one's idle issue slots, and the pair costs little more than the longer of the two.
 template <int KS, bool COL16, bool XT = false, bool ORD = false>
-__global__ __launch_bounds__(256, (COL16 ? (KS > 22 || ORD ? 3 : 4) : 2)) void knn_pair_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
+__global__ __launch_bounds__(256, (COL16 ? (KS > 22 ? 3 : 4) : 2)) void knn_pair_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
   const int bid = (int)blockIdx.x;
   if (bid < n64) {
     const int lin = xcd_chunk(bid, n64);

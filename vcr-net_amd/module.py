@@ -462,9 +462,12 @@ class VCRNet(nn.Module):
                    "dec_qkv": "fold.dec_qkv.w", "dec_self_wo": "dec_self.wo", "dec_cross_q": "fold.dec_cross_q.w",
                    "dec_cross_kv": "fold.dec_cross_kv.w", "dec_cross_wo": "dec_cross.wo", "dec_ffn1": "fold.dec_ffn1.w",
                    "dec_ffn2": "dec_ffn.w_2.weight", "encdec_qkv": "fold.encdec_qkv.w"}
-            for site, key in src.items():
-                if key in P:
-                    P["split." + site] = native.split_bf16x3(P[key])
+            # (`name`, not `key`: until round 6 this loop's variable shadowed the fingerprint argument, so the split modes stored
+            #  a weight NAME as their cache key, never hit the cache and re-packed -- 37 small launches, and since round 5 a
+            #  device drain -- on every forward: 0.63 ms of a 4.0 ms step, profiles/r6a_split_trace_gaps.json)
+            for site, name in src.items():
+                if name in P:
+                    P["split." + site] = native.split_bf16x3(P[name])
                     setattr(cw.split, site, native.ptr(P["split." + site]))
         cw.E, cw.F, cw.heads, cw.k = self.emb_dims, self._ff, self._n_heads, int(self.emb_nn.k)
         cw.head_mode = {"topK": 0, "dist": 1, "att": 2}[self._vcp]
