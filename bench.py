@@ -85,6 +85,8 @@ def parse(argv=None):
                     help="MFMA shape of the fp32 linears: 0 = the library's choice, 16 = v_mfma_f32_16x16x4_f32, 32 = 32x32x2")
     ap.add_argument("--knn-waves", type=int, default=0, choices=[0, 1, 8],
                     help="feature-space kNN kernel: 8 = 16-query waves (16x16x4 MFMA), 1 = 32-query waves, 0 = the library's choice")
+    ap.add_argument("--sdpa-variant", type=int, default=0, choices=[0, 1, 2],
+                    help="fp32 attention-output kernel: 0 = the library's choice, 1 = the tile kernel, 2 = the persistent kernel")
     ap.add_argument("--no-merge-encdec", action="store_true",
                     help="enc.qkv / dec.qkv and the two self-attentions as separate launches (default: one GEMM + one grouped launch)")
     ap.add_argument("--linear-bk", type=int, default=0, choices=[0, 16, 32], help="k-slab of the fp32 linears (0 = the library's choice)")
@@ -396,6 +398,7 @@ def measure(a, ctx, min_seconds):
     net.merge_encdec = not a.no_merge_encdec
     net.linear_mfma, net.linear_bk, net.knn_waves = a.linear_mfma, a.linear_bk, a.knn_waves
     net.linear_bm = a.linear_bm
+    net.sdpa_variant = a.sdpa_variant
     net = net.to(dev).eval()
 
     B, N = a.batch, a.points
@@ -661,7 +664,7 @@ OTHER_CONFIGS = [
 def is_headline(a):
     d = parse([])
     return all(getattr(a, k) == getattr(d, k) for k in ("gpus", "batch", "points", "k", "partial", "iters", "emb_nn", "strong", "regime",
-                                                        "linear_mode", "linear_mfma", "linear_bk", "linear_bm", "knn_waves",
+                                                        "linear_mode", "linear_mfma", "linear_bk", "linear_bm", "knn_waves", "sdpa_variant",
                                                         "no_merge_encdec"))
 
 

@@ -325,6 +325,10 @@ typedef struct {
    * floats fit (G = max(ngroups, 1); no key_keep / key_index / rowstat): partial outputs merged by sdpa_merge_kernel.
    * Scores are unaffected; sums and outputs merge in a different order.  A scratch too small for a split: no split. */
   float* split_work; long split_work_floats;
+  /* tuning / tests, never changes a bit of the result: 0 = the library's choice, 1 = the tile kernel (one workgroup per query
+   * block and batch x head), 2 = the persistent kernel (2 x CUs workgroups walk the same items; the fast attention-output form
+   * with at least two items per workgroup -- any other call runs the tile kernel).  vcr_sdpa_f32 only. */
+  int variant;
 } vcr_sdpa_args;
 #define VCR_SDPA_MAX_SPLIT 4
 int vcr_sdpa_f32(const vcr_sdpa_args*, vcr_stream_t);
@@ -541,6 +545,7 @@ typedef struct {
    * key-mass pass when they fit this many MiB of workspace (0 = 4096), and recomputed per head otherwise (< 0: never
    * kept).  Same kept-key set either way up to summation order. */
   int xscore_limit_mb;
+  int sdpa_variant;                                /* vcr_sdpa_args.variant of the fp32 attention-output launches (0 = automatic; benchmarks) */
   /* tests: != 0 lays the forward's workspace out with EVERY buffer live from the first launch to the last (no two buffers
    * share memory; vcr_vcrnet_workspace_bytes grows ~2.5x).  The default layout overlays buffers by their (first, last) launch;
    * a lifetime registered too short would let one launch overwrite what a later one still reads -- comparing the two

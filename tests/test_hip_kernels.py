@@ -495,6 +495,31 @@ def test_sdpa(nat, N, shift, bf16x3):
     assert e3 <= 1.25 * e32 + 5e-7 and e3 < 2e-5
 
 
+@pytest.mark.parametrize("nb,N,nk,shift,groups", [(32, 1024, 1024, 0, False), (32, 1000, 1000, 16, False), (48, 700, 650, 3, False),
+                                                   (24, 1024, 1024, 1, True), (64, 300, 300, 0, False)])
+def test_sdpa_persistent_kernel_is_bit_identical(nat, nb, N, nk, shift, groups):
+    """vcr_sdpa_args.variant 2: 2 x CUs workgroups walk the tile kernel's work items (next item's Q / K / V requested before the
+    current item's epilogue).  Same arithmetic in the same order: every bit of the output equals the tile kernel's -- full and
+    ragged query blocks and key tiles, a key-batch shift, the grouped (encoder + decoder) form, item counts that do and do not
+    divide over the workgroups.  A call it does not cover (here: fewer than two items per workgroup) runs the tile kernel."""
+    g = torch.Generator().manual_seed(nb * N + nk)
+    h = 4
+    if groups:
+        qkv = dev(torch.randn(nb * N, 6 * h * 128, generator=g))          # [enc Q|K|V | dec Q|K|V]
+        kw = dict(kv_batch_shift=shift, groups=(2, 1536, 1536, 1536))
+        run = lambda var: nat.sdpa(qkv[:, :512], qkv[:, 512:1024], qkv[:, 1024:1536], nb, h, N, nk, 1 / math.sqrt(128), variant=var, **kw)
+    else:
+        q = dev(torch.randn(nb * N, h * 128, generator=g))
+        kv = dev(torch.randn(nb * nk, 2 * h * 128, generator=g))
+        run = lambda var: nat.sdpa(q, kv[:, :512], kv[:, 512:], nb, h, N, nk, 1 / math.sqrt(128), kv_batch_shift=shift, variant=var)
+    a, b = run(1), run(2)
+    assert torch.equal(a, b), (a - b).abs().max().item()
+    assert torch.equal(run(0), a)
+    small = dev(torch.randn(2 * 256, 3 * h * 128, generator=g))             # 16 items: the tile kernel whatever the selector says
+    f = lambda var: nat.sdpa(small[:, :512], small[:, 512:1024], small[:, 1024:], 2, h, 256, 256, 1 / math.sqrt(128), variant=var)
+    assert torch.equal(f(1), f(2))
+
+
 def test_sdpa_bf16x3_masked_ragged_and_error_vs_fp64(nat):
     """Key mask + ragged nq != nk through the exact-split kernel; its error against an fp64 reference is no larger than
     the fp32-MFMA kernel's (the six-product split carries fp32-GEMM accuracy); statistics forms are refused."""

@@ -237,6 +237,165 @@ __global__ __launch_bounds__(256, 2) void sdpa_kernel(vcr_sdpa_args p, int nspli
   //@probe __builtin_amdgcn_s_waitcnt(0); VCR_PROBE_STAMP(3);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The attention-output fast path (no mask, no statistics, no split, no key list) as a PERSISTENT kernel: 2 x CUs workgroups, each
+// walks the work items (query block, batch x head) it would have been dispatched for in the tile kernel's own order (item =
+// workgroup + round x grid: the XCD of an item is the XCD the workgroup runs on, the items in flight at any time are the ones
+// the dispatcher would have in flight).  What it buys: the next item's Q rows and first K / V tile are requested BEFORE the
+// current item's epilogue (their registers are dead by then), so an item boundary costs the epilogue's LDS round trip and two
+// barriers instead of a workgroup's teardown, dispatch, Q fetch and first-tile fetch; the output stores drain under the next
+// item's first tiles.  Same arithmetic in the same order: bit-identical to sdpa_kernel<false, true>.
+__global__ __launch_bounds__(256, 2) void sdpa_persist_kernel(vcr_sdpa_args p, int nitems) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Stage* st = reinterpret_cast<Stage*>(smem);
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int nqb = (p.nq + 127) / 128, nbh = p.nbatch * p.heads * (p.ngroups > 1 ? p.ngroups : 1);
+  const int srow = t >> 5, sc4 = (t & 31) * 4;
+  const int ntiles = (p.nk + 31) / 32;
+  const float c2 = p.scale * LOG2E;
+
+  struct Item { int qb, b, head; const float *q, *kbase, *vbase; float* out; };
+  auto item_of = [&](int i) {
+    int qb, bh;
+    if ((nbh & 7) == 0) {
+      const int xcd = i & 7, j = i >> 3;
+      qb = j % nqb; bh = (j / nqb) * 8 + xcd;
+    } else {
+      qb = i % nqb; bh = i / nqb;
+    }
+    Item it;
+    it.qb = qb;
+    it.head = bh % p.heads;
+    const int grp = (bh / p.heads) / p.nbatch;
+    it.b = (bh / p.heads) % p.nbatch;
+    const int kvb = (it.b + p.kv_batch_shift) % p.nbatch;
+    it.q = p.q + (size_t)grp * p.q_group_stride;
+    it.kbase = p.k + (size_t)grp * p.k_group_stride + (size_t)kvb * p.nk * p.ldk + it.head * 128;
+    it.vbase = p.v + (size_t)grp * p.v_group_stride + (size_t)kvb * p.nk * p.ldv + it.head * 128;
+    it.out = p.out + (size_t)grp * p.out_group_stride;
+    return it;
+  };
+  f32x4 qf[16];
+  f32x4 rk[4], rv[4];
+  auto q_load = [&](const Item& it) {
+    const int q = min(it.qb * 128 + w * 32 + l31, p.nq - 1);
+    const float* qp = it.q + ((size_t)it.b * p.nq + q) * p.ldq + it.head * 128 + 4 * half;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) qf[g] = ld4(qp + 8 * g);
+  };
+  auto stage_load = [&](const Item& it, int tile) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = min(tile * 32 + srow + 8 * i, p.nk - 1);
+      rk[i] = ld4(it.kbase + (size_t)key * p.ldk + sc4);
+      rv[i] = ld4(it.vbase + (size_t)key * p.ldv + sc4);
+    }
+  };
+  auto stage_write = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      st4(&st[buf].k[srow + 8 * i][sc4], rk[i]);
+      st4(&st[buf].v[srow + 8 * i][sc4], rv[i]);
+    }
+  };
+
+  int i = blockIdx.x;
+  if (i >= nitems) return;
+  Item it = item_of(i);
+  q_load(it);
+  stage_load(it, 0);
+  stage_write(0);
+  __syncthreads();
+  for (;;) {
+    f32x16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = f32x16{0};
+    float m = VCR_NEG_INF, l = 0.f;
+    int cur = 0;
+    for (int tile = 0; tile < ntiles; ++tile) {
+      if (tile + 1 < ntiles) stage_load(it, tile + 1);
+      f32x16 s = {0};
+      __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const f32x4 kf = ld4(&st[cur].k[l31][8 * g + 4 * half]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = mfma32(kf[e], qf[g][e], s);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      float mt = VCR_NEG_INF, alpha, ls = 0.f;
+      if (tile * 32 + 32 <= p.nk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = tile * 32 + acc_row(r, half);
+          s[r] = key < p.nk ? s[r] : VCR_NEG_INF;
+          mt = fmaxf(mt, s[r]);
+        }
+      }
+      mt = fmaxf(mt, xhalf(mt)) * c2;
+      const float m_new = fmaxf(m, mt);
+      const float mref = (m_new == VCR_NEG_INF) ? 0.f : m_new;
+      alpha = __builtin_amdgcn_exp2f(m - mref);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -mref));
+        ls += s[r];
+      }
+      m = m_new;
+      l = l * alpha + ls;
+      if (__any(alpha != 1.f)) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = o[d] * alpha;
+      }
+      __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const f32x4 vf = ld4(&st[cur].v[acc_row(r, half)][4 * l31]);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = mfma32(vf[d], s[r], o[d]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (tile + 1 < ntiles) stage_write(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+    // ---- item boundary: the next item's rows are requested first, then this item's output leaves through the (free) stages
+    const Item done = it;
+    const int nxt = i + (int)gridDim.x;
+    const bool more = nxt < nitems;                        // (workgroup-uniform)
+    if (more) {
+      it = item_of(nxt);
+      q_load(it);
+      stage_load(it, 0);
+    }
+    const float inv = 1.f / (l + xhalf(l));
+    float* ot = reinterpret_cast<float*>(smem) + (size_t)w * 32 * KP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      st4(&ot[l31 * KP + 4 * acc_row(r, half)], f32x4{o[0][r] * inv, o[1][r] * inv, o[2][r] * inv, o[3][r] * inv});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (the LDS writes only: the next item's global loads stay in flight)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) {
+      const int row = 2 * r2 + half;
+      const int qq = done.qb * 128 + w * 32 + row;
+      if (qq < p.nq) {
+        const f32x4 v = ld4(&ot[row * KP + l31 * 4]);
+        st4(done.out + ((size_t)done.b * p.nq + qq) * p.ldo + done.head * 128 + l31 * 4, v);
+      }
+    }
+    if (!more) break;
+    __syncthreads();                                       // every wave has read its slice back: the stages are free again
+    stage_write(0);
+    __syncthreads();
+    i = nxt;
+  }
+}
+
 // rowstat[row] = merge over the nsplit partial (max, sum) pairs of a row, in split order
 __global__ __launch_bounds__(256) void rowstat_merge_kernel(const float* part, int nsplit, long rows, float* rowstat) {
   const long r = (long)blockIdx.x * 256 + threadIdx.x;
@@ -412,6 +571,15 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   dim3 grid((unsigned)(blocks * nsplit));
   const int lds = 2 * sizeof(Stage) + (a->key_index ? ((a->nk * 4 + 15) & ~15) : 0);
   hipStream_t s = (hipStream_t)stream;
+  // vcr_sdpa_args.variant 2: the persistent kernel (fast attention-output form only, at least two items per workgroup)
+  if (a->variant != 0 && a->variant != 1 && a->variant != 2) return VCR_EINVAL;
+  if (a->variant == 2 && pv && nsplit == 1 && !a->key_keep && !a->key_index && !a->rowstat && !a->score_out && a->scale > 0.f &&
+      blocks >= 2 * (long)vcr_cu_count() * 2) {
+    const int lds_p = 2 * sizeof(Stage);
+    VCR_DYN_LDS(sdpa_persist_kernel, lds_p);
+    hipLaunchKernelGGL(sdpa_persist_kernel, dim3((unsigned)(vcr_cu_count() * 2)), dim3(256), lds_p, s, *a, (int)blocks);
+    return VCR_LAUNCH_RC();
+  }
 #define VCR_SDPA_LAUNCH(M, P)                                                                                         \
   do {                                                                                                                 \
     VCR_DYN_LDS((sdpa_kernel<M, P>), lds);                                                                             \

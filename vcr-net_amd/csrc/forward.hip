@@ -249,6 +249,7 @@ struct Runner {
       a.ngroups = ngroups; a.q_group_stride = a.k_group_stride = a.v_group_stride = in_group_stride;
       a.out_group_stride = out_group_stride;
     }
+    a.variant = sdpa_variant;
     // linear_mode 2: the attention-output launches on the bf16 matrix pipe as exact splits; statistics passes stay fp32
     return ok((sdpa_split && out && !rowstat && !score_out) ? vcr_sdpa_bf16x3_f32(&a, stream) : vcr_sdpa_f32(&a, stream));
   }
@@ -282,6 +283,7 @@ struct Runner {
   bool sdpa_split = false;                               // linear_mode 2
   float* pv_split = nullptr; long pv_split_floats = 0;   // vcr_sdpa_args.split_work of the attention-output launches
   int linear_variant = 0;                                // MFMA shape / k-slab forced by vcr_vcrnet_weights.linear_mfma / linear_bk
+  int sdpa_variant = 0;                                  // vcr_vcrnet_weights.sdpa_variant
   vcr_knn_args deferred[2];                              // kNN launches whose tie replay is still owed (knn_ties)
   int n_deferred = 0;
   void knn(const char* nm, vcr_knn_args a, int which, bool defer = false) {
@@ -474,6 +476,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   R.ok(VCR_LAUNCH_RC());
 #define SP(site) (W->linear_mode != 0 ? W->split.site : nullptr)
   R.sdpa_split = W->linear_mode == 2;
+  R.sdpa_variant = W->sdpa_variant;
   R.pv_split = w.asplit; R.pv_split_floats = w.asplit_floats;
   R.linear_variant = (W->linear_mfma == 16 ? 16 : W->linear_mfma == 32 ? 1024 : 0) | (W->linear_bk == 16 ? 64 : W->linear_bk == 32 ? 8 : 0) |
                      (W->linear_bm == 96 ? 2048 : W->linear_bm == 128 ? 4096 : 0);

@@ -252,6 +252,7 @@ class VCRNet(nn.Module):
         # enc.qkv + dec.qkv as one GEMM and the two self-attentions as one grouped launch (fp32 mode; same arithmetic)
         self.merge_encdec = os.environ.get("VCRNET_MERGE_ENCDEC", "1") == "1"
         self.xscore_limit_mb = 0            # partial mode: keep the cross-attention scores up to this many MiB (0 = 4096)
+        self.sdpa_variant = 0               # fp32 attention-output kernel: 0 = the library's choice, 1 = tile, 2 = persistent (benchmarks)
         self.workspace_flat = False         # tests: no two workspace buffers share memory (vcr_vcrnet_weights.workspace_flat)
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
@@ -313,7 +314,7 @@ class VCRNet(nn.Module):
         dev = self._device()
         return (dev, ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]), self.emb_nn.k,
                 self.linear_mode, self.linear_mfma, self.linear_bk, self.linear_bm, self.knn_waves, self.xscore_limit_mb,
-                self.merge_encdec, bool(self.workspace_flat))
+                self.merge_encdec, bool(self.workspace_flat), int(self.sdpa_variant))
 
     def _pack(self):
         """Packed weights for this device and these parameter versions, shared with every replica / thread.  The packing
@@ -480,6 +481,7 @@ class VCRNet(nn.Module):
         cw.knn_waves = int(self.knn_waves)
         cw.xscore_limit_mb = int(self.xscore_limit_mb)
         cw.workspace_flat = int(bool(self.workspace_flat))
+        cw.sdpa_variant = int(self.sdpa_variant)
         cw.partial, cw.overlap2 = int(self._partial), self._overlap2
         self._packed, self._packed_key = P, key
         self._cw = cw

@@ -87,7 +87,7 @@ class SdpaArgs(C.Structure):
                 ("rowstat", f32p), ("score_out", f32p), ("ld_score", C.c_int),
                 ("ngroups", C.c_int), ("q_group_stride", C.c_long), ("k_group_stride", C.c_long), ("v_group_stride", C.c_long),
                 ("out_group_stride", C.c_long), ("key_index", f32p), ("nk_src", C.c_int), ("split_work", f32p),
-                ("split_work_floats", C.c_long)]
+                ("split_work_floats", C.c_long), ("variant", C.c_int)]
 
 
 class KeymassArgs(C.Structure):
@@ -203,7 +203,7 @@ class VcrnetWeights(_Sized):
                 ("partial", C.c_int), ("overlap2", C.c_double), ("emb_kind", C.c_int), ("dgcnn", DgcnnW), ("pointnet", PointnetW),
                 ("att_w0", f32p), ("att_b0", f32p), ("att_w1", f32p), ("att_b1", f32p), ("cycle", C.c_int),
                 ("linear_mfma", C.c_int), ("linear_bk", C.c_int), ("linear_bm", C.c_int), ("knn_waves", C.c_int),
-                ("xscore_limit_mb", C.c_int), ("workspace_flat", C.c_int)]
+                ("xscore_limit_mb", C.c_int), ("sdpa_variant", C.c_int), ("workspace_flat", C.c_int)]
 
 
 class VcrnetIo(C.Structure):
@@ -614,6 +614,7 @@ def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None,
     # scratch for a key split: statistics passes (small), attention-output launches of less than one round (planes)
     work = _f32(4 * ng * (nbatch * nq * heads * 128 * (1 if pv else 0) + nbatch * heads * nq * 2), device=q.device) if split else None
     a.split_work, a.split_work_floats = ptr(work), (work.numel() if split else 0)
+    a.variant = int(variant)                              # 1 = the tile kernel, 2 = the persistent kernel (where it applies)
     call("vcr_sdpa_bf16x3_f32" if bf16x3 else "vcr_sdpa_f32", a)
     if groups:
         out = out.view(ng, nbatch * nq, heads * 128)
