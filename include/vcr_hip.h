@@ -142,6 +142,11 @@ typedef struct {
 int vcr_knn_order_f32(const vcr_knn_order_args*, vcr_stream_t);
 int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
 size_t vcr_knn_tie_work_bytes(int N);
+/* Optional, the 16-query-wave launches (what vcr_knn_pair_f32 / vcr_knn_f32 take from 1024 query groups on, and for k > 20): with
+ * tie_work of at least this many bytes -- one 16 N-byte slot per workgroup of 64 queries -- a launch whose workgroups have no
+ * room for a row image in LDS (N > ~2400, or k > 20) still replays its tied rows ITSELF, the image in the finder's slot, instead
+ * of leaving them to a replay launch (vcr_knn_ties_inline() then says 1).  Same sets either way. */
+size_t vcr_knn_tie_slot_bytes(int B, int N);
 /* 1 when vcr_knn_f32 / vcr_knn_pair_f32 with these args replays the tied rows INSIDE the kNN launch (workgroups of 4 x 16
  * queries whose LDS holds a row's replay image: N <= ~2400): idx is then final when the launch ends, whatever tie_defer
  * says, and a later vcr_knn_ties_f32 on these args has nothing to do. */

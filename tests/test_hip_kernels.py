@@ -843,6 +843,42 @@ def test_ordered_knn_guard_fires_on_unrelated_features_and_changes_no_bit(nat, N
         assert torch.equal(torch.sort(a0, -1).values, torch.sort(a3, -1).values) and torch.equal(torch.sort(b0, -1).values, torch.sort(b3, -1).values)
 
 
+@pytest.mark.parametrize("B,N,k,ordered", [(16, 4096, 40, True), (16, 4096, 40, False), (24, 3000, 20, False), (32, 2048, 20, True),
+                                           (64, 512, 40, False), (2, 11000, 20, False)])
+def test_knn_in_launch_tie_replay_through_global_slots(nat, B, N, k, ordered):
+    """vcr_knn_args.tie_inline 2: where a row image does not fit the workgroups' LDS (rows beyond ~2400 points, or the lists of
+    k > 20) the launch replays its tied rows in per-workgroup slots of tie_work (vcr_knn_tie_slot_bytes) instead of leaving them to
+    a replay launch.  Lattice clouds and few-valued features tie on thousands of rows: every index must equal the replay
+    launch's (the order inside a row included -- the replay writes libstdc++'s own order), with and without the ordered search,
+    and also on rows so long that the replay launch itself needs global scratch."""
+    import ctypes as C
+    rs = np.random.RandomState(N + k)
+    side = int(np.ceil(N ** (1 / 3))) + 1
+    pts = np.stack([rs.permutation(side ** 3)[:N] for _ in range(B)])
+    xyz = (np.stack([pts // (side * side), pts // side % side, pts % side], -1).astype(np.float32)) / side
+    feat = dev(torch.from_numpy(rs.randint(0, 3, (B, N, 64)).astype(np.float32)))
+    x4 = dev(torch.from_numpy(np.concatenate((xyz, (xyz ** 2).sum(-1, keepdims=True)), -1).astype(np.float32)))
+    sq = (feat ** 2).sum(-1).contiguous()
+    ft = feat.view(B, N, 4, 4, 4).transpose(3, 4).reshape(B, N, 64).contiguous()
+    order = nat.knn_order(x4, ft, sq) if ordered else None
+    a0, b0 = nat.knn_pair(feat, sq, x4, k, xt=ft, order=order)                      # replay launch
+    a1, b1 = nat.knn_pair(feat, sq, x4, k, xt=ft, order=order, tie_slots=True)      # replayed inside the launch
+    assert torch.equal(a0, a1) and torch.equal(b0, b1)
+    lazy = nat.knn(x4, None, k, exact_ties=False)
+    assert not torch.equal(torch.sort(lazy, -1).values, torch.sort(b0, -1).values)       # the replay did matter on this input
+    # the single-search entry point, and what vcr_knn_ties_inline() answers
+    c1 = nat.knn(x4, None, k, tie_slots=True)
+    assert torch.equal(c1, nat.knn(x4, None, k))
+    L = nat.lib()
+    L.vcr_knn_ties_inline.argtypes, L.vcr_knn_ties_inline.restype = [C.POINTER(nat.KnnArgs)], C.c_int
+    L.vcr_knn_tie_slot_bytes.argtypes, L.vcr_knn_tie_slot_bytes.restype = [C.c_int, C.c_int], C.c_size_t
+    a = nat.KnnArgs(0x1000, 4, None, B, N, 4, k, 0x2000, 0x3000, B * N)
+    lds_fits = N <= 2300 and k <= 20
+    assert L.vcr_knn_ties_inline(C.byref(a)) == (1 if lds_fits and B * ((N + 15) // 16) >= 1024 else 0)
+    a.tie_work, a.tie_work_bytes = 0x4000, L.vcr_knn_tie_slot_bytes(B, N)
+    assert L.vcr_knn_ties_inline(C.byref(a)) == (1 if (B * ((N + 15) // 16) >= 1024 or k > 20) else 0)
+
+
 def test_knn_deferred_tie_replay_for_two_launches(nat):
     """vcr_knn_args.tie_defer + vcr_knn_ties_f32: the Cartesian and the feature-space launch list their tied rows, one
     replay launch serves both -- the same indices as two self-contained calls, on inputs built to tie massively."""

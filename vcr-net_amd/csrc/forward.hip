@@ -101,7 +101,14 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   Ws w{};
   pl.want(w.xyz4, M * 4, 0, END);   pl.want(w.feat64, M * 64, 0, 3);   pl.want(w.sq64, M, 0, 2);   // (PointNet: conv3 reads feat64 at 3)
   pl.want(w.idx1, M * k, 1, 3);     pl.want(w.idx3, M * k, 1, 5);      pl.want(w.ties, 2 * (1 + M), 0, 2);   // a slot for every row
-  w.tie_work_each = vcr_knn_tie_work_bytes(N);
+  // kNN tie replay scratch per search: slots for the in-launch replay where a row image does not fit the workgroups' LDS (long
+  // rows, or the lists of k > 20) -- while that stays below 1 GiB (it is live during the kNN launch only and overlaid by the
+  // Transformer's buffers) --, else what the replay launch needs for rows beyond 10 091 points
+  {
+    const size_t slots = vcr_knn_tie_slot_bytes(2 * B, N);
+    w.tie_work_each = ((N > 2300 || k > 20) && slots <= ((size_t)1 << 30)) ? slots : vcr_knn_tie_work_bytes(N);
+    w.tie_work_each = (w.tie_work_each + 255) & ~(size_t)255;
+  }
   pl.want(w.tie_work, w.tie_work_each ? 2 * w.tie_work_each : 0, 1, 2);
   pl.want(w.pq1, M * 256, 0, 4);    pl.want(w.cat, M * 512, 3, 6);     pl.want(w.pq3, M * 512, 4, 5);   // (PointNet: conv4 reads pq1 at 4)
   pl.want(w.emb, M * E, 0, 21);                          // (0 .. 2: the transposed feat64 rows of the 16-query kNN waves; 6 ..: the embeddings)

@@ -76,7 +76,10 @@ __host__ __device__ constexpr size_t inline_tie_offset(size_t log_bytes, int N) 
 }
 constexpr size_t INLINE_TIE_MAX_LDS = 40 * 1024;         // four workgroups per CU must still fit
 __device__ void tiebreak_row(const vcr_knn_args& a, int row, unsigned char* smem, unsigned char* gwork);
-__device__ __forceinline__ void replay_block_ties(const vcr_knn_args& a, int* blk_ties, unsigned char* smem) {
+// gwork (tie_inline == 2): the row image lives in THIS workgroup's 16 N-byte slot of vcr_knn_args.tie_work instead of LDS --
+// rows too long for an LDS image beside three or four resident workgroups (N > ~2400) are then replayed by the workgroup
+// that found them too, under the other workgroups' scans, instead of by a separate launch (0.16 ms at 64 x 4096, k = 40).
+__device__ __forceinline__ void replay_block_ties(const vcr_knn_args& a, int* blk_ties, unsigned char* smem, unsigned char* gwork = nullptr) {
   __syncthreads();                                       // every wave is done with its log: the LDS is free
   const int n = min(blk_ties[0], BLK_TIES);
   int rows[4];                                           // (the list itself lies behind the replay's LDS image)
@@ -85,7 +88,7 @@ __device__ __forceinline__ void replay_block_ties(const vcr_knn_args& a, int* bl
     for (int u = 0; u < 4; ++u) rows[u] = t0 + u < n ? blk_ties[1 + t0 + u] : -1;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (rows[u] >= 0) tiebreak_row(a, rows[u], smem, nullptr);
+      if (rows[u] >= 0) tiebreak_row(a, rows[u], smem, gwork);
   }
 }
 
@@ -678,7 +681,8 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   const int ntiles = (a.N + CT - 1) / CT;
 
   sel.init(lv, reinterpret_cast<int*>(lv + LROWS * 16), lane);
-  int* blk_ties = a.tie_inline ? reinterpret_cast<int*>(smem + inline_tie_offset((size_t)W * 2 * LROWS * 16 * 4, a.N)) : nullptr;
+  // (tie_inline 2: the replay's row image is in global scratch, only its query row + block scratch need LDS)
+  int* blk_ties = a.tie_inline ? reinterpret_cast<int*>(smem + inline_tie_offset((size_t)W * 2 * LROWS * 16 * 4, a.tie_inline == 2 ? 0 : a.N)) : nullptr;
   if (blk_ties) {
     if (threadIdx.x == 0) blk_ties[0] = 0;
     __syncthreads();
@@ -975,7 +979,12 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   }
   //@probe VCR_PROBE_ACC_FLUSH(threadIdx.x == 0 && blockIdx.y == 0, blockIdx.x);
   finish<G, KS, 1>(sel, a, b, q0 + col, wave, 0, smem, blk_ties, ord ? a.perm + (size_t)b * a.N : nullptr);
-  if (blk_ties) replay_block_ties(a, blk_ties, smem);
+  if (blk_ties) {
+    unsigned char* gwork = nullptr;
+    if (a.tie_inline == 2)                                 // this workgroup's slot: (cloud, query block) in launch-independent order
+      gwork = reinterpret_cast<unsigned char*>(a.tie_work) + ((size_t)b * ((a.N + 16 * W - 1) / (16 * W)) + bx) * 16 * (size_t)a.N;
+    replay_block_ties(a, blk_ties, smem, gwork);
+  }
 }
 // (k > 20: the logs of a workgroup take 51 KB, so three workgroups share a CU whatever the registers allow -- the bound
 //  says so and the lists of 42 keep their registers: at four waves per SIMD, 128 VGPRs, two spilled to scratch)
@@ -1498,9 +1507,16 @@ static size_t tiebreak_launch_lds(int N) { return tiebreak_lds(N) <= TB_LDS_MAX 
 extern "C" size_t vcr_knn_tie_work_bytes(int N) {
   return (N > 0 && tiebreak_lds(N) > TB_LDS_MAX) ? (size_t)TB_BLOCKS * 16 * (size_t)N : 0;
 }
+// one 16 N-byte slot per workgroup of the 16-query-wave kernels (64 queries each): with this much tie_work a launch whose rows
+// (or lists: k > 20) leave no room for an LDS image replays its tied rows itself (tie_inline 2)
+extern "C" size_t vcr_knn_tie_slot_bytes(int B, int N) {
+  return (B > 0 && N > 0) ? (size_t)B * ((N + 63) / 64) * 16 * (size_t)N : 0;
+}
+static int ties_inline(const vcr_knn_args* a);
 // a replay is owed (tie_scratch) but the rows need global scratch that the caller did not provide
 static bool tie_work_missing(const vcr_knn_args* a) {
   const size_t need = vcr_knn_tie_work_bytes(a->N);
+  if (ties_inline(a) == 2) return false;                 // (the launch replays its ties itself, in its workgroups' slots)
   return a->tie_scratch && need && (!a->tie_work || a->tie_work_bytes < need || ((uintptr_t)a->tie_work & 15));
 }
 
@@ -1550,13 +1566,17 @@ static int knn_s(const vcr_knn_args* a) {                  // candidate split of
   const long groups = (long)((a->N + (a->C == 64 ? 31 : 15)) / (a->C == 64 ? 32 : 16)) * a->B;
   return groups >= 1024 ? 1 : groups >= 512 ? 2 : 4;
 }
-static bool ties_inline(const vcr_knn_args* a) {
-  if (!a->tie_scratch) return false;
-  if (a->C == 64 ? !use_col16(a) : knn_s(a) != 1) return false;
-  return inline_tie_offset(knn_log_bytes(a), a->N) + (1 + BLK_TIES) * 4 <= INLINE_TIE_MAX_LDS;
+// 0: the tied rows go to a replay launch.  1: replayed by the workgroup that found them, row image in its LDS (N <= ~2400).
+// 2: likewise, row image in the workgroup's slot of tie_work (the caller gave vcr_knn_tie_slot_bytes(B, N) bytes of it).
+static int ties_inline(const vcr_knn_args* a) {
+  if (!a->tie_scratch) return 0;
+  if (a->C == 64 ? !use_col16(a) : knn_s(a) != 1) return 0;
+  if (inline_tie_offset(knn_log_bytes(a), a->N) + (1 + BLK_TIES) * 4 <= INLINE_TIE_MAX_LDS) return 1;
+  const size_t slots = vcr_knn_tie_slot_bytes(a->B, a->N);
+  return (slots && a->tie_work && a->tie_work_bytes >= slots && !((uintptr_t)a->tie_work & 15)) ? 2 : 0;
 }
-static size_t knn_lds_bytes(const vcr_knn_args* a, bool inl) {
-  return inl ? inline_tie_offset(knn_log_bytes(a), a->N) + (1 + BLK_TIES) * 4 : knn_log_bytes(a);
+static size_t knn_lds_bytes(const vcr_knn_args* a, int inl) {
+  return inl ? inline_tie_offset(knn_log_bytes(a), inl == 2 ? 0 : a->N) + (1 + BLK_TIES) * 4 : knn_log_bytes(a);
 }
 extern "C" int vcr_knn_ties_inline(const vcr_knn_args* ua) {
   vcr_knn_args na;
@@ -1604,9 +1624,9 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* u64, const vcr_knn_args* u3,
     const int gx64 = (a64->N + 32 * (4 / S64) - 1) / (32 * (4 / S64)), gx3 = (a3->N + 16 * (4 / S3) - 1) / (16 * (4 / S3));
     const int n64 = gx64 * a64->B, n3 = gx3 * a3->B;
     vcr_knn_args k64 = *a64, k3 = *a3;
-    k64.tie_inline = 0; k3.tie_inline = ties_inline(a3) ? 1 : 0;       // (only an unsplit Cartesian search replays in place)
+    k64.tie_inline = 0; k3.tie_inline = ties_inline(a3);               // (only an unsplit Cartesian search replays in place)
     const size_t lds64 = (size_t)4 * 2 * (pend_of<GeomMfma, 22>() + 1) * 32 * 4;
-    const size_t lds3 = knn_lds_bytes(a3, k3.tie_inline != 0), lds = lds64 > lds3 ? lds64 : lds3;
+    const size_t lds3 = knn_lds_bytes(a3, k3.tie_inline), lds = lds64 > lds3 ? lds64 : lds3;
     const dim3 grid(n64 + n3);
     int rc = VCR_EUNSUPPORTED;
 #define VCR_KPS(A, B_) rc = launch<knn_pair_small_kernel<22, A, B_>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3)
@@ -1636,11 +1656,11 @@ extern "C" int vcr_knn_pair_f32(const vcr_knn_args* u64, const vcr_knn_args* u3,
   const int gx64 = col16 ? (a64->N + 63) / 64 : (a64->N + 127) / 128, gx3 = (a3->N + 63) / 64;   // 4 waves x 16 (or 32) queries
   const int n64 = gx64 * a64->B, n3 = gx3 * a3->B;
   vcr_knn_args k64 = *a64, k3 = *a3;                     // (tie_inline is the library's own field)
-  k64.tie_inline = ties_inline(a64) ? 1 : 0; k3.tie_inline = ties_inline(a3) ? 1 : 0;
+  k64.tie_inline = col16 ? ties_inline(a64) : 0; k3.tie_inline = ties_inline(a3);
   if (!knn_ordered(a64)) k64.perm = nullptr;             // (incomplete ordered inputs: that search runs the plain way)
   if (!knn_ordered(a3)) k3.perm = nullptr;
-  const size_t lds64 = col16 ? knn_lds_bytes(a64, k64.tie_inline != 0) : (size_t)4 * 2 * (pend_of<GeomMfma, 22>() + 1) * 32 * 4;
-  const size_t lds3 = knn_lds_bytes(a3, k3.tie_inline != 0), lds = lds64 > lds3 ? lds64 : lds3;
+  const size_t lds64 = col16 ? knn_lds_bytes(a64, k64.tie_inline) : (size_t)4 * 2 * (pend_of<GeomMfma, 22>() + 1) * 32 * 4;
+  const size_t lds3 = knn_lds_bytes(a3, k3.tie_inline), lds = lds64 > lds3 ? lds64 : lds3;
   const dim3 grid(n64 + n3);
   int rc;
   if (!col16) rc = launch<knn_pair_kernel<22, false>>(grid, dim3(256), lds, s, k64, k3, n64, gx64, gx3);
@@ -1689,8 +1709,8 @@ extern "C" int vcr_knn_f32(const vcr_knn_args* ua, vcr_stream_t stream) {
   // (the fold of S > 1 waves parks the value lists behind the logs: there is room for that with k <= 20 only)
   auto pick_s = [&](long) { return knn_s(a); };
   vcr_knn_args ka = *a;                                  // (tie_inline is the library's own field)
-  const bool inl = ties_inline(a);
-  ka.tie_inline = inl ? 1 : 0;
+  const int inl = ties_inline(a);
+  ka.tie_inline = inl;
   if (a->C == 64 && use_col16(a)) {
     // the half-size-wave kernel (see use_col16)
     if (!a->sq || a->ldx < 64 || (a->ldx & 3)) return VCR_EINVAL;

@@ -390,9 +390,10 @@ def pointwise(x_cf, w1, b1, w2, b2, pq_w=None, pq_b=None, feat_t=None):
 
 
 @_guarded
-def knn(x, sq, k, exact_ties=True, waves=0, tie_work=True, xt=None):
+def knn(x, sq, k, exact_ties=True, waves=0, tie_work=True, xt=None, tie_slots=False):
     """x [B,N,C] rows (C = 64 with sq [B,N], or C = 4 xyz4 rows) -> int32 idx [B,N,k].  exact_ties: rows whose
-    (k+1)-th and (k+2)-th distances are equal get Tensor.topk's (libstdc++'s) pick instead of the lower index."""
+    (k+1)-th and (k+2)-th distances are equal get Tensor.topk's (libstdc++'s) pick instead of the lower index.
+    tie_slots: give the launch vcr_knn_tie_slot_bytes(B, N) of scratch -- it then replays its tied rows itself."""
     B, N, Cc = x.shape
     idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
     ties = torch.empty(1 + B * N, dtype=torch.int32, device=x.device) if exact_ties else None   # room for every row
@@ -400,6 +401,9 @@ def knn(x, sq, k, exact_ties=True, waves=0, tie_work=True, xt=None):
     L = lib()
     L.vcr_knn_tie_work_bytes.restype, L.vcr_knn_tie_work_bytes.argtypes = C.c_size_t, [C.c_int]
     need = L.vcr_knn_tie_work_bytes(N) if (exact_ties and tie_work) else 0
+    if exact_ties and tie_slots:
+        L.vcr_knn_tie_slot_bytes.restype, L.vcr_knn_tie_slot_bytes.argtypes = C.c_size_t, [C.c_int, C.c_int]
+        need = L.vcr_knn_tie_slot_bytes(B, N)
     work = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None            # long rows: replay scratch
     a.tie_work, a.tie_work_bytes = ptr(work), need
     a.xt = ptr(xt)               # the rows with their 16-channel groups transposed (pointwise(..., feat_t=)): same result
@@ -407,11 +411,13 @@ def knn(x, sq, k, exact_ties=True, waves=0, tie_work=True, xt=None):
     return idx
 
 
-def _tie_work(a, N, device, keep):
-    """Long rows (vcr_knn_tie_work_bytes(N) > 0, N > ~10 100): the replay's global scratch, as knn() provides it."""
+def _tie_work(a, N, device, keep, slots_for=0):
+    """Long rows (vcr_knn_tie_work_bytes(N) > 0, N > ~10 100): the replay's global scratch, as knn() provides it.
+    slots_for = B: vcr_knn_tie_slot_bytes(B, N) instead -- the launch replays its own ties (vcr_knn_args.tie_inline 2)."""
     L = lib()
     L.vcr_knn_tie_work_bytes.restype, L.vcr_knn_tie_work_bytes.argtypes = C.c_size_t, [C.c_int]
-    need = L.vcr_knn_tie_work_bytes(N)
+    L.vcr_knn_tie_slot_bytes.restype, L.vcr_knn_tie_slot_bytes.argtypes = C.c_size_t, [C.c_int, C.c_int]
+    need = L.vcr_knn_tie_slot_bytes(slots_for, N) if slots_for else L.vcr_knn_tie_work_bytes(N)
     if need:
         work = torch.empty(need, dtype=torch.uint8, device=device)
         a.tie_work, a.tie_work_bytes = ptr(work), need
@@ -419,9 +425,10 @@ def _tie_work(a, N, device, keep):
 
 
 @_guarded
-def knn_pair(feat, sq, xyz4, k, xt=None, order=None):
+def knn_pair(feat, sq, xyz4, k, xt=None, order=None, tie_slots=False):
     """vcr_knn_pair_f32: the feature-space (feat [B,N,64], sq [B,N]) and the Cartesian (xyz4 [B,N,4]) kNN in one launch
-    -> (idx_feat, idx_xyz), tie replay included.  order = knn_order()'s dict: the ordered search (vcr_knn_args.perm)."""
+    -> (idx_feat, idx_xyz), tie replay included.  order = knn_order()'s dict: the ordered search (vcr_knn_args.perm).
+    tie_slots: per-workgroup replay slots (vcr_knn_tie_slot_bytes) -- tied rows are replayed inside the launch."""
     L = lib()
     out, args, keep = [], [], []
     for x, s_ in ((feat, sq), (xyz4, None)):
@@ -429,7 +436,7 @@ def knn_pair(feat, sq, xyz4, k, xt=None, order=None):
         idx = torch.empty(B, N, k, dtype=torch.int32, device=x.device)
         ties = torch.empty(1 + B * N, dtype=torch.int32, device=x.device)
         args.append(KnnArgs(ptr(x), x.stride(1), ptr(s_), B, N, Cc, k, ptr(idx), ptr(ties), B * N, 0))
-        _tie_work(args[-1], N, x.device, keep)
+        _tie_work(args[-1], N, x.device, keep, slots_for=B if tie_slots else 0)
         out.append(idx); keep.append(ties)
     args[0].xt = ptr(xt)
     if order is not None:
