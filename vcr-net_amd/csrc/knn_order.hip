@@ -185,7 +185,10 @@ __global__ __launch_bounds__(256) void knn_rank_rows_kernel(vcr_knn_order_args a
 // The guard of the feature-space search (vcr_knn_order_args.ord_ok): one workgroup per cloud over the T tile balls.  lane = position
 // in the 64-float centroid row (any layout: only distances between centroids are taken), waves take every fourth tile.  Two passes
 // (mean, then squared deviations): post-ReLU features have |mean| >> spread.
-constexpr float ORDER_GUARD_RATIO = 1.0f;
+// measured (profiles/r6b_knn_guard.txt): the stem's features score 0.2-0.36 (LPD-pretrained and random weights), with noise of
+// 0.3 sigma 0.29-0.39 -- ordered still 0.66-0.84 of the plain time --, with 1 sigma 1.24-1.35 -- level at 4096 points, 1.10x at
+// 2048 --, unrelated features 23
+constexpr float ORDER_GUARD_RATIO = 0.8f;
 __global__ __launch_bounds__(256) void knn_order_guard_kernel(const float* cen64, const float* rad, int T, float ratio,
                                                               int32_t* ok, float* stat) {
   __shared__ float part[4][64];
