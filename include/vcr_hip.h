@@ -142,10 +142,10 @@ typedef struct {
 int vcr_knn_order_f32(const vcr_knn_order_args*, vcr_stream_t);
 int vcr_knn_f32(const vcr_knn_args*, vcr_stream_t);
 size_t vcr_knn_tie_work_bytes(int N);
-/* Optional, the 16-query-wave launches (what vcr_knn_pair_f32 / vcr_knn_f32 take from 1024 query groups on, and for k > 20): with
- * tie_work of at least this many bytes -- one 16 N-byte slot per workgroup of 64 queries -- a launch whose workgroups have no
- * room for a row image in LDS (N > ~2400, or k > 20) still replays its tied rows ITSELF, the image in the finder's slot, instead
- * of leaving them to a replay launch (vcr_knn_ties_inline() then says 1).  Same sets either way. */
+/* Optional, k > 20 (the launches whose workgroups have no room for a row image in LDS beside their lists): with tie_work of at
+ * least this many bytes -- one 16 N-byte slot per workgroup of 64 queries -- such a launch still replays its tied rows ITSELF,
+ * the image in the finder's slot, instead of leaving them to a replay launch (vcr_knn_ties_inline() then says 1).  Same sets
+ * either way.  (k <= 20: the LDS image up to ~2400 points, the replay launch beyond.) */
 size_t vcr_knn_tie_slot_bytes(int B, int N);
 /* 1 when vcr_knn_f32 / vcr_knn_pair_f32 with these args replays the tied rows INSIDE the kNN launch (workgroups of 4 x 16
  * queries whose LDS holds a row's replay image: N <= ~2400): idx is then final when the launch ends, whatever tie_defer
@@ -330,9 +330,10 @@ typedef struct {
    * floats fit (G = max(ngroups, 1); no key_keep / key_index / rowstat): partial outputs merged by sdpa_merge_kernel.
    * Scores are unaffected; sums and outputs merge in a different order.  A scratch too small for a split: no split. */
   float* split_work; long split_work_floats;
-  /* tuning / tests, never changes a bit of the result: 0 = the library's choice, 1 = the tile kernel (one workgroup per query
-   * block and batch x head), 2 = the persistent kernel (2 x CUs workgroups walk the same items; the fast attention-output form
-   * with at least two items per workgroup -- any other call runs the tile kernel).  vcr_sdpa_f32 only. */
+  /* tuning / tests, never changes a bit of the result: 0 = the library's choice (the persistent kernel where it applies), 1 = the
+   * tile kernel (one workgroup per query block and batch x head), 2 = the persistent kernel (2 x CUs workgroups walk the same
+   * items; the fast attention-output form with at least two items per workgroup -- any other call runs the tile kernel).
+   * vcr_sdpa_f32 only. */
   int variant;
 } vcr_sdpa_args;
 #define VCR_SDPA_MAX_SPLIT 4

@@ -756,7 +756,8 @@ def test_knn_pair_equals_the_two_launches(nat, B, N, k):
 
 
 @pytest.mark.parametrize("B,N,k,kind", [(8, 2048, 20, "smooth"), (4, 4096, 40, "smooth"), (8, 2048, 20, "random"), (16, 1024, 20, "smooth"),
-                                        (8, 2040, 20, "dup"), (8, 2048, 20, "lattice"), (6, 3000, 40, "lattice"), (4, 4096, 20, "equal")])
+                                        (8, 2040, 20, "dup"), (8, 2048, 20, "lattice"), (6, 3000, 40, "lattice"), (4, 4096, 20, "equal"),
+                                        (8, 4096, 20, "outlier")])
 def test_knn_ordered_search_keeps_the_sets(nat, B, N, k, kind):
     """The ordered search (vcr_knn_order_f32 + vcr_knn_args.perm: Morton ranking, tiles skipped by their balls) against the plain
     pair launch: the same neighbour SET on every row -- smooth features (a function of the coordinates, as the stem's are),
@@ -771,6 +772,8 @@ def test_knn_ordered_search_keeps_the_sets(nat, B, N, k, kind):
         xyz = rs.rand(B, N, 3).astype(np.float32) - 0.5
     if kind == "dup":
         xyz[:, N // 2:] = xyz[:, : N - N // 2]
+    if kind == "outlier":                                  # one far return per cloud: the ranking's box is then mean +- 4 sigma
+        xyz[:, 17] = np.float32(200.0)
     w1, w2 = rs.randn(3, 64).astype(np.float32) * 0.8, rs.randn(64, 64).astype(np.float32) * 0.2
     feat = np.maximum(np.maximum(xyz @ w1 + 0.1, 0) @ w2 + 0.05, 0)
     if kind == "random":
@@ -783,6 +786,26 @@ def test_knn_ordered_search_keeps_the_sets(nat, B, N, k, kind):
     perm = order["perm"].long().cpu()
     assert all(torch.equal(torch.sort(perm[b]).values, torch.arange(N)) for b in range(B))
     assert torch.equal(torch.gather(x4, 1, order["perm"].long()[..., None].expand(-1, -1, 4)), order["xyz4_p"])
+    if kind == "outlier":
+        # (the clamped box is the device's own fp32 mean / sigma: not re-derived here)
+        a0, b0 = nat.knn_pair(feat, sq, x4, k, xt=ft)
+        a1, b1 = nat.knn_pair(feat, sq, x4, k, xt=ft, order=order)
+        for plain, ordered in ((a0, a1), (b0, b1)):
+            assert torch.equal(torch.sort(plain, -1).values, torch.sort(ordered, -1).values)
+        # consecutive ranks stay spatial neighbours: the mean step between rank-adjacent points is what the same cloud WITHOUT its
+        # outlier gives (with the true, 200-wide box the other 4095 points would share ~5 levels per axis: steps ~1.6x longer)
+        def step(x4_, perm_):
+            p = x4_[0, perm_[0].long(), :3].cpu().numpy()
+            p = p[np.abs(p).max(1) < 10]
+            return float(np.linalg.norm(np.diff(p, axis=0), axis=1).mean())
+        clean = x4.clone()
+        clean[:, 17, :3] = 0.0
+        clean[:, 17, 3] = 0.0
+        ref = step(clean, nat.knn_order(clean)["perm"])
+        got = step(x4, order["perm"])
+        print(f"rank-adjacent step: with the outlier {got:.4f}, clean cloud {ref:.4f}")
+        assert got < 1.25 * ref, (got, ref)
+        return
     # the ranking IS the sort by (30-bit Morton code of the bounding-box-normalised coordinates, point index)
     lo, hi = xyz.min(1, keepdims=True), xyz.max(1, keepdims=True)
     ext = (hi - lo).astype(np.float32)
@@ -844,11 +867,11 @@ def test_ordered_knn_guard_fires_on_unrelated_features_and_changes_no_bit(nat, N
 
 
 @pytest.mark.parametrize("B,N,k,ordered", [(16, 4096, 40, True), (16, 4096, 40, False), (24, 3000, 20, False), (32, 2048, 20, True),
-                                           (64, 512, 40, False), (2, 11000, 20, False)])
+                                           (64, 512, 40, False), (2, 11000, 40, False)])
 def test_knn_in_launch_tie_replay_through_global_slots(nat, B, N, k, ordered):
-    """vcr_knn_args.tie_inline 2: where a row image does not fit the workgroups' LDS (rows beyond ~2400 points, or the lists of
-    k > 20) the launch replays its tied rows in per-workgroup slots of tie_work (vcr_knn_tie_slot_bytes) instead of leaving them to
-    a replay launch.  Lattice clouds and few-valued features tie on thousands of rows: every index must equal the replay
+    """vcr_knn_args.tie_inline 2: the k > 20 launches (no room for a row image in LDS beside their lists) replay their tied rows
+    in per-workgroup slots of tie_work (vcr_knn_tie_slot_bytes) instead of leaving them to a replay launch; k <= 20 ignores the
+    slots (LDS image, or the replay launch beyond ~2400 points).  Lattice clouds and few-valued features tie on thousands of rows: every index must equal the replay
     launch's (the order inside a row included -- the replay writes libstdc++'s own order), with and without the ordered search,
     and also on rows so long that the replay launch itself needs global scratch."""
     import ctypes as C
@@ -876,7 +899,7 @@ def test_knn_in_launch_tie_replay_through_global_slots(nat, B, N, k, ordered):
     lds_fits = N <= 2300 and k <= 20
     assert L.vcr_knn_ties_inline(C.byref(a)) == (1 if lds_fits and B * ((N + 15) // 16) >= 1024 else 0)
     a.tie_work, a.tie_work_bytes = 0x4000, L.vcr_knn_tie_slot_bytes(B, N)
-    assert L.vcr_knn_ties_inline(C.byref(a)) == (1 if (B * ((N + 15) // 16) >= 1024 or k > 20) else 0)
+    assert L.vcr_knn_ties_inline(C.byref(a)) == (1 if (k > 20 or (lds_fits and B * ((N + 15) // 16) >= 1024)) else 0)
 
 
 def test_knn_deferred_tie_replay_for_two_launches(nat):

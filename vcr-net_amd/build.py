@@ -33,6 +33,29 @@ def sources_sha16() -> str:
     return h.hexdigest()[:16]
 
 
+def kernel_resources():
+    """{demangled-ish kernel name: {"vgprs", "agprs", "sgprs", "scratch", "occupancy", "lds", "file"}} from the remarks of the last
+    build (build() first: objects without a remarks file are recompiled)."""
+    import re
+    out = {}
+    for f in sorted(os.listdir(OBJ)):
+        if not f.endswith(".remarks"):
+            continue
+        cur = None
+        for ln in open(os.path.join(OBJ, f)):
+            m = re.search(r"remark: (?:Function Name: (\S+)|\s+(\w[\w ]*?)(?: \[[^\]]*\])?: (\d+)) \[-Rpass", ln)
+            if not m:
+                continue
+            if m.group(1):
+                cur = out.setdefault(m.group(1), {"file": f[:-8] + ".hip"})
+            elif cur is not None:
+                key = {"VGPRs": "vgprs", "AGPRs": "agprs", "TotalSGPRs": "sgprs", "ScratchSize": "scratch",
+                       "Occupancy": "occupancy", "LDS Size": "lds", "VGPRs Spill": "vgpr_spill", "SGPRs Spill": "sgpr_spill"}.get(m.group(2))
+                if key:
+                    cur[key] = int(m.group(3))
+    return out
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -47,16 +70,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     jobs = []
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-        if force or _stale(obj, [src] + hdrs):
+        if force or _stale(obj, [src] + hdrs) or not os.path.exists(obj[:-2] + ".remarks"):
             jobs.append((src, obj))
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
-        if verbose:
-            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        # the compiler's per-kernel resource remarks (registers, scratch, occupancy) are kept next to the object:
+        # tests/test_kernel_resources.py holds the hot kernels to "no scratch" and to their resident-workgroup counts
+        cmd = [HIPCC, "-Rpass-analysis=kernel-resource-usage"] + FLAGS + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
-        return src, r.returncode, r.stdout + r.stderr
+        if r.returncode == 0:
+            with open(obj[:-2] + ".remarks", "w") as fh:
+                fh.write(r.stderr)
+        out = r.stdout + r.stderr
+        if r.returncode == 0 and not verbose:
+            out = "\n".join(ln for ln in out.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln)
+        return src, r.returncode, out
 
     failed = False
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:

@@ -536,7 +536,7 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   // Statistics passes (no P V, caller scratch given) split the keys over nsplit workgroups per query block when that
   // shortens the launch by a tenth in a simple round model (a partial last round filled to f costs 0.35 + 0.65 f of a round):
   // 1152 workgroups on 512 slots at BASELINE configs[2] = 2.25 rounds -> four times as many of a quarter the length.
-  const long blocks = (long)((a->nq + 127) / 128) * a->heads * a->nbatch * ng;
+  const long blocks = (long)((a->nq + VCR_SDPA_QROWS - 1) / VCR_SDPA_QROWS) * a->heads * a->nbatch * ng;
   int nsplit = 1;
   if (!pv && a->split_work && a->split_work_floats >= (long)VCR_SDPA_MAX_SPLIT * a->nbatch * a->heads * a->nq * 2) {
     const long slots = (long)vcr_cu_count() * 2;
@@ -558,7 +558,7 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   // keys too: every workgroup writes its unnormalised partial output and (max, sum) to a plane of the scratch, one more
   // kernel merges the planes (partial outputs: nsplit x the output bytes -- only worth it while that is a few MB).
   if (pv && a->split_work && !a->rowstat && !a->score_out && a->scale > 0.f && !a->key_keep && !a->key_index) {
-    const long slots = (long)vcr_cu_count() * 2;
+    const long slots = (long)vcr_cu_count() * VCR_SDPA_WG_PER_CU;
     const int ntiles = (a->nk + 31) / 32;
     const size_t plane = (size_t)ng * a->nbatch * a->nq * a->ldo * 4;
     for (int sp = VCR_SDPA_MAX_SPLIT; sp >= 2; sp >>= 1)
@@ -571,9 +571,12 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   dim3 grid((unsigned)(blocks * nsplit));
   const int lds = 2 * sizeof(Stage) + (a->key_index ? ((a->nk * 4 + 15) & ~15) : 0);
   hipStream_t s = (hipStream_t)stream;
-  // vcr_sdpa_args.variant 2: the persistent kernel (fast attention-output form only, at least two items per workgroup)
+  // The persistent kernel where it applies (the fast attention-output form with at least two items per workgroup) unless
+  // vcr_sdpa_args.variant asks for the tile kernel: same bits; measured inside the forward (profiles/r6c_sdpa_variant_bench.txt,
+  // alternated on one box) sdpa 1.570 -> 1.559 ms per step at configs[1], 6.18 -> 6.07 at configs[3]'s share, 4.86 -> 4.80 at
+  // configs[2], level at configs[4] (48.1 ms: 128 key tiles per item, the item boundary is 1 % of an item there)
   if (a->variant != 0 && a->variant != 1 && a->variant != 2) return VCR_EINVAL;
-  if (a->variant == 2 && pv && nsplit == 1 && !a->key_keep && !a->key_index && !a->rowstat && !a->score_out && a->scale > 0.f &&
+  if (a->variant != 1 && pv && nsplit == 1 && !a->key_keep && !a->key_index && !a->rowstat && !a->score_out && a->scale > 0.f &&
       blocks >= 2 * (long)vcr_cu_count() * 2) {
     const int lds_p = 2 * sizeof(Stage);
     VCR_DYN_LDS(sdpa_persist_kernel, lds_p);

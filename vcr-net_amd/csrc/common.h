@@ -127,6 +127,10 @@ struct vcr_stream_scope {                                 // first statement of 
   }
   ~vcr_stream_scope() { vcr_bound_device() = saved; }
 };
+// vcr_sdpa_f32: rows of a query block, resident workgroups per CU of its kernels -- shared with the forward's workspace plan
+// (forward.hip carve(): the key-split planes are only set aside where the launcher can take a split)
+constexpr int VCR_SDPA_QROWS = 128;
+constexpr int VCR_SDPA_WG_PER_CU = 2;
 inline int vcr_cu_count() {
   static std::atomic<int> cache[16];
   int dev = vcr_bound_device();

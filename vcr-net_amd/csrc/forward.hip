@@ -101,12 +101,12 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
   Ws w{};
   pl.want(w.xyz4, M * 4, 0, END);   pl.want(w.feat64, M * 64, 0, 3);   pl.want(w.sq64, M, 0, 2);   // (PointNet: conv3 reads feat64 at 3)
   pl.want(w.idx1, M * k, 1, 3);     pl.want(w.idx3, M * k, 1, 5);      pl.want(w.ties, 2 * (1 + M), 0, 2);   // a slot for every row
-  // kNN tie replay scratch per search: slots for the in-launch replay where a row image does not fit the workgroups' LDS (long
-  // rows, or the lists of k > 20) -- while that stays below 1 GiB (it is live during the kNN launch only and overlaid by the
-  // Transformer's buffers) --, else what the replay launch needs for rows beyond 10 091 points
+  // kNN tie replay scratch per search: k > 20 -- slots for the in-launch replay (the lists leave no room for a row image in
+  // LDS), while that stays below 1 GiB (live during the kNN launch only: it lies under the Transformer's buffers) --, else what
+  // the replay launch needs for rows beyond 10 091 points
   {
     const size_t slots = vcr_knn_tie_slot_bytes(2 * B, N);
-    w.tie_work_each = ((N > 2300 || k > 20) && slots <= ((size_t)1 << 30)) ? slots : vcr_knn_tie_work_bytes(N);
+    w.tie_work_each = (k > 20 && slots <= ((size_t)1 << 30)) ? slots : vcr_knn_tie_work_bytes(N);
     w.tie_work_each = (w.tie_work_each + 255) & ~(size_t)255;
   }
   pl.want(w.tie_work, w.tie_work_each ? 2 * w.tie_work_each : 0, 1, 2);
@@ -131,9 +131,10 @@ Ws carve(void* base, int B, int N, int k, int E, int F, int heads, int partial, 
     const size_t rows = 2 * M, ml = (size_t)VCR_SDPA_MAX_SPLIT * rows * heads * 2;
     const size_t want = (size_t)VCR_SDPA_MAX_SPLIT * rows * E, cap = ((size_t)64 << 20) / 4;
     w.asplit_floats = (long)((want < cap ? want : cap) + ml);
-    // ... and only for grids of at most half a round: vcr_sdpa_f32 splits the keys when blocks x split <= 2 x CUs (512 on
-    // MI355X); the smallest attention-output launch of the forward is the cross-attention (ceil(N / 128) x 2B x heads blocks)
-    if ((long)((N + 127) / 128) * 2 * B * heads > 256) w.asplit_floats = 0;
+    // ... and only for grids of at most half a round: vcr_sdpa_f32 splits the keys when blocks x split <= slots (the same
+    // constants and CU count as its launcher; 512 slots on MI355X); the smallest attention-output launch of the forward is the
+    // cross-attention (ceil(N / 128) x 2B x heads blocks)
+    if ((long)((N + VCR_SDPA_QROWS - 1) / VCR_SDPA_QROWS) * 2 * B * heads * 2 > (long)vcr_cu_count() * VCR_SDPA_WG_PER_CU) w.asplit_floats = 0;
     pl.want(w.asplit, (size_t)w.asplit_floats, 8, 17);
   }
   const size_t sn = M * (E / 64) * 2;

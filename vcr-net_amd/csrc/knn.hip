@@ -682,7 +682,7 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
 
   sel.init(lv, reinterpret_cast<int*>(lv + LROWS * 16), lane);
   // (tie_inline 2: the replay's row image is in global scratch, only its query row + block scratch need LDS)
-  int* blk_ties = a.tie_inline ? reinterpret_cast<int*>(smem + inline_tie_offset((size_t)W * 2 * LROWS * 16 * 4, a.tie_inline == 2 ? 0 : a.N)) : nullptr;
+  int* blk_ties = a.tie_inline ? reinterpret_cast<int*>(smem + inline_tie_offset((size_t)W * 2 * LROWS * 16 * 4, (KS > 22 && a.tie_inline == 2) ? 0 : a.N)) : nullptr;
   if (blk_ties) {
     if (threadIdx.x == 0) blk_ties[0] = 0;
     __syncthreads();
@@ -980,9 +980,13 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
   //@probe VCR_PROBE_ACC_FLUSH(threadIdx.x == 0 && blockIdx.y == 0, blockIdx.x);
   finish<G, KS, 1>(sel, a, b, q0 + col, wave, 0, smem, blk_ties, ord ? a.perm + (size_t)b * a.N : nullptr);
   if (blk_ties) {
+    // (the slot form exists in the k > 20 kernels only: they run three workgroups per CU and have the registers for it; with it
+    //  the k <= 20 kernels, held to 128 registers for their fourth workgroup, spill 32 of them -- 124 -> 142 us at configs[1])
     unsigned char* gwork = nullptr;
-    if (a.tie_inline == 2)                                 // this workgroup's slot: (cloud, query block) in launch-independent order
-      gwork = reinterpret_cast<unsigned char*>(a.tie_work) + ((size_t)b * ((a.N + 16 * W - 1) / (16 * W)) + bx) * 16 * (size_t)a.N;
+    if constexpr (KS > 22) {
+      if (a.tie_inline == 2)                               // this workgroup's slot: (cloud, query block) in launch-independent order
+        gwork = reinterpret_cast<unsigned char*>(a.tie_work) + ((size_t)b * ((a.N + 16 * W - 1) / (16 * W)) + bx) * 16 * (size_t)a.N;
+    }
     replay_block_ties(a, blk_ties, smem, gwork);
   }
 }
@@ -1111,7 +1115,7 @@ __global__ __launch_bounds__(256, 2) void knn3_kernel(vcr_knn_args a) {
 // alone is latency-bound at one wave per SIMD (1024 waves on 1024 SIMDs); launched together the second fills the
 // first one's idle issue slots, and the pair costs little more than the longer of the two.
 template <int KS, bool COL16, bool XT = false, bool ORD = false>
-__global__ __launch_bounds__(256, (COL16 ? (KS > 22 ? 3 : 4) : 2)) void knn_pair_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
+__global__ __launch_bounds__(256, (COL16 ? (KS > 22 || ORD ? 3 : 4) : 2)) void knn_pair_kernel(vcr_knn_args a64, vcr_knn_args a3, int n64, int gx64, int gx3) {
   const int bid = (int)blockIdx.x;
   if (bid < n64) {
     const int lin = xcd_chunk(bid, n64);
@@ -1567,11 +1571,12 @@ static int knn_s(const vcr_knn_args* a) {                  // candidate split of
   return groups >= 1024 ? 1 : groups >= 512 ? 2 : 4;
 }
 // 0: the tied rows go to a replay launch.  1: replayed by the workgroup that found them, row image in its LDS (N <= ~2400).
-// 2: likewise, row image in the workgroup's slot of tie_work (the caller gave vcr_knn_tie_slot_bytes(B, N) bytes of it).
+// 2 (k > 20): likewise, row image in the workgroup's slot of tie_work (the caller gave vcr_knn_tie_slot_bytes(B, N) bytes of it).
 static int ties_inline(const vcr_knn_args* a) {
   if (!a->tie_scratch) return 0;
   if (a->C == 64 ? !use_col16(a) : knn_s(a) != 1) return 0;
   if (inline_tie_offset(knn_log_bytes(a), a->N) + (1 + BLK_TIES) * 4 <= INLINE_TIE_MAX_LDS) return 1;
+  if (a->k <= 20) return 0;                              // (the slot form is compiled into the k > 20 kernels only)
   const size_t slots = vcr_knn_tie_slot_bytes(a->B, a->N);
   return (slots && a->tie_work && a->tie_work_bytes >= slots && !((uintptr_t)a->tie_work & 15)) ? 2 : 0;
 }

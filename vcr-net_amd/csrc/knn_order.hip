@@ -30,28 +30,48 @@ __global__ __launch_bounds__(1024) void knn_morton_kernel(const float* xyz4, int
   unsigned long long* seg = reinterpret_cast<unsigned long long*>(mo_smem);           // [N] keys, grouped by bucket
   int* cnt = reinterpret_cast<int*>(seg + N);                                          // [BUCKETS] counts -> next free slot
   int* start = cnt + ORDER_BUCKETS;                                                    // [BUCKETS] first slot of a bucket
-  float* red = reinterpret_cast<float*>(start + ORDER_BUCKETS);                        // [6][16]
-  int* wsum = reinterpret_cast<int*>(red + 96);                                        // [16] wave totals of the prefix
+  float* red = reinterpret_cast<float*>(start + ORDER_BUCKETS);                        // [12][16]: lo, hi, sum, sum of squares x 3 axes
+  int* wsum = reinterpret_cast<int*>(red + 192);                                       // [16] wave totals of the prefix
   const int t = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
   const float* rows = xyz4 + (size_t)b * N * 4;
   float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  float s1[3] = {0.f, 0.f, 0.f}, s2[3] = {0.f, 0.f, 0.f};
+  const f32x4 v0 = ld4(rows);                               // sums about the first point: no cancellation for clouds far from 0
   for (int i = t; i < N; i += nt) {
     const f32x4 v = ld4(rows + (size_t)i * 4);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], v[d]); hi[d] = fmaxf(hi[d], v[d]); }
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = fminf(lo[d], v[d]); hi[d] = fmaxf(hi[d], v[d]);
+      const float c = v[d] - v0[d];
+      s1[d] += c; s2[d] += c * c;
+    }
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     lo[d] = -wave_max(-lo[d]); hi[d] = wave_max(hi[d]);
-    if ((t & 63) == 0) { red[d * 16 + (t >> 6)] = lo[d]; red[(3 + d) * 16 + (t >> 6)] = hi[d]; }
+    s1[d] = wave_sum(s1[d]); s2[d] = wave_sum(s2[d]);
+    if ((t & 63) == 0) {
+      red[d * 16 + (t >> 6)] = lo[d]; red[(3 + d) * 16 + (t >> 6)] = hi[d];
+      red[(6 + d) * 16 + (t >> 6)] = s1[d]; red[(9 + d) * 16 + (t >> 6)] = s2[d];
+    }
   }
   for (int i = t; i < ORDER_BUCKETS; i += nt) cnt[i] = 0;
   __syncthreads();
   const int nw = nt >> 6;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    float l = red[d * 16], h = red[(3 + d) * 16];
-    for (int w = 1; w < nw; ++w) { l = fminf(l, red[d * 16 + w]); h = fmaxf(h, red[(3 + d) * 16 + w]); }
+    float l = red[d * 16], h = red[(3 + d) * 16], a1 = red[(6 + d) * 16], a2 = red[(9 + d) * 16];
+    for (int w = 1; w < nw; ++w) {
+      l = fminf(l, red[d * 16 + w]); h = fmaxf(h, red[(3 + d) * 16 + w]);
+      a1 += red[(6 + d) * 16 + w]; a2 += red[(9 + d) * 16 + w];
+    }
+    // A far outlier (one LiDAR return at 100 m) stretches the box and squeezes every other point into a handful of the
+    // 4096 buckets, whose in-bucket ranking is quadratic.  When an axis' extent exceeds 16 standard deviations --
+    // never for a cloud without outliers: a uniform cloud spans 3.5, 4096 gaussian points ~8 -- the box becomes mean +- 4
+    // sigma (inside the true one) and the points beyond it take the boundary's code.  The ranking only steers the visiting
+    // order: any box gives the same neighbour sets.
+    const float mc = a1 / (float)N, var = fmaxf(a2 / (float)N - mc * mc, 0.f), sd = __builtin_sqrtf(var), mean = v0[d] + mc;
+    if (h - l > 16.f * sd && sd > 0.f) { l = fmaxf(l, mean - 4.f * sd); h = fminf(h, mean + 4.f * sd); }
     lo[d] = l; hi[d] = h;
   }
   auto key_of = [&](int i) {
@@ -231,8 +251,8 @@ extern "C" int vcr_knn_order_f32(const vcr_knn_order_args* a, vcr_stream_t strea
     return VCR_EINVAL;
   if (a->N > ORDER_MAX_N) return VCR_EUNSUPPORTED;
   const int threads = a->N >= 2048 ? 1024 : a->N >= 512 ? 512 : 256;
-  const size_t lds = (size_t)a->N * 8 + 2 * ORDER_BUCKETS * 4 + 96 * 4 + 16 * 4;
-  VCR_DYN_LDS(knn_morton_kernel, (int)lds);               // (64.5 KB at 4096 points)
+  const size_t lds = (size_t)a->N * 8 + 2 * ORDER_BUCKETS * 4 + 192 * 4 + 16 * 4;
+  VCR_DYN_LDS(knn_morton_kernel, (int)lds);               // (64.9 KB at 4096 points)
   hipLaunchKernelGGL(knn_morton_kernel, dim3(a->B), dim3(threads), lds, (hipStream_t)stream, a->xyz4, a->N, a->perm);
   int rc = VCR_LAUNCH_RC();
   if (rc != 0) return rc;

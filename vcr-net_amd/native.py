@@ -602,7 +602,7 @@ def gathermax(pq, Cc, idx, n_per_cloud, variant=0):
 
 @_guarded
 def sdpa(q, k, v, nbatch, heads, nq, nk, scale, kv_batch_shift=0, key_keep=None, want_rowstat=False, pv=True,
-         score_out=None, bf16x3=False, groups=None, key_index=None, nk_src=0, split=False):
+         score_out=None, bf16x3=False, groups=None, key_index=None, nk_src=0, split=False, variant=0):
     """q [nbatch*nq, >=heads*128] (row views allowed), k/v likewise -> out [nbatch*nq, heads*128].
     score_out [nbatch, heads, nq, ld]: also keep the scaled scores (statistics pass of the partial path).
     groups = (ngroups, q_stride, k_stride, v_stride): that many problems in one launch, group g at element offset
