@@ -545,7 +545,7 @@ def measure(a, ctx, min_seconds):
                 # what a register-only fp32 MFMA loop holds on all 256 CUs after 2 s of load, with the shader clock read inside the
                 # kernel (round 4, three boxes): the pipe is NOT power-limited -- `frac` above is priced against the nominal peak
                 roof["peak_recorded"] = {"register_only_mfma_loop": 153.5, "unit": "TFLOP/s", "shader_clock_ghz": 2.39,
-                                         "source": "profiles/r4c_mfma_f32_clock.txt",
+                                         "source": "profiles/rounds4-5/r4c_mfma_f32_clock.txt",
                                          "note": "a RECORDED constant (round 4, two boxes, 2 s of load), not measured in this run: "
                                                  "the same kernels ran at 2.15-2.38 GHz from run to run on one box"}
             if split:

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_bf16x3_kernel(vcr_e
   // Gathers run AHEAD of the tile being multiplied, slab by slab (a slab = the 8 rows rs + 8 i of a tile): at the start of tile
   // t the rows of tile t + 1 are in flight (hp / hq) and the indices of tile t + 2 have been requested (nb).  In k-step 2 i + 1 of
   // tile t, slab i of tile t + 1 is split and committed to the other LDS buffer IN THE SHADOW of this wave's own MFMAs (beside the
-  // partner wave's MFMAs the same ~40 vector instructions per slab crawl at one per ~20 cycles: profiles/r4f_mfma_valu_coissue.txt),
+  // partner wave's MFMAs the same ~40 vector instructions per slab crawl at one per ~20 cycles: profiles/rounds4-5/r4f_mfma_valu_coissue.txt),
   // and its registers are re-used at once for slab i of tile t + 2, whose indices came in a tile ago; the indices of tile t + 3
   // follow.  Every request is unconditional (past the block's last group it re-reads that group: never committed).
   f32x4 hp[4], hq[4];                                    // neighbour P rows / centre Q rows of the tile after the current one

@@ -1,6 +1,6 @@
 """Phase clocks of edgeconv_bf16x3 (timing build: edgeconv_bf16x3_phase_clock_kernel.hip compiled in place of the product kernel into
 scratch/lib_ecprobe.so; lane 0 of every wave of workgroups 0 and 517 accumulates s_memtime differences per phase and writes them
-over x1 rows 0 / 1 -- results of that build are garbage by design).  Record: profiles/r5n_edgeconv_bf16x3_phase_clocks.txt."""
+over x1 rows 0 / 1 -- results of that build are garbage by design).  Record: profiles/rounds4-5/r5n_edgeconv_bf16x3_phase_clocks.txt."""
 import sys, torch
 sys.path.insert(0, '.')
 import vcrnet_amd

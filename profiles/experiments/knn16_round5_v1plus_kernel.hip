@@ -1684,7 +1684,7 @@ extern "C" int vcr_knn_ties_f32(const vcr_knn_args* a, const vcr_knn_args* b, vc
 
 // Which feature-space kernel: 16-query waves on 16x16x4 MFMAs (knn64c_body) or 32-query waves on 32x32x2 (knn64_body).
 // vcr_knn_args.waves: 8 forces the former; 1 / 2 / 4 the latter with that candidate split; 0 = the half-size waves as soon
-// as there are 1024 groups of 16 queries (a wave for every SIMD), by measurement on MI355X (profiles/r3i_bench_knn.txt;
+// as there are 1024 groups of 16 queries (a wave for every SIMD), by measurement on MI355X (profiles/rounds1-3/r3i_bench_knn.txt;
 // 16- vs 32-query waves): one-launch pair 32 clouds x 1024: 148 vs 176 us inside the forward; pair 32 x 2048: 452 vs 477;
 // 64 x 4096, k = 40: 2.39 vs 2.92 ms; alone they are level at k = 20 (32 x 1024: 112 vs 123 us, 32 x 2048: 315 vs 303).
 // Smaller grids keep the 32-query kernels, whose S = 2 / 4 waves split the candidates of a query group.  Results are

@@ -1,6 +1,6 @@
 // RECORD (not built): the bf16x3 linear as it stood until round 4 (256 x 128 tile, 8 waves, one workgroup per CU, 32x32x16 MFMAs,
 // LDS-DMA weight planes).  Replaced by vcr-net_amd/csrc/linear_bf16x3.hip (128 x 128 tile, 16x16x32 MFMAs, two workgroups per CU);
-// profiles/r4t_* are the measurements that led there, profiles/r4w_* the comparison.
+// profiles/rounds4-5/r4t_* are the measurements that led there, profiles/rounds4-5/r4w_* the comparison.
 
 // Pointwise linear on the bf16 matrix pipe with fp32-equivalent products ("bf16x3"):
 //   every fp32 operand is split EXACTLY into three bf16 pieces, x = x1 + x2 + x3 (8 + 8 + 8 significand bits),
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void linear_bf16x3_kernel(vcr_linear_args p
   // One slab = 2 k-steps of 16 x (2 x 2 output tiles) x 6 MFMAs.  The stream is laid out by hand (sched_barrier fences one
   // CHUNK = one output tile's six MFMAs = 192 cycles of the matrix pipe): beside a wave that issues MFMAs back to back a
   // SIMD lets the other wave's vector / LDS instructions through at one per 20-36 cycles, while a wave's own instructions
-  // issue in the shadow of its own MFMAs (profiles/r4f_mfma_valu_coissue.txt) -- and a slab carries ~150 of them per wave
+  // issue in the shadow of its own MFMAs (profiles/rounds4-5/r4f_mfma_valu_coissue.txt) -- and a slab carries ~150 of them per wave
   // (24 fragment reads, the 3-way split of 16 activations = ~110 VALU, 12 LDS stores, the next slab's requests) against 48
   // MFMAs.  hipcc grouped them in front of and behind the MFMA block, where both waves of a SIMD (one workgroup per CU: they
   // run in phase) crawled through them together.  Here k-step 0's chunks carry the fragment reads of k-step 1 and the

@@ -3,7 +3,7 @@
 // linear_persist_kernel: persistent workgroups (two per CU) that walk over their 128x128 tiles with the LDS-DMA slab
 // pipeline running across tile boundaries and the epilogue of tile i issued from the accumulator registers under the
 // first eight k-steps of tile i+1.  Bit-identical results to linear_glds_kernel, measured SLOWER on every shape of the
-// path (profiles/r2b_bench_linear_shapes.txt: qkv 479 vs 402 us, wo 156 vs 148, ffn2 281 vs 273; DESIGN.md 5.1 item 1:
+// path (profiles/rounds1-3/r2b_bench_linear_shapes.txt: qkv 479 vs 402 us, wo 156 vs 148, ffn2 281 vs 273; DESIGN.md 5.1 item 1:
 // persistent workgroups of equal work stay in phase and share the matrix pipe the whole time).  Known defect, never
 // fixed because the kernel was retired: with K < 256 and ln_stats_in the 3-slot rowst ring is read by the trailing
 // "short K" epilogue slices without a barrier before the next tile's row_stats() overwrites the slot.

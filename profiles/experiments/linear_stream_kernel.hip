@@ -4,7 +4,7 @@
 // incl. ragged M / N, LayerNorm-in, statistics-out, residual: profiles/experiments/check_linear_stream.py ran against it while
 // it was wired into vcr_linear_f32 behind variant bits 15 / 16), and SLOWER than the one-tile-per-workgroup kernels wherever
 // those run four workgroups per CU:  stacked QKV projection (M 32768, N 3072, K 512) 866 us = 119 TFLOP/s against 785 us = 131;
-// level on the residual shapes (wo 158 vs 161 us, ffn2 282 vs 282).  Timing ablations of the same launch (profiles/r4k_linear_stream.txt):
+// level on the residual shapes (wo 158 vs 161 us, ffn2 282 vs 282).  Timing ablations of the same launch (profiles/rounds4-5/r4k_linear_stream.txt):
 // everything 913 us; without the LDS-DMA slab requests 787; without the k-step barriers 885; without the drain 838; with
 // none of them 743 (138.7 TFLOP/s = 0.88: the MFMA + fragment-read loop of two waves per SIMD by itself).  What it shows: at
 // two waves per SIMD (two 64-register accumulator sets need 256 VGPRs) the slab requests (~100 cycles of the issuing wave
@@ -18,10 +18,10 @@
 // Why a second kernel.  linear.hip runs one 128 x 128 tile per workgroup, 2-4 workgroups per CU: a workgroup's prologue
 // and epilogue (LDS transpose, bias / LayerNorm / residual, stores: ~400 vector instructions per wave) run beside OTHER
 // workgroups' k loops -- and beside a wave that issues fp32 MFMAs back to back, a SIMD lets another wave's vector / LDS
-// instructions through at one per ~20 cycles (profiles/r4f_mfma_valu_coissue.txt), while a wave's OWN instructions issue
-// freely in the 64-cycle shadow of its own MFMA.  Measured with in-kernel stamps (profiles/r4f_timeline_linear.txt): the
+// instructions through at one per ~20 cycles (profiles/rounds4-5/r4f_mfma_valu_coissue.txt), while a wave's OWN instructions issue
+// freely in the 64-cycle shadow of its own MFMA.  Measured with in-kernel stamps (profiles/rounds4-5/r4f_timeline_linear.txt): the
 // stacked QKV projection spends 9.8 + 23 us of a workgroup's 134 us in prologue + epilogue, the k loop's own clock is
-// 2.25-2.39 GHz (profiles/r4c_clock_probe_linear.txt), and a bare MFMA loop sustains 153 TFLOP/s on the same boxes: the
+// 2.25-2.39 GHz (profiles/rounds4-5/r4c_clock_probe_linear.txt), and a bare MFMA loop sustains 153 TFLOP/s on the same boxes: the
 // 0.80 of peak is issue structure, not power.  So here
 //   * workgroups are PERSISTENT (two per CU, 256 threads, BK 32): tile after tile, the LDS-DMA slab pipeline runs across
 //     tile boundaries (the next tile's first slab is requested during the last k-step of the current one);

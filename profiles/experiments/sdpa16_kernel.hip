@@ -4,7 +4,7 @@
 // asked for the second fp32 MFMA shape in linear AND sdpa, "keep the faster by wall").  Correct (held to fp64 like the
 // 32x32x2 kernel, masked / statistics / stored-scores forms included) and SLOWER on every shape, 32x32x2 / 16x16x4:
 //   2B x H = 32 x 4, N = 1024: 583 / 588 us     48 x 4, N = 768: 517 / 524 us
-//   32 x 4, N = 2048: 2032 / 2160 us            64 x 4, N = 4096: 16.0 / 16.9 ms        (profiles/r3b_bench_sdpa.txt)
+//   32 x 4, N = 2048: 2032 / 2160 us            64 x 4, N = 4096: 16.0 / 16.9 ms        (profiles/rounds1-3/r3b_bench_sdpa.txt)
 //   whole step at BASELINE configs[1]: 5.209 vs 5.307 ms (profiles: r3b_bench_l32_s32 / l32_s16)
 // Why: a query column is spread over four lanes (two exchanges per soft-max statistic instead of one), a wave carries two
 // 16-query column groups (two sets of running max / sum, twice the accumulator rescales), and the kernel was already at

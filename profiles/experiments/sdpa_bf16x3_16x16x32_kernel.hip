@@ -1,6 +1,6 @@
 // RECORD (not built): round-4 attempt at vcr_sdpa_bf16x3_f32 on v_mfma_f32_16x16x32_bf16 (correct: tests pass except the tight error-vs-fp32
 // bound at N = 256, 1.12e-5 against 1.05e-5).  A timing ablation of the 32x32x16 kernel with every MFMA replaced by two 16x16x32 ran
-// 7828 cycles per tile at 1.86 GHz (8400 at 1.66 GHz for the product kernel, profiles/r4y_timeline_sdpa_bf16x3.txt) = 1.22x; this real
+// 7828 cycles per tile at 1.86 GHz (8400 at 1.66 GHz for the product kernel, profiles/rounds4-5/r4y_timeline_sdpa_bf16x3.txt) = 1.22x; this real
 // kernel needs more registers than a wave has at two waves per SIMD (Q 96 + O 64 + two query blocks of soft-max state): 10-13 VGPRs
 // spill, the V^T fragments are read twice, and it measured 9044 cycles per tile at 1.85 GHz = 365 us against 380 us: +4 %, not adopted.
 // What it would take: one wave per SIMD (512 registers: all 24 fragments of a tile resident, four query blocks software-pipelined).
@@ -29,7 +29,7 @@
 //
 // The bf16 matrix pipe is POWER limited here: round 4 measured the 32x32x16 form of this kernel at 1.65 GHz in the tile loop
 // and exactly 8400 cycles per tile (6144 of MFMAs), and the same loop on 16x16x32 MFMAs at 1.86 GHz and 7828 cycles
-// (profiles/r4y_timeline_sdpa_bf16x3.txt): hence this shape.  The vector work that does not depend on a tile's scores -- the
+// (profiles/rounds4-5/r4y_timeline_sdpa_bf16x3.txt): hence this shape.  The vector work that does not depend on a tile's scores -- the
 // 3-way split and LDS stores of the NEXT tile's K and V (loads issued a tile ago) -- rides in the shadow of the score
 // MFMAs, a piece per (key block, step).  (Splitting the second query block's probabilities in the shadow of the first's P V
 // MFMAs needs 12 more registers than the wave has: it spilled.)

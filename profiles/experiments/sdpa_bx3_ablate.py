@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Experiment: timing ABLATIONS of vcr_sdpa_bf16x3_f32's tile loop (results of the ablated builds are wrong by construction).
-The loop's cycle count per tile is deterministic (8400 in every run, profiles/r4y_timeline_sdpa_bf16x3.txt), so each removed
+The loop's cycle count per tile is deterministic (8400 in every run, profiles/rounds4-5/r4y_timeline_sdpa_bf16x3.txt), so each removed
 piece is an exact attribution.  Builds scratch/bx3/lib_sdpa_<name>.so (translation unit alone, probes on); timed by
 profiles/experiments/timeline_sdpa_bf16x3.py through VCR_TL_LIB.
   python profiles/experiments/sdpa_bx3_ablate.py build | run"""

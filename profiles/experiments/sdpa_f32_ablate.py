@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Experiment: timing ABLATIONS of vcr_sdpa_f32's key loop (fp32, the headline's attention; results of the ablated builds are wrong
 by construction).  NOTE: the patch anchors below are those of the LDS-DMA staging variant (profiles/experiments/sdpa_f32_lds_dma_staging.patch
-applied to attention.hip); profiles/r4ah_sdpa_f32_ablate.txt was taken with the anchors of the register-staged product kernel (git history).  attention.hip compiles alone; each variant is a textual patch with the `//@probe` stamps on; the runner reports
+applied to attention.hip); profiles/rounds4-5/r4ah_sdpa_f32_ablate.txt was taken with the anchors of the register-staged product kernel (git history).  attention.hip compiles alone; each variant is a textual patch with the `//@probe` stamps on; the runner reports
 us per launch, the key loop's shader clock and cycles per 32-key tile (two workgroups per CU: 2 waves per SIMD x 128 MFMAs x 64
 cycles = 16384 at the pipe rate).
   python profiles/experiments/sdpa_f32_ablate.py build | run"""

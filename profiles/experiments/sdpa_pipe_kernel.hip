@@ -5,17 +5,17 @@
 // launches for one build: outputs BIT-IDENTICAL (checksums of five shapes, profiles/experiments/bench_sdpa_ab.py), and the
 // launch times IDENTICAL too -- 32 x 1024: 577-587 us both builds, 32 x 2048: 2072-2083, 64 x 4096: 16.05-16.10 ms -- as
 // was a lighter variant that only requested the K / V fragments one group ahead (-0..1 %).  The key loop's 8.2 us per tile
-// against 6.8 at the matrix peak (profiles/r4n_timeline_sdpa.txt: prologue 5.4, key loop 263, epilogue 7.7 us of a workgroup
+// against 6.8 at the matrix peak (profiles/rounds4-5/r4n_timeline_sdpa.txt: prologue 5.4, key loop 263, epilogue 7.7 us of a workgroup
 // at 32 x 1024) is therefore neither exposed LDS latency nor the soft-max beside the partner's MFMAs.  It matches the 0.88
 // that the persistent linear's MFMA + fragment-read loop reached with everything else ablated away
-// (profiles/r4k_linear_stream.txt): LDS-fed fp32 MFMA loops at two waves per SIMD top out there.
+// (profiles/rounds4-5/r4k_linear_stream.txt): LDS-fed fp32 MFMA loops at two waves per SIMD top out there.
 // (kernel body as it was wired into attention.hip; Stage, KP, LOG2E, mfma32, acc_row, xhalf are that file's)
 
 // The attention-OUTPUT launches of the forward (no mask, no statistics, no stored scores, one run of keys per workgroup)
 // as a software pipeline.  In sdpa_kernel a tile is  QK^T (64 MFMAs) -> soft-max (~100 vector instructions, more with the
 // rescale of O) -> P V (64 MFMAs): the soft-max of one wave runs beside its SIMD partner's MFMAs, where a vector instruction
-// gets through once per ~20 cycles (profiles/r4f_mfma_valu_coissue.txt), and the key loop takes 8.2 us per tile against
-// 6.8 at the matrix peak (profiles/r4n_timeline_sdpa.txt).  Here the scores of tile t+1 are computed WHILE the soft-max of
+// gets through once per ~20 cycles (profiles/rounds4-5/r4f_mfma_valu_coissue.txt), and the key loop takes 8.2 us per tile against
+// 6.8 at the matrix peak (profiles/rounds4-5/r4n_timeline_sdpa.txt).  Here the scores of tile t+1 are computed WHILE the soft-max of
 // tile t runs -- QK^T(t+1)'s MFMAs and soft-max(t)'s instructions alternate inside chunks fenced by sched_barrier(0) --,
 // then P V(t) carries the LDS writes of the rows staged for later tiles.  K therefore runs one tile ahead of V in the two
 // LDS stages: during iteration t stage[cur] holds V[t] (and receives K[t+2]), stage[cur ^ 1] holds K[t+1] (and receives

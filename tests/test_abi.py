@@ -231,7 +231,7 @@ def test_host_side_dispatch_logic_without_a_gpu(lib):
 def test_linear_launch_choice_against_the_recorded_sweep(lib):
     """vcr_linear_config (host-only): the kernel configuration per launch.  The BASELINE shapes take what DESIGN says
     (128-row tiles at configs[1]; 96-row tiles for the residual launches of configs[2]; 32-row tiles and the 16x16x4 shape
-    for one pair per call), and replayed against the sweep recorded on the GPU (profiles/r3z_sweep_bm_after.txt: both
+    for one pair per call), and replayed against the sweep recorded on the GPU (profiles/rounds1-3/r3z_sweep_bm_after.txt: both
     forced heights timed at 56 shapes) the automatic height never loses more than 6 % to the better one."""
     import os
     import re
@@ -254,7 +254,7 @@ def test_linear_launch_choice_against_the_recorded_sweep(lib):
     assert cfg(2048, 3072, 512, False)[0] in (64, 128) and cfg(2048, 3072, 512, False)[2]
     assert cfg(8192, 512, 512, True) == (128, 32, True)               # 256 tiles: exactly one per CU (the first model took 96: -34 %)
     assert cfg(32768, 512, 512, True, variant=2048)[0] == 96 and cfg(2048, 512, 512, True, variant=4096 | 16)[0] == 128
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r3z_sweep_bm_after.txt")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "rounds1-3", "r3z_sweep_bm_after.txt")
     worst, n = 0.0, 0
     for line in open(path):
         m = re.match(r"K=(\d+) M=\s*(\d+) tiles128=\s*\d+: auto\s+[\d.]+\s+bm128\s+([\d.]+)\s+bm96\s+([\d.]+)", line)

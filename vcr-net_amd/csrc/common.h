@@ -83,7 +83,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // var is the unbiased one of Tensor.std() (transformer.py:142).
 // nseg = 8 (K = 512, the path's case): the row's 64 B arrive as four 16-B loads issued together -- ONE memory round trip.
 // The scalar loop below compiles to one load per iteration, each waited for before the next is issued: eight round
-// trips, 16-20 us of a workgroup's prologue under load (profiles/r4c_timeline_linear.txt).  Same values, same order.
+// trips, 16-20 us of a workgroup's prologue under load (profiles/rounds4-5/r4c_timeline_linear.txt).  Same values, same order.
 __device__ __forceinline__ void ln_row_moments(const float* sp, int nseg, int K, float& mean, float& var) {
   if (nseg == 8 && (((uintptr_t)sp) & 15) == 0) {
     typedef float v4 __attribute__((ext_vector_type(4)));

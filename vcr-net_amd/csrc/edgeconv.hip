@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_kernel(vcr_edgeconv
 
 // The packed kernel again, with every wave's instruction stream laid out by hand for the matrix pipe it shares.
 //
-// Measured (profiles/r4f_mfma_valu_coissue.txt): beside a wave that issues fp32 MFMAs back to back, another wave of the
+// Measured (profiles/rounds4-5/r4f_mfma_valu_coissue.txt): beside a wave that issues fp32 MFMAs back to back, another wave of the
 // same SIMD gets ONE vector / LDS instruction through per ~20 cycles (alone: 2.5-6), while a wave's OWN vector
 // instructions issue freely in the 64-cycle shadow of its own MFMA.  The kernel above runs two workgroups per CU; per tile
 // a wave has 64 MFMAs (4096 cycles of the pipe) and ~200 other instructions, which hipcc groups in front of and behind
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void edgeconv_dg_packed_kernel(vcr_edgeconv
 //     folded one chunk after it was requested;
 //   * the previous tile's accumulator is folded into the per-point maxima one register per chunk (two accumulators).
 // Results are bit-identical to the kernel above (same MFMA order per output; max is exact).
-constexpr int FRAG_AHEAD = 1;                            // 1 or 2 (profiles/r4i_edgeconv_ab.txt)
+constexpr int FRAG_AHEAD = 1;                            // 1 or 2 (profiles/rounds4-5/r4i_edgeconv_ab.txt)
 template <int KE>
 __global__ __launch_bounds__(256, 2) void edgeconv_dg_pipe_kernel(vcr_edgeconv_args p) {
   static_assert(KE % 2 == 0 && 160 % KE == 0, "parity split of the x1 pass");
@@ -599,7 +599,7 @@ extern "C" int vcr_gathermax_f32(const vcr_gathermax_args* a, vcr_stream_t strea
   int cs = 0;
   if (a->variant == 0) {
     // 32-channel slices up to N = 1066; 16-channel slices up to N = 2048 (a whole CU's LDS per workgroup; measured at 32
-    // clouds x 2048: 62.8 -> 57.2 us, profiles/r4j_bench_gathermax.txt; 8-channel slices lose everywhere: 121 us there)
+    // clouds x 2048: 62.8 -> 57.2 us, profiles/rounds4-5/r4j_bench_gathermax.txt; 8-channel slices lose everywhere: 121 us there)
     if (aligned && (long)(a->M / N) * ((a->C + 31) / 32) >= 192)
       cs = (size_t)N * 36 * 4 <= budget ? 32 : (size_t)N * 20 * 4 <= 160 * 1024 ? 16 : 0;
   } else if (a->variant == 32 || a->variant == 16 || a->variant == 8) {

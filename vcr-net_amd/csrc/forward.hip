@@ -570,7 +570,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     a64.tie_work_bytes = a3.tie_work_bytes = w.tie_work_each;
     a64.xt = W->E >= 64 ? w.emb : nullptr;
     // The ORDERED search (vcr_knn_args.perm) for the larger clouds: ranking the points along a Morton curve lets a 16-query
-    // wave skip the tiles whose balls cannot hold a neighbour -- measured (profiles/r5o_knn_ordered.txt) 416 -> 295 + 45 us
+    // wave skip the tiles whose balls cannot hold a neighbour -- measured (profiles/rounds4-5/r5o_knn_ordered.txt) 416 -> 295 + 45 us
     // (ranking) at 32 x 2048, 2970 -> 1850 + 93 at 64 x 4096, k = 40; at 1024 points the plain scan is faster (120 vs 143 + 30).
     // Its arrays live in the unused part of w.emb (free until conv3; feat64t is its first M2 x 64 floats).
     if (R.rc == 0 && W->E >= 256 && N >= KNN_ORDERED_MIN_N && N <= 4096 && (k == 20 || k == 40) && W->knn_waves == 0 &&

@@ -3,7 +3,7 @@
 // tile of 16 consecutive ranks a ball (centroid, radius) that holds its rows -- in coordinate space and in feature space.  The
 // features are a smooth function of the coordinates (lpdnet_model.py:111-112: two pointwise convs), so a tile of Morton
 // neighbours is compact in BOTH spaces: with the tiles' balls a 16-query wave needs 0.4-0.5 of a 1024-point cloud's tiles and
-// 0.2-0.3 of a 4096-point cloud's (profiles/r5n_knn_feat_prune_potential.txt).
+// 0.2-0.3 of a 4096-point cloud's (profiles/rounds4-5/r5n_knn_feat_prune_potential.txt).
 #include "common.h"
 
 namespace {

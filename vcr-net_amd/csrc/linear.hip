@@ -221,7 +221,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 // MS    : MFMA shape.  32 = v_mfma_f32_32x32x2_f32 (wave tile = 2x2 tiles, k = 8g + 4*half + s); 16 =
 //         v_mfma_f32_16x16x4_f32 (wave tile = 4x4 tiles of 16x16, a lane's quarter q = lane >> 4 owns chunk q of a 16-wide
 //         k group: k = 16g + 4q + s).  Same flops per cycle; the chip sustains a higher clock on the 16x16 shape under
-//         the matrix pipe's power limit (profiles/r2e_mfma_sustained_rates.txt: 132-140 vs 127-136 TFLOP/s).  The two
+//         the matrix pipe's power limit (profiles/rounds1-3/r2e_mfma_sustained_rates.txt: 132-140 vs 127-136 TFLOP/s).  The two
 //         shapes sum k in different orders: results agree to fp32 rounding, not bitwise.
 // (LN_IN = p.ln_stats_in != NULL and STATS_OUT = p.stats_out != NULL are run-time properties of the launch -- a uniform
 //  branch in the prologue and two in the epilogue -- not template parameters: a quarter of the instantiations)
@@ -250,7 +250,7 @@ __device__ __forceinline__ void linear_glds_body(const vcr_linear_args& p, int t
   // Tile order: M-major inside column GROUPS of <= 12 tiles (a 3 MB slice of W for K = 512), so that the weight slice an
   // XCD works on stays in its 4 MB L2 while the X panels stream past it.  Up to N = 1536 that is the plain M-major
   // order; for the stacked [6E, E] projection (24 column tiles, W = 6 MB) the plain order fetched 1.2 GB per launch
-  // (rocprofv3 FETCH_SIZE, profiles/r3f_pmc_summary.json) against 70 MB of operands.  A renumbering: same results.
+  // (rocprofv3 FETCH_SIZE, profiles/rounds1-3/r3f_pmc_summary.json) against 70 MB of operands.  A renumbering: same results.
   constexpr int GW = 12;
   const int grp = bid / (GW * tiles_m), wg = min(GW, tiles_n - grp * GW), loc = bid - grp * GW * tiles_m;
   const int tm = loc / wg, tn = grp * GW + loc % wg;
@@ -548,7 +548,7 @@ struct LinearPlan { bool glds, bk16, ms16, bm_free, small_free, ln_in, st_out; i
 
 // Launches of less than one round (t128 < 2 x CUs): tile height in {128, 96, 64, 32} minimising g(ceil(tiles / CUs)) x
 // (rows + 24) -- workgroups spread one per CU first; a workgroup costs its rows plus a fixed prologue / epilogue /
-// pipeline-fill share (~24 rows' worth); two co-resident ones take 1.75 x one (profiles/r3z_sweep_bm.txt), a third
+// pipeline-fill share (~24 rows' worth); two co-resident ones take 1.75 x one (profiles/rounds1-3/r3z_sweep_bm.txt), a third
 // waits for a slot.  tiles_by_h: the launch's (or the pair's) tile counts at the four heights.
 int small_grid_rows(const long* tiles_by_h) {
   static const int hs[4] = {128, 96, 64, 32};
@@ -564,7 +564,7 @@ int small_grid_rows(const long* tiles_by_h) {
 }
 
 // Relative cost of a launch of `tiles` workgroups of `rows`-row tiles on `slots` resident workgroups (two per CU), fitted to
-// a sweep of M at both tile heights (profiles/r3z_sweep_bm.txt: 56 shapes; the choice it makes loses 0.2 % on average and
+// a sweep of M at both tile heights (profiles/rounds1-3/r3z_sweep_bm.txt: 56 shapes; the choice it makes loses 0.2 % on average and
 // 5 % at worst against the better height, always-128 loses 8.9 % on average):  full rounds cost 1 each;  a LAST partial
 // round filled to f costs half a round up to f = 0.3 (its workgroups have a CU to themselves), a whole one from f = 0.7
 // (the dispatcher pairs them up on the CUs that free first), linear in between;  a launch of less than one round costs
@@ -615,7 +615,7 @@ int linear_plan(const vcr_linear_args* a, LinearPlan* pl, int bm_override = 0, b
   // ... except a launch of its own whose grid is at most ONE round of the BK 16 kernel's 1024 slots (conv3 at BASELINE
   // configs[1]: 1024 tiles): every workgroup then stores its tile at the same time with no k loop left to run under the
   // stores; two rounds of the BK 32 kernel's 512 slots drift apart instead.  Measured inside the forward on one box
-  // (profiles/r3r_ab_conv3_bk32.txt): conv3 0.148 -> 0.1425 ms.  K >= 512 only (sn1_pq, K = 128: 0.047 -> 0.049 with BK 32).
+  // (profiles/rounds1-3/r3r_ab_conv3_bk32.txt): conv3 0.148 -> 0.1425 ms.  K >= 512 only (sn1_pq, K = 128: 0.047 -> 0.049 with BK 32).
   const bool one_round16 = !in_pair && variant == 0 && a->M >= 16384 && a->K >= 512 &&
                            (long)((a->M + 127) / 128) * pl->tiles_n <= 4L * vcr_cu_count();
   pl->bk16 = ((!a->residual && !one_round16) || (variant & 64)) && !(variant & 8);

@@ -13,7 +13,7 @@
 // 128 x 128 x 32 block tile, 4 waves (2 x 2), wave tile 64 x 64 = 4 x 4 tiles of v_mfma_f32_16x16x32_bf16, TWO workgroups
 // per CU (49 KB LDS and <= 256 registers each).  Round 4 measured what held the first kernel (256 x 128 tile, 8 waves, one
 // workgroup per CU, 32x32x16 MFMAs; profiles/experiments/linear_bf16x3_round4a.hip) at 0.37 of 417 TFLOP/s-equivalent
-// (profiles/r4t_*): (1) the bf16 matrix pipe is POWER limited -- the shader clock sits at 1.8 GHz inside the k loop (2.2-2.4
+// (profiles/rounds4-5/r4t_*): (1) the bf16 matrix pipe is POWER limited -- the shader clock sits at 1.8 GHz inside the k loop (2.2-2.4
 // outside), and the 16x16x32 form delivers 1.14x the 32x32x16 form in the same MFMA-only loop; (2) with one workgroup per
 // CU nothing covers a tile's prologue and epilogue (5-10 us of 45-50); (3) the activation path (loads, 3-way split, LDS
 // stores) costs 15 % of the loop where both waves of a SIMD run it in phase.  Here a slab is ONE k-step: after barrier 1 a
@@ -27,7 +27,7 @@
 // 20-27}, {4-11, 16-19, 28-31} and the same + 32: MI355X_MICROARCH.md, LDS): with the 16x16x32 fragment (row = lane & 15, chunk =
 // lane >> 4) a group reads rows 0-3 and 12-15 of one chunk and rows 4-11 of the next, and this table puts those on 16
 // distinct 16-B slots of the 256-B bank row (the plain (row >> 2) & 3 is 2-way there: SQ_LDS_BANK_CONFLICT was a third of the
-// LDS cycles, profiles/r4u_pmc_bx3_3.txt).  The stores (16 / 8 contiguous lanes = 128 contiguous bytes) are conflict-free.
+// LDS cycles, profiles/rounds4-5/r4u_pmc_bx3_3.txt).  The stores (16 / 8 contiguous lanes = 128 contiguous bytes) are conflict-free.
 #include <type_traits>
 
 #include "common.h"
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void linear_bf16x3_kernel(vcr_linear_args p
 
   // The MFMA stream of a slab is laid out by hand (sched_barrier fences one CHUNK = one output tile's six MFMAs = 96 cycles
   // of the matrix pipe): a wave's own vector / LDS instructions issue in the shadow of its own MFMAs, while beside another
-  // wave that issues MFMAs back to back they get one slot per 20-36 cycles (profiles/r4f_mfma_valu_coissue.txt) -- and a
+  // wave that issues MFMAs back to back they get one slot per 20-36 cycles (profiles/rounds4-5/r4f_mfma_valu_coissue.txt) -- and a
   // 16x16x32 MFMA leaves room for about two of them (MI355X_MICROARCH.md: it holds the vector issue for 8 of its 16 cycles).
   // Chunks 0-7 carry the split of the next slab's activations and the requests for the slab after, chunks 8-13 the LDS
   // stores.  Same MFMA order per output element in every build: bit-identical results.
