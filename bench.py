@@ -567,7 +567,7 @@ def measure(a, ctx, min_seconds):
                        if ("bf16x3" in os.path.basename(p_)) == (a.linear_mode != "fp32")), key=_pmc_rank)
         if pmcs and (B, N, a.k, a.partial, a.iters, a.emb_nn) == (16, 1024, 20, False, 1, "lpdnet"):
             kname = {"linear": "linear_glds" if a.linear_mode == "fp32" else "linear_bf16x3_kernel",
-                     "sdpa": "sdpa_kernel<false, true>" if a.linear_mode != "bf16x3+sdpa" else "sdpa_bf16x3_kernel",
+                     "sdpa": "sdpa_persist_kernel" if a.linear_mode != "bf16x3+sdpa" else "sdpa_bf16x3_kernel",
                      "edgeconv": "edgeconv_dg_pipe_kernel<20>", "softcorr": "pairscore_kernel<0>"}.get(dom)
             # a family can be several template instantiations (linear: plain / statistics-out / LayerNorm-in):
             # launch-weighted mean over the entries whose name starts with the family's kernel name

@@ -24,7 +24,9 @@ def short(name):
                 "knn_pair_kernel", "knn64c_kernel", "sdpa16_kernel", "knn_tiebreak2_kernel", "edgechain_kernel",
                 "vcr_copy_words_kernel", "zero_i32_kernel", "pose_step_kernel", "edgeconv_dg_packed_bf16x3_kernel",
                 "keymass4_kernel", "keymass_kernel", "statmerge_kernel", "rowstat_merge_kernel", "score_colpass_kernel",
-                "score_rowpass_kernel", "gather_rows_kernel", "sdpa_bf16x3_kernel", "linear_bf16x3_kernel"):
+                "score_rowpass_kernel", "gather_rows_kernel", "sdpa_bf16x3_kernel", "linear_bf16x3_kernel", "sdpa_persist_kernel", "knn_morton_kernel",
+                "knn_rank_rows_kernel", "knn_order_guard_kernel", "split_bf16x3_kernel", "fold_layernorm_kernel", "make_pairs_kernel",
+                "gathermax_lds_kernel", "sdpa_merge_kernel", "icp_kernel", "zero_count_kernel"):
         if key in name:
             return key + (name[name.index(key) + len(key):].split("(")[0] if "<" in name else "")
     return name[:48]

@@ -202,37 +202,45 @@ __global__ __launch_bounds__(256) void knn_rank_rows_kernel(vcr_knn_order_args a
   }
 }
 
-// The guard of the feature-space search (vcr_knn_order_args.ord_ok): one workgroup per cloud over the T tile balls.  lane = position
-// in the 64-float centroid row (any layout: only distances between centroids are taken), waves take every fourth tile.  Two passes
-// (mean, then squared deviations): post-ReLU features have |mean| >> spread.
+// The guard of the feature-space search (vcr_knn_order_args.ord_ok): one workgroup of 16 waves per cloud over its T tile balls,
+// ONE pass.  lane = position in the 64-float centroid row (any layout: only distances between centroids are taken), wave w takes
+// the tiles w, w + 16, ...; sums and sums of squares are taken about the FIRST tile's centroid (post-ReLU features have a mean
+// of the order of their spread: the shift keeps the one-pass variance well conditioned; the verdict's margin is a factor 2-3).
+constexpr float ORDER_GUARD_RATIO = 0.8f;
 // measured (profiles/r6b_knn_guard.txt): the stem's features score 0.2-0.36 (LPD-pretrained and random weights), with noise of
 // 0.3 sigma 0.29-0.39 -- ordered still 0.66-0.84 of the plain time --, with 1 sigma 1.24-1.35 -- level at 4096 points, 1.10x at
 // 2048 --, unrelated features 23
-constexpr float ORDER_GUARD_RATIO = 0.8f;
-__global__ __launch_bounds__(256) void knn_order_guard_kernel(const float* cen64, const float* rad, int T, float ratio,
-                                                              int32_t* ok, float* stat) {
-  __shared__ float part[4][64];
-  __shared__ float red[8];
+__global__ __launch_bounds__(1024) void knn_order_guard_kernel(const float* cen64, const float* rad, int T, float ratio,
+                                                               int32_t* ok, float* stat) {
+  __shared__ float ps[16][64];                              // per wave: sum of (c - c0) per position
+  __shared__ float red[32];                                 // per wave: sum of |c - c0|^2, sum of rad^2
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
   const float* c = cen64 + (size_t)b * T * 64;
-  float s = 0.f;
-  for (int i = w; i < T; i += 4) s += c[(size_t)i * 64 + lane];
-  part[w][lane] = s;
-  __syncthreads();
-  const float mean = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (float)T;
-  float d2 = 0.f;
-  for (int i = w; i < T; i += 4) { const float d = c[(size_t)i * 64 + lane] - mean; d2 += d * d; }
+  const float c0 = c[lane];
+  float s = 0.f, q = 0.f;
+  for (int i = w; i < T; i += 16) { const float d = c[(size_t)i * 64 + lane] - c0; s += d; q += d * d; }
   float r2 = 0.f;
-  for (int i = t; i < T; i += 256) { const float r = rad[(size_t)b * T + i]; r2 += r * r; }
-  d2 = wave_sum(d2); r2 = wave_sum(r2);
-  if (lane == 0) { red[w] = d2; red[4 + w] = r2; }
+  for (int i = t; i < T; i += 1024) { const float r = rad[(size_t)b * T + i]; r2 += r * r; }
+  ps[w][lane] = s;
+  q = wave_sum(q); r2 = wave_sum(r2);
+  if (lane == 0) { red[w] = q; red[16 + w] = r2; }
   __syncthreads();
-  if (t == 0) {
-    const float between = (((red[0] + red[1]) + red[2]) + red[3]) / (float)T;
-    const float within = (((red[4] + red[5]) + red[6]) + red[7]) / (float)T;
-    const float q = within / fmaxf(between, 1e-37f);
-    ok[b] = q < ratio ? 1 : 0;
-    if (stat) stat[b] = q;
+  if (w == 0) {
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sm += ps[i][lane];
+    const float mean = sm / (float)T;                       // of (c - c0) at this position
+    const float m2 = wave_sum(mean * mean);
+    if (lane == 0) {
+      float qs = 0.f, rs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { qs += red[i]; rs += red[16 + i]; }
+      const float between = fmaxf(qs / (float)T - m2, 0.f);
+      const float within = rs / (float)T;
+      const float v = within / fmaxf(between, 1e-37f);
+      ok[b] = v < ratio ? 1 : 0;
+      if (stat) stat[b] = v;
+    }
   }
 }
 
@@ -261,7 +269,7 @@ extern "C" int vcr_knn_order_f32(const vcr_knn_order_args* a, vcr_stream_t strea
   hipLaunchKernelGGL(knn_rank_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a, T);
   rc = VCR_LAUNCH_RC();
   if (rc != 0 || !a->ord_ok) return rc;
-  hipLaunchKernelGGL(knn_order_guard_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, a->cen64, a->cen64_rad, T,
+  hipLaunchKernelGGL(knn_order_guard_kernel, dim3(a->B), dim3(1024), 0, (hipStream_t)stream, a->cen64, a->cen64_rad, T,
                      a->guard_ratio > 0.f ? a->guard_ratio : ORDER_GUARD_RATIO, a->ord_ok, a->ord_stat);
   return VCR_LAUNCH_RC();
 }
