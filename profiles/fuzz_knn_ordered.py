@@ -12,7 +12,7 @@ bad_total, t0 = 0, time.time()
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     k = int(rs.choice([20, 40])); N = int(rs.choice([1024, 1500, 2048, 2049, 2500, 3000, 4095, 4096]))
     B = int(np.ceil(1024 / ((N + 15) // 16))) + int(rs.randint(0, 3))
-    kind = str(rs.choice(["uniform", "clustered", "lattice", "dup", "smallscale", "bigscale"]))
+    kind = str(rs.choice(["uniform", "clustered", "lattice", "dup", "smallscale", "bigscale", "outlier"]))
     if kind == "lattice":
         xyz = rs.randint(0, 11, (B, N, 3)).astype(np.float32) / 10
     elif kind == "clustered":
@@ -22,6 +22,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
         xyz = rs.rand(B, N, 3).astype(np.float32) - 0.5
     if kind == "dup":
         xyz[:, N // 2:] = xyz[:, : N - N // 2]
+    if kind == "outlier":                                  # far returns: the ranking's box is clamped to mean +- 4 sigma
+        xyz[:, rs.randint(0, N, 3)] = np.float32(rs.choice([50.0, -200.0, 1e4]))
     scale = {"smallscale": 1e-3, "bigscale": 300.0}.get(kind, 1.0)
     xyz = (xyz * scale).astype(np.float32)
     w1, w2 = rs.randn(3, 64).astype(np.float32) / scale, rs.randn(64, 64).astype(np.float32) * 0.2
@@ -32,10 +34,12 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
     x4 = torch.from_numpy(np.concatenate((xyz, (xyz ** 2).sum(-1, keepdims=True)), -1).astype(np.float32)).cuda()
     sq = (feat ** 2).sum(-1).contiguous()
     ft = feat.view(B, N, 4, 4, 4).transpose(3, 4).reshape(B, N, 64).contiguous()
-    order = nat.knn_order(x4, ft, sq)
+    guard, slots = bool(rs.rand() < 0.7), bool(rs.rand() < 0.5)     # round 6: the per-cloud guard; ties replayed in the launch (k > 20)
+    order = nat.knn_order(x4, ft, sq, guard=guard)
     a0, b0 = nat.knn_pair(feat, sq, x4, k, xt=ft)
-    a1, b1 = nat.knn_pair(feat, sq, x4, k, xt=ft, order=order)
+    a1, b1 = nat.knn_pair(feat, sq, x4, k, xt=ft, order=order, tie_slots=slots)
     bad = [int((torch.sort(p, -1).values != torch.sort(o, -1).values).any(-1).sum()) for p, o in ((a0, a1), (b0, b1))]
     bad_total += sum(bad)
-    print(f"B={B:3d} N={N:5d} k={k} {kind:10s}: rows differing feat {bad[0]} xyz {bad[1]}", flush=True)
+    acc = int(order["ord_ok"].sum()) if guard else -1
+    print(f"B={B:3d} N={N:5d} k={k} {kind:10s} guard {'off' if not guard else f'{acc}/{B} accepted'} slots {int(slots)}: rows differing feat {bad[0]} xyz {bad[1]}", flush=True)
 print("TOTAL differing rows", bad_total, "elapsed", round(time.time() - t0, 1))
