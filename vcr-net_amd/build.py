@@ -56,21 +56,37 @@ def kernel_resources():
     return out
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra=""):
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for f in paths:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _recorded(path):
+    try:
+        with open(path) as fh:
+            return fh.read().strip()
+    except OSError:
+        return None
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile what changed and link.  Staleness is decided by CONTENT (a digest of the source, the headers and the flags,
+    recorded next to every object), not by modification times: a file transfer -- the snapshot that carries the tree to the
+    GPU box -- may reorder mtimes, and must neither trigger a rebuild there nor hide one that is needed."""
     os.makedirs(OBJ, exist_ok=True)
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "vcr_hip.h"))
-    jobs = []
+    flags = " ".join(FLAGS)
+    jobs, want = [], {}
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
-        if force or _stale(obj, [src] + hdrs) or not os.path.exists(obj[:-2] + ".remarks"):
+        want[obj] = _digest([src] + hdrs, flags)
+        if (force or not os.path.exists(obj) or not os.path.exists(obj[:-2] + ".remarks") or _recorded(obj + ".sha") != want[obj]):
             jobs.append((src, obj))
 
     def cc(job):
@@ -82,25 +98,40 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if r.returncode == 0:
             with open(obj[:-2] + ".remarks", "w") as fh:
                 fh.write(r.stderr)
+            with open(obj + ".sha", "w") as fh:
+                fh.write(want[obj])
         out = r.stdout + r.stderr
-        if r.returncode == 0 and not verbose:
-            out = "\n".join(ln for ln in out.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in ln)
+        if r.returncode == 0 and not verbose:                # keep warnings, drop the remarks and their source echoes
+            import re
+            keep, skip = [], False
+            for ln in out.splitlines():
+                if "-Rpass-analysis=kernel-resource-usage" in ln:
+                    skip = True
+                    continue
+                if skip and re.match(r"\s*(\d+\s*)?\|", ln):
+                    continue
+                skip = False
+                keep.append(ln)
+            out = "\n".join(keep) if any(("warning" in ln or "error" in ln) for ln in keep) else ""
         return src, r.returncode, out
 
     failed = False
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         for src, rc, out in ex.map(cc, jobs):
-            if rc != 0 or verbose:
+            if rc != 0 or verbose or out.strip():
                 sys.stderr.write(f"--- {os.path.basename(src)} (rc={rc})\n{out}\n")
             failed |= rc != 0
     if failed:
         raise RuntimeError("hipcc failed")
     objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in sources()]
-    if force or jobs or _stale(LIB, objs):
+    lib_want = _digest([], "".join(want[o] for o in objs))
+    if force or jobs or not os.path.exists(LIB) or _recorded(os.path.join(OBJ, "libvcr_hip.so.sha")) != lib_want:
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs,
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+        with open(os.path.join(OBJ, "libvcr_hip.so.sha"), "w") as fh:
+            fh.write(lib_want)
     return LIB
 
 
