@@ -506,7 +506,6 @@ typedef struct {
     const void *dg1_pq, *sn1_pq, *c3, *enc_qkv, *enc_wo, *enc_ffn1, *enc_ffn2, *dec_qkv, *dec_self_wo, *dec_cross_q,
                *dec_cross_kv, *dec_cross_wo, *dec_ffn1, *dec_ffn2;
     const void* encdec_qkv;                          /* optional: the split of fold_encdec_qkv.w [6E,E] (the merged first sublayers, below) */
-    /* (dg1_pq is not read since ABI 27: that projection rides on the stem launch in every mode) */
   } split;
   /* has_pointer 1 (every linear_mode): the six Linears that consume a LayerNorm, folded with it by
    * vcr_fold_layernorm_f32 (w [N,E], colsum [N], bias [N]).  dec_cross_kv is folded with the ENCODER's final norm. */

@@ -551,11 +551,12 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
              nullptr, const_cast<float*>(stats_for_ln));
   } else {
   // ---- emb_nn = LPDNet on both clouds (lpdnet_model.py:103-137)
-  // The first EdgeConv's per-point projection P | Q (K = 64) rides on the stem launch (conv2 and the projection on the matrix
-  // pipe, pointwise.hip) -- in every arithmetic mode since round 6: the projection is 0.27 GF, on the stem's 16x16x4 MFMAs it is
-  // fp32 arithmetic (bit-identical to the fp32 mode's), and the split modes save their separate launch; `split.dg1_pq` is no
-  // longer read
-  const bool pq_fused = true;
+  // fp32 mode: the first EdgeConv's per-point projection P | Q (K = 64) rides on the stem launch (conv2 and the projection
+  // on the matrix pipe, pointwise.hip); the split modes keep the separate launch on their pre-split weight.  (Round 6 tried the
+  // fused stem in the split modes too -- one launch less, 0.4 % of that line --: the fp32 chain is a little LESS accurate than
+  // the exact split, and the accuracy ledger's `trained` k = 40 fixture left its bound (R error vs the float64 twin 4.3e-6 ->
+  // 5.9e-6 against 1.5 x the reference's + 3e-6 = 4.9e-6).  Reverted.)
+  const bool pq_fused = W->linear_mode == 0;
   if (R.rc == 0) {                                       // both clouds in one launch: rows 0..M1-1 = src, then tgt
     R.mark(pq_fused ? "pointwise:src+tgt+dg1_pq" : "pointwise:src+tgt");
     vcr_pointwise_args a{io->src_cf, B, N, W->c1_w, W->c1_b, W->c2_w, W->c2_b, w.xyz4, w.feat64, w.sq64, io->tgt_cf, B};
