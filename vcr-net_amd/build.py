@@ -135,5 +135,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_host_example() -> str:
+    """examples/host_cpp/forward_host: the C-ABI driven from C++ with no Python / PyTorch in the process (its own hipMalloc'ed
+    memory and stream).  Host code only -- compiles in seconds, here or on the GPU box; rebuilt when its source, the header or
+    the library's digest changed."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "examples", "host_cpp", "forward_host.cpp")
+    exe = os.path.join(root, "examples", "host_cpp", "forward_host")
+    want = _digest([src, os.path.join(root, "include", "vcr_hip.h")], _recorded(os.path.join(OBJ, "libvcr_hip.so.sha")) or "")
+    if os.path.exists(exe) and _recorded(exe + ".sha") == want:
+        return exe
+    r = subprocess.run([HIPCC, "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), src, "-L" + HERE, "-lvcr_hip",
+                        "-Wl,-rpath,$ORIGIN/../../vcr-net_amd", "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("forward_host.cpp failed to build:\n" + r.stdout + r.stderr)
+    with open(exe + ".sha", "w") as fh:
+        fh.write(want)
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
