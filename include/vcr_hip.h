@@ -113,7 +113,7 @@ typedef struct {
    * bound of the distance of the tile's rows to it, cen_sqmax their largest squared norm.  A wave of 16 queries scans the 9 tiles
    * around its own rank, then only the tiles whose ball (centroid, radius) can still hold a neighbour of one of its queries --
    * decided with the fp32 rounding of the scores priced in, so the neighbour SETS are those of the plain search (rank-0 and
-   * boundary-tie rules included: indices are translated back before they are applied).  Ranked clouds up to 4096 points. */
+   * boundary-tie rules included: indices are translated back before they are applied).  Ranked clouds up to 8192 points. */
   const int32_t* perm; const float* xp; const float* sqp;
   const float* cen; const float* cen_sq; const float* cen_rad; const float* cen_sqmax;
   /* Optional, with perm: ord_ok[b] == 0 sends cloud b's search over the plain scan although it is ranked (vcr_knn_order_args.ord_ok:
@@ -125,7 +125,7 @@ typedef struct {
 /* Ranks the points of every cloud along a Morton curve of their coordinates and writes what the ordered search reads
  * (vcr_knn_args.perm ...): perm [B,N]; xyz4_p [B,N,4]; cen4 [B,T,4], cen4_rad / cen4_sqmax [B,T] with T = (N + 15) / 16; and,
  * when feat_t is given ([B,N,64] rows in vcr_knn_args.xt's layout, pitch ldf, with sq [B,N]): feat_p [B,N,64] (pitch 64),
- * sq_p [B,N], cen64 [B,T,64], cen64_sq / cen64_rad / cen64_sqmax [B,T].  N <= 4096 (VCR_EUNSUPPORTED beyond). */
+ * sq_p [B,N], cen64 [B,T,64], cen64_sq / cen64_rad / cen64_sqmax [B,T].  N <= 8192 (VCR_EUNSUPPORTED beyond). */
 typedef struct {
   const float* xyz4;                  /* [B,N,4] rows (x, y, z, |p|^2) */
   const float* feat_t; int ldf; const float* sq;

@@ -1,6 +1,6 @@
 """Random-shape soak of the ordered kNN search (vcr_knn_order_f32 + vcr_knn_args.perm) against the plain pair launch:
 python profiles/fuzz_knn_ordered.py <seed> <trials>.  Shapes with >= 1024 groups of 16 queries (the regime the ordered bodies run
-in), N up to 4096, k = 20 / 40; clouds: uniform / clustered / lattice (exact ties) / with duplicated points; features: a smooth map
+in), N up to 8192, k = 20 / 40; clouds: uniform / clustered / lattice (exact ties) / with duplicated points; features: a smooth map
 of the coordinates, or unrelated to them.  Prints the rows whose neighbour SET differs (must be 0)."""
 import sys, time
 import numpy as np, torch
@@ -10,7 +10,7 @@ from vcrnet_amd import native as nat
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad_total, t0 = 0, time.time()
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 20):
-    k = int(rs.choice([20, 40])); N = int(rs.choice([1024, 1500, 2048, 2049, 2500, 3000, 4095, 4096]))
+    k = int(rs.choice([20, 40])); N = int(rs.choice([1024, 1500, 2048, 2049, 2500, 3000, 4095, 4096, 4097, 5000, 6001, 8191, 8192]))
     B = int(np.ceil(1024 / ((N + 15) // 16))) + int(rs.randint(0, 3))
     kind = str(rs.choice(["uniform", "clustered", "lattice", "dup", "smallscale", "bigscale", "outlier"]))
     if kind == "lattice":

@@ -106,13 +106,13 @@ def test_argument_errors_do_not_need_a_gpu(lib):
     assert lib.vcr_pose_step_f32(ctypes.byref(ps), None) == -1
     ps.compose = 3
     assert lib.vcr_pose_step_f32(ctypes.byref(ps), None) == -1
-    # the ordered search's ranking entry point: NULL / missing outputs, then a cloud beyond its 4096 points
+    # the ordered search's ranking entry point: NULL / missing outputs, then a cloud beyond its 8192 points
     assert lib.vcr_knn_order_f32(None, None) == -1
     o = native.KnnOrderArgs()
     assert lib.vcr_knn_order_f32(ctypes.byref(o), None) == -1
     for f in ("xyz4", "perm", "xyz4_p", "cen4", "cen4_rad", "cen4_sqmax"):
         setattr(o, f, 0x1000)                                # (never dereferenced: the size check comes first)
-    o.B, o.N = 2, 5000
+    o.B, o.N = 2, 9000
     assert lib.vcr_knn_order_f32(ctypes.byref(o), None) == -3 and b"unsupported" in lib.vcr_strerror(-3)
     o.feat_t = 0x2000                                        # features without their norms / outputs
     assert lib.vcr_knn_order_f32(ctypes.byref(o), None) == -1
@@ -298,3 +298,16 @@ def test_module_contract_on_cpu():
     net.eval()
     with torch.no_grad(), pytest.raises(RuntimeError):   # no CPU fallback by design
         net(torch.zeros(1, 3, 64), torch.zeros(1, 3, 64))
+
+
+def test_cpp_host_example_builds_and_refuses_a_foreign_file(lib, tmp_path):
+    """examples/host_cpp/forward_host.cpp (the C-ABI from C++ without Python) compiles against the header and links the library;
+    without a GPU it can still be asked to read a file that is not a model blob."""
+    import subprocess
+    from vcrnet_amd import build
+    exe = build.build_host_example()
+    bad = tmp_path / "not_a_blob.bin"
+    bad.write_bytes(b"\0" * 256)
+    r = subprocess.run([exe, str(bad), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 2 and "not a VCRB blob" in r.stderr
+    assert subprocess.run([exe], capture_output=True, text=True).returncode == 2      # usage

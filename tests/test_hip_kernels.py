@@ -757,7 +757,8 @@ def test_knn_pair_equals_the_two_launches(nat, B, N, k):
 
 @pytest.mark.parametrize("B,N,k,kind", [(8, 2048, 20, "smooth"), (4, 4096, 40, "smooth"), (8, 2048, 20, "random"), (16, 1024, 20, "smooth"),
                                         (8, 2040, 20, "dup"), (8, 2048, 20, "lattice"), (6, 3000, 40, "lattice"), (4, 4096, 20, "equal"),
-                                        (8, 4096, 20, "outlier")])
+                                        (8, 4096, 20, "outlier"), (4, 8192, 40, "smooth"), (4, 5000, 20, "smooth"), (3, 8192, 20, "lattice"),
+                                        (3, 6000, 40, "random")])
 def test_knn_ordered_search_keeps_the_sets(nat, B, N, k, kind):
     """The ordered search (vcr_knn_order_f32 + vcr_knn_args.perm: Morton ranking, tiles skipped by their balls) against the plain
     pair launch: the same neighbour SET on every row -- smooth features (a function of the coordinates, as the stem's are),

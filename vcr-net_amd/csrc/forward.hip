@@ -576,7 +576,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     // wave skip the tiles whose balls cannot hold a neighbour -- measured (profiles/rounds4-5/r5o_knn_ordered.txt) 416 -> 295 + 45 us
     // (ranking) at 32 x 2048, 2970 -> 1850 + 93 at 64 x 4096, k = 40; at 1024 points the plain scan is faster (120 vs 143 + 30).
     // Its arrays live in the unused part of w.emb (free until conv3; feat64t is its first M2 x 64 floats).
-    if (R.rc == 0 && W->E >= 256 && N >= KNN_ORDERED_MIN_N && N <= 4096 && (k == 20 || k == 40) && W->knn_waves == 0 &&
+    if (R.rc == 0 && W->E >= 256 && N >= KNN_ORDERED_MIN_N && N <= 8192 && (k == 20 || k == 40) && W->knn_waves == 0 &&
         (long)2 * B * ((N + 15) / 16) >= 1024) {         // (fewer query groups: vcr_knn_pair_f32 takes its small-grid kernels)
       const size_t m = (size_t)M2, mt = (size_t)2 * B * ((N + 15) / 16);
       float* base = w.emb + m * 64;

@@ -55,6 +55,7 @@ struct GeomCol16;
 // + the tie list) = 157 KB of the 160): a compaction then frees 35 slots instead of 27.  Measured against 64: the pair
 // launch 151.4 -> 147.7 us at BASELINE configs[1], 147.5 -> 136.7 at N = 768 (configs[2]), 439 -> 432 at N = 2048.
 constexpr int KNN_ORD_NEAR = 4;                          // tiles on either side of the own one scanned first
+constexpr int KNN_ORD_MAX_TILES = 512;                   // the ordered search's wave-uniform tile mask: clouds of up to 8192 points
 constexpr int KNN_ORD_MODE = 0;                          // timing ablations of the ordered search: 1 = its loop over ALL tiles, 2 = the plain loop over the ranked rows
 constexpr int KNN_PEND_K40 = 96;                         // k = 21 .. 40 (lists of 42)
 constexpr int KNN_PEND_COL16 = 72;                       // (the sweeps: profiles/experiments/probe_build.py --set NAME=VALUE)
@@ -859,7 +860,10 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
     }
     if (FULL || hi - lo >= T) return;
     sel.drain();                                         // thr = the (k + 2)-th best of the near candidates, exactly
-    unsigned long long need[4] = {0ull, 0ull, 0ull, 0ull};                 // tiles still to visit (T <= 256)
+    constexpr int NEEDW = KNN_ORD_MAX_TILES / 64;                          // tiles still to visit: one bit each (T <= 512)
+    unsigned long long need[NEEDW];
+#pragma unroll
+    for (int i = 0; i < NEEDW; ++i) need[i] = 0ull;
     const float* cen = a.cen + (size_t)b * T * a.ldx;
     const float* crad = a.cen_rad + (size_t)b * T;
     const float* cmax = a.cen_sqmax + (size_t)b * T;
@@ -935,7 +939,7 @@ __device__ __forceinline__ void knn64c_body(const vcr_knn_args& a, int bx, int b
       int w = 0;
       unsigned long long cur = need[0];
       scan_seq([&]() {
-        while (cur == 0ull && w < 3) cur = need[++w];
+        while (cur == 0ull && w < NEEDW - 1) cur = need[++w];
         if (cur == 0ull) return -1;
         const int bit = __builtin_ctzll(cur);
         cur &= cur - 1ull;
@@ -1596,7 +1600,7 @@ extern "C" int vcr_knn_ties_inline(const vcr_knn_args* ua) {
 // the ordered search's inputs are all there and the cloud is small enough for the wave's tile mask (256 tiles of 16 ranks)
 // (vcr_knn_order_f32 writes the ranked rows and the centroids at pitch C: a padded x keeps the plain scan)
 static bool knn_ordered(const vcr_knn_args* a) {
-  return a->perm && a->xp && a->cen && a->cen_rad && a->cen_sqmax && (a->C == 4 || (a->sqp && a->cen_sq)) && a->N <= 4096 &&
+  return a->perm && a->xp && a->cen && a->cen_rad && a->cen_sqmax && (a->C == 4 || (a->sqp && a->cen_sq)) && a->N <= 16 * KNN_ORD_MAX_TILES &&
          a->ldx == a->C &&
          !(((uintptr_t)a->xp | (uintptr_t)a->cen) & 15);
 }

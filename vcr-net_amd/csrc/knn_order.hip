@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int ORDER_MAX_N = 4096;
+constexpr int ORDER_MAX_N = 8192;                     // = 16 x KNN_ORD_MAX_TILES (knn.hip): the search's tile mask
 
 __device__ __forceinline__ unsigned spread10(unsigned v) {           // 10 bits -> every third bit
   v = (v | (v << 16)) & 0x030000ffu;
@@ -260,7 +260,7 @@ extern "C" int vcr_knn_order_f32(const vcr_knn_order_args* a, vcr_stream_t strea
   if (a->N > ORDER_MAX_N) return VCR_EUNSUPPORTED;
   const int threads = a->N >= 2048 ? 1024 : a->N >= 512 ? 512 : 256;
   const size_t lds = (size_t)a->N * 8 + 2 * ORDER_BUCKETS * 4 + 192 * 4 + 16 * 4;
-  VCR_DYN_LDS(knn_morton_kernel, (int)lds);               // (64.9 KB at 4096 points)
+  VCR_DYN_LDS(knn_morton_kernel, (int)lds);               // (64.9 KB at 4096 points, 97.7 KB at 8192)
   hipLaunchKernelGGL(knn_morton_kernel, dim3(a->B), dim3(threads), lds, (hipStream_t)stream, a->xyz4, a->N, a->perm);
   int rc = VCR_LAUNCH_RC();
   if (rc != 0) return rc;
