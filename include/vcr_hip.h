@@ -269,6 +269,11 @@ typedef struct {
   int variant;   /* tuning / tests, 0 = automatic: 1 = neighbour rows gathered through L2 (one wave per point); 32 / 16 / 8 =
                     gathered out of LDS with that many channels per workgroup slice (VCR_EUNSUPPORTED when the slice of one
                     cloud does not fit a workgroup's LDS, k is not 20 / 40, or pq / y / idx are not 16-B aligned) */
+  /* Optional, the L2 form only: order [M] int32, cloud by cloud a permutation of 0 .. n_per_cloud - 1 (vcr_knn_args.perm: the
+   * clouds' Morton ranking).  Wave w then serves the point order[w] of its cloud instead of point w: waves that run side by side
+   * gather the rows of NEIGHBOURING points, most of which they share -- the gathers hit in the CU's L1 instead of L2.  Every
+   * point is still served exactly once, by the same arithmetic: the output does not depend on it. */
+  const int32_t* order;
 } vcr_gathermax_args;
 /* (automatic: k = 20 / 40, n_per_cloud <= 2048, >= 192 (cloud, 32-channel slice) workgroups, 16-B aligned pq / y / idx: the
  * neighbour rows are gathered out of LDS -- a workgroup stages its slice of one cloud's P rows once (32 channels up to

@@ -441,6 +441,11 @@ def test_gathermax_lds_and_l2_paths_are_exact(nat, B, N, k, C):
                 nat.gathermax(pq, C, idx, N, variant=variant)
     with pytest.raises(nat.VcrHipError):
         nat.gathermax(pq, C, idx, N, variant=5)
+    # vcr_gathermax_args.order: the L2 form's waves take the points of every cloud in a caller-given order (the forward hands
+    # it the clouds' Morton ranking): every point is still served once, by the same arithmetic
+    order = dev(torch.stack([torch.randperm(N, generator=g) for _ in range(B)]).to(torch.int32).view(-1))
+    assert torch.equal(nat.gathermax(pq, C, idx, N, variant=1, order=order), ref)
+    assert torch.equal(nat.gathermax(pq, C, idx, N, order=order), ref)          # (the LDS forms ignore it)
 
 
 @pytest.mark.parametrize("B,N,k", [(2, 300, 20), (3, 101, 20), (2, 130, 40), (16, 1024, 20), (1, 203, 7)])

@@ -371,15 +371,16 @@ constexpr int EDGECONV_PIPE = 1;                         // 1: the kernel above;
 
 __global__ __launch_bounds__(256) void gathermax_kernel(vcr_gathermax_args p) {
   const int lane = threadIdx.x & 63;
-  const int pt = xcd_chunk((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);
+  int pt = xcd_chunk((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);
   if (pt >= p.M) return;
   const int c = lane * 4;
   if (c >= p.C) return;
   const int base = (pt / p.n_per_cloud) * p.n_per_cloud;
+  if (p.order) pt = base + p.order[pt];                  // (wave-uniform: the point at this rank of the cloud's Morton order)
   const int32_t* id = p.idx + (size_t)pt * p.k;
   f32x4 m;
   int j;
-  if (p.k == 20) {
+  if (p.k == 20 || p.k == 40) {
     // the path's k: all 20 neighbour rows in flight at once (the kernel is bound by the latency of these L2 gathers)
     f32x4 a[20];
 #pragma unroll
@@ -390,6 +391,15 @@ __global__ __launch_bounds__(256) void gathermax_kernel(vcr_gathermax_args p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], a[u][i]);
     j = 20;
+    if (p.k == 40) {                                     // (BASELINE configs[4]: the second twenty likewise)
+#pragma unroll
+      for (int u = 0; u < 20; ++u) a[u] = ld4(p.pq + (size_t)(base + id[20 + u]) * p.ldpq + c);
+#pragma unroll
+      for (int u = 0; u < 20; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = fmaxf(m[i], a[u][i]);
+      j = 40;
+    }
   } else {
     m = ld4(p.pq + (size_t)(base + id[0]) * p.ldpq + c);
     j = 1;

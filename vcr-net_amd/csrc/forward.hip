@@ -566,6 +566,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   }
   // The feature-space and the Cartesian kNN (lpdnet_model.py:113,129) are independent: one launch for both, and one
   // tie replay for both right before the first consumer of the indices.
+  const int32_t* rank_perm = nullptr;                    // the clouds' Morton ranking, when the kNN took the ordered search
   {
     vcr_knn_args a64{(uint32_t)sizeof(vcr_knn_args), w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2, W->knn_waves};
     vcr_knn_args a3{(uint32_t)sizeof(vcr_knn_args), w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
@@ -595,6 +596,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       R.ok(vcr_knn_order_f32(&o, R.stream));
       a64.perm = a3.perm = perm;
       a64.ord_ok = ord_ok;
+      rank_perm = perm;                                  // (lives in w.emb until conv3 writes the embeddings: gathermax runs before)
       a64.xp = feat_p; a64.sqp = sq_p; a64.cen = cen64; a64.cen_sq = c64_sq; a64.cen_rad = c64_rad; a64.cen_sqmax = c64_max;
       a3.xp = xyz4_p; a3.cen = cen4; a3.cen_rad = c4_rad; a3.cen_sqmax = c4_max;
     }
@@ -612,6 +614,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (R.rc == 0) {
     R.mark("gathermax:sn1");
     vcr_gathermax_args a{w.pq3, 512, 256, w.idx3, k, M2, N, w.cat + 256, 512};
+    a.order = rank_perm;                                 // (clouds that were ranked for the kNN: the L2 form walks them in rank order)
     R.ok(vcr_gathermax_f32(&a, R.stream));
   }
   R.linear("linear:conv3", w.cat, 512, W->c3_w, SP(c3), W->c3_b, w.emb, E, M2, E, 512, 1, nullptr, 0, nullptr, nullptr,

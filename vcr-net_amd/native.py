@@ -77,7 +77,7 @@ class EdgeconvArgs(C.Structure):
 
 class GathermaxArgs(C.Structure):
     _fields_ = [("pq", f32p), ("ldpq", C.c_int), ("C", C.c_int), ("idx", f32p), ("k", C.c_int), ("M", C.c_int),
-                ("n_per_cloud", C.c_int), ("y", f32p), ("ldy", C.c_int), ("variant", C.c_int)]
+                ("n_per_cloud", C.c_int), ("y", f32p), ("ldy", C.c_int), ("variant", C.c_int), ("order", f32p)]
 
 
 class SdpaArgs(C.Structure):
@@ -591,12 +591,13 @@ def knn_order(xyz4, feat_t=None, sq=None, guard=False, guard_ratio=0.0):
 
 
 @_guarded
-def gathermax(pq, Cc, idx, n_per_cloud, variant=0):
-    """variant: 0 automatic, 1 = gathers through L2, 32 / 16 / 8 = out of LDS with that channel slice (vcr_gathermax_args)."""
+def gathermax(pq, Cc, idx, n_per_cloud, variant=0, order=None):
+    """variant: 0 automatic, 1 = gathers through L2, 32 / 16 / 8 = out of LDS with that channel slice (vcr_gathermax_args).
+    order: int32 [M], per cloud a permutation of its point numbers -- the order in which the L2 form's waves take the points."""
     M = pq.shape[0]
     k = idx.shape[-1]
     y = _f32(M, Cc, device=pq.device)
-    call("vcr_gathermax_f32", GathermaxArgs(ptr(pq), pq.stride(0), Cc, ptr(idx), k, M, n_per_cloud, ptr(y), Cc, variant))
+    call("vcr_gathermax_f32", GathermaxArgs(ptr(pq), pq.stride(0), Cc, ptr(idx), k, M, n_per_cloud, ptr(y), Cc, variant, ptr(order)))
     return y
 
 
