@@ -33,3 +33,8 @@ for B, N, k in ((16, 8192, 20), (16, 8192, 40), (24, 6000, 20), (32, 4096, 20), 
     print(f"{B:3d} x {N:5d} k={k:2d}: plain {tp:9.1f} us   ordered (ranking + guard included) {to:9.1f} us   ratio {to / tp:.2f}   sets equal: {same}", flush=True)
 PY
 cat $OUT/${TAG}_knn_ordered_8192.txt
+python profiles/bench_gathermax_order.py > $OUT/${TAG}_gathermax_order.txt 2>&1; cat $OUT/${TAG}_gathermax_order.txt
+python bench.py --points 4096 --k 40 --batch 32 --no-cpu-baseline --no-other-configs --min-seconds 3 --stages > $OUT/${TAG}_config5_bench.json 2> $OUT/${TAG}_config5_launch_table.txt
+grep "knn\|gathermax" $OUT/${TAG}_config5_launch_table.txt
+python -c "
+import json;d=json.load(open('$OUT/${TAG}_config5_bench.json'));print(d['value'], d['ms_per_step'], d['knn_edgeconv_stage']['hbm_frac'])"
