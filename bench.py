@@ -87,6 +87,9 @@ def parse(argv=None):
                     help="feature-space kNN kernel: 8 = 16-query waves (16x16x4 MFMA), 1 = 32-query waves, 0 = the library's choice")
     ap.add_argument("--sdpa-variant", type=int, default=0, choices=[0, 1, 2],
                     help="fp32 attention-output kernel: 0 = the library's choice, 1 = the tile kernel, 2 = the persistent kernel")
+    ap.add_argument("--no-iter-reuse", action="store_true",
+                    help="--iters > 1: every pass recomputes both clouds (as the reference does) instead of reusing what the first "
+                         "pass computed from the unchanged target cloud; same bits")
     ap.add_argument("--no-merge-encdec", action="store_true",
                     help="enc.qkv / dec.qkv and the two self-attentions as separate launches (default: one GEMM + one grouped launch)")
     ap.add_argument("--linear-bk", type=int, default=0, choices=[0, 16, 32], help="k-slab of the fp32 linears (0 = the library's choice)")
@@ -399,6 +402,7 @@ def measure(a, ctx, min_seconds):
     net.linear_mfma, net.linear_bk, net.knn_waves = a.linear_mfma, a.linear_bk, a.knn_waves
     net.linear_bm = a.linear_bm
     net.sdpa_variant = a.sdpa_variant
+    net.iter_reuse = not a.no_iter_reuse
     net = net.to(dev).eval()
 
     B, N = a.batch, a.points
@@ -600,10 +604,15 @@ def measure(a, ctx, min_seconds):
         emb_sites = ("pointwise:", "knn:", "edgeconv:", "gathermax:", "linear:dg1_pq", "linear:sn1_pq", "linear:conv3",
                      "linear:dg_c")
         emb_ms = sum(r[0] for n, r in rows.items() if n.startswith(emb_sites)) / nt
-        emb_bytes = 2.0 * N * (7448 + 784 * a.k) * B * a.iters
-        emb_gf = a.iters * sum(workmodel.launch_work(n, B, N, a.k)[0] for n in
+        # (vcrnetIter with target reuse: the passes after the first run this stage on the SOURCE clouds only -- the algorithmic
+        #  bytes count the clouds the launches really processed, 2 per pair in the first pass and 1 in each later one)
+        reuse = a.iters > 1 and a.emb_nn == "lpdnet" and bool(getattr(net, "iter_reuse", False)) and any(n.endswith("@src") for n in rows)
+        clouds = (2 + (a.iters - 1)) if reuse else 2 * a.iters
+        emb_bytes = 1.0 * N * (7448 + 784 * a.k) * B * clouds
+        emb_gf = 0.5 * clouds * sum(workmodel.launch_work(n, B, N, a.k)[0] for n in
                                ("linear:dg1_pq", "edgeconv:dg1_dg2", "linear:sn1_pq", "linear:conv3")) / 1e9
         emb_stage = None if a.emb_nn != "lpdnet" else {"ms_per_step": emb_ms, "algorithmic_bytes_per_pair": emb_bytes / B / a.iters, "iters": a.iters,
+                     "clouds_processed_per_pair": clouds,
                      "achieved_gbs": emb_bytes / (emb_ms * 1e-3) / 1e9,
                      "hbm_frac": emb_bytes / (emb_ms * 1e-3) / 1e9 / workmodel.PEAK_HBM_GBS,
                      "knn_ms_per_step": sum(r[0] for n, r in rows.items() if n.startswith("knn:")) / nt,
@@ -630,7 +639,11 @@ def measure(a, ctx, min_seconds):
                        "parallelism": f"dp{world} (pairs sharded per rank" + (
                            ")" if world == 1 else ", RCCL all-gather of R,t)" if a.backend == "nccl" else
                            f", {a.backend} all-gather of R,t staged through the host -- NOT RCCL)"),
-                       "entry_point": "vcrnet_amd.module.vcrnetIter(net, src, tgt, iter) -> vcr_vcrnet_iter_f32"},
+                       "entry_point": "vcrnet_amd.module.vcrnetIter(net, src, tgt, iter) -> vcr_vcrnet_iter_f32",
+                       **({"iter_target_reuse": "the target cloud does not change between the passes of one vcrnetIter call: what the "
+                           "first pass computes from it alone (its embedding, the encoder and the decoder's first sublayer on its "
+                           "rows, its K | V projection) is kept for the later passes of THAT call -- nothing is carried from one "
+                           "timed step to the next; bit-identical to recomputing (--no-iter-reuse)"} if reuse else {})},
             "timed_blocks": {"count": len(blocks), "steps_per_block": a.steps, "reported": "median",
                              "seconds": [round(b, 6) for b in blocks[:64]],
                              "per_launch_events": f"steps {traced_steps} of every block (a step that carries the ~35 event "
@@ -664,7 +677,7 @@ OTHER_CONFIGS = [
 def is_headline(a):
     d = parse([])
     return all(getattr(a, k) == getattr(d, k) for k in ("gpus", "batch", "points", "k", "partial", "iters", "emb_nn", "strong", "regime",
-                                                        "linear_mode", "linear_mfma", "linear_bk", "linear_bm", "knn_waves", "sdpa_variant",
+                                                        "linear_mode", "linear_mfma", "linear_bk", "linear_bm", "knn_waves", "sdpa_variant", "no_iter_reuse",
                                                         "no_merge_encdec"))
 
 

@@ -557,6 +557,11 @@ typedef struct {
    * kept).  Same kept-key set either way up to summation order. */
   int xscore_limit_mb;
   int sdpa_variant;                                /* vcr_sdpa_args.variant of the fp32 attention-output launches (0 = automatic; benchmarks) */
+  /* vcr_vcrnet_iter_f32 with iters > 1: 0 = the passes after the first reuse what the first computed from the TARGET cloud alone
+   * (it does not change between passes: its embedding, the encoder on its rows, the decoder's self-attention sublayer and
+   * cross-attention query on its rows, the K | V projection of its encoder memory) -- when the workspace was sized with
+   * vcr_vcrnet_iter_workspace_bytes; 1 = every pass recomputes both clouds, as the reference does.  Bit-identical either way. */
+  int iter_reuse;
   /* tests: != 0 lays the forward's workspace out with EVERY buffer live from the first launch to the last (no two buffers
    * share memory; vcr_vcrnet_workspace_bytes grows ~2.5x).  The default layout overlays buffers by their (first, last) launch;
    * a lifetime registered too short would let one launch overwrite what a later one still reads -- comparing the two
@@ -586,6 +591,10 @@ typedef struct {
 } vcr_vcrnet_io;
 
 size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights*, int B, int N);
+/* The same for vcr_vcrnet_iter_f32(iters): with iters > 1, the LPDNet embedding and the Transformer pointer it adds the cache of the
+ * target cloud's loop-invariant rows (B N x 2592 floats) behind the forward's workspace; a workspace of only
+ * vcr_vcrnet_workspace_bytes still works -- every pass then recomputes both clouds. */
+size_t vcr_vcrnet_iter_workspace_bytes(const vcr_vcrnet_weights*, int B, int N, int iters);
 /* Correspondences per sample in corr4/src4: N, or int(int(N*0.84*overlap2)*0.52*overlap2) for partial + head_mode 0. */
 int vcr_vcrnet_pairs(const vcr_vcrnet_weights*, int N);
 int vcr_vcrnet_forward_f32(const vcr_vcrnet_weights*, const vcr_vcrnet_io*, void* workspace,

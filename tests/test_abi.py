@@ -156,6 +156,24 @@ def test_sized_structs_refuse_what_they_cannot_read(lib):
         assert lib.vcr_knn_ties_f32(ctypes.byref(a), None, None) == -1
 
 
+def test_iter_workspace_adds_the_target_cache_where_it_applies(lib):
+    """vcr_vcrnet_iter_workspace_bytes: the forward's workspace + B N x 2592 floats of target rows for a vcrnetIter loop of more
+    than one pass over the LPDNet + Transformer configuration; nothing for one pass, another embedding, or iter_reuse = 1."""
+    from vcrnet_amd import native
+    w = native.VcrnetWeights()
+    w.E, w.F, w.heads, w.k, w.has_pointer = 512, 1024, 4, 20, 1
+    base = lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 24, 768)
+    it = lambda n: lib.vcr_vcrnet_iter_workspace_bytes(ctypes.byref(w), 24, 768, n)
+    assert it(1) == base and it(2) == it(3) == base + 24 * 768 * 2592 * 4
+    w.iter_reuse = 1
+    assert it(3) == base
+    w.iter_reuse, w.emb_kind = 0, 1
+    assert it(3) == lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 24, 768)
+    w.emb_kind, w.has_pointer = 0, 2
+    assert it(3) == lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 24, 768)
+    assert lib.vcr_vcrnet_iter_workspace_bytes(ctypes.byref(w), 24, 768, 0) == 0
+
+
 def test_workspace_plan_sizes_of_the_baseline_configs(lib):
     """The forward's workspace is laid out by buffer liveness (forward.hip: Plan): pure host arithmetic, so the
     sizes of the BASELINE configs are pinned here -- a buffer registered with too long a life, or the bump allocator coming

@@ -236,3 +236,67 @@ def test_fused_driver_covers_the_variant_and_matches_kernel_by_kernel(kw):
     for i, tol in ((2, R_TOL), (3, t_tol), (4, R_TOL), (5, t_tol)):
         np.testing.assert_allclose(f[i].cpu().numpy(), c[i].cpu().numpy(), atol=tol)
     assert_mostly_close(f[1].cpu().numpy(), c[1].cpu().numpy(), atol=5e-4)
+
+
+@pytest.mark.parametrize("kw,mode,merge,B,N,iters", [({}, "fp32", True, 2, 320, 3), ({}, "fp32", False, 2, 320, 2),
+                                                      ({}, "bf16x3+sdpa", True, 2, 320, 3), (dict(partial=True), "fp32", True, 3, 400, 3),
+                                                      (dict(partial=True), "bf16x3", True, 2, 400, 2),
+                                                      ({}, "fp32", True, 16, 1024, 2),                  # M >= 16 384: the regular shape rules
+                                                      ({}, "fp32", False, 9, 1024, 2),                  # half of it below, all of it above 16 384 rows
+                                                      (dict(partial=True), "fp32", True, 24, 1024, 3),  # BASELINE configs[2]
+                                                      (dict(vcp_nn="att", cycle=True), "fp32", True, 4, 512, 2),
+                                                      ({}, "fp32", True, 4, 2048, 2)])                  # the ordered kNN search on half the clouds
+def test_iter_target_reuse_changes_no_bit(kw, mode, merge, B, N, iters):
+    """vcrnetIter, iter > 1: the target cloud does not change between passes, so the passes after the first launch everything in
+    front of the cross-attention on the SOURCE rows only and take the target's rows from the first pass (vcr_vcrnet_weights.iter_reuse,
+    vcr_vcrnet_iter_workspace_bytes).  A half-row linear pins the MFMA shape of the full-row launch it stands for -- the one choice
+    its bits depend on --, every other kernel computes a row from that row's cloud alone: poses, correspondences and (partial
+    mode) every discrete selection of every pass equal the recomputing loop's bit for bit, in each arithmetic mode, merged or
+    not, on both sides of the 16 384-row rule of the linears."""
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import synth
+    kw = dict(kw)
+    partial = bool(kw.get("partial"))
+    src, tgt, _, _, _ = synth.make_batch(93, B, N, partial=partial, kind="object" if N < 2048 else "uniform")
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    outs = []
+    for reuse in (False, True):
+        net, _ = build_net(**kw)
+        net.linear_mode, net.merge_encdec, net.iter_reuse = mode, merge, reuse
+        with torch.no_grad():
+            out = net._forward_fused(s, t, iters=iters, iter_api=True, want_selections=partial)
+        torch.cuda.synchronize()
+        sel = out[-1] if partial else {}
+        outs.append([o.clone() for o in out if torch.is_tensor(o)] + [sel[k_].clone() for k_ in sorted(sel)])
+        ws = [b["ws"].numel() for idle in net._shared.pool.values() for b in idle]
+        assert len(ws) == 1
+        outs[-1].append(ws[0])
+    assert outs[1][-1] > outs[0][-1]                          # the reusing loop keeps its cache behind the workspace
+    for i, (a, b) in enumerate(zip(outs[0][:-1], outs[1][:-1])):
+        assert torch.equal(a, b), (i, (a.float() - b.float()).abs().max().item())
+
+
+def test_iter_with_a_forward_sized_workspace_still_runs():
+    """A caller that sizes the workspace with vcr_vcrnet_workspace_bytes (as before ABI 27) gets the recomputing loop: same bits."""
+    import ctypes as C
+    import vcrnet_amd  # noqa: F401
+    from vcrnet_amd import native, synth
+    net, _ = build_net()
+    src, tgt, _, _, _ = synth.make_batch(94, 2, 256)
+    s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    with torch.no_grad():
+        ref = net._forward_fused(s, t, iters=3, iter_api=True)
+    L, cw = native.lib(), net._cw
+    B, N = 2, 256
+    n_small, n_big = L.vcr_vcrnet_workspace_bytes(C.byref(cw), B, N), L.vcr_vcrnet_iter_workspace_bytes(C.byref(cw), B, N, 3)
+    assert n_big > n_small == L.vcr_vcrnet_iter_workspace_bytes(C.byref(cw), B, N, 1)
+    ws = torch.empty(n_small + 256, dtype=torch.uint8, device="cuda")
+    off = (-ws.data_ptr()) % 256
+    f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device="cuda")
+    corr4, src4, R, tt, Rb, tb = f(B, N, 4), f(B, N, 4), f(B, 3, 3), f(B, 3), f(B, 3, 3), f(B, 3)
+    io = native.VcrnetIo(native.ptr(s.contiguous()), native.ptr(t.contiguous()), B, N, native.ptr(corr4), native.ptr(src4), native.ptr(R),
+                         native.ptr(tt), native.ptr(Rb), native.ptr(tb), None)
+    rc = L.vcr_vcrnet_iter_f32(C.byref(cw), C.byref(io), 3, C.c_void_p(ws.data_ptr() + off), n_small, C.c_void_p(native.stream_ptr()), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(R, ref[2]) and torch.equal(tt, ref[3]) and torch.equal(Rb, ref[4])

@@ -86,7 +86,15 @@ struct Ws {
   // vcrnetIter
   float *cur_cf, *Ri, *ti, *Rb, *tb;
   size_t bytes;
+  // vcrnetIter with target reuse (see TgtCache): what the first pass computed from the TARGET cloud alone, kept across passes.
+  // Lives BEHIND the planned workspace (vcr_vcrnet_iter_workspace_bytes); NULL = no reuse.
+  float *c_emb, *c_st_emb, *c_d1, *c_st_d1, *c_qc, *c_kvc;
 };
+// floats of the target cache: emb | st_emb | d1 | st_d1 | qc | kvc for the M1 = B N target rows
+inline size_t tgt_cache_floats(int B, int N, int E) {
+  const size_t M1 = (size_t)B * N, sn = M1 * (E / 64) * 2;
+  return M1 * E * 3 + sn * 2 + M1 * 2 * E;
+}
 
 // vcrnet_model.py:208-209 and :284 -- Python truncates float64 products, so do we
 inline int overlap_k1(int N, double o2) { return (int)((double)N * 0.84 * o2); }
@@ -191,8 +199,23 @@ __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* p, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = 0;
 }
+extern "C" int vcr_linear_shapes_(const vcr_linear_args* a, const vcr_linear_args* b, int* shape_a, int* shape_b);   // linear.hip
+
 struct Runner {
   hipStream_t stream; vcr_trace* tr; int rc = 0;
+  // A later vcrnetIter pass with target reuse launches its pre-cross-attention linears on the SOURCE rows only.  The one
+  // configuration choice a linear's bits depend on is its MFMA shape, which the library picks from the row count among other
+  // things: such a launch pins the shape the full-row launch it stands for would take (shape_rows = that row count; 0 = off).
+  int shape_rows = 0;
+  void pin_shape(vcr_linear_args& a, vcr_linear_args* b = nullptr) {
+    if (!shape_rows || a.M >= shape_rows || (a.variant & (16 | 1024))) return;
+    vcr_linear_args fa = a, fb = b ? *b : a;
+    fa.M = shape_rows; fb.M = shape_rows;
+    int sa = 0, sb = 0;
+    if (vcr_linear_shapes_(&fa, b ? &fb : nullptr, &sa, &sb) != VCR_OK) return;
+    a.variant |= sa ? 16 : 1024;
+    if (b) b->variant |= sb ? 16 : 1024;
+  }
   void mark(const char* name) {
     if (!tr) return;
     if (tr->count < VCR_TRACE_MAX) tr->names[tr->count] = name;
@@ -217,6 +240,7 @@ struct Runner {
     if (ln_stats) { a.ln_stats_in = ln_stats; a.ln_nseg = K / 64; a.ln_colsum = ln_colsum; a.ln_eps = 1e-6f; }
     a.stats_out = stats_out;
     a.variant = linear_variant;
+    if (!wsplit) pin_shape(a);                           // (the exact-split kernel has one configuration)
     return ok(wsplit ? vcr_linear_bf16x3_f32(&a, wsplit, stream) : vcr_linear_f32(&a, stream));
   }
   // the argument block of linear() without launching it, and two such blocks as one launch (vcr_linear_pair_f32)
@@ -229,9 +253,10 @@ struct Runner {
     a.variant = linear_variant;
     return a;
   }
-  bool linear2(const char* nm, const vcr_linear_args& a, const vcr_linear_args& b) {
+  bool linear2(const char* nm, vcr_linear_args a, vcr_linear_args b) {
     if (rc) return false;
     mark(nm);
+    pin_shape(a, &b);
     return ok(vcr_linear_pair_f32(&a, &b, stream));
   }
   bool norm(const char* nm, const float* x, const vcr_norm_w& n, float* y, int M, int E,
@@ -443,8 +468,14 @@ struct Runner {
   }
 };
 
+// pass: 0 = a forward on its own.  Target reuse inside vcrnetIter (the target cloud does not change between the passes of
+// vcrnet_model.py:21-43, so everything computed from it ALONE is loop-invariant: its LPDNet embedding, the encoder on its rows,
+// the decoder's self-attention sublayer and cross-attention query on its rows, the K | V projection of its encoder memory):
+// 1 = the first pass, which saves those rows behind the workspace; 2 = a later pass, whose launches in front of the
+// cross-attention run on the SOURCE rows only (names end in "@src") and whose target halves are restored from that cache.
+// Every launch computes what the full-row launch would (linears pin its MFMA shape): the loop's results do not change by a bit.
 int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* workspace, size_t ws_bytes,
-                 vcr_stream_t stream, vcr_trace* tr, bool last = true) {
+                 vcr_stream_t stream, vcr_trace* tr, bool last = true, int pass = 0) {
   if (!W || !io || !workspace || !io->src_cf || !io->tgt_cf || !io->corr4 || !io->src4 || !io->R_ab || !io->t_ab)
     return VCR_EINVAL;
   const int B = io->B, N = io->N, E = W->E, F = W->F, k = W->k;
@@ -476,8 +507,31 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   Ws w = carve(workspace, B, N, k, E, F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W), W->workspace_flat);
   if (ws_bytes < w.bytes) return VCR_EWORKSPACE;
   const int M1 = B * N, M2 = 2 * M1;
+  if (pass != 0) {
+    if (W->emb_kind != 0 || W->has_pointer != 1 || ws_bytes < w.bytes + tgt_cache_floats(B, N, E) * sizeof(float)) return VCR_EINVAL;
+    const size_t sn = (size_t)M1 * (E / 64) * 2;
+    float* c = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + w.bytes);
+    w.c_emb = c;     c += (size_t)M1 * E;
+    w.c_d1 = c;      c += (size_t)M1 * E;
+    w.c_qc = c;      c += (size_t)M1 * E;
+    w.c_kvc = c;     c += (size_t)M1 * 2 * E;
+    w.c_st_emb = c;  c += sn;
+    w.c_st_d1 = c;
+  }
+  const bool half = pass == 2;                           // launches in front of the cross-attention: source rows only
+  const int Bq = half ? B : 2 * B, Mq = half ? M1 : M2;
+#define NM(site) (half ? site "@src" : site)
   Runner R{(hipStream_t)stream, tr};
   R.io_ = io;
+  R.shape_rows = half ? M2 : 0;
+  // the target halves (rows M1 .. M2 - 1) of the buffers a later pass does not recompute: saved by pass 1, restored by pass 2
+  auto tgt_rows = [&](const char* nm, float* buf, float* cache, size_t per_row) {
+    if (pass == 0 || R.rc) return;
+    R.mark(nm);
+    float* rows = buf + (size_t)M1 * per_row;
+    R.ok(pass == 1 ? vcr_copy_d2d(cache, rows, (size_t)M1 * per_row * sizeof(float), R.stream)
+                   : vcr_copy_d2d(rows, cache, (size_t)M1 * per_row * sizeof(float), R.stream));
+  };
   // both tie counters (and the first block).  A kernel, not hipMemsetAsync: the forward then records into a HIP graph of
   // kernel nodes only
   hipLaunchKernelGGL(zero_i32_kernel, dim3((unsigned)((M2 + 2 + 255) / 256)), dim3(256), 0, R.stream, w.ties, (long)(M2 + 2));
@@ -558,8 +612,9 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   // 5.9e-6 against 1.5 x the reference's + 3e-6 = 4.9e-6).  Reverted.)
   const bool pq_fused = W->linear_mode == 0;
   if (R.rc == 0) {                                       // both clouds in one launch: rows 0..M1-1 = src, then tgt
-    R.mark(pq_fused ? "pointwise:src+tgt+dg1_pq" : "pointwise:src+tgt");
-    vcr_pointwise_args a{io->src_cf, B, N, W->c1_w, W->c1_b, W->c2_w, W->c2_b, w.xyz4, w.feat64, w.sq64, io->tgt_cf, B};
+    R.mark(pq_fused ? NM("pointwise:src+tgt+dg1_pq") : NM("pointwise:src+tgt"));
+    vcr_pointwise_args a{io->src_cf, B, N, W->c1_w, W->c1_b, W->c2_w, W->c2_b, w.xyz4, w.feat64, w.sq64, half ? nullptr : io->tgt_cf,
+                         half ? 0 : B};
     if (pq_fused) { a.pq_w = W->dg1_wpq; a.pq_b = W->dg1_bpq; a.pq = w.pq1; a.ldpq = 256; }
     a.feat64t = W->E >= 64 ? w.emb : nullptr;                                   // operand layout of the 16-query kNN waves (w.emb is free until conv3)
     R.ok(vcr_pointwise_f32(&a, R.stream));
@@ -568,8 +623,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   // tie replay for both right before the first consumer of the indices.
   const int32_t* rank_perm = nullptr;                    // the clouds' Morton ranking, when the kNN took the ordered search
   {
-    vcr_knn_args a64{(uint32_t)sizeof(vcr_knn_args), w.feat64, 64, w.sq64, 2 * B, N, 64, k, w.idx1, w.ties, M2, W->knn_waves};
-    vcr_knn_args a3{(uint32_t)sizeof(vcr_knn_args), w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
+    vcr_knn_args a64{(uint32_t)sizeof(vcr_knn_args), w.feat64, 64, w.sq64, Bq, N, 64, k, w.idx1, w.ties, M2, W->knn_waves};
+    vcr_knn_args a3{(uint32_t)sizeof(vcr_knn_args), w.xyz4, 4, nullptr, Bq, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
     a64.tie_work = w.tie_work; a3.tie_work = w.tie_work ? w.tie_work + w.tie_work_each : nullptr;
     a64.tie_work_bytes = a3.tie_work_bytes = w.tie_work_each;
     a64.xt = W->E >= 64 ? w.emb : nullptr;
@@ -578,7 +633,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     // (ranking) at 32 x 2048, 2970 -> 1850 + 93 at 64 x 4096, k = 40; at 1024 points the plain scan is faster (120 vs 143 + 30).
     // Its arrays live in the unused part of w.emb (free until conv3; feat64t is its first M2 x 64 floats).
     if (R.rc == 0 && W->E >= 256 && N >= KNN_ORDERED_MIN_N && N <= 8192 && (k == 20 || k == 40) && W->knn_waves == 0 &&
-        (long)2 * B * ((N + 15) / 16) >= 1024) {         // (fewer query groups: vcr_knn_pair_f32 takes its small-grid kernels)
+        (long)Bq * ((N + 15) / 16) >= 1024) {            // (fewer query groups: vcr_knn_pair_f32 takes its small-grid kernels)
       const size_t m = (size_t)M2, mt = (size_t)2 * B * ((N + 15) / 16);
       float* base = w.emb + m * 64;
       float* feat_p = base;                 base += m * 64;
@@ -590,8 +645,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       float* c64_sq = base;  base += mt;  float* c64_rad = base;  base += mt;  float* c64_max = base;  base += mt;
       float* c4_rad = base;  base += mt;  float* c4_max = base;  base += mt;
       int32_t* ord_ok = reinterpret_cast<int32_t*>(base);                  // the ranking's per-cloud verdict on the feature tiles
-      R.mark("knn:rank");
-      vcr_knn_order_args o{w.xyz4, w.emb, 64, w.sq64, 2 * B, N, perm, xyz4_p, cen4, c4_rad, c4_max, feat_p, sq_p, cen64, c64_sq,
+      R.mark(NM("knn:rank"));
+      vcr_knn_order_args o{w.xyz4, w.emb, 64, w.sq64, Bq, N, perm, xyz4_p, cen4, c4_rad, c4_max, feat_p, sq_p, cen64, c64_sq,
                            c64_rad, c64_max, ord_ok, nullptr, 0.f};
       R.ok(vcr_knn_order_f32(&o, R.stream));
       a64.perm = a3.perm = perm;
@@ -600,25 +655,27 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       a64.xp = feat_p; a64.sqp = sq_p; a64.cen = cen64; a64.cen_sq = c64_sq; a64.cen_rad = c64_rad; a64.cen_sqmax = c64_max;
       a3.xp = xyz4_p; a3.cen = cen4; a3.cen_rad = c4_rad; a3.cen_sqmax = c4_max;
     }
-    R.knn_pair("knn:feat64+xyz", a64, a3);
+    R.knn_pair(NM("knn:feat64+xyz"), a64, a3);
   }
-  if (!pq_fused) R.linear("linear:dg1_pq", w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, M2, 256, 64, 0);
+  if (!pq_fused) R.linear(NM("linear:dg1_pq"), w.feat64, 64, W->dg1_wpq, SP(dg1_pq), W->dg1_bpq, w.pq1, 256, Mq, 256, 64, 0);
   R.knn_ties();                                          // both tie replays in one launch (one latency instead of two)
   if (R.rc == 0) {
-    R.mark("edgeconv:dg1_dg2");
-    vcr_edgeconv_args a{w.pq1, 256, w.idx1, k, M2, N, W->dg2_w, W->dg2_b, w.cat, 512, w.cat + 128, 512};
+    R.mark(NM("edgeconv:dg1_dg2"));
+    vcr_edgeconv_args a{w.pq1, 256, w.idx1, k, Mq, N, W->dg2_w, W->dg2_b, w.cat, 512, w.cat + 128, 512};
     // (linear_mode 1 / 2: convDG2 as exact bf16 splits at the path's k; other k keep the fp32 kernel)
     R.ok(W->linear_mode != 0 && (k == 20 || k == 40) ? vcr_edgeconv_bf16x3_f32(&a, R.stream) : vcr_edgeconv_f32(&a, R.stream));
   }
-  R.linear("linear:sn1_pq", w.cat + 128, 512, W->sn1_wpq, SP(sn1_pq), W->sn1_bpq, w.pq3, 512, M2, 512, 128, 0);
+  R.linear(NM("linear:sn1_pq"), w.cat + 128, 512, W->sn1_wpq, SP(sn1_pq), W->sn1_bpq, w.pq3, 512, Mq, 512, 128, 0);
   if (R.rc == 0) {
-    R.mark("gathermax:sn1");
-    vcr_gathermax_args a{w.pq3, 512, 256, w.idx3, k, M2, N, w.cat + 256, 512};
+    R.mark(NM("gathermax:sn1"));
+    vcr_gathermax_args a{w.pq3, 512, 256, w.idx3, k, Mq, N, w.cat + 256, 512};
     a.order = rank_perm;                                 // (clouds that were ranked for the kNN: the L2 form walks them in rank order)
     R.ok(vcr_gathermax_f32(&a, R.stream));
   }
-  R.linear("linear:conv3", w.cat, 512, W->c3_w, SP(c3), W->c3_b, w.emb, E, M2, E, 512, 1, nullptr, 0, nullptr, nullptr,
+  R.linear(NM("linear:conv3"), w.cat, 512, W->c3_w, SP(c3), W->c3_b, w.emb, E, Mq, E, 512, 1, nullptr, 0, nullptr, nullptr,
            W->has_pointer == 1 ? w.st_emb : nullptr);
+  tgt_rows(pass == 1 ? "select:reuse.save.emb" : "select:reuse.restore.emb", w.emb, w.c_emb, (size_t)E);
+  tgt_rows(pass == 1 ? "select:reuse.save.st" : "select:reuse.restore.st", w.st_emb, w.c_st_emb, (size_t)(E / 64) * 2);
 
   }
 
@@ -635,61 +692,65 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     if (merged) {
       // both first sublayers read the embedding rows with the same row statistics: one [M, 6E] projection, and the two
       // independent self-attentions as one grouped launch (group 0 = encoder, 1 = decoder)
-      R.linear("linear:encdec.qkv", w.emb, E, W->fold_encdec_qkv.w, SP(encdec_qkv), W->fold_encdec_qkv.bias, w.qkv, 6 * E, M2, 6 * E, E, 0,
+      R.linear(NM("linear:encdec.qkv"), w.emb, E, W->fold_encdec_qkv.w, SP(encdec_qkv), W->fold_encdec_qkv.bias, w.qkv, 6 * E, Mq, 6 * E, E, 0,
                nullptr, 0, w.st_emb, W->fold_encdec_qkv.colsum);
-      R.sdpa("sdpa:encdec.self", w.qkv, 6 * E, w.qkv + E, 6 * E, w.qkv + 2 * E, 6 * E, w.att, E, 2 * B, H, N, N, 0, nullptr, nullptr,
+      R.sdpa(NM("sdpa:encdec.self"), w.qkv, 6 * E, w.qkv + E, 6 * E, w.qkv + 2 * E, 6 * E, w.att, E, Bq, H, N, N, 0, nullptr, nullptr,
              nullptr, 0, 2, 3 * E, (long)M2 * E);
       att_dec = w.att + (size_t)M2 * E;
     } else {
-    R.linear("linear:enc.qkv", w.emb, E, W->fold_enc_qkv.w, SP(enc_qkv), W->fold_enc_qkv.bias, w.qkv, 3 * E, M2, 3 * E, E, 0,
+    R.linear(NM("linear:enc.qkv"), w.emb, E, W->fold_enc_qkv.w, SP(enc_qkv), W->fold_enc_qkv.bias, w.qkv, 3 * E, Mq, 3 * E, E, 0,
              nullptr, 0, w.st_emb, W->fold_enc_qkv.colsum);
-    R.sdpa("sdpa:enc.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
+    R.sdpa(NM("sdpa:enc.self"), w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, Bq, H, N, N, 0);
     }
     if (merged && W->linear_mode != 0) {
       // the split-arithmetic linears have no paired launcher: the same sequence, one launch each
-      R.linear("linear:enc.wo", w.att, E, W->enc_self.wo, SP(enc_wo), W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E,
+      R.linear(NM("linear:enc.wo"), w.att, E, W->enc_self.wo, SP(enc_wo), W->enc_self.bo, w.e1, E, Mq, E, E, 0, w.emb, E,
                nullptr, nullptr, w.st_e1);
-      R.linear("linear:dec.self.wo", att_dec, E, W->dec_self.wo, SP(dec_self_wo), W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E,
+      R.linear(NM("linear:dec.self.wo"), att_dec, E, W->dec_self.wo, SP(dec_self_wo), W->dec_self.bo, w.d1, E, Mq, E, E, 0, w.emb, E,
                nullptr, nullptr, w.st_d1);
-      R.linear("linear:enc.ffn1", w.e1, E, W->fold_enc_ffn1.w, SP(enc_ffn1), W->fold_enc_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
+      R.linear(NM("linear:enc.ffn1"), w.e1, E, W->fold_enc_ffn1.w, SP(enc_ffn1), W->fold_enc_ffn1.bias, w.hid, F, Mq, F, E, 1, nullptr, 0,
                w.st_e1, W->fold_enc_ffn1.colsum);
-      R.linear("linear:dec.cross.q", w.d1, E, W->fold_dec_cross_q.w, SP(dec_cross_q), W->fold_dec_cross_q.bias, w.qc, E, M2, E, E, 0, nullptr, 0,
+      R.linear(NM("linear:dec.cross.q"), w.d1, E, W->fold_dec_cross_q.w, SP(dec_cross_q), W->fold_dec_cross_q.bias, w.qc, E, Mq, E, E, 0, nullptr, 0,
                w.st_d1, W->fold_dec_cross_q.colsum);
-      R.linear("linear:enc.ffn2", w.hid, F, W->enc_ffn.w2, SP(enc_ffn2), W->enc_ffn.b2, w.e2, E, M2, E, F, 0, w.e1, E,
+      R.linear(NM("linear:enc.ffn2"), w.hid, F, W->enc_ffn.w2, SP(enc_ffn2), W->enc_ffn.b2, w.e2, E, Mq, E, F, 0, w.e1, E,
                nullptr, nullptr, w.st_e2);
     } else if (merged) {
       // independent launches of one kernel configuration run as pairs: the two output projections (inputs = the two
       // attention outputs, residual = the embedding), then the encoder's FFN-in beside the decoder's cross-attention query
-      R.linear2("linear:enc.wo+dec.self.wo",
-                R.linear_args(w.att, E, W->enc_self.wo, W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E, nullptr, nullptr, w.st_e1),
-                R.linear_args(att_dec, E, W->dec_self.wo, W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E, nullptr, nullptr, w.st_d1));
-      R.linear2("linear:enc.ffn1+dec.cross.q",
-                R.linear_args(w.e1, E, W->fold_enc_ffn1.w, W->fold_enc_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0, w.st_e1,
+      R.linear2(NM("linear:enc.wo+dec.self.wo"),
+                R.linear_args(w.att, E, W->enc_self.wo, W->enc_self.bo, w.e1, E, Mq, E, E, 0, w.emb, E, nullptr, nullptr, w.st_e1),
+                R.linear_args(att_dec, E, W->dec_self.wo, W->dec_self.bo, w.d1, E, Mq, E, E, 0, w.emb, E, nullptr, nullptr, w.st_d1));
+      R.linear2(NM("linear:enc.ffn1+dec.cross.q"),
+                R.linear_args(w.e1, E, W->fold_enc_ffn1.w, W->fold_enc_ffn1.bias, w.hid, F, Mq, F, E, 1, nullptr, 0, w.st_e1,
                               W->fold_enc_ffn1.colsum),
-                R.linear_args(w.d1, E, W->fold_dec_cross_q.w, W->fold_dec_cross_q.bias, w.qc, E, M2, E, E, 0, nullptr, 0, w.st_d1,
+                R.linear_args(w.d1, E, W->fold_dec_cross_q.w, W->fold_dec_cross_q.bias, w.qc, E, Mq, E, E, 0, nullptr, 0, w.st_d1,
                               W->fold_dec_cross_q.colsum));
-      R.linear("linear:enc.ffn2", w.hid, F, W->enc_ffn.w2, nullptr, W->enc_ffn.b2, w.e2, E, M2, E, F, 0, w.e1, E,
+      R.linear(NM("linear:enc.ffn2"), w.hid, F, W->enc_ffn.w2, nullptr, W->enc_ffn.b2, w.e2, E, Mq, E, F, 0, w.e1, E,
                nullptr, nullptr, w.st_e2);
     } else {
-    R.linear("linear:enc.wo", w.att, E, W->enc_self.wo, SP(enc_wo), W->enc_self.bo, w.e1, E, M2, E, E, 0, w.emb, E,
+    R.linear(NM("linear:enc.wo"), w.att, E, W->enc_self.wo, SP(enc_wo), W->enc_self.bo, w.e1, E, Mq, E, E, 0, w.emb, E,
              nullptr, nullptr, w.st_e1);
-    R.linear("linear:enc.ffn1", w.e1, E, W->fold_enc_ffn1.w, SP(enc_ffn1), W->fold_enc_ffn1.bias, w.hid, F, M2, F, E, 1, nullptr, 0,
+    R.linear(NM("linear:enc.ffn1"), w.e1, E, W->fold_enc_ffn1.w, SP(enc_ffn1), W->fold_enc_ffn1.bias, w.hid, F, Mq, F, E, 1, nullptr, 0,
              w.st_e1, W->fold_enc_ffn1.colsum);
-    R.linear("linear:enc.ffn2", w.hid, F, W->enc_ffn.w2, SP(enc_ffn2), W->enc_ffn.b2, w.e2, E, M2, E, F, 0, w.e1, E,
+    R.linear(NM("linear:enc.ffn2"), w.hid, F, W->enc_ffn.w2, SP(enc_ffn2), W->enc_ffn.b2, w.e2, E, Mq, E, F, 0, w.e1, E,
              nullptr, nullptr, w.st_e2);
     // decoder; batch b attends to the encoder memory (= enc.norm(e2), applied inside the K/V projection) of
     // batch (b + B) mod 2B
-    R.linear("linear:dec.qkv", w.emb, E, W->fold_dec_qkv.w, SP(dec_qkv), W->fold_dec_qkv.bias, w.qkv, 3 * E, M2, 3 * E, E, 0,
+    R.linear(NM("linear:dec.qkv"), w.emb, E, W->fold_dec_qkv.w, SP(dec_qkv), W->fold_dec_qkv.bias, w.qkv, 3 * E, Mq, 3 * E, E, 0,
              nullptr, 0, w.st_emb, W->fold_dec_qkv.colsum);
-    R.sdpa("sdpa:dec.self", w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, 2 * B, H, N, N, 0);
-    R.linear("linear:dec.self.wo", att_dec, E, W->dec_self.wo, SP(dec_self_wo), W->dec_self.bo, w.d1, E, M2, E, E, 0, w.emb, E,
+    R.sdpa(NM("sdpa:dec.self"), w.qkv, 3 * E, w.qkv + E, 3 * E, w.qkv + 2 * E, 3 * E, w.att, E, Bq, H, N, N, 0);
+    R.linear(NM("linear:dec.self.wo"), att_dec, E, W->dec_self.wo, SP(dec_self_wo), W->dec_self.bo, w.d1, E, Mq, E, E, 0, w.emb, E,
              nullptr, nullptr, w.st_d1);
-    R.linear("linear:dec.cross.q", w.d1, E, W->fold_dec_cross_q.w, SP(dec_cross_q), W->fold_dec_cross_q.bias, w.qc, E, M2, E, E, 0, nullptr, 0,
+    R.linear(NM("linear:dec.cross.q"), w.d1, E, W->fold_dec_cross_q.w, SP(dec_cross_q), W->fold_dec_cross_q.bias, w.qc, E, Mq, E, E, 0, nullptr, 0,
              w.st_d1, W->fold_dec_cross_q.colsum);
     }
     // batch b attends to the encoder memory (= enc.norm(e2), applied inside the K/V projection) of batch (b + B) mod 2B
-    R.linear("linear:dec.cross.kv", w.e2, E, W->fold_dec_cross_kv.w, SP(dec_cross_kv), W->fold_dec_cross_kv.bias, w.kvc, 2 * E, M2, 2 * E, E, 0,
+    R.linear(NM("linear:dec.cross.kv"), w.e2, E, W->fold_dec_cross_kv.w, SP(dec_cross_kv), W->fold_dec_cross_kv.bias, w.kvc, 2 * E, Mq, 2 * E, E, 0,
              nullptr, 0, w.st_e2, W->fold_dec_cross_kv.colsum);
+    tgt_rows(pass == 1 ? "select:reuse.save.d1" : "select:reuse.restore.d1", w.d1, w.c_d1, (size_t)E);
+    tgt_rows(pass == 1 ? "select:reuse.save.st" : "select:reuse.restore.st", w.st_d1, w.c_st_d1, (size_t)(E / 64) * 2);
+    tgt_rows(pass == 1 ? "select:reuse.save.qc" : "select:reuse.restore.qc", w.qc, w.c_qc, (size_t)E);
+    tgt_rows(pass == 1 ? "select:reuse.save.kvc" : "select:reuse.restore.kvc", w.kvc, w.c_kvc, (size_t)2 * E);
     R.cross_attention(W, io, w, B, N);
     R.linear("linear:dec.cross.wo", w.attx, E, W->dec_cross.wo, SP(dec_cross_wo), W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E,
              nullptr, nullptr, w.st_d2);
@@ -767,6 +828,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (R.rc == 0 && io->emb_out) R.ok(vcr_copy_d2d(io->emb_out, w.embf, (size_t)M2 * E * sizeof(float), R.stream));
   if (last) R.finish();
 #undef SP
+#undef NM
   return R.rc;
 }
 
@@ -827,6 +889,19 @@ extern "C" size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights* UW, int B
   return carve(nullptr, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W), W->workspace_flat).bytes;
 }
 
+// vcrnetIter with target reuse: LPDNet embedding + Transformer pointer (the reference's default), more than one pass, not
+// switched off (vcr_vcrnet_weights.iter_reuse == 1)
+static bool iter_reuse_applies(const vcr_vcrnet_weights* W, int iters) {
+  return iters > 1 && W->emb_kind == 0 && W->has_pointer == 1 && W->iter_reuse != 1;
+}
+extern "C" size_t vcr_vcrnet_iter_workspace_bytes(const vcr_vcrnet_weights* UW, int B, int N, int iters) {
+  vcr_vcrnet_weights Wn;
+  const vcr_vcrnet_weights* W = &Wn;
+  if (weights_take(UW, &Wn) || B <= 0 || N <= 0 || iters < 1) return 0;
+  const size_t base = carve(nullptr, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W), W->workspace_flat).bytes;
+  return base + (iter_reuse_applies(W, iters) ? tgt_cache_floats(B, N, W->E) * sizeof(float) : 0);
+}
+
 extern "C" int vcr_vcrnet_pairs(const vcr_vcrnet_weights* UW, int N) {
   vcr_vcrnet_weights Wn;
   const vcr_vcrnet_weights* W = &Wn;
@@ -873,6 +948,8 @@ extern "C" int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights* UW, const vcr_vcrne
   }
   const Ws w = carve(ws, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W), W->workspace_flat);
   if (bytes < w.bytes) return VCR_EWORKSPACE;
+  // target reuse (forward_impl, `pass`): taken when the caller sized the workspace with vcr_vcrnet_iter_workspace_bytes
+  const bool reuse = iter_reuse_applies(W, iters) && bytes >= w.bytes + tgt_cache_floats(B, N, W->E) * sizeof(float);
   const size_t nkeys = W->partial ? (size_t)2 * B * (int)((double)N * W->overlap2) : 0;
   const size_t nsel = W->partial ? (size_t)B * overlap_k1(N, W->overlap2) : 0;
   const size_t npair = W->partial ? (size_t)B * overlap_k2(N, W->overlap2) : 0;
@@ -888,7 +965,7 @@ extern "C" int vcr_vcrnet_iter_f32(const vcr_vcrnet_weights* UW, const vcr_vcrne
     step.force_argmax = at(io->force_argmax, nsel);    step.out_argmax = at(io->out_argmax, nsel);
     step.force_pairs = at(io->force_pairs, npair);     step.out_pairs = at(io->out_pairs, npair);
     const bool last = it + 1 == iters;
-    const int rc = forward_impl(W, &step, ws, bytes, stream, tr, false);
+    const int rc = forward_impl(W, &step, ws, bytes, stream, tr, false, reuse ? (it == 0 ? 1 : 2) : 0);
     if (rc) return rc;
     if (last && it == 0) break;
     Runner R{(hipStream_t)stream, tr};

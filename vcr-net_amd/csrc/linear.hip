@@ -709,9 +709,8 @@ extern "C" int vcr_linear_f32(const vcr_linear_args* a, vcr_stream_t stream) {
 
 // Two independent linears as one launch when they resolve to the same LDS-DMA kernel configuration (k-slab, MFMA shape,
 // tile rows; neither with a fused max); otherwise exactly the two vcr_linear_f32 calls.  Same results.
-extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_args* b, vcr_stream_t stream) {
-  vcr_stream_scope bound(stream);
-  LinearPlan pa{}, pb{};
+// the planning half of vcr_linear_pair_f32: both plans as a paired launch would take them, and whether it IS one launch
+static int linear_pair_plan(const vcr_linear_args* a, const vcr_linear_args* b, LinearPlan& pa, LinearPlan& pb, bool& same) {
   int rc = linear_plan(a, &pa, 0, true);
   if (rc == VCR_OK) rc = linear_plan(b, &pb, 0, true);
   if (rc != VCR_OK) return rc;
@@ -734,8 +733,40 @@ extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_ar
     linear_plan(a, &pa, joint, true);
     linear_plan(b, &pb, joint, true);
   }
-  const bool same = pa.glds && pb.glds && pa.bk16 == pb.bk16 && pa.ms16 == pb.ms16 && pa.bm == pb.bm &&
-                    !a->segmax_out && !b->segmax_out;  // (LayerNorm-in / statistics-out may differ: run-time flags of each half)
+  same = pa.glds && pb.glds && pa.bk16 == pb.bk16 && pa.ms16 == pb.ms16 && pa.bm == pb.bm &&
+         !a->segmax_out && !b->segmax_out;             // (LayerNorm-in / statistics-out may differ: run-time flags of each half)
+  return VCR_OK;
+}
+
+// Host-only, library-internal (forward.hip): the MFMA shape -- 1 = 16x16x4, 0 = 32x32x2, the one choice of a linear's
+// configuration that its BITS depend on -- that vcr_linear_f32 (b == NULL) or vcr_linear_pair_f32 would compute these arguments
+// with.  The forward's src-only launches of a later vcrnetIter pass pin the shape of the full-row launch they stand for.
+extern "C" int vcr_linear_shapes_(const vcr_linear_args* a, const vcr_linear_args* b, int* shape_a, int* shape_b) {
+  LinearPlan pa{}, pb{};
+  if (!b) {
+    const int rc = linear_plan(a, &pa);
+    if (rc == VCR_OK && shape_a) *shape_a = pa.glds ? (pa.ms16 ? 1 : 0) : 0;
+    return rc;
+  }
+  bool same = false;
+  int rc = linear_pair_plan(a, b, pa, pb, same);
+  if (rc != VCR_OK) return rc;
+  if (!same) {                                           // two separate launches, each planned on its own
+    rc = linear_plan(a, &pa);
+    if (rc == VCR_OK) rc = linear_plan(b, &pb);
+    if (rc != VCR_OK) return rc;
+  }
+  if (shape_a) *shape_a = pa.glds ? (pa.ms16 ? 1 : 0) : 0;
+  if (shape_b) *shape_b = pb.glds ? (pb.ms16 ? 1 : 0) : 0;
+  return VCR_OK;
+}
+
+extern "C" int vcr_linear_pair_f32(const vcr_linear_args* a, const vcr_linear_args* b, vcr_stream_t stream) {
+  vcr_stream_scope bound(stream);
+  LinearPlan pa{}, pb{};
+  bool same = false;
+  int rc = linear_pair_plan(a, b, pa, pb, same);
+  if (rc != VCR_OK) return rc;
   if (pb.lds > pa.lds) pa.lds = pb.lds;
   if (!same) {
     rc = vcr_linear_f32(a, stream);

@@ -253,6 +253,7 @@ class VCRNet(nn.Module):
         self.merge_encdec = os.environ.get("VCRNET_MERGE_ENCDEC", "1") == "1"
         self.xscore_limit_mb = 0            # partial mode: keep the cross-attention scores up to this many MiB (0 = 4096)
         self.sdpa_variant = 0               # fp32 attention-output kernel: 0 = the library's choice, 1 = tile, 2 = persistent (benchmarks)
+        self.iter_reuse = True              # vcrnetIter, iter > 1: later passes reuse what the first computed from the target alone
         self.workspace_flat = False         # tests: no two workspace buffers share memory (vcr_vcrnet_weights.workspace_flat)
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_key = None
@@ -314,7 +315,7 @@ class VCRNet(nn.Module):
         dev = self._device()
         return (dev, ps[0].device, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps[:4]), self.emb_nn.k,
                 self.linear_mode, self.linear_mfma, self.linear_bk, self.linear_bm, self.knn_waves, self.xscore_limit_mb,
-                self.merge_encdec, bool(self.workspace_flat), int(self.sdpa_variant))
+                self.merge_encdec, bool(self.workspace_flat), int(self.sdpa_variant), bool(self.iter_reuse))
 
     def _pack(self):
         """Packed weights for this device and these parameter versions, shared with every replica / thread.  The packing
@@ -482,16 +483,18 @@ class VCRNet(nn.Module):
         cw.xscore_limit_mb = int(self.xscore_limit_mb)
         cw.workspace_flat = int(bool(self.workspace_flat))
         cw.sdpa_variant = int(self.sdpa_variant)
+        cw.iter_reuse = 0 if self.iter_reuse else 1
         cw.partial, cw.overlap2 = int(self._partial), self._overlap2
         self._packed, self._packed_key = P, key
         self._cw = cw
 
-    def _take_buffers(self, B: int, N: int, device) -> Tuple[Tuple, Dict[str, torch.Tensor]]:
+    def _take_buffers(self, B: int, N: int, device, iters: int = 1) -> Tuple[Tuple, Dict[str, torch.Tensor]]:
         """A forward workspace for this shape from the shared pool (an idle one, or a new one): concurrent calls -- two host
         threads, DataParallel replicas -- never share one; _give_buffers returns it with the stream it was used on."""
         sh = self._shared
         key = (B, N, device, int(self.emb_nn.k), int(self.xscore_limit_mb), bool(self.merge_encdec), self.linear_mode,
-               self._emb_kind, self._vcp, self._partial, self._overlap2, bool(self.workspace_flat))
+               self._emb_kind, self._vcp, self._partial, self._overlap2, bool(self.workspace_flat),
+               bool(self.iter_reuse) and iters > 1)        # (a loop with target reuse keeps its cache behind the workspace)
         with sh.lock:
             idle = sh.pool.get(key)
             if idle:
@@ -499,7 +502,9 @@ class VCRNet(nn.Module):
             for k_ in [k_ for k_ in sh.pool if k_[2] == device and k_ != key]:     # keep one shape resident per device
                 for b_ in sh.pool.pop(k_):
                     self._retire(b_)
-        nbytes = native.lib().vcr_vcrnet_workspace_bytes(C.byref(self._cw), B, N)
+        L = native.lib()
+        L.vcr_vcrnet_iter_workspace_bytes.restype = C.c_size_t
+        nbytes = L.vcr_vcrnet_iter_workspace_bytes(C.byref(self._cw), B, N, int(iters))
         return key, {"ws": torch.empty(nbytes + 256, dtype=torch.uint8, device=device)}
 
     MAX_IDLE_WORKSPACES = 4                                # per shape: more concurrent calls than this allocate and free
@@ -587,7 +592,7 @@ class VCRNet(nn.Module):
         B, _, N = src.shape
         dev = native.same_device(src, tgt, next(iter(self._tensors().values())))
         srcc, tgtc = src.contiguous().float(), tgt.contiguous().float()
-        bkey, bufs = self._take_buffers(B, N, dev)
+        bkey, bufs = self._take_buffers(B, N, dev, iters)
         try:
             return self._forward_with(bufs, srcc, tgtc, src, B, N, dev, trace, want_emb, iters, force, want_selections,
                                       iter_api)

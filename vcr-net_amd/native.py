@@ -203,7 +203,7 @@ class VcrnetWeights(_Sized):
                 ("partial", C.c_int), ("overlap2", C.c_double), ("emb_kind", C.c_int), ("dgcnn", DgcnnW), ("pointnet", PointnetW),
                 ("att_w0", f32p), ("att_b0", f32p), ("att_w1", f32p), ("att_b1", f32p), ("cycle", C.c_int),
                 ("linear_mfma", C.c_int), ("linear_bk", C.c_int), ("linear_bm", C.c_int), ("knn_waves", C.c_int),
-                ("xscore_limit_mb", C.c_int), ("sdpa_variant", C.c_int), ("workspace_flat", C.c_int)]
+                ("xscore_limit_mb", C.c_int), ("sdpa_variant", C.c_int), ("iter_reuse", C.c_int), ("workspace_flat", C.c_int)]
 
 
 class VcrnetIo(C.Structure):
@@ -260,6 +260,8 @@ def lib() -> C.CDLL:
                               "rebuild with `python vcr-net_amd/build.py`")
         L.vcr_vcrnet_workspace_bytes.argtypes = [C.POINTER(VcrnetWeights), C.c_int, C.c_int]
         L.vcr_vcrnet_workspace_bytes.restype = C.c_size_t
+        L.vcr_vcrnet_iter_workspace_bytes.argtypes = [C.POINTER(VcrnetWeights), C.c_int, C.c_int, C.c_int]
+        L.vcr_vcrnet_iter_workspace_bytes.restype = C.c_size_t
         L.vcr_vcrnet_forward_f32.argtypes = [C.POINTER(VcrnetWeights), C.POINTER(VcrnetIo), C.c_void_p, C.c_size_t,
                                              C.c_void_p]
         L.vcr_vcrnet_forward_f32.restype = C.c_int

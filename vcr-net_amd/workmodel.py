@@ -38,7 +38,11 @@ def overlap_sizes(N: int, overlap2: float) -> Tuple[int, int, int]:
 
 def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1024,
                 overlap2: float = 0.765970880926229) -> Tuple[float, float]:
-    """(flops, bytes) of one launch called `name` ("family:site") for B pairs of N points."""
+    """(flops, bytes) of one launch called `name` ("family:site") for B pairs of N points.  A name ending in "@src" is the
+    launch of a later vcrnetIter pass that runs on the source clouds' rows only (target reuse): half the work."""
+    if name.endswith("@src"):
+        fl, by = launch_work(name[:-4], B, N, k, E, F, overlap2)
+        return 0.5 * fl, 0.5 * by
     fam, site = name.split(":", 1)
     M1, M2 = B * N, 2 * B * N
     sym = {"E": E, "2E": 2 * E, "3E": 3 * E, "6E": 6 * E, "F": F}
@@ -109,6 +113,9 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
             return 4.0 * 2 * B * 4 * N * N, 4.0 * 2 * B * 4 * N * N
         return 8.0 * B * N * N, 4.0 * 2 * B * N * N
     if fam == "select":
+        if site.startswith("reuse."):                      # target rows saved behind / restored from the workspace (vcrnetIter)
+            width = {"emb": E, "d1": E, "qc": E, "kvc": 2 * E, "st": 2 * (E // 64)}[site.rsplit(".", 1)[1]]
+            return 0.0, 4.0 * 2 * M1 * width
         if site.endswith(".forced") or site.endswith(".out"):   # device-to-device copy of an index block
             return 0.0, 8.0 * 2 * B * N
         if site.startswith("gather"):
@@ -133,6 +140,8 @@ def gather_bytes(name: str, B: int, N: int, k: int = 20) -> float:
     """Bytes a launch moves through L2 for its neighbour gathers (k rows per point, each row re-read ~k times across
     the cloud): NOT HBM traffic.  edgeconv gathers 128-float P rows, gathermax:sn1 256-float rows, DGCNN's
     edge-row builder 64-float rows."""
+    if name.endswith("@src"):
+        return 0.5 * gather_bytes(name[:-4], B, N, k)
     fam, site = name.split(":", 1)
     M2 = 2 * B * N
     if fam == "edgeconv":
