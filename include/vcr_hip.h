@@ -340,6 +340,11 @@ typedef struct {
    * items; the fast attention-output form with at least two items per workgroup -- any other call runs the tile kernel).
    * vcr_sdpa_f32 only. */
   int variant;
+  /* 0, or the number of batches of the launch this one stands for (>= nbatch): the key-split decision -- the one choice of
+   * this entry point that changes the summation order of its results -- is then taken for a grid of that many batches.  The
+   * forward's source-only attention launches of a later vcrnetIter pass (nbatch = B) give 2 B here and so compute every row
+   * exactly as the full launch of the first pass did. */
+  int plan_nbatch;
 } vcr_sdpa_args;
 #define VCR_SDPA_MAX_SPLIT 4
 int vcr_sdpa_f32(const vcr_sdpa_args*, vcr_stream_t);

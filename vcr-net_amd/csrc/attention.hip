@@ -537,12 +537,15 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
   // shortens the launch by a tenth in a simple round model (a partial last round filled to f costs 0.35 + 0.65 f of a round):
   // 1152 workgroups on 512 slots at BASELINE configs[2] = 2.25 rounds -> four times as many of a quarter the length.
   const long blocks = (long)((a->nq + VCR_SDPA_QROWS - 1) / VCR_SDPA_QROWS) * a->heads * a->nbatch * ng;
+  if (a->plan_nbatch != 0 && a->plan_nbatch < a->nbatch) return VCR_EINVAL;
+  // (the split decisions below count the blocks of the launch this one stands for: vcr_sdpa_args.plan_nbatch)
+  const long plan_blocks = a->plan_nbatch ? blocks / a->nbatch * a->plan_nbatch : blocks;
   int nsplit = 1;
   if (!pv && a->split_work && a->split_work_floats >= (long)VCR_SDPA_MAX_SPLIT * a->nbatch * a->heads * a->nq * 2) {
     const long slots = (long)vcr_cu_count() * 2;
     const int ntiles = (a->nk + 31) / 32;
     auto cost = [&](int sp) {
-      const long t = blocks * sp, full = t / slots;
+      const long t = plan_blocks * sp, full = t / slots;
       const double f = (double)(t - full * slots) / slots;
       return ((double)full + (f > 0.0 ? 0.35 + 0.65 * f : 0.0)) / sp;
     };
@@ -561,9 +564,11 @@ extern "C" int vcr_sdpa_f32(const vcr_sdpa_args* a, vcr_stream_t stream) {
     const long slots = (long)vcr_cu_count() * VCR_SDPA_WG_PER_CU;
     const int ntiles = (a->nk + 31) / 32;
     const size_t plane = (size_t)ng * a->nbatch * a->nq * a->ldo * 4;
+    const size_t plan_plane = plane / a->nbatch * (a->plan_nbatch ? a->plan_nbatch : a->nbatch);     // (of the launch this one stands for)
+    const size_t plan_ml = (size_t)ng * (a->plan_nbatch ? a->plan_nbatch : a->nbatch) * a->heads * a->nq * 8;
     for (int sp = VCR_SDPA_MAX_SPLIT; sp >= 2; sp >>= 1)
-      if (blocks * sp <= slots && ntiles / sp >= 4 && (sp - 1) * ((ntiles + sp - 1) / sp) < ntiles && plane * sp <= ((size_t)64 << 20) &&
-          (size_t)a->split_work_floats * 4 >= sp * (plane + (size_t)ng * a->nbatch * a->heads * a->nq * 8)) {
+      if (plan_blocks * sp <= slots && ntiles / sp >= 4 && (sp - 1) * ((ntiles + sp - 1) / sp) < ntiles && plan_plane * sp <= ((size_t)64 << 20) &&
+          (size_t)a->split_work_floats * 4 >= sp * (plan_plane + plan_ml)) {
         nsplit = sp;
         break;
       }

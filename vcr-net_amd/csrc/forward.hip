@@ -207,6 +207,7 @@ struct Runner {
   // configuration choice a linear's bits depend on is its MFMA shape, which the library picks from the row count among other
   // things: such a launch pins the shape the full-row launch it stands for would take (shape_rows = that row count; 0 = off).
   int shape_rows = 0;
+  int plan_nbatch = 0;                                   // likewise for the attention launches' key split (vcr_sdpa_args.plan_nbatch)
   void pin_shape(vcr_linear_args& a, vcr_linear_args* b = nullptr) {
     if (!shape_rows || a.M >= shape_rows || (a.variant & (16 | 1024))) return;
     vcr_linear_args fa = a, fb = b ? *b : a;
@@ -283,6 +284,7 @@ struct Runner {
       a.out_group_stride = out_group_stride;
     }
     a.variant = sdpa_variant;
+    if (plan_nbatch > nb) a.plan_nbatch = plan_nbatch;    // (a source-only launch of a later vcrnetIter pass: split as the full one)
     // linear_mode 2: the attention-output launches on the bf16 matrix pipe as exact splits; statistics passes stay fp32
     return ok((sdpa_split && out && !rowstat && !score_out) ? vcr_sdpa_bf16x3_f32(&a, stream) : vcr_sdpa_f32(&a, stream));
   }
@@ -524,6 +526,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   Runner R{(hipStream_t)stream, tr};
   R.io_ = io;
   R.shape_rows = half ? M2 : 0;
+  R.plan_nbatch = half ? 2 * B : 0;
   // the target halves (rows M1 .. M2 - 1) of the buffers a later pass does not recompute: saved by pass 1, restored by pass 2
   auto tgt_rows = [&](const char* nm, float* buf, float* cache, size_t per_row) {
     if (pass == 0 || R.rc) return;

@@ -87,7 +87,7 @@ class SdpaArgs(C.Structure):
                 ("rowstat", f32p), ("score_out", f32p), ("ld_score", C.c_int),
                 ("ngroups", C.c_int), ("q_group_stride", C.c_long), ("k_group_stride", C.c_long), ("v_group_stride", C.c_long),
                 ("out_group_stride", C.c_long), ("key_index", f32p), ("nk_src", C.c_int), ("split_work", f32p),
-                ("split_work_floats", C.c_long), ("variant", C.c_int)]
+                ("split_work_floats", C.c_long), ("variant", C.c_int), ("plan_nbatch", C.c_int)]
 
 
 class KeymassArgs(C.Structure):
