@@ -88,13 +88,13 @@ struct Ws {
   size_t bytes;
   // vcrnetIter with target reuse (see TgtCache): what the first pass computed from the TARGET cloud alone, kept across passes.
   // Lives BEHIND the planned workspace (vcr_vcrnet_iter_workspace_bytes); NULL = no reuse.
-  float *c_emb, *c_st_emb, *c_d1, *c_st_d1, *c_qc, *c_kvc;
+  float *c_emb, *c_d1, *c_qc, *c_kvc;
 };
-// floats of the target cache: emb | st_emb | d1 | st_d1 | qc | kvc for the M1 = B N target rows
-inline size_t tgt_cache_floats(int B, int N, int E) {
-  const size_t M1 = (size_t)B * N, sn = M1 * (E / 64) * 2;
-  return M1 * E * 3 + sn * 2 + M1 * 2 * E;
-}
+// floats of the target cache: emb | d1 | qc | kvc for the M1 = B N target rows -- exactly what a later pass reads of them behind
+// the cross-attention (the final residual, the cross sublayer's residual, its queries, its keys | values).  The LayerNorm
+// statistics of those rows are consumed in front of it, by launches a later pass runs on the source rows only; their
+// buffers are dead -- and their memory re-used -- by the time the cache is written or read: they must NOT be part of it.
+inline size_t tgt_cache_floats(int B, int N, int E) { return (size_t)B * N * 5 * E; }
 
 // vcrnet_model.py:208-209 and :284 -- Python truncates float64 products, so do we
 inline int overlap_k1(int N, double o2) { return (int)((double)N * 0.84 * o2); }
@@ -511,14 +511,11 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   const int M1 = B * N, M2 = 2 * M1;
   if (pass != 0) {
     if (W->emb_kind != 0 || W->has_pointer != 1 || ws_bytes < w.bytes + tgt_cache_floats(B, N, E) * sizeof(float)) return VCR_EINVAL;
-    const size_t sn = (size_t)M1 * (E / 64) * 2;
     float* c = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + w.bytes);
     w.c_emb = c;     c += (size_t)M1 * E;
     w.c_d1 = c;      c += (size_t)M1 * E;
     w.c_qc = c;      c += (size_t)M1 * E;
-    w.c_kvc = c;     c += (size_t)M1 * 2 * E;
-    w.c_st_emb = c;  c += sn;
-    w.c_st_d1 = c;
+    w.c_kvc = c;
   }
   const bool half = pass == 2;                           // launches in front of the cross-attention: source rows only
   const int Bq = half ? B : 2 * B, Mq = half ? M1 : M2;
@@ -678,7 +675,6 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   R.linear(NM("linear:conv3"), w.cat, 512, W->c3_w, SP(c3), W->c3_b, w.emb, E, Mq, E, 512, 1, nullptr, 0, nullptr, nullptr,
            W->has_pointer == 1 ? w.st_emb : nullptr);
   tgt_rows(pass == 1 ? "select:reuse.save.emb" : "select:reuse.restore.emb", w.emb, w.c_emb, (size_t)E);
-  tgt_rows(pass == 1 ? "select:reuse.save.st" : "select:reuse.restore.st", w.st_emb, w.c_st_emb, (size_t)(E / 64) * 2);
 
   }
 
@@ -751,7 +747,6 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     R.linear(NM("linear:dec.cross.kv"), w.e2, E, W->fold_dec_cross_kv.w, SP(dec_cross_kv), W->fold_dec_cross_kv.bias, w.kvc, 2 * E, Mq, 2 * E, E, 0,
              nullptr, 0, w.st_e2, W->fold_dec_cross_kv.colsum);
     tgt_rows(pass == 1 ? "select:reuse.save.d1" : "select:reuse.restore.d1", w.d1, w.c_d1, (size_t)E);
-    tgt_rows(pass == 1 ? "select:reuse.save.st" : "select:reuse.restore.st", w.st_d1, w.c_st_d1, (size_t)(E / 64) * 2);
     tgt_rows(pass == 1 ? "select:reuse.save.qc" : "select:reuse.restore.qc", w.qc, w.c_qc, (size_t)E);
     tgt_rows(pass == 1 ? "select:reuse.save.kvc" : "select:reuse.restore.kvc", w.kvc, w.c_kvc, (size_t)2 * E);
     R.cross_attention(W, io, w, B, N);
