@@ -15,6 +15,15 @@ grep -n "passed\|failed\|smoke" $OUT/${TAG}_gpu_tests.txt
 bash profiles/profile_round.sh $TAG > $OUT/${TAG}_profile_round.log 2>&1
 bash profiles/split_line_session.sh $TAG scratch/none > $OUT/${TAG}_split_session.log 2>&1
 bash profiles/profile_configs.sh $TAG > $OUT/${TAG}_profile_configs.log 2>&1
+# vcrnetIter with and without the reuse of the loop-invariant target cloud, alternated (BASELINE configs[2]; whole mode, 3 passes)
+pick='import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);s=d["stages"];print(sys.argv[1], round(d["value"],1), round(d["ms_per_step"],4), "stage", round(d["knn_edgeconv_stage"]["hbm_frac"],4), "clouds/pair", d["knn_edgeconv_stage"].get("clouds_processed_per_pair"), "acc", round(d["accounted_frac"],3), "frac", round(d["roofline"]["frac"],3), {k: round(v["ms_per_step"],3) for k,v in s.items()})'
+for rep in 1 2; do
+  python bench.py --partial --points 1024 --batch 24 --iters 3 --no-iter-reuse --no-cpu-baseline --no-other-configs --min-seconds 4 2>/dev/null | python -c "$pick" "configs[2] recompute"
+  python bench.py --partial --points 1024 --batch 24 --iters 3 --no-cpu-baseline --no-other-configs --min-seconds 4 2>/dev/null | python -c "$pick" "configs[2] reuse    "
+done > $OUT/${TAG}_config3_reuse_ab.txt 2>&1
+python bench.py --iters 3 --no-iter-reuse --no-cpu-baseline --no-other-configs --min-seconds 3 2>/dev/null | python -c "$pick" "whole N=1024 B=16 iters 3 recompute" >> $OUT/${TAG}_config3_reuse_ab.txt 2>&1
+python bench.py --iters 3 --no-cpu-baseline --no-other-configs --min-seconds 3 2>/dev/null | python -c "$pick" "whole N=1024 B=16 iters 3 reuse    " >> $OUT/${TAG}_config3_reuse_ab.txt 2>&1
+cat $OUT/${TAG}_config3_reuse_ab.txt
 python - <<PY
 import json
 d=json.load(open("$OUT/${TAG}_bench.json"))

@@ -294,7 +294,8 @@ def test_iter_with_a_forward_sized_workspace_still_runs():
     off = (-ws.data_ptr()) % 256
     f = lambda *sh: torch.empty(*sh, dtype=torch.float32, device="cuda")
     corr4, src4, R, tt, Rb, tb = f(B, N, 4), f(B, N, 4), f(B, 3, 3), f(B, 3), f(B, 3, 3), f(B, 3)
-    io = native.VcrnetIo(native.ptr(s.contiguous()), native.ptr(t.contiguous()), B, N, native.ptr(corr4), native.ptr(src4), native.ptr(R),
+    sc, tc = s.contiguous(), t.contiguous()                  # (synth's clouds are transposed views: the C-ABI takes [B,3,N] rows)
+    io = native.VcrnetIo(native.ptr(sc), native.ptr(tc), B, N, native.ptr(corr4), native.ptr(src4), native.ptr(R),
                          native.ptr(tt), native.ptr(Rb), native.ptr(tb), None)
     rc = L.vcr_vcrnet_iter_f32(C.byref(cw), C.byref(io), 3, C.c_void_p(ws.data_ptr() + off), n_small, C.c_void_p(native.stream_ptr()), None)
     assert rc == 0
