@@ -245,6 +245,7 @@ def test_fused_driver_covers_the_variant_and_matches_kernel_by_kernel(kw):
                                                       ({}, "fp32", False, 9, 1024, 2),                  # half of it below, all of it above 16 384 rows
                                                       (dict(partial=True), "fp32", True, 24, 1024, 3),  # BASELINE configs[2]
                                                       (dict(vcp_nn="att", cycle=True), "fp32", True, 4, 512, 2),
+                                                      (dict(vcp_nn="att"), "fp32", True, 18, 1024, 2),   # the head's one-cloud linears: 18 432 rows, own shape rule
                                                       ({}, "fp32", True, 4, 2048, 2)])                  # the ordered kNN search on half the clouds
 def test_iter_target_reuse_changes_no_bit(kw, mode, merge, B, N, iters):
     """vcrnetIter, iter > 1: the target cloud does not change between passes, so the passes after the first launch everything in

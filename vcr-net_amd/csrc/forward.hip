@@ -86,7 +86,7 @@ struct Ws {
   // vcrnetIter
   float *cur_cf, *Ri, *ti, *Rb, *tb;
   size_t bytes;
-  // vcrnetIter with target reuse (see TgtCache): what the first pass computed from the TARGET cloud alone, kept across passes.
+  // vcrnetIter with target reuse (forward_impl's `pass`): what the first pass computed from the TARGET cloud alone, kept across passes.
   // Lives BEHIND the planned workspace (vcr_vcrnet_iter_workspace_bytes); NULL = no reuse.
   float *c_emb, *c_d1, *c_qc, *c_kvc;
 };
@@ -749,6 +749,8 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     tgt_rows(pass == 1 ? "select:reuse.save.d1" : "select:reuse.restore.d1", w.d1, w.c_d1, (size_t)E);
     tgt_rows(pass == 1 ? "select:reuse.save.qc" : "select:reuse.restore.qc", w.qc, w.c_qc, (size_t)E);
     tgt_rows(pass == 1 ? "select:reuse.save.kvc" : "select:reuse.restore.kvc", w.kvc, w.c_kvc, (size_t)2 * E);
+    R.shape_rows = 0; R.plan_nbatch = 0;                 // from here on every launch has its own, full row count (the VcpAtt head's
+                                                         // one-cloud linears included: nothing stands for a larger launch any more)
     R.cross_attention(W, io, w, B, N);
     R.linear("linear:dec.cross.wo", w.attx, E, W->dec_cross.wo, SP(dec_cross_wo), W->dec_cross.bo, w.d2, E, M2, E, E, 0, w.d1, E,
              nullptr, nullptr, w.st_d2);
