@@ -69,8 +69,8 @@ def parse(argv=None):
                     help="SURVEY 8d protocol without a budget: every thread count, B = --batch, median of 5")
     ap.add_argument("--min-seconds", type=float, default=12.0, help="repeat the timed K-step block for this long")
     ap.add_argument("--no-other-configs", action="store_true",
-                    help="the default single-GPU run appends `other_configs` (BASELINE configs[2], configs[3]'s per-GPU share, "
-                         "configs[4] and the bf16x3+sdpa line, --other-seconds of timed blocks each) AFTER the headline has "
+                    help="the default single-GPU run appends `other_configs` (BASELINE configs[2] -- also with every pass recomputing "
+                         "both clouds --, configs[3]'s per-GPU share, configs[4] and the bf16x3+sdpa line, --other-seconds of timed blocks each) AFTER the headline has "
                          "been measured; this switch leaves them out")
     ap.add_argument("--other-seconds", type=float, default=2.0, help="timed seconds per entry of `other_configs`")
     ap.add_argument("--stages", action="store_true", help="print the per-launch table to stderr")
@@ -668,6 +668,9 @@ def measure(a, ctx, min_seconds):
 # the BASELINE configs that are not the headline, and the labelled split-arithmetic line, as bench.py flag overrides
 OTHER_CONFIGS = [
     ("configs[2]", dict(partial=True, points=1024, batch=24, iters=3)),
+    # the same with every pass recomputing both clouds, as the reference's loop does (the default reuses, inside ONE
+    # vcrnetIter call, what the first pass computed from the unchanged target cloud; bit-identical; nothing crosses a step)
+    ("configs[2], --no-iter-reuse", dict(partial=True, points=1024, batch=24, iters=3, no_iter_reuse=True)),
     ("configs[3] (one GPU's share)", dict(points=2048, batch=16)),
     ("configs[4]", dict(points=4096, k=40, batch=32)),
     ("configs[1], --linear-mode bf16x3+sdpa", dict(linear_mode="bf16x3+sdpa")),
@@ -704,6 +707,7 @@ def run_rank(a):
                                "timed_blocks": o["timed_blocks"]["count"], "dtype": o["dtype"],
                                "roofline": {k_: r[k_] for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac")},
                                "accounted_frac": o["accounted_frac"],
+                               **({"iter_target_reuse": True} if "iter_target_reuse" in o["config"] else {}),
                                "knn_edgeconv_stage": {k_: o["knn_edgeconv_stage"][k_] for k_ in
                                                       ("ms_per_step", "hbm_frac", "achieved_gbs", "knn_ms_per_step")},
                                "wall_s": round(time.perf_counter() - t0, 2)})
