@@ -158,7 +158,7 @@ def test_sized_structs_refuse_what_they_cannot_read(lib):
 
 def test_iter_workspace_adds_the_target_cache_where_it_applies(lib):
     """vcr_vcrnet_iter_workspace_bytes: the forward's workspace + B N x 2560 floats of target rows for a vcrnetIter loop of more
-    than one pass over the LPDNet + Transformer configuration; nothing for one pass, another embedding, or iter_reuse = 1."""
+    than one pass (every embedding and pointer); nothing for one pass or with iter_reuse = 1."""
     from vcrnet_amd import native
     w = native.VcrnetWeights()
     w.E, w.F, w.heads, w.k, w.has_pointer = 512, 1024, 4, 20, 1
@@ -168,9 +168,9 @@ def test_iter_workspace_adds_the_target_cache_where_it_applies(lib):
     w.iter_reuse = 1
     assert it(3) == base
     w.iter_reuse, w.emb_kind = 0, 1
-    assert it(3) == lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 24, 768)
+    assert it(3) == lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 24, 768) + 24 * 768 * 2560 * 4
     w.emb_kind, w.has_pointer = 0, 2
-    assert it(3) == lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 24, 768)
+    assert it(3) == lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 24, 768) + 24 * 768 * 2560 * 4
     assert lib.vcr_vcrnet_iter_workspace_bytes(ctypes.byref(w), 24, 768, 0) == 0
 
 

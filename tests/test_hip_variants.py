@@ -246,10 +246,14 @@ def test_fused_driver_covers_the_variant_and_matches_kernel_by_kernel(kw):
                                                       (dict(partial=True), "fp32", True, 24, 1024, 3),  # BASELINE configs[2]
                                                       (dict(vcp_nn="att", cycle=True), "fp32", True, 4, 512, 2),
                                                       (dict(vcp_nn="att"), "fp32", True, 18, 1024, 2),   # the head's one-cloud linears: 18 432 rows, own shape rule
-                                                      ({}, "fp32", True, 4, 2048, 2)])                  # the ordered kNN search on half the clouds
+                                                      ({}, "fp32", True, 4, 2048, 2),                   # the ordered kNN search on half the clouds
+                                                      (dict(emb_nn="dgcnn"), "fp32", True, 3, 320, 3), (dict(emb_nn="dgcnn", _k=7), "fp32", True, 2, 200, 2),
+                                                      (dict(emb_nn="pointnet"), "bf16x3", True, 3, 320, 2), (dict(pointer="identity"), "fp32", True, 3, 320, 3),
+                                                      (dict(pointer="identity", vcp_nn="att"), "fp32", True, 18, 1024, 2),
+                                                      (dict(emb_nn="dgcnn", partial=True), "fp32", True, 2, 400, 2)])
 def test_iter_target_reuse_changes_no_bit(kw, mode, merge, B, N, iters):
-    """vcrnetIter, iter > 1: the target cloud does not change between passes, so the passes after the first launch everything in
-    front of the cross-attention on the SOURCE rows only and take the target's rows from the first pass (vcr_vcrnet_weights.iter_reuse,
+    """vcrnetIter, iter > 1 (every embedding, every pointer): the target cloud does not change between passes, so the passes after the
+    first launch everything in front of the cross-attention on the SOURCE rows only and take the target's rows from the first pass (vcr_vcrnet_weights.iter_reuse,
     vcr_vcrnet_iter_workspace_bytes).  A half-row linear pins the MFMA shape of the full-row launch it stands for -- the one choice
     its bits depend on --, every other kernel computes a row from that row's cloud alone: poses, correspondences and (partial
     mode) every discrete selection of every pass equal the recomputing loop's bit for bit, in each arithmetic mode, merged or
@@ -257,6 +261,7 @@ def test_iter_target_reuse_changes_no_bit(kw, mode, merge, B, N, iters):
     import vcrnet_amd  # noqa: F401
     from vcrnet_amd import synth
     kw = dict(kw)
+    k_override = kw.pop("_k", None)                        # (DGCNN with k other than 20 / 40: the per-edge linears with the fused max)
     partial = bool(kw.get("partial"))
     src, tgt, _, _, _ = synth.make_batch(93, B, N, partial=partial, kind="object" if N < 2048 else "uniform")
     s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
@@ -264,6 +269,8 @@ def test_iter_target_reuse_changes_no_bit(kw, mode, merge, B, N, iters):
     for reuse in (False, True):
         net, _ = build_net(**kw)
         net.linear_mode, net.merge_encdec, net.iter_reuse = mode, merge, reuse
+        if k_override:
+            net.emb_nn.k = k_override
         with torch.no_grad():
             out = net._forward_fused(s, t, iters=iters, iter_api=True, want_selections=partial)
         torch.cuda.synchronize()

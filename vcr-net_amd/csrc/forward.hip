@@ -510,7 +510,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (ws_bytes < w.bytes) return VCR_EWORKSPACE;
   const int M1 = B * N, M2 = 2 * M1;
   if (pass != 0) {
-    if (W->emb_kind != 0 || W->has_pointer != 1 || ws_bytes < w.bytes + tgt_cache_floats(B, N, E) * sizeof(float)) return VCR_EINVAL;
+    if (ws_bytes < w.bytes + tgt_cache_floats(B, N, E) * sizeof(float)) return VCR_EINVAL;
     float* c = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + w.bytes);
     w.c_emb = c;     c += (size_t)M1 * E;
     w.c_d1 = c;      c += (size_t)M1 * E;
@@ -549,17 +549,17 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     // split (per-point P/Q + gather), conv2..conv4 as N*k-row GEMMs, max over the k edges after each, conv5 on the
     // 512-wide concatenation.  BatchNorm (eval mode) is folded into the weights by the host.  (linear_mode 1 / 2: the
     // embedding's own GEMMs stay fp32 MFMA -- the chain kernel has no split variant -- the Transformer takes the mode.)
-    for (int c = 0; c < 2 && R.rc == 0; ++c) {             // rows (x, y, z, |p|^2) and conv1's per-point (P | Q), one pass
+    for (int c = 0; c < (half ? 1 : 2) && R.rc == 0; ++c) {   // rows (x, y, z, |p|^2) and conv1's per-point (P | Q), one pass
       R.mark(c ? "pointwise:tgt" : "pointwise:src");
       R.ok(vcr_rows4_pq_f32(c ? io->tgt_cf : io->src_cf, w.xyz4 + (size_t)c * M1 * 4, B, N, W->dgcnn.c1_wpq, 32,
                             W->dgcnn.c1_bpq, 128, w.pq1 + (size_t)c * M1 * 128, 128, R.stream));
     }
     {
-      vcr_knn_args a3{(uint32_t)sizeof(vcr_knn_args), w.xyz4, 4, nullptr, 2 * B, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
+      vcr_knn_args a3{(uint32_t)sizeof(vcr_knn_args), w.xyz4, 4, nullptr, Bq, N, 4, k, w.idx3, w.ties + 1 + M2, M2};
       a3.tie_work = w.tie_work; a3.tie_work_bytes = w.tie_work_each;
-      R.knn("knn:xyz", a3, 1);
+      R.knn(NM("knn:xyz"), a3, 1);
     }
-    const int Mk = M2 * k;
+    const int Mk = Mq * k;
     // Every x.max(dim=-1) of vcrnet_model.py:109-118 rides on the kernel that produces the per-edge rows: the edge-row
     // builder writes x1 (and the zero base of x2..x4), conv2..conv4 fold the max over each point's k rows into their
     // epilogues (integer atomic max on post-ReLU values), and conv4's 256-wide per-edge activations are never written.
@@ -574,34 +574,35 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     if (k == 20 || k == 40) {
       // the path's k: the whole chain in one kernel, the per-edge activations stay in LDS (edgechain.hip)
       if (R.rc == 0) {
-        R.mark("edgeconv:dg_chain");
-        vcr_edgechain_args a{w.pq1, 128, w.idx3, k, M2, N, W->dgcnn.c2_w, W->dgcnn.c2_b, W->dgcnn.c3_w, W->dgcnn.c3_b,
+        R.mark(NM("edgeconv:dg_chain"));
+        vcr_edgechain_args a{w.pq1, 128, w.idx3, k, Mq, N, W->dgcnn.c2_w, W->dgcnn.c2_b, W->dgcnn.c3_w, W->dgcnn.c3_b,
                              W->dgcnn.c4_w, W->dgcnn.c4_b, w.cat, 512};
         R.ok(vcr_edgechain_f32(&a, R.stream));
       }
     } else {
       if (R.rc == 0) {
-        R.mark("gathermax:dg_c1");
-        vcr_edgerows_args a{w.pq1, 128, 64, w.idx3, k, M2, N, w.eh1, 64, w.cat, 512, 512};
+        R.mark(NM("gathermax:dg_c1"));
+        vcr_edgerows_args a{w.pq1, 128, 64, w.idx3, k, Mq, N, w.eh1, 64, w.cat, 512, 512};
         R.ok(vcr_edgerows_f32(&a, R.stream));
       }
-      conv_max("linear:dg_c2", w.eh1, 64, W->dgcnn.c2_w, W->dgcnn.c2_b, w.eh2, 64, 64);
-      conv_max("linear:dg_c3", w.eh2, 64, W->dgcnn.c3_w, W->dgcnn.c3_b, w.eh3, 128, 128);
-      conv_max("linear:dg_c4", w.eh3, 128, W->dgcnn.c4_w, W->dgcnn.c4_b, nullptr, 256, 256);
+      conv_max(NM("linear:dg_c2"), w.eh1, 64, W->dgcnn.c2_w, W->dgcnn.c2_b, w.eh2, 64, 64);
+      conv_max(NM("linear:dg_c3"), w.eh2, 64, W->dgcnn.c3_w, W->dgcnn.c3_b, w.eh3, 128, 128);
+      conv_max(NM("linear:dg_c4"), w.eh3, 128, W->dgcnn.c4_w, W->dgcnn.c4_b, nullptr, 256, 256);
     }
-    R.linear("linear:conv3", w.cat, 512, W->dgcnn.c5_w, nullptr, W->dgcnn.c5_b, w.emb, E, M2, E, 512, 1, nullptr, 0, nullptr,
+    R.linear(NM("linear:conv3"), w.cat, 512, W->dgcnn.c5_w, nullptr, W->dgcnn.c5_b, w.emb, E, Mq, E, 512, 1, nullptr, 0, nullptr,
              nullptr, const_cast<float*>(stats_for_ln));
   } else if (W->emb_kind == 2) {
     // ---- emb_nn = PointNet on both clouds (vcrnet_model.py:81-87): five pointwise convs + BatchNorm (eval mode, folded
     // into weight and bias by the host) + ReLU, no graph.  conv1 / conv2 have the shape of LPDNet's stem: same kernel.
     if (R.rc == 0) {
-      R.mark("pointwise:src+tgt");
-      vcr_pointwise_args a{io->src_cf, B, N, W->c1_w, W->c1_b, W->c2_w, W->c2_b, w.xyz4, w.feat64, w.sq64, io->tgt_cf, B};
+      R.mark(NM("pointwise:src+tgt"));
+      vcr_pointwise_args a{io->src_cf, B, N, W->c1_w, W->c1_b, W->c2_w, W->c2_b, w.xyz4, w.feat64, w.sq64, half ? nullptr : io->tgt_cf,
+                           half ? 0 : B};
       R.ok(vcr_pointwise_f32(&a, R.stream));
     }
-    R.linear("linear:pn_c3", w.feat64, 64, W->pointnet.c3_w, nullptr, W->pointnet.c3_b, w.pq1, 64, M2, 64, 64, 1);
-    R.linear("linear:pn_c4", w.pq1, 64, W->pointnet.c4_w, nullptr, W->pointnet.c4_b, w.cat, 128, M2, 128, 64, 1);
-    R.linear("linear:pn_c5", w.cat, 128, W->pointnet.c5_w, nullptr, W->pointnet.c5_b, w.emb, E, M2, E, 128, 1, nullptr, 0, nullptr,
+    R.linear(NM("linear:pn_c3"), w.feat64, 64, W->pointnet.c3_w, nullptr, W->pointnet.c3_b, w.pq1, 64, Mq, 64, 64, 1);
+    R.linear(NM("linear:pn_c4"), w.pq1, 64, W->pointnet.c4_w, nullptr, W->pointnet.c4_b, w.cat, 128, Mq, 128, 64, 1);
+    R.linear(NM("linear:pn_c5"), w.cat, 128, W->pointnet.c5_w, nullptr, W->pointnet.c5_b, w.emb, E, Mq, E, 128, 1, nullptr, 0, nullptr,
              nullptr, const_cast<float*>(stats_for_ln));
   } else {
   // ---- emb_nn = LPDNet on both clouds (lpdnet_model.py:103-137)
@@ -674,9 +675,11 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   }
   R.linear(NM("linear:conv3"), w.cat, 512, W->c3_w, SP(c3), W->c3_b, w.emb, E, Mq, E, 512, 1, nullptr, 0, nullptr, nullptr,
            W->has_pointer == 1 ? w.st_emb : nullptr);
-  tgt_rows(pass == 1 ? "select:reuse.save.emb" : "select:reuse.restore.emb", w.emb, w.c_emb, (size_t)E);
 
   }
+  // (every embedding: the target clouds' rows are the first pass's)
+  tgt_rows(pass == 1 ? "select:reuse.save.emb" : "select:reuse.restore.emb", w.emb, w.c_emb, (size_t)E);
+  if (W->has_pointer != 1) { R.shape_rows = 0; R.plan_nbatch = 0; }     // (no Transformer: nothing else runs on half the rows)
 
   // ---- pointer (transformer.py:264-272) + residual (vcrnet_model.py:504-505)
   const float* head_emb = w.embf;
@@ -889,11 +892,10 @@ extern "C" size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights* UW, int B
   return carve(nullptr, B, N, W->k, W->E, W->F, W->heads, W->partial, W->overlap2, W->emb_kind, W->xscore_limit_mb, merged_encdec(W), W->workspace_flat).bytes;
 }
 
-// vcrnetIter with target reuse: LPDNet embedding + Transformer pointer (the reference's default), more than one pass, not
-// switched off (vcr_vcrnet_weights.iter_reuse == 1)
-static bool iter_reuse_applies(const vcr_vcrnet_weights* W, int iters) {
-  return iters > 1 && W->emb_kind == 0 && W->has_pointer == 1 && W->iter_reuse != 1;
-}
+// vcrnetIter with target reuse: more than one pass, not switched off (vcr_vcrnet_weights.iter_reuse == 1).  Every embedding
+// (its stage runs on the source clouds only in the later passes) and every pointer (with the Transformer also the encoder, the
+// decoder's first sublayer and the K | V projection)
+static bool iter_reuse_applies(const vcr_vcrnet_weights* W, int iters) { return iters > 1 && W->iter_reuse != 1; }
 extern "C" size_t vcr_vcrnet_iter_workspace_bytes(const vcr_vcrnet_weights* UW, int B, int N, int iters) {
   vcr_vcrnet_weights Wn;
   const vcr_vcrnet_weights* W = &Wn;
