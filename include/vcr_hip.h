@@ -596,9 +596,9 @@ typedef struct {
 } vcr_vcrnet_io;
 
 size_t vcr_vcrnet_workspace_bytes(const vcr_vcrnet_weights*, int B, int N);
-/* The same for vcr_vcrnet_iter_f32(iters): with iters > 1 it adds the cache of the target cloud's loop-invariant rows
- * (B N x 2560 floats) behind the forward's workspace; a workspace of only vcr_vcrnet_workspace_bytes still works -- every pass
- * then recomputes both clouds. */
+/* The same for vcr_vcrnet_iter_f32(iters): with iters > 1 it adds room behind the forward's workspace (2 B N x 2560 floats) for the
+ * four buffers whose target-cloud rows the later passes reuse; a workspace of only vcr_vcrnet_workspace_bytes still works -- every
+ * pass then recomputes both clouds. */
 size_t vcr_vcrnet_iter_workspace_bytes(const vcr_vcrnet_weights*, int B, int N, int iters);
 /* Correspondences per sample in corr4/src4: N, or int(int(N*0.84*overlap2)*0.52*overlap2) for partial + head_mode 0. */
 int vcr_vcrnet_pairs(const vcr_vcrnet_weights*, int N);

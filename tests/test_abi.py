@@ -157,20 +157,20 @@ def test_sized_structs_refuse_what_they_cannot_read(lib):
 
 
 def test_iter_workspace_adds_the_target_cache_where_it_applies(lib):
-    """vcr_vcrnet_iter_workspace_bytes: the forward's workspace + B N x 2560 floats of target rows for a vcrnetIter loop of more
+    """vcr_vcrnet_iter_workspace_bytes: the forward's workspace + 2 B N x 2560 floats (the four buffers whose target rows persist) for a vcrnetIter loop of more
     than one pass (every embedding and pointer); nothing for one pass or with iter_reuse = 1."""
     from vcrnet_amd import native
     w = native.VcrnetWeights()
     w.E, w.F, w.heads, w.k, w.has_pointer = 512, 1024, 4, 20, 1
     base = lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 24, 768)
     it = lambda n: lib.vcr_vcrnet_iter_workspace_bytes(ctypes.byref(w), 24, 768, n)
-    assert it(1) == base and it(2) == it(3) == base + 24 * 768 * 2560 * 4
+    assert it(1) == base and it(2) == it(3) == base + 2 * 24 * 768 * 2560 * 4
     w.iter_reuse = 1
     assert it(3) == base
     w.iter_reuse, w.emb_kind = 0, 1
-    assert it(3) == lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 24, 768) + 24 * 768 * 2560 * 4
+    assert it(3) == lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 24, 768) + 2 * 24 * 768 * 2560 * 4
     w.emb_kind, w.has_pointer = 0, 2
-    assert it(3) == lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 24, 768) + 24 * 768 * 2560 * 4
+    assert it(3) == lib.vcr_vcrnet_workspace_bytes(ctypes.byref(w), 24, 768) + 2 * 24 * 768 * 2560 * 4
     assert lib.vcr_vcrnet_iter_workspace_bytes(ctypes.byref(w), 24, 768, 0) == 0
 
 

@@ -86,15 +86,14 @@ struct Ws {
   // vcrnetIter
   float *cur_cf, *Ri, *ti, *Rb, *tb;
   size_t bytes;
-  // vcrnetIter with target reuse (forward_impl's `pass`): what the first pass computed from the TARGET cloud alone, kept across passes.
-  // Lives BEHIND the planned workspace (vcr_vcrnet_iter_workspace_bytes); NULL = no reuse.
-  float *c_emb, *c_d1, *c_qc, *c_kvc;
 };
-// floats of the target cache: emb | d1 | qc | kvc for the M1 = B N target rows -- exactly what a later pass reads of them behind
-// the cross-attention (the final residual, the cross sublayer's residual, its queries, its keys | values).  The LayerNorm
-// statistics of those rows are consumed in front of it, by launches a later pass runs on the source rows only; their
-// buffers are dead -- and their memory re-used -- by the time the cache is written or read: they must NOT be part of it.
-inline size_t tgt_cache_floats(int B, int N, int E) { return (size_t)B * N * 5 * E; }
+// vcrnetIter with target reuse (forward_impl's `pass`): the four buffers whose TARGET halves a later pass reads behind the
+// cross-attention -- emb (the final residual), d1 (the cross sublayer's residual), qc (its queries), kvc (its keys | values) --
+// then live BEHIND the planned workspace, 2 B N x 5 E floats that nothing else is ever laid over: the first pass writes all
+// their rows, a later pass only the source rows, and the target rows simply stay.  (The LayerNorm statistics of the target
+// rows are consumed in front of the cross-attention, by launches a later pass runs on the source rows only: nothing of them
+// needs to persist.)
+inline size_t tgt_cache_floats(int B, int N, int E) { return (size_t)2 * B * N * 5 * E; }
 
 // vcrnet_model.py:208-209 and :284 -- Python truncates float64 products, so do we
 inline int overlap_k1(int N, double o2) { return (int)((double)N * 0.84 * o2); }
@@ -473,8 +472,8 @@ struct Runner {
 // pass: 0 = a forward on its own.  Target reuse inside vcrnetIter (the target cloud does not change between the passes of
 // vcrnet_model.py:21-43, so everything computed from it ALONE is loop-invariant: its LPDNet embedding, the encoder on its rows,
 // the decoder's self-attention sublayer and cross-attention query on its rows, the K | V projection of its encoder memory):
-// 1 = the first pass, which saves those rows behind the workspace; 2 = a later pass, whose launches in front of the
-// cross-attention run on the SOURCE rows only (names end in "@src") and whose target halves are restored from that cache.
+// 1 = the first pass, which keeps the four buffers those rows are read from behind the workspace; 2 = a later pass, whose
+// launches in front of the cross-attention run on the SOURCE rows only (names end in "@src") and leave the target rows alone.
 // Every launch computes what the full-row launch would (linears pin its MFMA shape): the loop's results do not change by a bit.
 int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* workspace, size_t ws_bytes,
                  vcr_stream_t stream, vcr_trace* tr, bool last = true, int pass = 0) {
@@ -512,10 +511,10 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   if (pass != 0) {
     if (ws_bytes < w.bytes + tgt_cache_floats(B, N, E) * sizeof(float)) return VCR_EINVAL;
     float* c = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + w.bytes);
-    w.c_emb = c;     c += (size_t)M1 * E;
-    w.c_d1 = c;      c += (size_t)M1 * E;
-    w.c_qc = c;      c += (size_t)M1 * E;
-    w.c_kvc = c;
+    w.emb = c;       c += (size_t)M2 * E;                // (the planned copies of these four stay unused in such a loop)
+    w.d1 = c;        c += (size_t)M2 * E;
+    w.qc = c;        c += (size_t)M2 * E;
+    w.kvc = c;
   }
   const bool half = pass == 2;                           // launches in front of the cross-attention: source rows only
   const int Bq = half ? B : 2 * B, Mq = half ? M1 : M2;
@@ -524,14 +523,6 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
   R.io_ = io;
   R.shape_rows = half ? M2 : 0;
   R.plan_nbatch = half ? 2 * B : 0;
-  // the target halves (rows M1 .. M2 - 1) of the buffers a later pass does not recompute: saved by pass 1, restored by pass 2
-  auto tgt_rows = [&](const char* nm, float* buf, float* cache, size_t per_row) {
-    if (pass == 0 || R.rc) return;
-    R.mark(nm);
-    float* rows = buf + (size_t)M1 * per_row;
-    R.ok(pass == 1 ? vcr_copy_d2d(cache, rows, (size_t)M1 * per_row * sizeof(float), R.stream)
-                   : vcr_copy_d2d(rows, cache, (size_t)M1 * per_row * sizeof(float), R.stream));
-  };
   // both tie counters (and the first block).  A kernel, not hipMemsetAsync: the forward then records into a HIP graph of
   // kernel nodes only
   hipLaunchKernelGGL(zero_i32_kernel, dim3((unsigned)((M2 + 2 + 255) / 256)), dim3(256), 0, R.stream, w.ties, (long)(M2 + 2));
@@ -677,8 +668,6 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
            W->has_pointer == 1 ? w.st_emb : nullptr);
 
   }
-  // (every embedding: the target clouds' rows are the first pass's)
-  tgt_rows(pass == 1 ? "select:reuse.save.emb" : "select:reuse.restore.emb", w.emb, w.c_emb, (size_t)E);
   if (W->has_pointer != 1) { R.shape_rows = 0; R.plan_nbatch = 0; }     // (no Transformer: nothing else runs on half the rows)
 
   // ---- pointer (transformer.py:264-272) + residual (vcrnet_model.py:504-505)
@@ -749,9 +738,6 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
     // batch b attends to the encoder memory (= enc.norm(e2), applied inside the K/V projection) of batch (b + B) mod 2B
     R.linear(NM("linear:dec.cross.kv"), w.e2, E, W->fold_dec_cross_kv.w, SP(dec_cross_kv), W->fold_dec_cross_kv.bias, w.kvc, 2 * E, Mq, 2 * E, E, 0,
              nullptr, 0, w.st_e2, W->fold_dec_cross_kv.colsum);
-    tgt_rows(pass == 1 ? "select:reuse.save.d1" : "select:reuse.restore.d1", w.d1, w.c_d1, (size_t)E);
-    tgt_rows(pass == 1 ? "select:reuse.save.qc" : "select:reuse.restore.qc", w.qc, w.c_qc, (size_t)E);
-    tgt_rows(pass == 1 ? "select:reuse.save.kvc" : "select:reuse.restore.kvc", w.kvc, w.c_kvc, (size_t)2 * E);
     R.shape_rows = 0; R.plan_nbatch = 0;                 // from here on every launch has its own, full row count (the VcpAtt head's
                                                          // one-cloud linears included: nothing stands for a larger launch any more)
     R.cross_attention(W, io, w, B, N);

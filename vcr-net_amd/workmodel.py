@@ -113,9 +113,6 @@ def launch_work(name: str, B: int, N: int, k: int = 20, E: int = 512, F: int = 1
             return 4.0 * 2 * B * 4 * N * N, 4.0 * 2 * B * 4 * N * N
         return 8.0 * B * N * N, 4.0 * 2 * B * N * N
     if fam == "select":
-        if site.startswith("reuse."):                      # target rows saved behind / restored from the workspace (vcrnetIter)
-            width = {"emb": E, "d1": E, "qc": E, "kvc": 2 * E}[site.rsplit(".", 1)[1]]
-            return 0.0, 4.0 * 2 * M1 * width
         if site.endswith(".forced") or site.endswith(".out"):   # device-to-device copy of an index block
             return 0.0, 8.0 * 2 * B * N
         if site.startswith("gather"):
