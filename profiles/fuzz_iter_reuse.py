@@ -10,6 +10,7 @@ from vcrnet_amd import synth
 from test_hip_forward import build_net
 rs = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad, t0 = 0, time.time()
+only = {int(x) for x in sys.argv[3].split(",")} if len(sys.argv) > 3 else None     # re-run these trials of the seed only
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     partial = bool(rs.rand() < 0.4)
     emb = str(rs.choice(["lpdnet", "lpdnet", "lpdnet", "dgcnn", "pointnet"]))
@@ -26,6 +27,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     kw = dict(emb_nn=emb, pointer=pointer, vcp_nn=vcp, partial=partial)
     src, tgt, _, _, _ = synth.make_batch(int(rs.randint(0, 1000)), B, N, partial=partial, kind="object" if N < 2048 else "uniform")
     s, t = torch.from_numpy(src).cuda(), torch.from_numpy(tgt).cuda()
+    if only is not None and trial not in only:
+        continue
     outs = []
     for reuse in (False, True):
         net, _ = build_net(regime=regime, **kw) if emb == "lpdnet" else build_net(**kw)
@@ -38,6 +41,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
         outs.append([o.clone() for o in out if torch.is_tensor(o)] + [sel[k_].clone() for k_ in sorted(sel)])
         del net
     same = all(torch.equal(a, b) for a, b in zip(*outs))
+    if not same:
+        print("   max |difference| per output:", [float((a.float() - b.float()).abs().max()) for a, b in zip(*outs)])
     bad += 0 if same else 1
     print(f"{emb:8s} {pointer:11s} {vcp:4s} {'partial' if partial else 'whole  '} {mode:12s} merged={int(merge)} {regime:8s} B={B:2d} N={N:4d} k={k:2d} "
           f"passes={iters}: {'bit-identical' if same else 'DIFFERENT  <<<<<<'}", flush=True)

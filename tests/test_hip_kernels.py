@@ -150,6 +150,50 @@ def test_knn_duplicates_drop_rank0(nat):
     idx = nat.knn(dev(xyz4), None, 4).cpu().numpy()
     assert (1 in idx[0, 0]) != (0 in idx[0, 0])   # exactly one of the twin copies survives for point 0
     assert (1 in idx[0, 1]) != (0 in idx[0, 1])
+    assert (np.sort(idx, -1) == np.sort(oracle.knn_indices(src, 4).numpy(), -1)).all()     # ... the one Tensor.topk keeps
+
+
+@pytest.mark.parametrize("N,k", [(64, 4), (300, 20), (747, 20), (1024, 20), (1343, 20), (1344, 20), (2048, 20), (700, 40), (2700, 40),
+                                 (333, 62), (4100, 62)])     # (k + 1) * 64 <= N switches Tensor.topk's algorithm
+def test_knn_shared_best_value_follows_torch_topk(nat, N, k):
+    """Copies of a point (pairs, triples, one point more often than there are neighbours; in real clouds also a neighbour whose
+    distance ROUNDS to the point's own): the best value of such a row is shared, and which of the tied entries Tensor.topk returns first -- the
+    one util.py:159 drops -- comes out of ATen's sort of the selected entries (std::sort after nth_element, or partial_sort's
+    heap sort), not out of the point index.  The kernels list such rows like boundary ties and the replay sorts the way ATen
+    does: every row's neighbour set equals the reference's, in every launch form (candidate splits, pair launch, 16-query waves)."""
+    rs = np.random.RandomState(N * 7 + k)
+    B = 3
+    def with_copies(x):                                    # x [B, C, N]
+        for b in range(B):
+            perm, pos = rs.permutation(N), 0
+            for copies, groups in ((2, N // 8), (3, N // 16), (k + 3, 1)):
+                for _ in range(groups):
+                    if pos + copies <= N:
+                        x[b][:, perm[pos + 1: pos + copies]] = x[b][:, perm[pos]: perm[pos] + 1]
+                        pos += copies
+        return x
+    # (coordinates on a 1/64 grid: every product and sum of the distance is exact in fp32, whatever order a BLAS adds them in)
+    p = with_copies(rs.randint(-64, 65, (B, 3, N)).astype(np.float32) / 64)
+    src = torch.from_numpy(p)
+    xyz4 = dev(torch.cat((src.transpose(1, 2), (src ** 2).sum(1).unsqueeze(-1)), -1))
+    D = oracle.neg_sqdist_knn(src)
+    top2 = torch.topk(D, 2, dim=-1).values
+    assert int((top2[..., 0] == top2[..., 1]).sum()) >= N // 4, "the input was meant to share the best value on many rows"
+    ref3 = np.sort(oracle.knn_indices(src, k).numpy(), -1)
+    for waves in (0, 1, 2, 4):
+        got = np.sort(nat.knn(xyz4, None, k, waves=waves).cpu().numpy(), -1)
+        assert (got == ref3).all(), f"waves {waves}: {int((got != ref3).any(-1).sum())} rows differ (xyz)"
+    f = torch.from_numpy(with_copies(rs.randint(0, 3, size=(B, 64, N)).astype(np.float32) + (rs.rand(B, 64, N) < 0.1).astype(np.float32) * 0.5))
+    feat, sq = dev(f.transpose(1, 2)), dev((f ** 2).sum(1))
+    ref64 = np.sort(oracle.knn_indices(f, k).numpy(), -1)
+    for waves in (0, 1, 8) + ((2, 4) if k <= 20 else ()):
+        got = np.sort(nat.knn(feat, sq, k, waves=waves).cpu().numpy(), -1)
+        assert (got == ref64).all(), f"waves {waves}: {int((got != ref64).any(-1).sum())} rows differ (features)"
+    a, b = nat.knn_pair(feat, sq, xyz4, k)
+    assert (np.sort(a.cpu().numpy(), -1) == ref64).all() and (np.sort(b.cpu().numpy(), -1) == ref3).all()
+    ft = feat.view(B, N, 4, 4, 4).transpose(3, 4).reshape(B, N, 64).contiguous()
+    a, b = nat.knn_pair(feat, sq, xyz4, k, xt=ft)
+    assert (np.sort(a.cpu().numpy(), -1) == ref64).all() and (np.sort(b.cpu().numpy(), -1) == ref3).all()
 
 
 @pytest.mark.parametrize("M,N,K,relu,res", [(300, 200, 64, True, False), (1024, 512, 512, False, True),
@@ -950,11 +994,8 @@ def test_knn_exact_ties_follow_torch_topk(nat, N, k):
     f = torch.from_numpy(rs.randint(0, 3, size=(B, 64, N)).astype(np.float32))
     got = np.sort(nat.knn(dev(f.transpose(1, 2)), dev((f ** 2).sum(1)), k).cpu().numpy(), -1)
     ref = np.sort(oracle.knn_indices(f, k).numpy(), -1)
-    # (duplicate feature vectors make rank 0 itself ambiguous -- exclude rows whose best value is shared)
-    D = oracle.neg_sqdist_knn(f)
-    top2 = torch.topk(D, 2, dim=-1).values
-    ok = (top2[..., 0] != top2[..., 1]).numpy()
-    assert (got == ref)[ok].all(), f"{int((got != ref).any(-1)[ok].sum())} rows differ (features)"
+    # (duplicate feature vectors share the best value: which copy Tensor.topk returns first, and util.py:159 drops, is replayed too)
+    assert (got == ref).all(), f"{int((got != ref).any(-1).sum())} rows differ (features)"
 
 
 def test_knn_long_rows_replay_ties_through_global_scratch(nat):

@@ -207,10 +207,11 @@ struct Runner {
   // things: such a launch pins the shape the full-row launch it stands for would take (shape_rows = that row count; 0 = off).
   int shape_rows = 0;
   int plan_nbatch = 0;                                   // likewise for the attention launches' key split (vcr_sdpa_args.plan_nbatch)
-  void pin_shape(vcr_linear_args& a, vcr_linear_args* b = nullptr) {
-    if (!shape_rows || a.M >= shape_rows || (a.variant & (16 | 1024))) return;
+  void pin_shape(vcr_linear_args& a, vcr_linear_args* b = nullptr, int full_rows = 0) {   // full_rows: of the launch this one stands for
+    const int fm = full_rows ? full_rows : shape_rows;    // (default: the point rows; DGCNN's per-edge linears pass rows x k)
+    if (!shape_rows || a.M >= fm || (a.variant & (16 | 1024))) return;
     vcr_linear_args fa = a, fb = b ? *b : a;
-    fa.M = shape_rows; fb.M = shape_rows;
+    fa.M = fm; fb.M = fm;
     int sa = 0, sb = 0;
     if (vcr_linear_shapes_(&fa, b ? &fb : nullptr, &sa, &sb) != VCR_OK) return;
     a.variant |= sa ? 16 : 1024;
@@ -560,6 +561,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       R.mark(nm);
       vcr_linear_args a{x, K, wt, bias, nullptr, 0, y, Nout, Mk, Nout, K, 1};
       a.segmax_out = w.cat + col; a.ld_segmax = 512; a.seg_k = k;
+      R.pin_shape(a, nullptr, M2 * k);                   // (a source-only pass: the MFMA shape of the launch over both clouds' edges)
       R.ok(vcr_linear_f32(&a, R.stream));
     };
     if (k == 20 || k == 40) {

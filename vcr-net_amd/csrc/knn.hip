@@ -13,6 +13,12 @@
 //          reference's on every row (validated against torch.topk on tie-heavy inputs).  A row WITHOUT a boundary tie
 //          has a set that depends on the values only; without tie_scratch a boundary tie keeps the tied candidates
 //          that were scanned first.
+//          A shared BEST value (copies of a point, or a neighbour so close that its distance rounds to the point's own --
+//          fp32 self-distances are not exactly 0) is the other tie that matters: util.py:159 drops whichever entry topk
+//          returns first, and that is position 0 after ATen's sort of the selected entries (std::sort of the first k after
+//          nth_element, or partial_sort's heap sort), not the lowest index.  Such rows are listed and replayed as well; the
+//          replay ends with a port of that sort.  (Found in round 6 by the vcrnetIter reuse soak: two launch forms of the
+//          Cartesian search logged such a pair in different orders and kept different copies.)
 //
 // Selection, round 2 (measured on the round-1 kernels: 40 % of their time went into the sorted-insert network that
 // moved (value, index) pairs through 22-42 register slots, ~100 issue slots per insertion):
@@ -70,7 +76,8 @@ template <class G, int KS> constexpr int pend_of() {
 // once its four waves have written their results -- the separate, latency-bound replay launch (36 us at BASELINE
 // configs[1] for a handful of rows) disappears; only the few workgroups that own a tied row run ~20 us longer.
 constexpr int BLK_TIES = 64;                             // a 64-query workgroup cannot list more
-__host__ __device__ constexpr size_t tiebreak_lds(int N) { return (size_t)N * 16 + 256 + (16 + 2 * 256 + 2) * 4; }
+constexpr int TB_LDS_PAD = 8;                            // see tiebreak_row (8: N = 10 091 still fits 160 KB)
+__host__ __device__ constexpr size_t tiebreak_lds(int N) { return TB_LDS_PAD + (size_t)N * 16 + 256 + (16 + 2 * 256 + 2) * 4; }
 // the list sits behind whichever is larger, the waves' logs or the replay's LDS image of a row
 __host__ __device__ constexpr size_t inline_tie_offset(size_t log_bytes, int N) {
   return ((log_bytes > tiebreak_lds(N) ? log_bytes : tiebreak_lds(N)) + 15) & ~(size_t)15;
@@ -404,8 +411,11 @@ __device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args&
       }
     }
   }
-  // rank 0 = the largest value (the point itself; the first logged on an exact tie, e.g. duplicate points): dropped
-  int imax = 0;
+  // rank 0 = the largest value (the point itself): dropped.  When that value is SHARED (duplicate points, or a neighbour so
+  // close that its distance rounds to the point's own), WHICH of the tied entries Tensor.topk returns first is an outcome of
+  // its sort (util.py:159 then drops that one and keeps the others): such a row is replayed like a boundary tie (nmax > 1
+  // below; tiebreak_row sorts the kept entries the way ATen does).  Without tie_scratch: the first logged is dropped.
+  int imax = 0, nmax = 0;
   float vmax = VCR_NEG_INF;
   if (perm) {
     // (the plain scan logs in index order, so "the first logged" is the LOWEST point index among the largest values)
@@ -415,11 +425,13 @@ __device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args&
       const int ic = min(i, PEND - 1);
       const float d = i < sel.cnt ? sel.lv[ic * G::COLS + sel.col] : VCR_NEG_INF;
       const int j = sel.li[ic * G::COLS + sel.col];
+      nmax = d > vmax ? 1 : nmax + ((d == vmax && i < sel.cnt) ? 1 : 0);
       if (d > vmax || (d == vmax && i < sel.cnt && j < jmax)) { vmax = d; imax = i; jmax = j; }
     }
   } else {
   for (int i = 0; __any(i < sel.cnt); ++i) {
     const float d = i < sel.cnt ? sel.lv[min(i, PEND - 1) * G::COLS + sel.col] : VCR_NEG_INF;
+    nmax = d > vmax ? 1 : nmax + ((d == vmax && i < sel.cnt) ? 1 : 0);
     if (d > vmax) { vmax = d; imax = i; }
   }
   }
@@ -428,7 +440,7 @@ __device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args&
     int32_t* o = a.idx + ((size_t)b * a.N + q) * a.k;
     for (int i = sel.sg; i < sel.cnt && i <= a.k; i += G::LPQ)
       if (i != imax) o[i - (i > imax ? 1 : 0)] = sel.li[i * G::COLS + sel.col];
-    if (sel.sg == 0 && vk1 == vk && vk1 > VCR_NEG_INF) {
+    if (sel.sg == 0 && ((vk1 == vk && vk1 > VCR_NEG_INF) || nmax > 1)) {
       if (blk_ties) {                                    // replayed by this very workgroup (replay_block_ties)
         const int pos = atomicAdd(&blk_ties[0], 1);
         if (pos < BLK_TIES) blk_ties[1 + pos] = b * a.N + q;
@@ -1247,6 +1259,88 @@ __device__ void tb_nth_element(PairArr& q, int first, int last, int nth, int dep
   }
 }
 
+// std::__sort_heap(first, first + len): what std::partial_sort runs on its heap, and std::sort when its depth limit runs out
+__device__ void tb_sort_heap(PairArr& q, int first, int len) {
+  while (len > 1) {
+    --len;                                               // std::__pop_heap(first, last, last)
+    const float val = q.v[first + len]; const int vid = q.id[first + len];
+    q.v[first + len] = q.v[first]; q.id[first + len] = q.id[first];
+    tb_adjust_heap(q, first, 0, len, val, vid);
+  }
+}
+
+__device__ void tb_unguarded_linear_insert(PairArr& q, int last) {
+  const float val = q.v[last]; const int vid = q.id[last];
+  int next = last - 1;
+  while (val > q.v[next]) { q.v[last] = q.v[next]; q.id[last] = q.id[next]; last = next; --next; }
+  q.v[last] = val; q.id[last] = vid;
+}
+__device__ void tb_insertion_sort(PairArr& q, int first, int last) {
+  for (int i = first + 1; i < last; ++i) {
+    if (q.v[i] > q.v[first]) {
+      const float val = q.v[i]; const int vid = q.id[i];
+      for (int j = i; j > first; --j) { q.v[j] = q.v[j - 1]; q.id[j] = q.id[j - 1]; }
+      q.v[first] = val; q.id[first] = vid;
+    } else {
+      tb_unguarded_linear_insert(q, i);
+    }
+  }
+}
+// Sequential port of libstdc++'s std::sort on [first, last) (__introsort_loop: median-of-three to first + unguarded partition
+// while a range is longer than 16, depth limit 2 log2 n with the heap sort fallback; then __final_insertion_sort) with the
+// value-only comparator: the ORDER it leaves equal values in is what decides Tensor.topk's rank 0 among tied best values.
+// Ranges here are the <= 62 kept entries of a row.  The recursion on the right-hand parts: only a part of more than 16 entries
+// has work left, the parts are disjoint (the order they are finished in does not matter) -- at most three are ever pending,
+// kept packed (first | last << 8 | depth << 16) in the caller's LDS scratch (stk[0..2]).
+__device__ void tb_sort(PairArr& q, int first, int last, int* stk) {
+  if (last - first < 2) return;
+  int depth0 = 0;
+  for (int m = last - first; m > 1; m >>= 1) ++depth0;
+  depth0 *= 2;
+  int sp = 1;
+  stk[0] = first | (last << 8) | (depth0 << 16);
+  while (sp > 0) {
+    --sp;
+    const int e = stk[sp];
+    int f = e & 255, l = (e >> 8) & 255, depth = e >> 16;
+    while (l - f > 16) {
+      if (depth == 0) {                                  // std::__partial_sort(f, l, l): heap sort of the range
+        tb_heap_select(q, f, l, l);
+        tb_sort_heap(q, f, l - f);
+        break;
+      }
+      --depth;
+      const int mid = f + (l - f) / 2, a = f + 1, b = mid, c = l - 1;
+      if (q.gt(a, b)) {
+        if (q.gt(b, c)) q.swap(f, b);
+        else if (q.gt(a, c)) q.swap(f, c);
+        else q.swap(f, a);
+      } else if (q.gt(a, c)) q.swap(f, a);
+      else if (q.gt(b, c)) q.swap(f, c);
+      else q.swap(f, b);
+      int lo = f + 1, hi = l;
+      for (;;) {
+        while (q.gt(lo, f)) ++lo;
+        --hi;
+        while (q.gt(f, hi)) --hi;
+        if (!(lo < hi)) break;
+        q.swap(lo, hi);
+        ++lo;
+      }
+      if (l - lo > 16 && sp < 3) {                       // __introsort_loop(cut, last, depth_limit): later
+        stk[sp++] = lo | (l << 8) | (depth << 16);
+      }
+      l = lo;
+    }
+  }
+  if (last - first > 16) {                               // std::__final_insertion_sort
+    tb_insertion_sort(q, first, first + 16);
+    for (int i = first + 16; i < last; ++i) tb_unguarded_linear_insert(q, i);
+  } else {
+    tb_insertion_sort(q, first, last);
+  }
+}
+
 // std::partial_sort's __heap_select(first = 0, middle = K, last = n) with the K-entry heap held ACROSS THE LANES of one
 // wave (lane j = heap[j]; K <= 64): every heap access is a v_readlane / v_writelane with a scalar index instead of a
 // dependent LDS round trip, and the scan over the n - K remaining values tests 64 of them per step.  Same compares,
@@ -1400,7 +1494,11 @@ __device__ void tiebreak_row(const vcr_knn_args& a, int row, unsigned char* smem
   float *val, *qrow;
   int *id, *A, *Bd, *red;
   if (!gwork) {
-    val = reinterpret_cast<float*>(smem);
+    // (8 bytes of padding in front -- the ports index at most one entry below their position --: the arrays the sequential ports walk downwards must not start at LDS offset 0 -- this code
+    // reaches LDS through flat instructions wherever val / id may also be global (see below), the compiler turns the `v[j - 1]` of
+    // a descending loop into (base - 4) + an immediate offset of 4, and a flat address below the LDS aperture faults whatever
+    // the offset: MEMORY_APERTURE_VIOLATION in the replay launch, found with rocgdb when the rank-0 sort was added)
+    val = reinterpret_cast<float*>(smem) + TB_LDS_PAD / 4;
     id = reinterpret_cast<int*>(val + a.N);
     qrow = reinterpret_cast<float*>(id + a.N);           // [64]
     A = reinterpret_cast<int*>(qrow + 64);               // [N] left stoppers, [N] right stoppers, block scratch
@@ -1466,9 +1564,18 @@ __device__ void tiebreak_row(const vcr_knn_args& a, int row, unsigned char* smem
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      int best = 0;                                      // rank 0 = the largest of the K kept (lowest index on ties)
-      for (int i = 1; i < K; ++i)
-        if (val[i] > val[best] || (val[i] == val[best] && id[i] < id[best])) best = i;
+      // rank 0 = the largest of the K kept.  Shared by two or more of them (duplicate points ...): the one Tensor.topk
+      // returns FIRST, i.e. position 0 after what ATen does next with the selected entries -- std::sort of the first K - 1
+      // (the nth_element branch; the K-th is not above any of them) or partial_sort's __sort_heap of the K-entry heap
+      int best = 0, nbest = 1;
+      for (int i = 1; i < K; ++i) {
+        if (val[i] > val[best]) { best = i; nbest = 1; }
+        else if (val[i] == val[best]) ++nbest;
+      }
+      if (nbest > 1) {
+        if (use_heap) tb_sort_heap(q, 0, K); else tb_sort(q, 0, K - 1, red);
+        best = 0;
+      }
       int32_t* o = a.idx + (size_t)row * a.k;
       int w = 0;
       for (int i = 0; i < K; ++i)
