@@ -1494,10 +1494,11 @@ __device__ void tiebreak_row(const vcr_knn_args& a, int row, unsigned char* smem
   float *val, *qrow;
   int *id, *A, *Bd, *red;
   if (!gwork) {
-    // (8 bytes of padding in front -- the ports index at most one entry below their position --: the arrays the sequential ports walk downwards must not start at LDS offset 0 -- this code
-    // reaches LDS through flat instructions wherever val / id may also be global (see below), the compiler turns the `v[j - 1]` of
-    // a descending loop into (base - 4) + an immediate offset of 4, and a flat address below the LDS aperture faults whatever
-    // the offset: MEMORY_APERTURE_VIOLATION in the replay launch, found with rocgdb when the rank-0 sort was added)
+    // (8 bytes of padding in front: the arrays the sequential ports walk downwards must not start at LDS offset 0.  This code
+    // reaches LDS through flat instructions wherever val / id may also be global (see below); the compiler turns the `v[j - 1]`
+    // of a descending loop into (base - 4) + an immediate offset of 4, and a flat address below the LDS aperture faults
+    // whatever the offset -- MEMORY_APERTURE_VIOLATION in the replay launch, located with rocgdb when the rank-0 sort was
+    // added.  The ports never index more than one entry below their position.)
     val = reinterpret_cast<float*>(smem) + TB_LDS_PAD / 4;
     id = reinterpret_cast<int*>(val + a.N);
     qrow = reinterpret_cast<float*>(id + a.N);           // [64]
