@@ -4,11 +4,14 @@ Which index does ``Tensor.topk`` keep when the k-th and (k+1)-th values are EXAC
 ``topk`` (aten/src/ATen/native/cpu/TopKImpl.h, not vendored in the reference; torch 2.10.0) fills a vector of
 ``(value, index)`` pairs and runs libstdc++'s ``std::partial_sort`` when ``k * 64 <= n`` and otherwise
 ``std::nth_element(k - 1)`` + ``std::sort`` of the first k-1, all with a comparator that looks at the VALUE only.
-The kept SET is therefore an artefact of introselect's pivoting / the heap's shape.  The reference's ``knn``
-(util/util.py:159) inherits that behaviour, and the HIP kNN kernels replay it for rows with such a tie
-(vcr-net_amd/csrc/knn.hip, knn_tiebreak_kernel).  This module restates the libstdc++ algorithms
+The kept SET is therefore an artefact of introselect's pivoting / the heap's shape, and so is the ORDER equal values are
+returned in -- which matters once: the reference's ``knn`` (util/util.py:159) drops the entry ``topk`` returns FIRST, so
+when the best value of a row is shared (copies of a point; a neighbour whose distance rounds to the point's own) WHICH of the
+tied entries is dropped comes out of that sort.  The HIP kNN kernels replay both for rows with such a tie
+(vcr-net_amd/csrc/knn.hip, knn_tiebreak_kernel / tiebreak_row).  This module restates the libstdc++ algorithms
 (bits/stl_algo.h: __introselect, __unguarded_partition_pivot, __move_median_to_first, __insertion_sort;
-bits/stl_heap.h: __make_heap, __adjust_heap, __push_heap, __pop_heap, __heap_select) in plain Python;
+__introsort_loop, __final_insertion_sort; bits/stl_heap.h: __make_heap, __adjust_heap, __push_heap, __pop_heap,
+__heap_select, __sort_heap) in plain Python;
 tests/test_oracle_topk_ties.py pins it against ``torch.topk`` itself on tie-heavy inputs."""
 import math
 
@@ -120,3 +123,48 @@ def topk_set_emulated(values, k):
         nth_element(q, k - 1)
     return sorted(j for _, j in q[:k])
 
+
+
+def sort_heap(q, first, last):
+    while last - first > 1:
+        last -= 1
+        pop_heap(q, first, last, last)
+
+def unguarded_linear_insert(q, last):
+    val = q[last]
+    nxt = last - 1
+    while comp(val, q[nxt]):
+        q[last] = q[nxt]; last = nxt; nxt -= 1
+    q[last] = val
+
+def introsort_loop(q, first, last, depth_limit):
+    while last - first > 16:
+        if depth_limit == 0:                # __partial_sort(first, last, last)
+            heap_select(q, first, last, last)
+            sort_heap(q, first, last)
+            return
+        depth_limit -= 1
+        cut = unguarded_partition_pivot(q, first, last)
+        introsort_loop(q, cut, last, depth_limit)
+        last = cut
+
+def std_sort(q, first, last):
+    if first == last: return
+    introsort_loop(q, first, last, 2 * int(math.floor(math.log2(last - first))))
+    if last - first > 16:                   # __final_insertion_sort
+        insertion_sort(q, first, first + 16)
+        for i in range(first + 16, last): unguarded_linear_insert(q, i)
+    else:
+        insertion_sort(q, first, last)
+
+def topk_order_emulated(values, k):
+    """The k indices in the ORDER Tensor.topk(sorted=True) returns them (ties included)."""
+    n = len(values)
+    q = [(float(v), j) for j, v in enumerate(values)]
+    if k * 64 <= n:
+        heap_select(q, 0, k, n)
+        sort_heap(q, 0, k)
+    else:
+        nth_element(q, k - 1)
+        std_sort(q, 0, k - 1)
+    return [j for _, j in q[:k]]
