@@ -76,7 +76,10 @@ int vcr_rows4_pq_f32(const float* x_cf, float* xyz4, int B, int N, const float* 
  * (vcr_forward_f32) keeps N <= 65535: its other stages were never validated beyond.
  * Exact ties at the (k+1)-th value: with tie_scratch the kept SET equals what Tensor.topk (libstdc++ nth_element /
  * partial_sort on the CPU) keeps; without it one of the tied candidates is kept (deterministically, but not by a
- * documented rule).  The replay holds a row's N distances in LDS up to N = 10 091; longer rows need tie_work
+ * documented rule).  A best value shared by two or more entries (copies of a point; a neighbour whose distance rounds to
+ * the point's own) is the other tie that decides a set: "rank 0" is the entry Tensor.topk returns FIRST, an outcome of its
+ * sort; with tie_scratch such rows are replayed too and the copy the reference drops is dropped, without it the first
+ * logged one is.  The replay holds a row's N distances in LDS up to N = 10 091; longer rows need tie_work
  * (vcr_knn_tie_work_bytes(N) bytes of 16-B aligned device scratch) -- with tie_scratch set and tie_work missing such a
  * call returns VCR_EUNSUPPORTED: the replay is never skipped silently. */
 typedef struct {
@@ -87,8 +90,9 @@ typedef struct {
   const float* sq;                    /* [B,N] squared norms (C==64); ignored for C==4 */
   int B, N, C, k;
   int32_t* idx;                       /* [B,N,k], neighbour index within the cloud     */
-  int32_t* tie_scratch; int tie_cap;  /* optional: [1 + tie_cap] ints of scratch (count, then the rows with a boundary
-                                         tie; 256 entries are plenty: ~1 row in 10^4 ties) */
+  int32_t* tie_scratch; int tie_cap;  /* optional: [1 + tie_cap] ints of scratch (count, then the rows with a tie: ~1 row in
+                                         10^4 has a boundary tie, and EVERY copy of a repeated point is such a row; rows
+                                         beyond tie_cap are not replayed -- B * N entries are always enough) */
   int waves;                          /* tuning / tests, never changes a result.  0 = chosen from the shape.  C == 64: 8 = the
                                          16-query-wave kernel (v_mfma_f32_16x16x4_f32, four lanes per query); 1 / 2 / 4 = the
                                          32-query-wave kernel with that many waves sharing one group of queries and splitting
