@@ -312,7 +312,7 @@ def test_iter_with_a_forward_sized_workspace_still_runs():
 
 
 @pytest.mark.parametrize("kw,mode,half,N,k", [({}, "fp32", 7, 747, 20), (dict(vcp_nn="dist"), "bf16x3", 5, 1024, 20),
-                                              (dict(emb_nn="dgcnn"), "fp32", 6, 640, 7), ({}, "fp32", 9, 500, 40)])
+                                              (dict(emb_nn="dgcnn"), "fp32", 7, 640, 7), ({}, "fp32", 9, 500, 40)])
 def test_batch_composition_changes_no_embedding_bit(kw, mode, half, N, k):
     """A pair's results must not depend on WHICH batch it travels in: every kernel computes a row from that row's cloud alone,
     and what the library picks from the grid size (the kNN launch forms: candidate splits, 16- / 32-query waves, pair /
@@ -324,6 +324,7 @@ def test_batch_composition_changes_no_embedding_bit(kw, mode, half, N, k):
     from vcrnet_amd import synth
     rs = np.random.RandomState(N + k)
     B = 2 * half
+    assert ((N + 127) // 128) * 2 * half * 4 * 2 > 512, "a half whose cross-attention splits its keys: not the same arithmetic"
     src, tgt, _, _, _ = synth.make_batch(11, B, N)
     for x in (src, tgt):
         for b in range(B):
