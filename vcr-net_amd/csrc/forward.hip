@@ -561,6 +561,7 @@ int forward_impl(const vcr_vcrnet_weights* W, const vcr_vcrnet_io* io, void* wor
       R.mark(nm);
       vcr_linear_args a{x, K, wt, bias, nullptr, 0, y, Nout, Mk, Nout, K, 1};
       a.segmax_out = w.cat + col; a.ld_segmax = 512; a.seg_k = k;
+      a.variant = R.linear_variant;                      // (vcr_vcrnet_weights.linear_mfma / linear_bk / linear_bm reach every fp32 linear)
       R.pin_shape(a, nullptr, M2 * k);                   // (a source-only pass: the MFMA shape of the launch over both clouds' edges)
       R.ok(vcr_linear_f32(&a, R.stream));
     };

@@ -413,9 +413,11 @@ __device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args&
   }
   // rank 0 = the largest value (the point itself): dropped.  When that value is SHARED (duplicate points, or a neighbour so
   // close that its distance rounds to the point's own), WHICH of the tied entries Tensor.topk returns first is an outcome of
-  // its sort (util.py:159 then drops that one and keeps the others): such a row is replayed like a boundary tie (nmax > 1
+  // its sort (util.py:159 then drops that one and keeps the others): such a row is replayed like a boundary tie (best_shared
   // below; tiebreak_row sorts the kept entries the way ATen does).  Without tie_scratch: the first logged is dropped.
-  int imax = 0, nmax = 0;
+  // (Whether it is shared is read off the sorted value list: its two best entries are equal.)
+  const bool best_shared = sel.rank_value(0) == sel.rank_value(1);
+  int imax = 0;
   float vmax = VCR_NEG_INF;
   if (perm) {
     // (the plain scan logs in index order, so "the first logged" is the LOWEST point index among the largest values)
@@ -425,13 +427,11 @@ __device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args&
       const int ic = min(i, PEND - 1);
       const float d = i < sel.cnt ? sel.lv[ic * G::COLS + sel.col] : VCR_NEG_INF;
       const int j = sel.li[ic * G::COLS + sel.col];
-      nmax = d > vmax ? 1 : nmax + ((d == vmax && i < sel.cnt) ? 1 : 0);
       if (d > vmax || (d == vmax && i < sel.cnt && j < jmax)) { vmax = d; imax = i; jmax = j; }
     }
   } else {
   for (int i = 0; __any(i < sel.cnt); ++i) {
     const float d = i < sel.cnt ? sel.lv[min(i, PEND - 1) * G::COLS + sel.col] : VCR_NEG_INF;
-    nmax = d > vmax ? 1 : nmax + ((d == vmax && i < sel.cnt) ? 1 : 0);
     if (d > vmax) { vmax = d; imax = i; }
   }
   }
@@ -440,7 +440,7 @@ __device__ __forceinline__ void finish(Selector<G, KS>& sel, const vcr_knn_args&
     int32_t* o = a.idx + ((size_t)b * a.N + q) * a.k;
     for (int i = sel.sg; i < sel.cnt && i <= a.k; i += G::LPQ)
       if (i != imax) o[i - (i > imax ? 1 : 0)] = sel.li[i * G::COLS + sel.col];
-    if (sel.sg == 0 && ((vk1 == vk && vk1 > VCR_NEG_INF) || nmax > 1)) {
+    if (sel.sg == 0 && ((vk1 == vk && vk1 > VCR_NEG_INF) || best_shared)) {
       if (blk_ties) {                                    // replayed by this very workgroup (replay_block_ties)
         const int pos = atomicAdd(&blk_ties[0], 1);
         if (pos < BLK_TIES) blk_ties[1 + pos] = b * a.N + q;
